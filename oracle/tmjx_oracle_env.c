@@ -1,0 +1,337 @@
+/* oracle/tmjx_oracle_env.c — CPU ORACLE, task/env/learner part (test infrastructure only).
+ *
+ * Restates, one env at a time:
+ *   reset     : multi_clip_tracking.py:74-96 -> single_clip_tracking.py:121-205 (noise and
+ *               (clip_idx,start_frame) are injected by the caller: JAX threefry is out of scope)
+ *   step      : wrappers.py:104-144 (auto-reset) ∘ brax EpisodeWrapper ∘ single_clip_tracking.py:207-320
+ *   rewards   : reward.py:57-485            obs : single_clip_tracking.py:322-450, walker/base.py:170-258
+ *   GAE       : agent/mlp_ppo/losses.py:39-100
+ * Compiled with -ffp-contract=off so that `floor(time*hz + start)` is evaluated the un-fused way.
+ */
+#include "tmjx_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifdef ORACLE_DOUBLE
+#define R_SQRT sqrt
+#define R_EXP exp
+#define R_ACOS acos
+#define R_FLOOR floor
+#define R_FABS fabs
+#define R_FMIN fmin
+#define R_MAX DBL_MAX
+#else
+#define R_SQRT sqrtf
+#define R_EXP expf
+#define R_ACOS acosf
+#define R_FLOOR floorf
+#define R_FABS fabsf
+#define R_FMIN fminf
+#define R_MAX FLT_MAX
+#endif
+
+size_t oracle_sizeof_env(void) { return sizeof(OEnv); }
+
+int oracle_set_clips(OModel *m, const float *pos, const float *quat, const float *joints,
+                     const float *bodypos, const float *angvel, int n_clips, int n_frames) {
+  int nj = m->nq - 7, nbp = m->nbody - 1;
+  size_t cf = (size_t)n_clips * n_frames;
+  free(m->clip_pos); free(m->clip_quat); free(m->clip_joints); free(m->clip_bodypos); free(m->clip_angvel);
+  m->clip_pos = (float *)malloc(cf * 3 * 4); m->clip_quat = (float *)malloc(cf * 4 * 4);
+  m->clip_joints = (float *)malloc(cf * nj * 4); m->clip_bodypos = (float *)malloc(cf * nbp * 3 * 4);
+  m->clip_angvel = (float *)malloc(cf * 3 * 4);
+  memcpy(m->clip_pos, pos, cf * 3 * 4); memcpy(m->clip_quat, quat, cf * 4 * 4);
+  memcpy(m->clip_joints, joints, cf * nj * 4); memcpy(m->clip_bodypos, bodypos, cf * nbp * 3 * 4);
+  memcpy(m->clip_angvel, angvel, cf * 3 * 4);
+  m->n_clips = n_clips; m->n_frames_clip = n_frames;
+  return 0;
+}
+
+/* reward_f layout (host: track_mjx_amd/config.py REWARD_F) */
+enum { RW_TOO_FAR, RW_BAD_POSE, RW_BAD_QUAT, RW_CTRL_W, RW_CTRL_DIFF_W, RW_ENERGY_W, RW_POS_W, RW_QUAT_W, RW_JOINT_W,
+       RW_ANGVEL_W, RW_BODYPOS_W, RW_ENDEFF_W, RW_ZLO, RW_ZHI, RW_POS_S, RW_QUAT_S, RW_JOINT_S, RW_ANGVEL_S,
+       RW_BODYPOS_S, RW_ENDEFF_S, RW_PEN0, RW_PEN1, RW_PEN2, RW_VAR_COEFF, RW_JERK_COEFF };
+
+static inline real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void brax_rotate(real *o, const real *v, const real *q) { /* brax.math.rotate(vec, quat) */
+  real s = q[0]; const real *u = q + 1; real uv = dot3(u, v), uu = dot3(u, u);
+  real c[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+  for (int i = 0; i < 3; i++) o[i] = 2 * (uv * u[i]) + (s * s - uu) * v[i] + 2 * s * c[i];
+}
+static void quat_mul(real *o, const real *a, const real *b) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+static int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* single_clip_tracking.py:452-454 — f32 time accumulated by the physics, un-fused multiply-add */
+static int cur_frame(const OModel *m, const OEnv *e) {
+  real t = e->d.time * (real)m->mocap_hz;
+  real f = t + (real)e->start_frame;
+  return (int)R_FLOOR(f);
+}
+static const float *clip_row(const OModel *m, const float *tab, int width, int clip, int frame) {
+  clip = clampi(clip, 0, m->n_clips - 1); frame = clampi(frame, 0, m->n_frames_clip - 1); /* XLA gather clamps */
+  return tab + ((size_t)clip * m->n_frames_clip + frame) * width;
+}
+
+/* _get_obs: reference 470 ‖ proprioception 226 */
+static int get_obs(const OModel *m, const OEnv *e, real *obs) {
+  const OData *d = &e->d;
+  int nj = m->nq - 7, nbp = m->nbody - 1, T = m->traj_length, o = 0;
+  int start = clampi(cur_frame(m, e) + 1, 0, m->n_frames_clip - T); /* dynamic_slice_in_dim clamps the start */
+  const real *root = d->qpos, *quat = d->qpos + 3;
+  for (int t = 0; t < T; t++) { /* compute_local_track_positions */
+    const float *rp = clip_row(m, m->clip_pos, 3, e->clip_idx, start + t);
+    real v[3] = {(real)rp[0] - root[0], (real)rp[1] - root[1], (real)rp[2] - root[2]};
+    brax_rotate(obs + o, v, quat); o += 3;
+  }
+  for (int t = 0; t < T; t++) { /* compute_quat_distances: relative_quat(ref, agent) = agent * conj(ref) */
+    const float *rq = clip_row(m, m->clip_quat, 4, e->clip_idx, start + t);
+    real inv[4] = {(real)rq[0], -(real)rq[1], -(real)rq[2], -(real)rq[3]};
+    quat_mul(obs + o, quat, inv); o += 4;
+  }
+  for (int t = 0; t < T; t++) { /* compute_local_joint_distances, "OB1 hot fix": idx - 1 */
+    const float *rj = clip_row(m, m->clip_joints, nj, e->clip_idx, start + t);
+    for (int k = 0; k < m->n_joint_idx; k++) { int i = clampi(m->joint_idxs[k] - 1, 0, nj - 1); obs[o++] = (real)rj[i] - d->qpos[7 + i]; }
+  }
+  for (int t = 0; t < T; t++) { /* compute_local_body_positions on xpos[1:], OOB index clamped */
+    const float *rb = clip_row(m, m->clip_bodypos, nbp * 3, e->clip_idx, start + t);
+    for (int k = 0; k < m->n_body_idx; k++) {
+      int i = clampi(m->body_idxs[k], 0, nbp - 1);
+      real v[3] = {(real)rb[i * 3] - d->xpos[1 + i][0], (real)rb[i * 3 + 1] - d->xpos[1 + i][1], (real)rb[i * 3 + 2] - d->xpos[1 + i][2]};
+      brax_rotate(obs + o, v, quat); o += 3;
+    }
+  }
+  /* _get_proprioception */
+  for (int i = 7; i < m->nq; i++) obs[o++] = d->qpos[i];
+  for (int i = 6; i < m->nv; i++) obs[o++] = d->qvel[i];
+  for (int i = 0; i < m->nv; i++) obs[o++] = d->qfrc_actuator[i];
+  int tb = m->torso_idx;
+  obs[o++] = d->xpos[tb][2];
+  for (int k = 6; k < 9; k++) obs[o++] = d->xmat[tb][k];
+  for (int k = 0; k < m->n_endeff_idx; k++) { /* named bodies: the correct ids, egocentric = v @ xmat */
+    int b = m->endeff_idxs[k];
+    real v[3] = {d->xpos[b][0] - d->xpos[tb][0], d->xpos[b][1] - d->xpos[tb][1], d->xpos[b][2] - d->xpos[tb][2]};
+    const real *X = d->xmat[tb];
+    for (int c = 0; c < 3; c++) obs[o++] = v[0] * X[c] + v[1] * X[3 + c] + v[2] * X[6 + c];
+  }
+  return o;
+}
+int oracle_obs_size(const OModel *m) {
+  int T = m->traj_length;
+  return T * 3 + T * 4 + T * m->n_joint_idx + T * m->n_body_idx * 3 + (m->nq - 7) + (m->nv - 6) + m->nv + 1 + 3 + 3 * m->n_endeff_idx;
+}
+
+static int data_has_nan(const OModel *m, const OData *d) {
+  int bad = 0;
+#define CHK(p, n) for (int i_ = 0; i_ < (n); i_++) bad |= isnan((double)((const real *)(p))[i_])
+  CHK(d->qpos, m->nq); CHK(d->qvel, m->nv); CHK(d->act, m->nu); CHK(d->qacc_warmstart, m->nv); CHK(&d->time, 1);
+  CHK(d->ctrl, m->nu); CHK(d->xpos, m->nbody * 3); CHK(d->xquat, m->nbody * 4); CHK(d->qfrc_actuator, m->nv);
+  CHK(d->qacc, m->nv); CHK(d->qfrc_constraint, m->nv); CHK(d->qfrc_smooth, m->nv); CHK(d->qfrc_bias, m->nv);
+  CHK(d->efc_force, m->nefc); CHK(d->con_dist, m->ncon);
+#undef CHK
+  return bad;
+}
+static real nan_to_num(real x) { if (isnan((double)x)) return 0; if (isinf((double)x)) return x > 0 ? R_MAX : -R_MAX; return x; }
+
+void oracle_env_reset(const OModel *m, OEnv *e, int clip_idx, int start_frame, const double *qn, const double *vn) {
+  memset(e, 0, sizeof(OEnv));
+  e->clip_idx = clip_idx; e->start_frame = start_frame;
+  int nj = m->nq - 7;
+  const float *rp = clip_row(m, m->clip_pos, 3, clip_idx, start_frame);
+  const float *rq = clip_row(m, m->clip_quat, 4, clip_idx, start_frame);
+  const float *rj = clip_row(m, m->clip_joints, nj, clip_idx, start_frame);
+  OData *d = &e->d;
+  for (int k = 0; k < 3; k++) d->qpos[k] = (real)rp[k] + (real)qn[k];
+  for (int k = 0; k < 4; k++) d->qpos[3 + k] = (real)rq[k] + (real)qn[3 + k];
+  for (int k = 0; k < nj; k++) d->qpos[7 + k] = (real)rj[k] + (real)qn[7 + k];
+  for (int i = 0; i < m->nv; i++) d->qvel[i] = (real)vn[i];
+  oracle_forward(m, d); /* pipeline_init = make_data + forward */
+  get_obs(m, e, e->obs);
+  /* auto-reset snapshot */
+  memcpy(&e->first_d, d, sizeof(OData));
+  memcpy(e->first_obs, e->obs, sizeof(e->obs));
+  memset(e->first_prev_ctrl, 0, sizeof(e->first_prev_ctrl));
+}
+
+void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_physics) {
+  OData *d = &e->d;
+  int nu = m->nu, W = m->window;
+  real a[O_MAXU];
+  for (int i = 0; i < nu; i++) a[i] = (real)action[i];
+  /* auto-reset wrapper prologue: zero steps of envs that finished on the previous call; clear done */
+  if (e->done != 0) e->steps = 0;
+  e->done = 0;
+  /* pipeline_step: n_frames x (ctrl = action; mjx.step) */
+  for (int i = 0; i < nu; i++) d->ctrl[i] = a[i];
+  if (do_physics) for (int f = 0; f < m->n_frames; f++) oracle_step(m, d);
+  /* current reference frame */
+  int frame = cur_frame(m, e), nj = m->nq - 7, nbp = m->nbody - 1;
+  const float *rp = clip_row(m, m->clip_pos, 3, e->clip_idx, frame);
+  const float *rq = clip_row(m, m->clip_quat, 4, e->clip_idx, frame);
+  const float *rj = clip_row(m, m->clip_joints, nj, e->clip_idx, frame);
+  const float *rb = clip_row(m, m->clip_bodypos, nbp * 3, e->clip_idx, frame);
+  const float *rw = clip_row(m, m->clip_angvel, 3, e->clip_idx, frame);
+  /* info updates happen BEFORE the reward call (single_clip_tracking.py:227-234): prev_ctrl == action there */
+  for (int i = 0; i < nu; i++) e->prev_ctrl[i] = a[i];
+  for (int i = 0; i < nu; i++) e->action_buffer[e->buffer_index][i] = a[i];
+  e->buffer_index = (e->buffer_index + 1) % W;
+  const real *w = m->rw;
+  /* compute_tracking_rewards */
+  real pd[3], s = 0;
+  for (int k = 0; k < 3; k++) { pd[k] = d->qpos[k] - (real)rp[k]; s += pd[k] * pd[k]; }
+  real pos_reward = w[RW_POS_W] * R_EXP(-w[RW_POS_S] * s);
+  real q1[4], q2[4], n1 = 0, n2 = 0, dt = 0;
+  for (int k = 0; k < 4; k++) { q1[k] = d->qpos[3 + k]; q2[k] = (real)rq[k]; n1 += q1[k] * q1[k]; n2 += q2[k] * q2[k]; }
+  n1 = R_SQRT(n1); n2 = R_SQRT(n2);
+  for (int k = 0; k < 4; k++) { q1[k] /= n1; q2[k] /= n2; dt += q1[k] * q2[k]; }
+  real dist = 2 * dt * dt - 1; dist = R_FMIN((real)1, dist);
+  real bq = (real)0.5 * R_ACOS(dist);
+  real quat_distance = bq * bq;
+  real quat_reward = w[RW_QUAT_W] * R_EXP(-w[RW_QUAT_S] * quat_distance);
+  real joint_distance = 0;
+  for (int k = 0; k < nj; k++) { real df = d->qpos[7 + k] - (real)rj[k]; joint_distance += df * df; }
+  real joint_reward = w[RW_JOINT_W] * R_EXP(-w[RW_JOINT_S] * joint_distance);
+  s = 0; for (int k = 0; k < 3; k++) { real df = d->qvel[3 + k] - (real)rw[k]; s += df * df; }
+  real angvel_reward = w[RW_ANGVEL_W] * R_EXP(-w[RW_ANGVEL_S] * s);
+  s = 0;
+  for (int k = 0; k < m->n_body_idx; k++) { int i = clampi(m->body_idxs[k], 0, nbp - 1); for (int c = 0; c < 3; c++) { real df = d->xpos[1 + i][c] - (real)rb[i * 3 + c]; s += df * df; } }
+  real bodypos_reward = w[RW_BODYPOS_W] * R_EXP(-w[RW_BODYPOS_S] * s);
+  s = 0;
+  for (int k = 0; k < m->n_endeff_idx; k++) { int i = clampi(m->endeff_idxs[k], 0, nbp - 1); for (int c = 0; c < 3; c++) { real df = d->xpos[1 + i][c] - (real)rb[i * 3 + c]; s += df * df; } }
+  real endeff_reward = w[RW_ENDEFF_W] * R_EXP(-w[RW_ENDEFF_S] * s);
+  s = 0; for (int i = 0; i < nu; i++) s += a[i] * a[i];
+  real ctrl_cost = w[RW_CTRL_W] * s;
+  s = 0; for (int i = 0; i < nu; i++) { real df = e->prev_ctrl[i] - a[i]; s += df * df; }
+  real ctrl_diff_cost = w[RW_CTRL_DIFF_W] * s;
+  s = 0; for (int i = 6; i < m->nv; i++) s += R_FABS(d->qvel[i]) * R_FABS(d->qfrc_actuator[i]);
+  real energy_cost = w[RW_ENERGY_W] * R_FMIN(s, (real)50);
+  real torso_z = d->xpos[m->torso_idx][2];
+  real healthy = torso_z < w[RW_ZLO] ? 0 : 1; if (torso_z > w[RW_ZHI]) healthy = 0;
+  real fall = 1 - healthy;
+  real spd = 0; for (int k = 0; k < 3; k++) { real x = pd[k] * w[RW_PEN0 + k]; spd += x * x; }
+  real too_far = spd > w[RW_TOO_FAR] ? 1 : 0, bad_pose = joint_distance > w[RW_BAD_POSE] ? 1 : 0, bad_quat = quat_distance > w[RW_BAD_QUAT] ? 1 : 0;
+  real var_sum = 0;
+  for (int i = 0; i < nu; i++) {
+    real mean = 0, var = 0;
+    for (int r = 0; r < W; r++) mean += e->action_buffer[r][i];
+    mean /= (real)W;
+    for (int r = 0; r < W; r++) { real df = e->action_buffer[r][i] - mean; var += df * df; }
+    var_sum += var / (real)W;
+  }
+  real var_cost = w[RW_VAR_COEFF] * var_sum;
+  real jerk = 0;
+  for (int r = 0; r + 2 < W; r++) {
+    const real *o0 = e->action_buffer[(e->buffer_index + r) % W], *o1 = e->action_buffer[(e->buffer_index + r + 1) % W],
+               *o2 = e->action_buffer[(e->buffer_index + r + 2) % W];
+    for (int i = 0; i < nu; i++) { real j = o2[i] - 2 * o1[i] + o0[i]; jerk += j * j; }
+  }
+  real jerk_cost = w[RW_JERK_COEFF] * jerk;
+  get_obs(m, e, e->obs);
+  real reward = joint_reward + pos_reward + quat_reward + angvel_reward + bodypos_reward + endeff_reward - ctrl_cost -
+                ctrl_diff_cost - energy_cost - var_cost - jerk_cost;
+  real done = fall; if (too_far > done) done = too_far; if (bad_pose > done) done = bad_pose; if (bad_quat > done) done = bad_quat;
+  reward = nan_to_num(reward);
+  int no = oracle_obs_size(m);
+  for (int i = 0; i < no; i++) e->obs[i] = nan_to_num(e->obs[i]);
+  real nanf_ = data_has_nan(m, d) ? 1 : 0;
+  if (nanf_ > done) done = nanf_;
+  real *M = e->metrics;
+  M[0] = pos_reward; M[1] = quat_reward; M[2] = joint_reward; M[3] = angvel_reward; M[4] = bodypos_reward; M[5] = endeff_reward;
+  M[6] = -ctrl_cost; M[7] = -ctrl_diff_cost; M[8] = -energy_cost; M[9] = done; M[10] = too_far; M[11] = bad_pose; M[12] = bad_quat;
+  M[13] = fall; M[14] = nanf_; M[15] = joint_distance; M[16] = spd; M[17] = quat_distance; M[18] = -var_cost; M[19] = -jerk_cost;
+  e->reward = reward;
+  /* brax EpisodeWrapper */
+  e->steps += 1;
+  int over = e->steps >= (real)m->episode_length;
+  e->truncation = over ? 1 - done : 0;
+  if (over) done = 1;
+  e->done = done;
+  /* auto-reset epilogue: pipeline_state, obs, prev_ctrl <- first_*; nothing else */
+  if (done != 0) {
+    memcpy(d, &e->first_d, sizeof(OData));
+    memcpy(e->obs, e->first_obs, sizeof(e->obs));
+    memcpy(e->prev_ctrl, e->first_prev_ctrl, sizeof(e->prev_ctrl));
+  }
+}
+
+void oracle_env_step(const OModel *m, OEnv *e, const double *action) { oracle_env_step_ex(m, e, action, 1); }
+
+void oracle_env_step_batch(const OModel *m, OEnv *envs, int n, const double *actions, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int i = 0; i < n; i++) oracle_env_step(m, &envs[i], actions + (size_t)i * m->nu);
+  (void)nthreads;
+}
+
+int oracle_env_get(const OModel *m, const OEnv *e, const char *name, double *out, int cap) {
+  const real *p = NULL; int n = 0;
+  if (!strcmp(name, "obs")) { p = e->obs; n = oracle_obs_size(m); }
+  else if (!strcmp(name, "reward")) { p = &e->reward; n = 1; }
+  else if (!strcmp(name, "done")) { p = &e->done; n = 1; }
+  else if (!strcmp(name, "truncation")) { p = &e->truncation; n = 1; }
+  else if (!strcmp(name, "steps")) { p = &e->steps; n = 1; }
+  else if (!strcmp(name, "metrics")) { p = e->metrics; n = 20; }
+  else if (!strcmp(name, "prev_ctrl")) { p = e->prev_ctrl; n = m->nu; }
+  else if (!strcmp(name, "action_buffer")) {
+    if (cap < m->window * m->nu) return -1;
+    for (int r = 0; r < m->window; r++) for (int i = 0; i < m->nu; i++) out[r * m->nu + i] = e->action_buffer[r][i];
+    return m->window * m->nu;
+  }
+  else if (!strcmp(name, "buffer_index")) { out[0] = e->buffer_index; return 1; }
+  else if (!strcmp(name, "clip_idx")) { out[0] = e->clip_idx; return 1; }
+  else if (!strcmp(name, "start_frame")) { out[0] = e->start_frame; return 1; }
+  else if (!strcmp(name, "cur_frame")) { out[0] = cur_frame(m, e); return 1; }
+  else return oracle_data_get(m, &e->d, name, out, cap);
+  if (n > cap) return -1;
+  for (int i = 0; i < n; i++) out[i] = p[i];
+  return n;
+}
+
+int oracle_env_set(const OModel *m, OEnv *e, const char *name, const double *in, int n) {
+  if (!strcmp(name, "clip_idx")) { e->clip_idx = (int)in[0]; return 1; }
+  if (!strcmp(name, "start_frame")) { e->start_frame = (int)in[0]; return 1; }
+  if (!strcmp(name, "buffer_index")) { e->buffer_index = (int)in[0]; return 1; }
+  if (!strcmp(name, "steps")) { e->steps = (real)in[0]; return 1; }
+  if (!strcmp(name, "done")) { e->done = (real)in[0]; return 1; }
+  if (!strcmp(name, "prev_ctrl")) { for (int i = 0; i < m->nu && i < n; i++) e->prev_ctrl[i] = (real)in[i]; return m->nu; }
+  if (!strcmp(name, "action_buffer")) {
+    if (n != m->window * m->nu) return -1;
+    for (int r = 0; r < m->window; r++) for (int i = 0; i < m->nu; i++) e->action_buffer[r][i] = (real)in[r * m->nu + i];
+    return n;
+  }
+  return oracle_data_set(m, &e->d, name, in, n);
+}
+
+/* losses.py:39-100 compute_gae, [T,B] row-major */
+void oracle_gae(const double *truncation, const double *termination, const double *rewards, const double *values,
+                const double *bootstrap, double lambda_, double discount, double *vs, double *adv, int T, int B) {
+  real lam = (real)lambda_, disc = (real)discount;
+  for (int b = 0; b < B; b++) {
+    real acc = 0;
+    for (int t = T - 1; t >= 0; t--) {
+      real tm = 1 - (real)truncation[t * B + b], term = (real)termination[t * B + b];
+      real v1 = t + 1 < T ? (real)values[(t + 1) * B + b] : (real)bootstrap[b];
+      real delta = (real)rewards[t * B + b] + disc * (1 - term) * v1 - (real)values[t * B + b];
+      delta *= tm;
+      acc = delta + disc * (1 - term) * tm * lam * acc;
+      vs[t * B + b] = (double)(acc + (real)values[t * B + b]);
+    }
+    for (int t = 0; t < T; t++) {
+      real tm = 1 - (real)truncation[t * B + b], term = (real)termination[t * B + b];
+      real v1 = t + 1 < T ? (real)vs[(t + 1) * B + b] : (real)bootstrap[b];
+      adv[t * B + b] = (double)(((real)rewards[t * B + b] + disc * (1 - term) * v1 - (real)values[t * B + b]) * tm);
+    }
+  }
+}
