@@ -1,0 +1,104 @@
+/* include/tmjx.h — C-ABI of libtmjx_hip.so: the MI355X-native hot path of talmolab/track-mjx.
+ *
+ * The reference has no FFI/plugin boundary for this path (it is 100 % Python on JAX/XLA); the
+ * entry points below are what a binding for the reference's Python interfaces would call.
+ * Each entry cites the reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - return 0 on success, a negative TMJX_E* code on failure; never throws; the message of the
+ *     last failure on the calling thread is available from tmjx_last_error().
+ *   - every per-env buffer is CALLER-OWNED DEVICE memory (e.g. a torch tensor's data_ptr) laid
+ *     out structure-of-arrays with the ENV INDEX CONTIGUOUS:  buf[field_index * n_env + env].
+ *   - the library owns only the immutable model constants and the clip table of a handle.
+ *   - all work is enqueued on the caller's HIP stream; no hidden synchronisation.
+ *   - one handle per host thread / GPU (thread-compatible, not thread-safe).
+ *   - `stream` is a hipStream_t passed as void* so that this header needs no HIP include.
+ */
+#ifndef TMJX_H
+#define TMJX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMJX_OK 0
+#define TMJX_EINVAL (-22)
+#define TMJX_ENOMEM (-12)
+#define TMJX_EHIP (-5)
+
+typedef struct tmjx_model tmjx_model;
+
+/* Float state layout (rows of the `state` buffer, each row n_env floats). Query with tmjx_layout(). */
+typedef struct tmjx_layout_t {
+  int32_t nq, nv, nu, nbody, ncon, nefc, obs_size, ref_obs_size, n_metrics, window;
+  /* rows of the float state buffer */
+  int32_t qpos, qvel, act, qacc_warmstart, time;          /* physics state (mjx.Data fields carried)      */
+  int32_t xpos, xmat_torso, qfrc_actuator;                 /* outputs of the last mjx.forward read by K3   */
+  int32_t prev_ctrl, action_buffer, done, steps_f;         /* task info (single_clip_tracking.py:227-234)  */
+  int32_t first_phys, first_obs, first_prev_ctrl;          /* auto-reset snapshot (wrappers.py:93-95)       */
+  int32_t state_rows;                                      /* total float rows                              */
+  /* rows of the int32 state buffer */
+  int32_t i_clip_idx, i_start_frame, i_buffer_index, i_nan_count, istate_rows;
+  int32_t ws_rows;                                         /* float rows of the scratch workspace           */
+} tmjx_layout_t;
+
+/* Model handle from the compiled blob (model constants + env/task configuration).
+ * Replaces: SingleClipTracking.__init__ (track_mjx/environment/task/single_clip_tracking.py:25-92:
+ * solver options, mjcf load, mjx.put_model) and RewardConfig (task/reward.py:15-54). */
+int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out);
+void tmjx_model_destroy(tmjx_model *m);
+int tmjx_layout(const tmjx_model *m, tmjx_layout_t *out);
+
+/* Upload the ReferenceClip table (HOST pointers, float32, shapes (C,F,3) (C,F,4) (C,F,nq-7)
+ * (C,F,nbody-1,3) (C,F,3)); the table becomes a resident device constant of the handle.
+ * Replaces: the `reference_clip` constructor argument (task/multi_clip_tracking.py:16-72) whose
+ * leaves are laid out by track_mjx/io/load.py:16-38,105-137. */
+int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quaternion, const float *joints,
+                      const float *body_positions, const float *angular_velocity, int n_clips, int n_frames);
+
+/* reset: MultiClipTracking.reset -> reset_from_clip (task/multi_clip_tracking.py:74-96,
+ * task/single_clip_tracking.py:121-205) + the wrappers' reset (wrappers.py:88-102, brax
+ * EpisodeWrapper.reset).  (clip_idx, start_frame, noise) are inputs because JAX's threefry stream
+ * is outside this path; qpos_noise is [nq][n_env], qvel_noise [nv][n_env].  Writes obs [obs][n_env]. */
+int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip_idx, const int32_t *start_frame,
+               const float *qpos_noise, const float *qvel_noise, float *obs, float *workspace, int n_env, void *stream);
+
+/* step: wrappers.wrap(env).step = LSTMAutoResetWrapperTracking.step ∘ VmapWrapper ∘ EpisodeWrapper.step ∘
+ * MultiClipTracking.step (wrappers.py:104-144; task/single_clip_tracking.py:207-320).
+ * action [nu][n_env]; outputs obs [obs][n_env], reward/done/truncation [n_env], metrics [20][n_env]. */
+int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward,
+              float *done, float *truncation, float *metrics, float *workspace, int n_env, void *stream);
+
+/* K2 alone: `n_substeps` x (ctrl = action; mjx.step) on the physics rows of `state`
+ * (brax PipelineEnv.pipeline_step, called at task/single_clip_tracking.py:219). */
+int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substeps, float *workspace, int n_env,
+                 void *stream);
+/* mjx.forward alone on the physics rows of `state` (pipeline_init, task/single_clip_tracking.py:163). */
+int tmjx_forward(tmjx_model *m, float *state, float *workspace, int n_env, void *stream);
+
+/* K3 alone: everything in step() except the physics substeps: frame index, clip gather, rewards,
+ * observation, done/NaN guard, episode + auto-reset wrappers (task/single_clip_tracking.py:220-320,
+ * task/reward.py:359-485, wrappers.py:104-144). */
+int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward,
+                    float *done, float *truncation, float *metrics, int n_env, void *stream);
+
+/* GAE reverse scan: compute_gae (track_mjx/agent/mlp_ppo/losses.py:39-100). All arrays [T][B] row-major
+ * (B contiguous), bootstrap [B]; outputs vs, advantages [T][B]. */
+int tmjx_gae(const float *truncation, const float *termination, const float *rewards, const float *values,
+             const float *bootstrap, float lambda_, float discount, float *vs, float *advantages, int T, int B,
+             void *stream);
+
+/* Debug/test access: copy a named per-env workspace/intermediate array of the last tmjx_forward /
+ * tmjx_physics call into `out` (device pointer, [count][n_env]); returns count or a negative code.
+ * Names: "qM" (sparse rows), "qfrc_smooth", "qacc", "qacc_smooth", "efc_D", "efc_aref", "con_dist", ... */
+int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count);
+
+const char *tmjx_last_error(void);
+const char *tmjx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -116,10 +116,10 @@ OModel *oracle_model_create(const void *blob, size_t n) {
   BF("opt_f", optf, 4); BI("opt_i", opti, 3);
   m->timestep = optf[0]; m->tolerance = optf[1]; m->ls_tolerance = optf[2]; m->impratio = optf[3];
   m->iterations = opti[0]; m->ls_iterations = opti[1]; m->n_frames = opti[2];
-  int envi[6];
-  BI("env_i", envi, 6);
+  int envi[7];
+  BI("env_i", envi, 7);
   m->mocap_hz = envi[0]; m->clip_length = envi[1]; m->traj_length = envi[2]; m->window = envi[3];
-  m->torso_idx = envi[4]; m->episode_length = envi[5];
+  m->torso_idx = envi[4]; m->episode_length = envi[5]; m->auto_reset = envi[6];
   m->n_joint_idx = blob_i(blob, n, "joint_idxs", m->joint_idxs, O_MAXV);
   m->n_body_idx = blob_i(blob, n, "body_idxs", m->body_idxs, O_MAXB);
   m->n_endeff_idx = blob_i(blob, n, "endeff_idxs", m->endeff_idxs, 16);

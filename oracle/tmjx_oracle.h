@@ -60,7 +60,7 @@ typedef struct {
   real timestep, tolerance, ls_tolerance, impratio;
   int iterations, ls_iterations, n_frames;
   /* env / task config */
-  int mocap_hz, clip_length, traj_length, window, torso_idx, episode_length;
+  int mocap_hz, clip_length, traj_length, window, torso_idx, episode_length, auto_reset;
   int n_joint_idx, n_body_idx, n_endeff_idx;
   int joint_idxs[O_MAXV], body_idxs[O_MAXB], endeff_idxs[16];
   real rw[32];
@@ -91,7 +91,6 @@ typedef struct {
   real steps, truncation;
   real obs[O_OBS], reward, done, metrics[20];
   /* auto-reset snapshot (wrappers.py:93-95) */
-  real first_qpos[O_MAXQ], first_qvel[O_MAXV], first_act[O_MAXU], first_warm[O_MAXV], first_time;
   real first_obs[O_OBS], first_prev_ctrl[O_MAXU];
   OData first_d;
 } OEnv;

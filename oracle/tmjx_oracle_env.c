@@ -257,7 +257,7 @@ void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_p
   if (over) done = 1;
   e->done = done;
   /* auto-reset epilogue: pipeline_state, obs, prev_ctrl <- first_*; nothing else */
-  if (done != 0) {
+  if (done != 0 && m->auto_reset) {
     memcpy(d, &e->first_d, sizeof(OData));
     memcpy(e->obs, e->first_obs, sizeof(e->obs));
     memcpy(e->prev_ctrl, e->first_prev_ctrl, sizeof(e->prev_ctrl));

@@ -1,0 +1,68 @@
+// csrc/dmodel.h — device-resident model constants and buffer layout of the hot path.
+//
+// One DModel lives in device memory per handle; kernels read it through wave-uniform indices so the
+// compiler can use scalar (s_load) loads.  All floats are fp32 (MJX narrows MuJoCo's float64 model the
+// same way: mjx.put_model, reference call site track_mjx/environment/task/single_clip_tracking.py:91).
+#pragma once
+#include <stdint.h>
+
+#define TM_MAXB 72    // bodies
+#define TM_MAXV 76    // dofs
+#define TM_MAXQ 76
+#define TM_MAXU 40
+#define TM_MAXC 32    // contact slots
+#define TM_MAXG 8     // contact groups (distinct paw bodies)
+#define TM_MAXIDX 40
+#define TM_NMETRIC 20
+
+struct DModel {
+  int nbody, njnt, nq, nv, nu, ncon, nlim, nefc, ngroup, nnz;
+  int root_body;  // the single moving tree's root (walker)
+  // kinematic tree
+  int body_parentid[TM_MAXB], body_jntadr[TM_MAXB], body_jntnum[TM_MAXB], body_dofadr[TM_MAXB], body_dofnum[TM_MAXB];
+  int body_moving[TM_MAXB];  // 1 if rootid == root_body
+  int jnt_type[TM_MAXV], jnt_bodyid[TM_MAXV], jnt_qposadr[TM_MAXV], jnt_dofadr[TM_MAXV];
+  int dof_bodyid[TM_MAXV], dof_parentid[TM_MAXV], dof_Madr[TM_MAXV], dof_depth[TM_MAXV];
+  int lim_jnt[TM_MAXV];
+  float body_pos[TM_MAXB][3], body_quat[TM_MAXB][4], body_mass[TM_MAXB], body_ipos[TM_MAXB][3], body_iquat[TM_MAXB][4],
+      body_inertia[TM_MAXB][3];
+  float jnt_pos[TM_MAXV][3], jnt_axis[TM_MAXV][3], jnt_range[TM_MAXV][2], jnt_stiffness[TM_MAXV];
+  float jnt_solref[TM_MAXV][2], jnt_solimp[TM_MAXV][5], jnt_margin[TM_MAXV];
+  float qpos0[TM_MAXQ], qpos_spring[TM_MAXQ], dof_damping[TM_MAXV], dof_armature[TM_MAXV], dof_invweight0[TM_MAXV];
+  // actuators: sparse moment (joint transmissions are one-hot, fixed tendons a few entries)
+  int act_madr[TM_MAXU + 1], act_mdof[128];
+  float act_mval[128], act_gain[TM_MAXU], act_tau[TM_MAXU], act_ctrlrange[TM_MAXU][2];
+  float gravity[3], meaninertia;
+  // contact slots in MJX order; slots of one paw body are contiguous ("group")
+  int con_type[TM_MAXC], con_sub[TM_MAXC], con_body1[TM_MAXC], con_body2[TM_MAXC];
+  float con_mu[TM_MAXC], con_solref[TM_MAXC][2], con_solimp[TM_MAXC][5], con_invweight[TM_MAXC];
+  float con_g1_pos[TM_MAXC][3], con_g1_quat[TM_MAXC][4], con_g2_pos[TM_MAXC][3], con_g2_quat[TM_MAXC][4], con_g2_size[TM_MAXC][3];
+  int grp_body[TM_MAXG], grp_lastdof[TM_MAXG], grp_start[TM_MAXG], grp_count[TM_MAXG];
+  // options
+  float timestep, tolerance, ls_tolerance, impratio;
+  int iterations, ls_iterations, n_frames;
+  // task
+  int mocap_hz, clip_length, traj_length, window, torso_idx, episode_length, auto_reset;
+  int n_joint_idx, n_body_idx, n_endeff_idx;
+  int joint_idxs[TM_MAXIDX], body_idxs[TM_MAXIDX], endeff_idxs[TM_MAXIDX];
+  float rw[32];
+  int obs_size, ref_obs_size;
+  // clip table (device pointers, float32)
+  int n_clips, n_frames_clip;
+  const float *clip_pos, *clip_quat, *clip_joints, *clip_bodypos, *clip_angvel;
+  // ---- row offsets: float state buffer
+  int s_qpos, s_qvel, s_act, s_warm, s_time, s_xpos, s_xmat_torso, s_qfrc_actuator, s_prev_ctrl, s_action_buffer,
+      s_done, s_steps, s_first_phys, s_first_obs, s_first_prev_ctrl, s_rows;
+  int nphys;  // qpos..time rows (contiguous)
+  // int state buffer
+  int i_clip_idx, i_start_frame, i_buffer_index, i_nan_count, i_rows;
+  // ---- row offsets: workspace
+  int w_ctrl, w_xquat, w_xanchor, w_xaxis, w_xipos, w_cinert, w_cdof, w_crb, w_M, w_LD, w_Dinv, w_cvel, w_cdof_dot, w_cacc,
+      w_cfrc, w_qfrc_smooth, w_qacc_smooth, w_act_dot, w_con_dist, w_con_off, w_con_frame, w_efc_D, w_efc_aref,
+      w_efc_Jaref, w_efc_jv, w_lim_sign, w_qacc, w_Ma, w_grad, w_Mgrad, w_search, w_mv, w_qfrc_constraint, w_tmp,
+      w_efc_force, w_com, w_rows;
+};
+
+enum { RW_TOO_FAR, RW_BAD_POSE, RW_BAD_QUAT, RW_CTRL_W, RW_CTRL_DIFF_W, RW_ENERGY_W, RW_POS_W, RW_QUAT_W, RW_JOINT_W,
+       RW_ANGVEL_W, RW_BODYPOS_W, RW_ENDEFF_W, RW_ZLO, RW_ZHI, RW_POS_S, RW_QUAT_S, RW_JOINT_S, RW_ANGVEL_S,
+       RW_BODYPOS_S, RW_ENDEFF_S, RW_PEN0, RW_PEN1, RW_PEN2, RW_VAR_COEFF, RW_JERK_COEFF };

@@ -1,0 +1,232 @@
+// csrc/env_core.h — per-env task logic of the hot path (K1 reset tail, K3 reward/obs/done/wrappers).
+//
+// Replaces, per env (paths relative to /root/reference/track_mjx):
+//   environment/task/single_clip_tracking.py:220-320  step() after pipeline_step
+//   environment/task/single_clip_tracking.py:322-454  _get_proprioception/_get_reference_trajectory/_get_obs/_get_cur_frame
+//   environment/task/reward.py:57-485                  the 18 reward / cost / termination terms
+//   environment/walker/base.py:170-258                 egocentric observation maths (brax.math.rotate / relative_quat)
+//   environment/wrappers.py:104-144                    auto-reset (+ brax EpisodeWrapper steps/truncation)
+// Quirks reproduced on purpose: prev_ctrl is overwritten before the reward call (ctrl_diff_cost == 0),
+// xpos[1:][body id] off-by-one with index clamp, joint id - 1, action window / clip / start frame survive auto-reset.
+#pragma once
+#include <float.h>
+
+#include "physics_core.h"
+
+#define IS(off) r_is[(size_t)(off) * (size_t)r.n + (size_t)r.e]
+#define OUTROW(buf, row) (buf)[(size_t)(row) * (size_t)r.n + (size_t)r.e]
+
+#ifdef TM_HOST_EMU
+TM_DEV float tm_mul_noc(float a, float b) { volatile float t = a * b; return t; }
+TM_DEV float tm_add_noc(float a, float b) { volatile float t = a + b; return t; }
+#else
+TM_DEV float tm_mul_noc(float a, float b) { return __fmul_rn(a, b); }
+TM_DEV float tm_add_noc(float a, float b) { return __fadd_rn(a, b); }
+#endif
+
+TM_DEV int tm_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// single_clip_tracking.py:452-454: floor(time * mocap_hz + start_frame) in fp32, multiply and add NOT fused
+TM_DEV int tm_cur_frame(const DModel &m, float time, int start) {
+  return (int)floorf(tm_add_noc(tm_mul_noc(time, (float)m.mocap_hz), (float)start));
+}
+TM_DEV size_t tm_clip_row(const DModel &m, int clip, int frame) {
+  clip = tm_clampi(clip, 0, m.n_clips - 1);
+  frame = tm_clampi(frame, 0, m.n_frames_clip - 1);
+  return (size_t)clip * (size_t)m.n_frames_clip + (size_t)frame;
+}
+TM_DEV float tm_nan_to_num(float x) {
+  if (x != x) return 0.f;
+  if (x > FLT_MAX) return FLT_MAX;
+  if (x < -FLT_MAX) return -FLT_MAX;
+  return x;
+}
+
+// _get_obs -> obs[obs_size][n]; applies nan_to_num when `sanitize`
+TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *obs, bool sanitize) {
+  int nj = m.nq - 7, nbp = m.nbody - 1, T = m.traj_length, o = 0;
+  int start = tm_clampi(frame + 1, 0, m.n_frames_clip - T);
+  float root[3], quat[4];
+  TM_LD(root, ST, m.s_qpos, 0, 3);
+  TM_LD(quat, ST, m.s_qpos, 3, 4);
+#define PUT(v) do { float v_ = (v); OUTROW(obs, o) = sanitize ? tm_nan_to_num(v_) : v_; o++; } while (0)
+  for (int t = 0; t < T; t++) {
+    const float *rp = m.clip_pos + tm_clip_row(m, clip, start + t) * 3;
+    float v[3] = {rp[0] - root[0], rp[1] - root[1], rp[2] - root[2]}, w[3];
+    tm_rotate(w, v, quat);
+    PUT(w[0]); PUT(w[1]); PUT(w[2]);
+  }
+  for (int t = 0; t < T; t++) {
+    const float *rq = m.clip_quat + tm_clip_row(m, clip, start + t) * 4;
+    float inv[4] = {rq[0], -rq[1], -rq[2], -rq[3]}, w[4];
+    tm_quat_mul(w, quat, inv);
+    PUT(w[0]); PUT(w[1]); PUT(w[2]); PUT(w[3]);
+  }
+  for (int t = 0; t < T; t++) {
+    const float *rj = m.clip_joints + tm_clip_row(m, clip, start + t) * nj;
+    for (int k = 0; k < m.n_joint_idx; k++) { int i = tm_clampi(m.joint_idxs[k] - 1, 0, nj - 1); PUT(rj[i] - ST(m.s_qpos, 7 + i)); }
+  }
+  for (int t = 0; t < T; t++) {
+    const float *rb = m.clip_bodypos + tm_clip_row(m, clip, start + t) * (size_t)(nbp * 3);
+    for (int k = 0; k < m.n_body_idx; k++) {
+      int i = tm_clampi(m.body_idxs[k], 0, nbp - 1);
+      float v[3] = {rb[i * 3] - ST(m.s_xpos, (1 + i) * 3), rb[i * 3 + 1] - ST(m.s_xpos, (1 + i) * 3 + 1), rb[i * 3 + 2] - ST(m.s_xpos, (1 + i) * 3 + 2)}, w[3];
+      tm_rotate(w, v, quat);
+      PUT(w[0]); PUT(w[1]); PUT(w[2]);
+    }
+  }
+  for (int i = 7; i < m.nq; i++) PUT(ST(m.s_qpos, i));
+  for (int i = 6; i < m.nv; i++) PUT(ST(m.s_qvel, i));
+  for (int i = 0; i < m.nv; i++) PUT(ST(m.s_qfrc_actuator, i));
+  int tb = m.torso_idx;
+  float tp[3], X[9];
+  TM_LD(tp, ST, m.s_xpos, tb * 3, 3);
+  TM_LD(X, ST, m.s_xmat_torso, 0, 9);
+  PUT(tp[2]); PUT(X[6]); PUT(X[7]); PUT(X[8]);
+  for (int k = 0; k < m.n_endeff_idx; k++) {
+    int b = m.endeff_idxs[k];
+    float v[3] = {ST(m.s_xpos, b * 3) - tp[0], ST(m.s_xpos, b * 3 + 1) - tp[1], ST(m.s_xpos, b * 3 + 2) - tp[2]};
+    for (int c = 0; c < 3; c++) PUT(v[0] * X[c] + v[1] * X[3 + c] + v[2] * X[6 + c]);
+  }
+#undef PUT
+}
+
+TM_DEV bool tm_state_has_nan(const DModel &m, EnvRef r) {
+  bool bad = false;
+  for (int i = 0; i < m.nphys; i++) { float v = ST(m.s_qpos, i); bad |= (v != v); }
+  for (int i = 0; i < m.nbody * 3; i++) { float v = ST(m.s_xpos, i); bad |= (v != v); }
+  for (int i = 0; i < m.nv; i++) { float v = ST(m.s_qfrc_actuator, i); bad |= (v != v); }
+  return bad;
+}
+
+// Everything of wrappers.wrap(env).step around/after the physics.  Call tm_step_prologue BEFORE the physics.
+TM_DEV void tm_step_prologue(const DModel &m, EnvRef r) {
+  if (ST(m.s_done, 0) != 0.f) ST(m.s_steps, 0) = 0.f;
+  ST(m.s_done, 0) = 0.f;
+}
+TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *action, float *obs, float *reward, float *done_out,
+                         float *trunc_out, float *metrics) {
+  int nu = m.nu, W = m.window, nj = m.nq - 7, nbp = m.nbody - 1;
+  int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame), bi = IS(m.i_buffer_index);
+  int frame = tm_cur_frame(m, ST(m.s_time, 0), start);
+  size_t row = tm_clip_row(m, clip, frame);
+  const float *rp = m.clip_pos + row * 3, *rq = m.clip_quat + row * 4, *rj = m.clip_joints + row * nj;
+  const float *rb = m.clip_bodypos + row * (size_t)(nbp * 3), *rwv = m.clip_angvel + row * 3;
+  const float *w = m.rw;
+  // info updates precede the reward call
+  float ctrl_sq = 0.f, ctrl_diff = 0.f;
+  for (int i = 0; i < nu; i++) {
+    float a = OUTROW(action, i);
+    ST(m.s_prev_ctrl, i) = a;
+    ST(m.s_action_buffer, bi * nu + i) = a;
+    ctrl_sq += a * a;
+    float df = a - a;  // prev_ctrl == action at this point (reference quirk); keeps NaN/inf propagation
+    ctrl_diff += df * df;
+  }
+  bi = (bi + 1) % W;
+  IS(m.i_buffer_index) = bi;
+  float pd[3], s = 0.f;
+  for (int k = 0; k < 3; k++) { pd[k] = ST(m.s_qpos, k) - rp[k]; s += pd[k] * pd[k]; }
+  float pos_reward = w[RW_POS_W] * expf(-w[RW_POS_S] * s);
+  float q1[4], q2[4], n1 = 0.f, n2 = 0.f, dt = 0.f;
+  for (int k = 0; k < 4; k++) { q1[k] = ST(m.s_qpos, 3 + k); q2[k] = rq[k]; n1 += q1[k] * q1[k]; n2 += q2[k] * q2[k]; }
+  n1 = sqrtf(n1); n2 = sqrtf(n2);
+  for (int k = 0; k < 4; k++) dt += (q1[k] / n1) * (q2[k] / n2);
+  float dist = fminf(1.f, 2.f * dt * dt - 1.f), bq = 0.5f * acosf(dist), quat_distance = bq * bq;
+  float quat_reward = w[RW_QUAT_W] * expf(-w[RW_QUAT_S] * quat_distance);
+  float joint_distance = 0.f;
+  for (int k = 0; k < nj; k++) { float df = ST(m.s_qpos, 7 + k) - rj[k]; joint_distance += df * df; }
+  float joint_reward = w[RW_JOINT_W] * expf(-w[RW_JOINT_S] * joint_distance);
+  s = 0.f;
+  for (int k = 0; k < 3; k++) { float df = ST(m.s_qvel, 3 + k) - rwv[k]; s += df * df; }
+  float angvel_reward = w[RW_ANGVEL_W] * expf(-w[RW_ANGVEL_S] * s);
+  s = 0.f;
+  for (int k = 0; k < m.n_body_idx; k++) {
+    int i = tm_clampi(m.body_idxs[k], 0, nbp - 1);
+    for (int c = 0; c < 3; c++) { float df = ST(m.s_xpos, (1 + i) * 3 + c) - rb[i * 3 + c]; s += df * df; }
+  }
+  float bodypos_reward = w[RW_BODYPOS_W] * expf(-w[RW_BODYPOS_S] * s);
+  s = 0.f;
+  for (int k = 0; k < m.n_endeff_idx; k++) {
+    int i = tm_clampi(m.endeff_idxs[k], 0, nbp - 1);
+    for (int c = 0; c < 3; c++) { float df = ST(m.s_xpos, (1 + i) * 3 + c) - rb[i * 3 + c]; s += df * df; }
+  }
+  float endeff_reward = w[RW_ENDEFF_W] * expf(-w[RW_ENDEFF_S] * s);
+  float ctrl_cost = w[RW_CTRL_W] * ctrl_sq, ctrl_diff_cost = w[RW_CTRL_DIFF_W] * ctrl_diff;
+  s = 0.f;
+  for (int i = 6; i < m.nv; i++) s += fabsf(ST(m.s_qvel, i)) * fabsf(ST(m.s_qfrc_actuator, i));
+  float energy_cost = w[RW_ENERGY_W] * fminf(s, 50.f);
+  float torso_z = ST(m.s_xpos, m.torso_idx * 3 + 2);
+  float healthy = torso_z < w[RW_ZLO] ? 0.f : 1.f;
+  if (torso_z > w[RW_ZHI]) healthy = 0.f;
+  float fall = 1.f - healthy, spd = 0.f;
+  for (int k = 0; k < 3; k++) { float x = pd[k] * w[RW_PEN0 + k]; spd += x * x; }
+  float too_far = spd > w[RW_TOO_FAR] ? 1.f : 0.f, bad_pose = joint_distance > w[RW_BAD_POSE] ? 1.f : 0.f,
+        bad_quat = quat_distance > w[RW_BAD_QUAT] ? 1.f : 0.f;
+  // action-variance and jerk costs over the ring buffer (reward.py:314-356)
+  float var_sum = 0.f, jerk = 0.f;
+  for (int i = 0; i < nu; i++) {
+    float mean = 0.f, var = 0.f;
+    for (int rr = 0; rr < W; rr++) mean += ST(m.s_action_buffer, rr * nu + i);
+    mean /= (float)W;
+    for (int rr = 0; rr < W; rr++) { float df = ST(m.s_action_buffer, rr * nu + i) - mean; var += df * df; }
+    var_sum += var / (float)W;
+    int i0 = bi % W, i1 = (bi + 1) % W;
+    float o0 = ST(m.s_action_buffer, i0 * nu + i), o1 = ST(m.s_action_buffer, i1 * nu + i);
+    for (int rr = 0; rr + 2 < W; rr++) {
+      int i2 = (bi + rr + 2) % W;
+      float o2 = ST(m.s_action_buffer, i2 * nu + i), j = o2 - 2.f * o1 + o0;
+      jerk += j * j;
+      o0 = o1; o1 = o2;
+    }
+  }
+  float var_cost = w[RW_VAR_COEFF] * var_sum, jerk_cost = w[RW_JERK_COEFF] * jerk;
+  tm_get_obs(m, r, clip, frame, obs, true);
+  float rew = joint_reward + pos_reward + quat_reward + angvel_reward + bodypos_reward + endeff_reward - ctrl_cost -
+              ctrl_diff_cost - energy_cost - var_cost - jerk_cost;
+  float done = fmaxf(fmaxf(fall, too_far), fmaxf(bad_pose, bad_quat));
+  rew = tm_nan_to_num(rew);
+  float nanf_ = tm_state_has_nan(m, r) ? 1.f : 0.f;
+  done = fmaxf(done, nanf_);
+  OUTROW(metrics, 0) = pos_reward; OUTROW(metrics, 1) = quat_reward; OUTROW(metrics, 2) = joint_reward;
+  OUTROW(metrics, 3) = angvel_reward; OUTROW(metrics, 4) = bodypos_reward; OUTROW(metrics, 5) = endeff_reward;
+  OUTROW(metrics, 6) = -ctrl_cost; OUTROW(metrics, 7) = -ctrl_diff_cost; OUTROW(metrics, 8) = -energy_cost;
+  OUTROW(metrics, 9) = done; OUTROW(metrics, 10) = too_far; OUTROW(metrics, 11) = bad_pose; OUTROW(metrics, 12) = bad_quat;
+  OUTROW(metrics, 13) = fall; OUTROW(metrics, 14) = nanf_; OUTROW(metrics, 15) = joint_distance; OUTROW(metrics, 16) = spd;
+  OUTROW(metrics, 17) = quat_distance; OUTROW(metrics, 18) = -var_cost; OUTROW(metrics, 19) = -jerk_cost;
+  // EpisodeWrapper
+  float steps = ST(m.s_steps, 0) + 1.f;
+  ST(m.s_steps, 0) = steps;
+  bool over = steps >= (float)m.episode_length;
+  float trunc = over ? 1.f - done : 0.f;
+  if (over) done = 1.f;
+  ST(m.s_done, 0) = done;
+  reward[r.e] = rew; done_out[r.e] = done; trunc_out[r.e] = trunc;
+  // auto-reset: pipeline_state, obs, prev_ctrl <- snapshot taken at reset
+  if (done != 0.f && m.auto_reset) {
+    for (int i = 0; i < m.nphys; i++) ST(m.s_qpos, i) = ST(m.s_first_phys, i);
+    for (int i = 0; i < m.obs_size; i++) OUTROW(obs, i) = ST(m.s_first_obs, i);
+    for (int i = 0; i < nu; i++) ST(m.s_prev_ctrl, i) = ST(m.s_first_prev_ctrl, i);
+  }
+}
+
+// reset_from_clip before pipeline_init: state from the clip frame + injected noise, zeroed task info
+TM_DEV void tm_reset_pre(const DModel &m, EnvRef r, int *r_is, int clip, int start, const float *qn, const float *vn) {
+  int nj = m.nq - 7;
+  size_t row = tm_clip_row(m, clip, start);
+  const float *rp = m.clip_pos + row * 3, *rq = m.clip_quat + row * 4, *rj = m.clip_joints + row * nj;
+  for (int k = 0; k < 3; k++) ST(m.s_qpos, k) = rp[k] + OUTROW(qn, k);
+  for (int k = 0; k < 4; k++) ST(m.s_qpos, 3 + k) = rq[k] + OUTROW(qn, 3 + k);
+  for (int k = 0; k < nj; k++) ST(m.s_qpos, 7 + k) = rj[k] + OUTROW(qn, 7 + k);
+  for (int i = 0; i < m.nv; i++) { ST(m.s_qvel, i) = OUTROW(vn, i); ST(m.s_warm, i) = 0.f; }
+  for (int a = 0; a < m.nu; a++) { ST(m.s_act, a) = 0.f; WS(m.w_ctrl, a) = 0.f; ST(m.s_prev_ctrl, a) = 0.f; ST(m.s_first_prev_ctrl, a) = 0.f; }
+  ST(m.s_time, 0) = 0.f; ST(m.s_done, 0) = 0.f; ST(m.s_steps, 0) = 0.f;
+  for (int i = 0; i < m.window * m.nu; i++) ST(m.s_action_buffer, i) = 0.f;
+  IS(m.i_clip_idx) = clip; IS(m.i_start_frame) = start; IS(m.i_buffer_index) = 0; IS(m.i_nan_count) = 0;
+}
+// after pipeline_init (mjx.forward): first observation and the auto-reset snapshot
+TM_DEV void tm_reset_post(const DModel &m, EnvRef r, int *r_is, float *obs) {
+  int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame);
+  tm_get_obs(m, r, clip, tm_cur_frame(m, ST(m.s_time, 0), start), obs, false);
+  for (int i = 0; i < m.nphys; i++) ST(m.s_first_phys, i) = ST(m.s_qpos, i);
+  for (int i = 0; i < m.obs_size; i++) ST(m.s_first_obs, i) = OUTROW(obs, i);
+}

@@ -1,0 +1,204 @@
+// csrc/model_host.h — host side: model blob -> DModel (constants, sparse tables, buffer layouts).
+// Plain C++ (no HIP) so that the test-only host emulation of the kernel bodies can share it.
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "dmodel.h"
+
+namespace tmjx_host {
+
+struct BlobEntry { int code = -1, count = 0; const unsigned char *data = nullptr; };
+
+inline bool blob_find(const void *blob, size_t n, const char *name, BlobEntry &out) {
+  const unsigned char *p = (const unsigned char *)blob;
+  if (n < 16) return false;
+  uint32_t magic, ver, ne;
+  memcpy(&magic, p, 4); memcpy(&ver, p + 4, 4); memcpy(&ne, p + 8, 4);
+  if (magic != 0x584A4D54u || ver != 1) return false;
+  size_t off = 16;
+  for (uint32_t i = 0; i < ne && off + 40 <= n; i++) {
+    int32_t code, count;
+    memcpy(&code, p + off + 32, 4); memcpy(&count, p + off + 36, 4);
+    size_t nb = (size_t)count * (code == 0 ? 4 : 8), padded = nb + ((8 - nb % 8) % 8);
+    if (off + 40 + nb > n) return false;
+    if (strncmp((const char *)(p + off), name, 32) == 0) { out.code = code; out.count = count; out.data = p + off + 40; return true; }
+    off += 40 + padded;
+  }
+  return false;
+}
+
+struct Reader {
+  const void *blob; size_t n; std::string err;
+  bool ints(const char *name, int *dst, int expect, int cap = -1) {
+    BlobEntry e;
+    if (!blob_find(blob, n, name, e) || e.code != 0) { err = std::string("blob entry missing: ") + name; return false; }
+    if ((expect >= 0 && e.count != expect) || (cap >= 0 && e.count > cap)) { err = std::string("blob entry has wrong size: ") + name; return false; }
+    for (int i = 0; i < e.count; i++) { int32_t v; memcpy(&v, e.data + 4 * i, 4); dst[i] = v; }
+    return true;
+  }
+  int count(const char *name) { BlobEntry e; return blob_find(blob, n, name, e) ? e.count : -1; }
+  bool floats(const char *name, float *dst, int expect) {
+    BlobEntry e;
+    if (!blob_find(blob, n, name, e) || e.code != 1) { err = std::string("blob entry missing: ") + name; return false; }
+    if (e.count != expect) { err = std::string("blob entry has wrong size: ") + name; return false; }
+    for (int i = 0; i < e.count; i++) { double v; memcpy(&v, e.data + 8 * i, 8); dst[i] = (float)v; }
+    return true;
+  }
+};
+
+// Fills every field of DModel except the clip pointers. Returns false and sets `err` on malformed input.
+inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string &err) {
+  memset(&m, 0, sizeof(DModel));
+  Reader R{blob, nbytes, ""};
+  int dims[6];
+  if (!R.ints("dims", dims, 6)) { err = R.err; return false; }
+  m.nbody = dims[0]; m.njnt = dims[1]; m.nq = dims[2]; m.nv = dims[3]; m.nu = dims[4]; m.ncon = dims[5];
+  if (m.nbody > TM_MAXB || m.nv > TM_MAXV || m.nq > TM_MAXQ || m.nu > TM_MAXU || m.ncon > TM_MAXC || m.njnt > TM_MAXV) {
+    err = "model exceeds the compiled-in maximum dimensions"; return false;
+  }
+  bool ok = true;
+  std::vector<int> rootid(m.nbody), jlim(m.njnt), dof_jnt(m.nv);
+  ok = ok && R.ints("body_parentid", m.body_parentid, m.nbody) && R.ints("body_rootid", rootid.data(), m.nbody) &&
+       R.ints("body_jntadr", m.body_jntadr, m.nbody) && R.ints("body_jntnum", m.body_jntnum, m.nbody) &&
+       R.ints("body_dofadr", m.body_dofadr, m.nbody) && R.ints("body_dofnum", m.body_dofnum, m.nbody) &&
+       R.ints("jnt_type", m.jnt_type, m.njnt) && R.ints("jnt_bodyid", m.jnt_bodyid, m.njnt) &&
+       R.ints("jnt_qposadr", m.jnt_qposadr, m.njnt) && R.ints("jnt_dofadr", m.jnt_dofadr, m.njnt) &&
+       R.ints("jnt_limited", jlim.data(), m.njnt) && R.ints("dof_bodyid", m.dof_bodyid, m.nv) &&
+       R.ints("dof_parentid", m.dof_parentid, m.nv);
+  ok = ok && R.floats("body_pos", &m.body_pos[0][0], m.nbody * 3) && R.floats("body_quat", &m.body_quat[0][0], m.nbody * 4) &&
+       R.floats("body_mass", m.body_mass, m.nbody) && R.floats("body_ipos", &m.body_ipos[0][0], m.nbody * 3) &&
+       R.floats("body_iquat", &m.body_iquat[0][0], m.nbody * 4) && R.floats("body_inertia", &m.body_inertia[0][0], m.nbody * 3) &&
+       R.floats("jnt_pos", &m.jnt_pos[0][0], m.njnt * 3) && R.floats("jnt_axis", &m.jnt_axis[0][0], m.njnt * 3) &&
+       R.floats("jnt_range", &m.jnt_range[0][0], m.njnt * 2) && R.floats("jnt_stiffness", m.jnt_stiffness, m.njnt) &&
+       R.floats("jnt_solref", &m.jnt_solref[0][0], m.njnt * 2) && R.floats("jnt_solimp", &m.jnt_solimp[0][0], m.njnt * 5) &&
+       R.floats("jnt_margin", m.jnt_margin, m.njnt) && R.floats("qpos0", m.qpos0, m.nq) &&
+       R.floats("qpos_spring", m.qpos_spring, m.nq) && R.floats("dof_damping", m.dof_damping, m.nv) &&
+       R.floats("dof_armature", m.dof_armature, m.nv) && R.floats("dof_invweight0", m.dof_invweight0, m.nv) &&
+       R.floats("act_gain", m.act_gain, m.nu) && R.floats("act_tau", m.act_tau, m.nu) &&
+       R.floats("act_ctrlrange", &m.act_ctrlrange[0][0], m.nu * 2) && R.floats("gravity", m.gravity, 3) &&
+       R.floats("meaninertia", &m.meaninertia, 1);
+  if (!ok) { err = R.err; return false; }
+  for (int j = 0; j < m.njnt; j++)
+    if (m.jnt_type[j] != 0 && m.jnt_type[j] != 3) { err = "only free and hinge joints are supported on this path"; return false; }
+  // sparse actuator moments
+  std::vector<float> mom((size_t)m.nu * m.nv);
+  if (!R.floats("act_moment", mom.data(), m.nu * m.nv)) { err = R.err; return false; }
+  int ne = 0;
+  for (int a = 0; a < m.nu; a++) {
+    m.act_madr[a] = ne;
+    for (int i = 0; i < m.nv; i++) if (mom[(size_t)a * m.nv + i] != 0.f) {
+      if (ne >= 128) { err = "actuator moment has too many non-zeros"; return false; }
+      m.act_mdof[ne] = i; m.act_mval[ne] = mom[(size_t)a * m.nv + i]; ne++;
+    }
+  }
+  m.act_madr[m.nu] = ne;
+  // single moving tree
+  m.root_body = -1;
+  for (int b = 1; b < m.nbody; b++) {
+    bool moving = false;
+    for (int c = b; c > 0; c = m.body_parentid[c]) if (m.body_dofnum[c] > 0) moving = true;
+    if (moving) { if (m.root_body < 0) m.root_body = rootid[b]; if (rootid[b] != m.root_body) { err = "more than one moving tree"; return false; } }
+    m.body_moving[b] = rootid[b] == m.root_body && m.root_body >= 0;
+    if (!m.body_moving[b] && m.body_mass[b] != 0.f) { err = "static bodies must be massless"; return false; }
+  }
+  // tree-sparse M layout: row i = [M(i,i), M(i,parent), M(i,grandparent), ...]
+  int nnz = 0;
+  for (int i = 0; i < m.nv; i++) {
+    int d = 0;
+    for (int j = m.dof_parentid[i]; j >= 0; j = m.dof_parentid[j]) d++;
+    m.dof_depth[i] = d; m.dof_Madr[i] = nnz; nnz += d + 1;
+  }
+  m.nnz = nnz;
+  m.nlim = 0;
+  for (int j = 0; j < m.njnt; j++) if (jlim[j] && m.jnt_type[j] == 3) m.lim_jnt[m.nlim++] = j;
+  m.nefc = m.nlim + 4 * m.ncon;
+  // contacts
+  std::vector<float> fr(m.ncon * 3), binv(m.nbody * 2);
+  ok = R.ints("con_type", m.con_type, m.ncon) && R.ints("con_sub", m.con_sub, m.ncon) && R.ints("con_body1", m.con_body1, m.ncon) &&
+       R.ints("con_body2", m.con_body2, m.ncon) && R.floats("con_friction", fr.data(), m.ncon * 3) &&
+       R.floats("con_solref", &m.con_solref[0][0], m.ncon * 2) && R.floats("con_solimp", &m.con_solimp[0][0], m.ncon * 5) &&
+       R.floats("con_g1_pos", &m.con_g1_pos[0][0], m.ncon * 3) && R.floats("con_g1_quat", &m.con_g1_quat[0][0], m.ncon * 4) &&
+       R.floats("con_g2_pos", &m.con_g2_pos[0][0], m.ncon * 3) && R.floats("con_g2_quat", &m.con_g2_quat[0][0], m.ncon * 4) &&
+       R.floats("con_g2_size", &m.con_g2_size[0][0], m.ncon * 3) && R.floats("body_invweight0", binv.data(), m.nbody * 2);
+  if (!ok) { err = R.err; return false; }
+  float optf[4]; int opti[3], envi[7];
+  ok = R.floats("opt_f", optf, 4) && R.ints("opt_i", opti, 3) && R.ints("env_i", envi, 7) && R.floats("reward_f", m.rw, 25);
+  if (!ok) { err = R.err; return false; }
+  m.timestep = optf[0]; m.tolerance = optf[1]; m.ls_tolerance = optf[2]; m.impratio = optf[3];
+  m.iterations = opti[0]; m.ls_iterations = opti[1]; m.n_frames = opti[2];
+  m.mocap_hz = envi[0]; m.clip_length = envi[1]; m.traj_length = envi[2]; m.window = envi[3]; m.torso_idx = envi[4]; m.episode_length = envi[5]; m.auto_reset = envi[6];
+  m.ngroup = 0;
+  for (int c = 0; c < m.ncon; c++) {
+    if (m.body_moving[m.con_body1[c]] || !m.body_moving[m.con_body2[c]]) { err = "contact slots must be (static geom, moving geom)"; return false; }
+    float mu = fr[c * 3];
+    m.con_mu[c] = mu;
+    float t = binv[m.con_body1[c] * 2] + binv[m.con_body2[c] * 2];
+    m.con_invweight[c] = (t + mu * mu * t) * 2.f * mu * mu / m.impratio;  // pyramidal edge, condim 3
+    int b = m.con_body2[c];
+    if (m.ngroup == 0 || m.grp_body[m.ngroup - 1] != b) {
+      if (m.ngroup >= TM_MAXG) {  // a body may re-appear non-contiguously: start a new group anyway
+        err = "too many contact groups"; return false;
+      }
+      int g = m.ngroup++;
+      m.grp_body[g] = b; m.grp_start[g] = c; m.grp_count[g] = 0;
+      int last = -1;
+      for (int bb = b; bb > 0 && last < 0; bb = m.body_parentid[bb]) if (m.body_dofnum[bb]) last = m.body_dofadr[bb] + m.body_dofnum[bb] - 1;
+      m.grp_lastdof[g] = last;
+    }
+    m.grp_count[m.ngroup - 1]++;
+  }
+  m.n_joint_idx = R.count("joint_idxs"); m.n_body_idx = R.count("body_idxs"); m.n_endeff_idx = R.count("endeff_idxs");
+  if (m.n_joint_idx <= 0 || m.n_body_idx <= 0 || m.n_endeff_idx <= 0 || m.n_joint_idx > TM_MAXIDX || m.n_body_idx > TM_MAXIDX || m.n_endeff_idx > TM_MAXIDX) {
+    err = "bad tracked index lists"; return false;
+  }
+  R.ints("joint_idxs", m.joint_idxs, -1); R.ints("body_idxs", m.body_idxs, -1); R.ints("endeff_idxs", m.endeff_idxs, -1);
+  for (int k = 0; k < m.n_endeff_idx; k++) if (m.endeff_idxs[k] < 0 || m.endeff_idxs[k] >= m.nbody) { err = "end effector id out of range"; return false; }
+  if (m.torso_idx < 0 || m.torso_idx >= m.nbody || m.window < 3 || m.traj_length < 1) { err = "bad task configuration"; return false; }
+  int T = m.traj_length;
+  m.ref_obs_size = T * 3 + T * 4 + T * m.n_joint_idx + T * m.n_body_idx * 3;
+  m.obs_size = m.ref_obs_size + (m.nq - 7) + (m.nv - 6) + m.nv + 1 + 3 + 3 * m.n_endeff_idx;
+  // ---- layouts
+  int s = 0;
+  m.s_qpos = s; s += m.nq; m.s_qvel = s; s += m.nv; m.s_act = s; s += m.nu; m.s_warm = s; s += m.nv; m.s_time = s; s += 1;
+  m.nphys = s;
+  m.s_xpos = s; s += m.nbody * 3; m.s_xmat_torso = s; s += 9; m.s_qfrc_actuator = s; s += m.nv;
+  m.s_prev_ctrl = s; s += m.nu; m.s_action_buffer = s; s += m.window * m.nu; m.s_done = s; s += 1; m.s_steps = s; s += 1;
+  m.s_first_phys = s; s += m.nphys; m.s_first_obs = s; s += m.obs_size; m.s_first_prev_ctrl = s; s += m.nu;
+  m.s_rows = s;
+  m.i_clip_idx = 0; m.i_start_frame = 1; m.i_buffer_index = 2; m.i_nan_count = 3; m.i_rows = 4;
+  int w = 0;
+#define WROW(f, cnt) m.f = w; w += (cnt)
+  WROW(w_ctrl, m.nu); WROW(w_xquat, m.nbody * 4); WROW(w_xanchor, m.njnt * 3); WROW(w_xaxis, m.njnt * 3); WROW(w_xipos, m.nbody * 3);
+  WROW(w_cinert, m.nbody * 10); WROW(w_cdof, m.nv * 6); WROW(w_crb, m.nbody * 10); WROW(w_M, m.nnz); WROW(w_LD, m.nnz); WROW(w_Dinv, m.nv);
+  WROW(w_cvel, m.nbody * 6); WROW(w_cdof_dot, m.nv * 6); WROW(w_cacc, m.nbody * 6); WROW(w_cfrc, m.nbody * 6);
+  WROW(w_qfrc_smooth, m.nv); WROW(w_qacc_smooth, m.nv); WROW(w_act_dot, m.nu);
+  WROW(w_con_dist, m.ncon); WROW(w_con_off, m.ncon * 3); WROW(w_con_frame, m.ncon * 9);
+  WROW(w_efc_D, m.nefc); WROW(w_efc_aref, m.nefc); WROW(w_efc_Jaref, m.nefc); WROW(w_efc_jv, m.nefc); WROW(w_lim_sign, m.nlim);
+  WROW(w_qacc, m.nv); WROW(w_Ma, m.nv); WROW(w_grad, m.nv); WROW(w_Mgrad, m.nv); WROW(w_search, m.nv); WROW(w_mv, m.nv);
+  WROW(w_qfrc_constraint, m.nv); WROW(w_tmp, m.nefc > m.nv ? m.nefc : m.nv); WROW(w_efc_force, m.nefc); WROW(w_com, 3);
+#undef WROW
+  m.w_rows = w;
+  return true;
+}
+
+struct NamedRows { const char *name; int row0, count; bool in_state; };
+inline std::vector<NamedRows> debug_rows(const DModel &m) {
+  return {
+      {"qpos", m.s_qpos, m.nq, true}, {"qvel", m.s_qvel, m.nv, true}, {"act", m.s_act, m.nu, true},
+      {"qacc_warmstart", m.s_warm, m.nv, true}, {"time", m.s_time, 1, true}, {"xpos", m.s_xpos, m.nbody * 3, true},
+      {"xmat_torso", m.s_xmat_torso, 9, true}, {"qfrc_actuator", m.s_qfrc_actuator, m.nv, true},
+      {"xquat", m.w_xquat, m.nbody * 4, false}, {"cinert", m.w_cinert, m.nbody * 10, false}, {"cdof", m.w_cdof, m.nv * 6, false},
+      {"qM", m.w_M, m.nnz, false}, {"qfrc_smooth", m.w_qfrc_smooth, m.nv, false}, {"qacc_smooth", m.w_qacc_smooth, m.nv, false},
+      {"qacc", m.w_qacc, m.nv, false}, {"qfrc_constraint", m.w_qfrc_constraint, m.nv, false},
+      {"con_dist", m.w_con_dist, m.ncon, false}, {"con_frame", m.w_con_frame, m.ncon * 9, false},
+      {"efc_D", m.w_efc_D, m.nefc, false}, {"efc_aref", m.w_efc_aref, m.nefc, false}, {"efc_force", m.w_efc_force, m.nefc, false},
+      {"subtree_com", m.w_com, 3, false},
+  };
+}
+
+}  // namespace tmjx_host

@@ -1,0 +1,228 @@
+// csrc/tmjx_hip.hip — kernels and C-ABI of libtmjx_hip.so (gfx950 / MI355X only).
+//
+// v1 mapping: one lane per env, env index = coalesced axis of every buffer (include/tmjx.h layout rules).
+// The per-env bodies live in physics_core.h (K2) and env_core.h (K1/K3); this file launches them.
+#include <hip/hip_runtime.h>
+
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tmjx.h"
+#include "env_core.h"
+#include "model_host.h"
+
+struct tmjx_model {
+  DModel h;           // host copy (clip pointers are device pointers)
+  DModel *d = nullptr;  // device copy
+  float *clips[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int block = 16;     // lanes per workgroup for the per-env kernels
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(TMJX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------- kernels
+__global__ void k_reset(const DModel *__restrict__ mp, float *st, int *is, const int *clip, const int *start,
+                        const float *qn, const float *vn, float *obs, float *ws, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, ws, n, e};
+  tm_reset_pre(m, r, is, clip[e], start[e], qn, vn);
+  tm_forward(m, r);
+  tm_reset_post(m, r, is, obs);
+}
+
+__global__ void k_step(const DModel *__restrict__ mp, float *st, int *is, const float *action, float *obs, float *reward,
+                       float *done, float *trunc, float *metrics, float *ws, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, ws, n, e};
+  tm_step_prologue(m, r);
+  for (int a = 0; a < m.nu; a++) WS(m.w_ctrl, a) = action[(size_t)a * n + e];
+  for (int f = 0; f < m.n_frames; f++) { tm_forward(m, r); tm_euler(m, r); }
+  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics);
+}
+
+__global__ void k_physics(const DModel *__restrict__ mp, float *st, const float *action, int nsub, int do_euler, float *ws, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, ws, n, e};
+  for (int a = 0; a < m.nu; a++) WS(m.w_ctrl, a) = action ? action[(size_t)a * n + e] : 0.f;
+  for (int f = 0; f < nsub; f++) { tm_forward(m, r); if (do_euler) tm_euler(m, r); }
+}
+
+__global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const float *action, float *obs, float *reward,
+                       float *done, float *trunc, float *metrics, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, nullptr, n, e};
+  tm_step_prologue(m, r);
+  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics);
+}
+
+// compute_gae (losses.py:39-100): one lane per batch column, reverse scan over T then the advantage pass
+__global__ void k_gae(const float *__restrict__ trunc, const float *__restrict__ term, const float *__restrict__ rew,
+                      const float *__restrict__ val, const float *__restrict__ boot, float lam, float disc, float *vs,
+                      float *adv, int T, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.f, bv = boot[b], vnext = bv;
+  for (int t = T - 1; t >= 0; t--) {
+    size_t i = (size_t)t * B + b;
+    float tm = 1.f - trunc[i], te = term[i], v = val[i];
+    float delta = (rew[i] + disc * (1.f - te) * vnext - v) * tm;
+    acc = delta + disc * (1.f - te) * tm * lam * acc;
+    vs[i] = acc + v;
+    vnext = v;
+  }
+  float vsn = bv;
+  for (int t = T - 1; t >= 0; t--) {
+    size_t i = (size_t)t * B + b;
+    float tm = 1.f - trunc[i], te = term[i];
+    float cur = vs[i];
+    adv[i] = (rew[i] + disc * (1.f - te) * vsn - val[i]) * tm;
+    vsn = cur;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- C-ABI
+extern "C" {
+
+const char *tmjx_last_error(void) { return g_err.c_str(); }
+const char *tmjx_version(void) { return "tmjx-hip 0.1 (gfx950, lane-per-env)"; }
+
+int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
+  if (!blob || !out) return fail(TMJX_EINVAL, "null argument");
+  tmjx_model *m = new tmjx_model();
+  std::string err;
+  if (!tmjx_host::build_dmodel(blob, nbytes, m->h, err)) { delete m; return fail(TMJX_EINVAL, err); }
+  const char *bs = getenv("TMJX_BLOCK");
+  if (bs) { int v = atoi(bs); if (v >= 1 && v <= 256) m->block = v; }
+  hipError_t e = hipMalloc((void **)&m->d, sizeof(DModel));
+  if (e != hipSuccess) { delete m; return fail(TMJX_ENOMEM, std::string("hipMalloc(DModel): ") + hipGetErrorString(e)); }
+  e = hipMemcpy(m->d, &m->h, sizeof(DModel), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(m->d); delete m; return fail(TMJX_EHIP, std::string("hipMemcpy(DModel): ") + hipGetErrorString(e)); }
+  *out = m;
+  return TMJX_OK;
+}
+
+void tmjx_model_destroy(tmjx_model *m) {
+  if (!m) return;
+  for (int i = 0; i < 5; i++) if (m->clips[i]) hipFree(m->clips[i]);
+  if (m->d) hipFree(m->d);
+  delete m;
+}
+
+int tmjx_layout(const tmjx_model *mm, tmjx_layout_t *o) {
+  if (!mm || !o) return fail(TMJX_EINVAL, "null argument");
+  const DModel &m = mm->h;
+  o->nq = m.nq; o->nv = m.nv; o->nu = m.nu; o->nbody = m.nbody; o->ncon = m.ncon; o->nefc = m.nefc;
+  o->obs_size = m.obs_size; o->ref_obs_size = m.ref_obs_size; o->n_metrics = TM_NMETRIC; o->window = m.window;
+  o->qpos = m.s_qpos; o->qvel = m.s_qvel; o->act = m.s_act; o->qacc_warmstart = m.s_warm; o->time = m.s_time;
+  o->xpos = m.s_xpos; o->xmat_torso = m.s_xmat_torso; o->qfrc_actuator = m.s_qfrc_actuator;
+  o->prev_ctrl = m.s_prev_ctrl; o->action_buffer = m.s_action_buffer; o->done = m.s_done; o->steps_f = m.s_steps;
+  o->first_phys = m.s_first_phys; o->first_obs = m.s_first_obs; o->first_prev_ctrl = m.s_first_prev_ctrl;
+  o->state_rows = m.s_rows;
+  o->i_clip_idx = m.i_clip_idx; o->i_start_frame = m.i_start_frame; o->i_buffer_index = m.i_buffer_index;
+  o->i_nan_count = m.i_nan_count; o->istate_rows = m.i_rows; o->ws_rows = m.w_rows;
+  return TMJX_OK;
+}
+
+int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quaternion, const float *joints,
+                      const float *body_positions, const float *angular_velocity, int n_clips, int n_frames) {
+  if (!m || !position || !quaternion || !joints || !body_positions || !angular_velocity) return fail(TMJX_EINVAL, "null argument");
+  if (n_clips < 1 || n_frames < m->h.traj_length) return fail(TMJX_EINVAL, "clip table needs >= 1 clip and >= traj_length frames");
+  size_t cf = (size_t)n_clips * n_frames;
+  size_t widths[5] = {3, 4, (size_t)(m->h.nq - 7), (size_t)(m->h.nbody - 1) * 3, 3};
+  const float *src[5] = {position, quaternion, joints, body_positions, angular_velocity};
+  for (int i = 0; i < 5; i++) {
+    if (m->clips[i]) { hipFree(m->clips[i]); m->clips[i] = nullptr; }
+    HIP_TRY(hipMalloc((void **)&m->clips[i], cf * widths[i] * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->clips[i], src[i], cf * widths[i] * sizeof(float), hipMemcpyHostToDevice));
+  }
+  m->h.clip_pos = m->clips[0]; m->h.clip_quat = m->clips[1]; m->h.clip_joints = m->clips[2];
+  m->h.clip_bodypos = m->clips[3]; m->h.clip_angvel = m->clips[4];
+  m->h.n_clips = n_clips; m->h.n_frames_clip = n_frames;
+  HIP_TRY(hipMemcpy(m->d, &m->h, sizeof(DModel), hipMemcpyHostToDevice));
+  return TMJX_OK;
+}
+
+static int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(TMJX_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+  return TMJX_OK;
+}
+#define GRID(m, n) dim3(((n) + (m)->block - 1) / (m)->block), dim3((m)->block)
+
+int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip_idx, const int32_t *start_frame,
+               const float *qpos_noise, const float *qvel_noise, float *obs, float *workspace, int n_env, void *stream) {
+  if (!m || !state || !istate || !clip_idx || !start_frame || !qpos_noise || !qvel_noise || !obs || !workspace) return fail(TMJX_EINVAL, "null argument");
+  if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+  if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
+  hipLaunchKernelGGL(k_reset, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, clip_idx, start_frame, qpos_noise,
+                     qvel_noise, obs, workspace, n_env);
+  return check_launch("k_reset");
+}
+
+int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
+              float *truncation, float *metrics, float *workspace, int n_env, void *stream) {
+  if (!m || !state || !istate || !action || !obs || !reward || !done || !truncation || !metrics || !workspace) return fail(TMJX_EINVAL, "null argument");
+  if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+  if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
+  hipLaunchKernelGGL(k_step, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
+                     metrics, workspace, n_env);
+  return check_launch("k_step");
+}
+
+int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substeps, float *workspace, int n_env, void *stream) {
+  if (!m || !state || !workspace) return fail(TMJX_EINVAL, "null argument");
+  if (n_env < 1 || n_substeps < 0) return fail(TMJX_EINVAL, "bad n_env / n_substeps");
+  hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, action, n_substeps, 1, workspace, n_env);
+  return check_launch("k_physics");
+}
+
+int tmjx_forward(tmjx_model *m, float *state, float *workspace, int n_env, void *stream) {
+  if (!m || !state || !workspace) return fail(TMJX_EINVAL, "null argument");
+  if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+  hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, (const float *)nullptr, 1, 0, workspace, n_env);
+  return check_launch("k_forward");
+}
+
+int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
+                    float *truncation, float *metrics, int n_env, void *stream) {
+  if (!m || !state || !istate || !action || !obs || !reward || !done || !truncation || !metrics) return fail(TMJX_EINVAL, "null argument");
+  if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+  if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
+  hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
+                     metrics, n_env);
+  return check_launch("k_post");
+}
+
+int tmjx_gae(const float *truncation, const float *termination, const float *rewards, const float *values, const float *bootstrap,
+             float lambda_, float discount, float *vs, float *advantages, int T, int B, void *stream) {
+  if (!truncation || !termination || !rewards || !values || !bootstrap || !vs || !advantages) return fail(TMJX_EINVAL, "null argument");
+  if (T < 1 || B < 1) return fail(TMJX_EINVAL, "T and B must be >= 1");
+  hipLaunchKernelGGL(k_gae, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, truncation, termination, rewards, values,
+                     bootstrap, lambda_, discount, vs, advantages, T, B);
+  return check_launch("k_gae");
+}
+
+int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {
+  if (!m || !name || !row0 || !count) return fail(TMJX_EINVAL, "null argument");
+  for (const auto &e : tmjx_host::debug_rows(m->h))
+    if (!strcmp(e.name, name)) { *row0 = e.row0; *count = e.count; return e.in_state ? 1 : 0; }
+  return fail(TMJX_EINVAL, std::string("unknown debug array: ") + name);
+}
+
+}  // extern "C"

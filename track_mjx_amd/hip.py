@@ -1,0 +1,86 @@
+"""ctypes binding of libtmjx_hip.so (the C-ABI declared in include/tmjx.h).
+
+The HIP library is the product: there is no CPU fallback.  Importing this module never fails
+(so host-only tooling keeps working), but `lib()` raises if the shared object is missing or does
+not load, and every entry point raises `TmjxError` on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+SO_PATH = _PKG / "libtmjx_hip.so"
+CSRC = _PKG / "csrc"
+
+
+class TmjxError(RuntimeError):
+    pass
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nq", "nv", "nu", "nbody", "ncon", "nefc", "obs_size", "ref_obs_size", "n_metrics", "window",
+        "qpos", "qvel", "act", "qacc_warmstart", "time", "xpos", "xmat_torso", "qfrc_actuator",
+        "prev_ctrl", "action_buffer", "done", "steps_f", "first_phys", "first_obs", "first_prev_ctrl", "state_rows",
+        "i_clip_idx", "i_start_frame", "i_buffer_index", "i_nan_count", "istate_rows", "ws_rows")]
+
+
+EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
+           "tmjx_physics", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_debug_rows", "tmjx_last_error",
+           "tmjx_version")
+
+_lib = None
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", str(SO_PATH), str(CSRC / "tmjx_hip.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise TmjxError("hipcc failed:\n" + res.stderr[-4000:])
+    if verbose:
+        print(" ".join(cmd))
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not SO_PATH.exists():
+        raise TmjxError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+    try:
+        L = C.CDLL(str(SO_PATH))
+    except OSError as e:  # e.g. no ROCm runtime on this machine
+        raise TmjxError(f"cannot load {SO_PATH}: {e}") from e
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
+    L.tmjx_model_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.tmjx_model_destroy.argtypes = [vp]
+    L.tmjx_model_destroy.restype = None
+    L.tmjx_layout.argtypes = [vp, C.POINTER(Layout)]
+    L.tmjx_clips_upload.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
+    L.tmjx_reset.argtypes = [vp, fp, vp, vp, vp, fp, fp, fp, fp, C.c_int, vp]
+    L.tmjx_step.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
+    L.tmjx_physics.argtypes = [vp, fp, fp, C.c_int, fp, C.c_int, vp]
+    L.tmjx_forward.argtypes = [vp, fp, fp, C.c_int, vp]
+    L.tmjx_reward_obs.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
+    L.tmjx_gae.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, vp]
+    L.tmjx_debug_rows.argtypes = [vp, C.c_char_p, ip, ip]
+    L.tmjx_last_error.restype = C.c_char_p
+    L.tmjx_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise TmjxError(f"{what} failed ({rc}): {lib().tmjx_last_error().decode()}")
+
+
+def block_override() -> str | None:
+    return os.environ.get("TMJX_BLOCK")

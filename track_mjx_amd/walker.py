@@ -54,12 +54,12 @@ class Rodent:
 def build_blob(walker: Rodent, *, n_frames: int, iterations: int, ls_iterations: int, timestep: float,
                mocap_hz: int, clip_length: int, traj_length: int, window: int, episode_length: int,
                reward_f: np.ndarray, tolerance: float = 1e-8, ls_tolerance: float = 0.01,
-               impratio: float = 1.0) -> bytes:
+               impratio: float = 1.0, auto_reset: bool = True) -> bytes:
     """Model constants + env/task configuration -> the blob `tmjx_model_create` consumes."""
     e = OrderedDict(walker.model)
     e["opt_f"] = np.array([timestep, tolerance, ls_tolerance, impratio], dtype=np.float64)
     e["opt_i"] = np.array([iterations, ls_iterations, n_frames], dtype=np.int32)
-    e["env_i"] = np.array([mocap_hz, clip_length, traj_length, window, walker.torso_idx, episode_length], dtype=np.int32)
+    e["env_i"] = np.array([mocap_hz, clip_length, traj_length, window, walker.torso_idx, episode_length, int(auto_reset)], dtype=np.int32)
     e["joint_idxs"] = walker.joint_idxs
     e["body_idxs"] = walker.body_idxs
     e["endeff_idxs"] = walker.endeff_idxs
