@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the rodent tracking hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): rodent tracking, 4096 envs per GPU, PPO with 2x256 encoder/decoder/critic MLPs,
+fp32, synthetic reference clips.  One "step" = one PPO training step as the reference defines it
+(track_mjx/agent/mlp_ppo/ppo.py:320-395): batch_size*num_minibatches/num_envs = 4 unrolls of unroll_length = 20
+env steps on every env (each = 10 physics substeps + reward/obs), the normaliser update, and
+num_updates_per_batch*num_minibatches = 64 minibatch SGD updates with the gradient all-reduce.
+value = env steps collected by all ranks / wall time (the reference's own `training/sps`, ppo.py:427-431).
+Weak scaling: 4096 envs and 1024 minibatch rows per GPU; global batch_size = 1024*N.
+
+Usage: python bench.py [--gpus N --steps K --warmup W]   (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ALGO_BYTES_PER_ENV_STEP = 15644        # SURVEY.md §8 d4 / BASELINE.md §2: 3911 four-byte words per env step (K2+K3)
+HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md)
+ENVS_PER_GPU = 4096
+
+
+def cpu_baseline(blob, clip, seconds_budget: float = 15.0):
+    """The oracle (CPU restatement, kind "port") stepping the same kind of workload on the host cores."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    cores = os.cpu_count() or 1
+    O = Oracle(blob, "f32")
+    O.set_clips(clip.as_dict())
+    n = max(cores * 4, 16)
+    envs = O.new_envs(n)
+    rng = np.random.default_rng(0)
+    for e in range(n):
+        O.env_reset(envs, e, e % clip.position.shape[0], e % 44, rng.uniform(-1e-3, 1e-3, 74), rng.uniform(-1e-3, 1e-3, 73))
+    acts = np.clip(rng.normal(size=(n, 38)), -1, 1)
+    O.env_step_batch(envs, n, acts, cores)  # warm up threads
+    t0, steps = time.time(), 0
+    while time.time() - t0 < seconds_budget:
+        O.env_step_batch(envs, n, acts, cores)
+        steps += n
+    dt = time.time() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {steps // n} control steps (10 substeps each), OpenMP over envs, oracle/liboracle_f32.so"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from track_mjx_amd import config as _config
+    from track_mjx_amd.agent import ppo
+    from track_mjx_amd.environment import wrap
+    from track_mjx_amd.train import build_env
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = _config.default_config()
+    cfg["network_config"].update(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256])
+    tc = cfg["train_setup"]["train_config"]
+    n_local = args.envs_per_gpu
+    env = build_env(cfg, n_local, device, n_clips=64)
+    env = wrap(env, episode_length=195)
+    nc = cfg["network_config"]
+    learner = ppo.PPOLearner(env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"],
+                             critic_layers=nc["critic_layer_sizes"], latents=nc["intention_size"], learning_rate=tc["learning_rate"],
+                             entropy_cost=tc["entropy_cost"], discounting=tc["discounting"], unroll_length=tc["unroll_length"],
+                             batch_size=tc["batch_size"] * world * n_local // ENVS_PER_GPU, num_minibatches=tc["num_minibatches"],
+                             num_updates_per_batch=tc["num_updates_per_batch"], normalize_observations=True, kl_weight=nc["kl_weight"],
+                             seed=0)
+    # deterministic synthetic reset inputs: clip = env % 64, start_frame = env % 44
+    g = torch.Generator().manual_seed(1 + rank)
+    idx = torch.arange(n_local, dtype=torch.int32) + rank * n_local
+    learner.state = env.reset(g, (idx % 64).to(torch.int32), start_frame=(idx % 44).to(torch.int32))
+
+    # HIP-event timing of the dominant kernel (the fused physics+reward/obs launch) on the launch stream
+    ev = []
+    orig_step = env.step
+
+    def timed_step(state, action):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(device))
+        out = orig_step(state, action)
+        b.record(torch.cuda.current_stream(device))
+        ev.append((a, b))
+        return out
+
+    for _ in range(args.warmup):
+        learner.training_step(1)
+    env.step = timed_step
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        learner.training_step(1)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    env_steps = learner.env_steps_per_training_step * args.steps
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+
+    if rank == 0:
+        achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node), rodent task @ 4096 envs/GPU", "value": env_steps / elapsed,
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rodent tracking PPO training step: 4096 envs/GPU, 4x20-step unrolls (10 physics substeps each) + 64 minibatch updates, 2x256 intention policy + critic, fp32",
+                       "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
+                       "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}",
+                       "policy_params": learner.n_params(), "physics_kernel_ms": kernel_ms,
+                       "rollout_env_steps_per_s_per_gpu": n_local / (kernel_ms * 1e-3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_step (physics substeps + reward/obs, one launch per control step)",
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local, "avg_launch_ms": kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(env._blob, env._reference_clips)
+            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,9 +158,10 @@ def test_reward_obs_alone_random_states():
     env, O, cl = make_env_and_oracle(num_envs=n, wrappers=True)
     rng = np.random.default_rng(7)
     g = torch.Generator().manual_seed(7)
-    st = env.reset(g)
+    clip_t = torch.randint(0, 4, (n,), generator=g, dtype=torch.int32); start_t = torch.randint(0, 44, (n,), generator=g, dtype=torch.int32)
+    st = env.reset(g, clip_t, start_frame=start_t, qpos_noise=torch.zeros((74, n)), qvel_noise=torch.zeros((73, n)))
     envs = O.new_envs(n)
-    clip = env.istate_buf[0].cpu().numpy(); start = env.istate_buf[1].cpu().numpy()
+    clip = clip_t.numpy(); start = start_t.numpy()
     L = env.layout
     vals = {"qpos": rng.normal(size=(74, n)) * 0.3, "qvel": rng.normal(size=(73, n)), "xpos": rng.normal(size=(204, n)) * 0.1,
             "qfrc_actuator": rng.normal(size=(73, n)), "time": rng.integers(0, 190, size=(1, n)) * np.float32(0.02)}

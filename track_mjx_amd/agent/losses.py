@@ -1,0 +1,85 @@
+"""PPO loss of the tracking learner.
+
+Mirrors track_mjx/agent/mlp_ppo/losses.py:
+  compute_gae          :39-100   -> HIP kernel `tmjx_gae` (include/tmjx.h), called under no_grad
+  compute_ppo_loss     :103-245  clipped surrogate, value loss * 0.5 * 0.5, entropy bonus, AR(1)-prior latent KL
+  create_ramp_schedule :248-290  linear KL-weight ramp (indexed by epoch)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import hip as _hip
+from .networks import NormalTanh
+
+
+def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambda_: float = 1.0, discount: float = 0.99):
+    """[T,B] fp32 device tensors -> (vs, advantages), both [T,B] (losses.py:39-100). Runs the HIP scan kernel."""
+    T, B = rewards.shape
+    args = [x.detach().contiguous().float() for x in (truncation, termination, rewards, values, bootstrap_value)]
+    if not args[0].is_cuda:
+        raise _hip.TmjxError("compute_gae runs on the GPU only (tmjx_gae); there is no CPU fallback")
+    vs = torch.empty((T, B), dtype=torch.float32, device=rewards.device)
+    adv = torch.empty_like(vs)
+    L = _hip.lib()
+    with torch.cuda.device(rewards.device):
+        stream = C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
+        _hip.check(L.tmjx_gae(*[C.c_void_p(a.data_ptr()) for a in args], float(lambda_), float(discount),
+                              C.c_void_p(vs.data_ptr()), C.c_void_p(adv.data_ptr()), T, B, stream), "tmjx_gae")
+    return vs, adv
+
+
+def create_ramp_schedule(max_value: float = 0.1, min_value: float = 0.0001, ramp_steps: int = 1000, warmup_steps: int = 0):
+    """Linear ramp (losses.py:263-269): clip((step - warmup)/ramp_steps, min_value, 1) * max_value."""
+    def schedule_fn(step: float) -> float:
+        if step < warmup_steps:
+            return min_value
+        progress = min(max((step - warmup_steps) / ramp_steps, min_value), 1.0)
+        return progress * max_value
+    return schedule_fn
+
+
+def compute_ppo_loss(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
+                     discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
+                     clipping_epsilon: float = 0.3, normalize_advantage: bool = True, gae_fn=compute_gae):
+    """data (time-major): observation [T,B,obs], next_observation_last [B,obs], reward/discount/truncation/log_prob [T,B],
+    raw_action [T,B,nu].  Returns (total_loss, metrics) exactly as losses.py:103-245."""
+    obs = normalizer.normalize(data["observation"])
+    logits, latent_mean, latent_logvar = policy(obs)
+    baseline = value(obs)
+    with torch.no_grad():
+        bootstrap_value = value(normalizer.normalize(data["next_observation_last"]))
+    rewards = data["reward"] * reward_scaling
+    truncation = data["truncation"]
+    termination = (1 - data["discount"]) * (1 - truncation)
+    target_log_probs = NormalTanh.log_prob(logits, data["raw_action"])
+    behaviour_log_probs = data["log_prob"]
+    vs, advantages = gae_fn(truncation, termination, rewards, baseline.detach(), bootstrap_value, gae_lambda, discounting)
+    if normalize_advantage:
+        advantages = (advantages - advantages.mean()) / (advantages.std(unbiased=False) + 1e-8)
+    rho = torch.exp(target_log_probs - behaviour_log_probs)
+    policy_loss = -torch.mean(torch.minimum(rho * advantages, torch.clamp(rho, 1 - clipping_epsilon, 1 + clipping_epsilon) * advantages))
+    v_error = vs - baseline
+    v_loss = torch.mean(v_error * v_error) * 0.5 * 0.5
+    entropy = torch.mean(NormalTanh.entropy(logits))
+    entropy_loss = entropy_cost * -entropy
+    # latent KL: t = 0 against N(0, I); t >= 1 against the AR(1) prior N(0.95 mu_{t-1}, (1 - 0.95^2) I)
+    alpha = 0.95
+    prior_variance = 1 - alpha ** 2
+    kl_0 = -0.5 * torch.mean(1 + latent_logvar[0] - latent_mean[0] ** 2 - torch.exp(latent_logvar[0]))
+    T = latent_mean.shape[0]
+    if T > 1:
+        z_prev, mu_curr, logvar_curr = latent_mean[:-1], latent_mean[1:], latent_logvar[1:]
+        var_ratio = torch.exp(logvar_curr) / prior_variance
+        mean_diff_sq = (alpha * z_prev - mu_curr) ** 2 / prior_variance
+        log_var_ratio = torch.log(torch.tensor(prior_variance, device=obs.device)) - logvar_curr
+        kl_t = 0.5 * torch.mean(var_ratio + mean_diff_sq - 1 + log_var_ratio)
+        kl_latent_loss = kl_weight * ((kl_0 + kl_t * (T - 1)) / T)
+    else:
+        kl_latent_loss = kl_weight * kl_0
+    total = policy_loss + v_loss + entropy_loss + kl_latent_loss
+    return total, {"total_loss": total.detach(), "policy_loss": policy_loss.detach(), "v_loss": v_loss.detach(),
+                   "kl_latent_loss": kl_latent_loss.detach(), "entropy_loss": entropy_loss.detach(),
+                   "kl_weight": torch.as_tensor(kl_weight)}

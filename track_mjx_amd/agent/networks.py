@@ -1,0 +1,185 @@
+"""Actor / critic networks of the PPO learner.
+
+Mirrors (paths relative to /root/reference/track_mjx/agent/mlp_ppo):
+  intention_network.py:14-142   Encoder / Decoder / reparameterize / IntentionNetwork
+                                (Dense -> SiLU -> LayerNorm per hidden layer: the LayerNorm comes AFTER the
+                                activation; fc2_mean / fc2_logvar heads; decoder's last Dense is un-activated)
+  ppo_networks.py:34-100,157-190  make_inference_fn policy (sample / log_prob / postprocess) and
+                                make_intention_ppo_networks (value net = brax make_value_network: swish MLP -> 1)
+  brax.training.distribution.NormalTanhDistribution (third-party, restated from its published definition):
+                                loc, raw = split(logits); scale = softplus(raw) + 0.001; tanh bijector
+The dense contractions go to the matrix cores through rocBLAS/hipBLASLt (plain library GEMMs); everything is fp32
+as in the reference unless `matmul_dtype=torch.bfloat16` is requested (BASELINE config 5).
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _lecun_uniform_(w: torch.Tensor) -> None:
+    fan_in = w.shape[1]
+    lim = math.sqrt(3.0 / fan_in)
+    with torch.no_grad():
+        w.uniform_(-lim, lim)
+
+
+def _lecun_normal_(w: torch.Tensor) -> None:
+    fan_in = w.shape[1]
+    std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+    with torch.no_grad():
+        nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std)
+
+
+def _dense(i: int, o: int, init=_lecun_uniform_) -> nn.Linear:
+    lin = nn.Linear(i, o)
+    init(lin.weight)
+    nn.init.zeros_(lin.bias)
+    return lin
+
+
+class _Block(nn.Module):
+    """Dense -> SiLU -> LayerNorm (flax LayerNorm defaults: eps 1e-6, scale + bias)."""
+
+    def __init__(self, i: int, o: int):
+        super().__init__()
+        self.dense = _dense(i, o)
+        self.norm = nn.LayerNorm(o, eps=1e-6)
+
+    def forward(self, x):
+        return self.norm(F.silu(self.dense(x)))
+
+
+class IntentionPolicy(nn.Module):
+    """Encoder-decoder "intention" policy (intention_network.py:90-142)."""
+
+    def __init__(self, obs_size: int, reference_obs_size: int, action_size: int, latents: int = 60,
+                 encoder_layers: Sequence[int] = (1024, 1024), decoder_layers: Sequence[int] = (1024, 1024)):
+        super().__init__()
+        self.reference_obs_size, self.latents, self.action_size = reference_obs_size, latents, action_size
+        enc, d = [], reference_obs_size
+        for h in encoder_layers:
+            enc.append(_Block(d, h)); d = h
+        self.encoder = nn.Sequential(*enc)
+        self.fc2_mean = _dense(d, latents, _lecun_normal_)
+        self.fc2_logvar = _dense(d, latents, _lecun_normal_)
+        dec, d = [], latents + (obs_size - reference_obs_size)
+        for h in decoder_layers:
+            dec.append(_Block(d, h)); d = h
+        self.decoder = nn.Sequential(*dec)
+        self.head = _dense(d, 2 * action_size)
+
+    def forward(self, obs: torch.Tensor, eps: torch.Tensor | None = None, deterministic: bool = False):
+        """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar)."""
+        traj = obs[..., :self.reference_obs_size]
+        h = self.encoder(traj)
+        mean, logvar = self.fc2_mean(h), self.fc2_logvar(h)
+        if deterministic:
+            z = mean
+        else:
+            if eps is None:
+                eps = torch.randn_like(mean)
+            z = mean + eps * torch.exp(0.5 * logvar)
+        x = torch.cat([z, obs[..., self.reference_obs_size:]], dim=-1)
+        return self.head(self.decoder(x)), mean, logvar
+
+
+class ValueNet(nn.Module):
+    """brax make_value_network: MLP(hidden..., 1), swish activations, lecun_uniform, output squeezed."""
+
+    def __init__(self, obs_size: int, hidden: Sequence[int] = (1024, 1024)):
+        super().__init__()
+        layers, d = [], obs_size
+        for h in hidden:
+            layers += [_dense(d, h), nn.SiLU()]; d = h
+        layers.append(_dense(d, 1))
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, obs):
+        return self.net(obs).squeeze(-1)
+
+
+class NormalTanh:
+    """NormalTanhDistribution over `logits = [loc, raw_scale]` (min_std 0.001)."""
+    MIN_STD = 0.001
+    LOG2 = math.log(2.0)
+
+    @staticmethod
+    def params(logits):
+        loc, raw = torch.chunk(logits, 2, dim=-1)
+        return loc, F.softplus(raw) + NormalTanh.MIN_STD
+
+    @staticmethod
+    def sample_no_postprocessing(logits, noise=None):
+        loc, scale = NormalTanh.params(logits)
+        if noise is None:
+            noise = torch.randn_like(loc)
+        return loc + scale * noise
+
+    @staticmethod
+    def _fldj(x):  # log |d tanh(x)/dx|
+        return 2.0 * (NormalTanh.LOG2 - x - F.softplus(-2.0 * x))
+
+    @staticmethod
+    def log_prob(logits, raw_action):
+        loc, scale = NormalTanh.params(logits)
+        lp = -0.5 * ((raw_action - loc) / scale) ** 2 - torch.log(scale) - 0.5 * math.log(2 * math.pi)
+        return (lp - NormalTanh._fldj(raw_action)).sum(-1)
+
+    @staticmethod
+    def entropy(logits, noise=None):
+        loc, scale = NormalTanh.params(logits)
+        ent = 0.5 + 0.5 * math.log(2 * math.pi) + torch.log(scale)
+        x = NormalTanh.sample_no_postprocessing(logits, noise)
+        return (ent + NormalTanh._fldj(x)).sum(-1)
+
+    @staticmethod
+    def postprocess(raw_action):
+        return torch.tanh(raw_action)
+
+    @staticmethod
+    def mode(logits):
+        return torch.tanh(torch.chunk(logits, 2, dim=-1)[0])
+
+
+class RunningStatistics:
+    """Batched Welford observation normaliser (reference math: agent/masked_running_statistics.py:95-236;
+    the learner calls brax's copy of the same code at mlp_ppo/ppo.py:357-361,503-505).
+    With `group` set, count / mean_update / variance_update are summed across ranks (the reference's three psums)."""
+
+    def __init__(self, size: int, device, std_min: float = 1e-6, std_max: float = 1e6):
+        self.count = torch.zeros((), dtype=torch.float32, device=device)
+        self.mean = torch.zeros(size, dtype=torch.float32, device=device)
+        self.summed_variance = torch.zeros(size, dtype=torch.float32, device=device)
+        self.std = torch.ones(size, dtype=torch.float32, device=device)
+        self.std_min, self.std_max = std_min, std_max
+
+    @torch.no_grad()
+    def update(self, batch: torch.Tensor, group=None) -> None:
+        import torch.distributed as dist
+        flat = batch.reshape(-1, batch.shape[-1])
+        inc = torch.tensor(float(flat.shape[0]), device=flat.device)
+        if group is not None:
+            dist.all_reduce(inc, group=group)
+        count = self.count + inc
+        diff_old = flat - self.mean
+        mean_update = diff_old.sum(0) / count
+        if group is not None:
+            dist.all_reduce(mean_update, group=group)
+        mean = self.mean + mean_update
+        var_update = (diff_old * (flat - mean)).sum(0)
+        if group is not None:
+            dist.all_reduce(var_update, group=group)
+        self.summed_variance = self.summed_variance + var_update
+        self.mean, self.count = mean, count
+        self.std = torch.sqrt(torch.clamp(self.summed_variance, min=0) / count).clamp(self.std_min, self.std_max)
+
+    def normalize(self, x: torch.Tensor) -> torch.Tensor:
+        return (x - self.mean) / self.std
+
+    def state_dict(self):
+        return {"count": self.count, "mean": self.mean, "summed_variance": self.summed_variance, "std": self.std}

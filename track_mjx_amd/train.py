@@ -1,0 +1,76 @@
+"""`python -m track_mjx_amd.train key=value ...` — mirror of the reference entrypoint
+(`python -m track_mjx.train`, track_mjx/train.py:56-363): builds walker, reward config, clips, env and the
+network sizes from the config and calls ppo.train.  hydra/wandb/orbax/rendering are out of scope;
+the derived quantities follow train.py:221-225 (episode_length) and :298-301 (num_evals, num_resets_per_eval).
+
+Multi-GPU: launch one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m track_mjx_amd.train`);
+`train_config.num_envs` is the GLOBAL env count as in the reference and is sharded across ranks.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+from . import clips as _clips
+from . import config as _config
+from .agent import ppo
+from .environment import MultiClipTracking, RewardConfig
+from .walker import Rodent
+
+
+def build_env(cfg: dict, num_envs_local: int, device, n_clips: int = 64, clip_seed: int = 0):
+    walker = Rodent(**cfg["walker_config"])
+    reward_config = RewardConfig(**cfg["env_config"]["reward_weights"])
+    if cfg.get("data_path", "synthetic") != "synthetic":
+        raise NotImplementedError("HDF5 clip loading is a 'next' item (SURVEY.md §8 f2); use data_path=synthetic")
+    reference_clip = _clips.make_synthetic_clips(walker.model, n_clips, n_frames=cfg["reference_config"]["clip_length"], seed=clip_seed,
+                                                 mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"])
+    env = MultiClipTracking(reference_clip, walker, reward_config, **cfg["env_config"]["env_args"], **cfg["reference_config"],
+                            num_envs=num_envs_local, device=device)
+    return env
+
+
+def main(argv=None) -> None:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cfg_path = None
+    if argv and argv[0].endswith((".yaml", ".yml")):
+        cfg_path = argv.pop(0)
+    cfg = _config.load_config(cfg_path, argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    tc = cfg["train_setup"]["train_config"]
+    lo, hi = ppo.shard_range(int(tc["num_envs"]), int(os.environ.get("RANK", "0")), world)
+    env = build_env(cfg, hi - lo, device, n_clips=int(cfg.get("n_synthetic_clips", 64)))
+    rc, ts = cfg["reference_config"], cfg["train_setup"]
+    # train.py:221-225
+    episode_length = (rc["clip_length"] - rc["random_init_range"] - rc["traj_length"]) * env._steps_for_cur_frame
+    nc = cfg["network_config"]
+    num_evals = int(tc["num_timesteps"] / ts["eval_every"])
+    num_resets_per_eval = ts["eval_every"] // ts["reset_every"]
+
+    def progress(num_steps, metrics):
+        print(f"[train] steps={num_steps} " + " ".join(f"{k}={v:.4g}" for k, v in sorted(metrics.items())), flush=True)
+
+    ppo.train(env, num_timesteps=tc["num_timesteps"], episode_length=int(episode_length), num_evals=num_evals,
+              num_resets_per_eval=num_resets_per_eval, learning_rate=tc["learning_rate"], entropy_cost=tc["entropy_cost"],
+              discounting=tc["discounting"], seed=tc["seed"], unroll_length=tc["unroll_length"], batch_size=tc["batch_size"],
+              num_minibatches=tc["num_minibatches"], num_updates_per_batch=tc["num_updates_per_batch"],
+              normalize_observations=tc["normalize_observations"], reward_scaling=tc["reward_scaling"],
+              clipping_epsilon=tc["clipping_epsilon"], kl_weight=nc["kl_weight"], use_kl_schedule=nc["kl_schedule"],
+              encoder_hidden_layer_sizes=nc["encoder_layer_sizes"], decoder_hidden_layer_sizes=nc["decoder_layer_sizes"],
+              value_hidden_layer_sizes=nc["critic_layer_sizes"], intention_latent_size=nc["intention_size"], progress_fn=progress,
+              max_training_steps=cfg.get("max_training_steps"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
