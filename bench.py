@@ -32,7 +32,13 @@ def cpu_baseline(blob, clip, seconds_budget: float = 15.0):
     """The oracle (CPU restatement, kind "port") stepping the same kind of workload on the host cores."""
     import numpy as np
     from oracle.oracle import Oracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a cgroup CPU quota (containers) bounds the usable cores below the affinity mask
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except Exception:
+        pass
     O = Oracle(blob, "f32")
     O.set_clips(clip.as_dict())
     n = max(cores * 4, 16)

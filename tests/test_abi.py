@@ -1,0 +1,42 @@
+"""CPU: the C-ABI shared library exists in-tree, loads, and exports every symbol include/tmjx.h declares."""
+import ctypes
+import re
+import subprocess
+from pathlib import Path
+
+from track_mjx_amd import hip
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared():
+    text = (ROOT / "include" / "tmjx.h").read_text()
+    return sorted(set(re.findall(r"\b(tmjx_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    if not hip.SO_PATH.exists():
+        hip.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", str(hip.SO_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (tmjx_[a-z_]+)", out))
+    declared = _declared()
+    assert len(declared) >= 12
+    assert not [s for s in declared if s not in exported], exported
+    assert set(hip.EXPORTS) <= exported
+
+
+def test_library_loads_and_reports_errors_without_gpu():
+    L = hip.lib()
+    assert b"gfx950" in L.tmjx_version()
+    h = ctypes.c_void_p()
+    assert L.tmjx_model_create(None, 0, ctypes.byref(h)) == -22       # TMJX_EINVAL, no compute call
+    assert L.tmjx_last_error()
+
+
+def test_no_product_import_of_oracle_or_emulation():
+    """The product package must not reach into oracle/ or the host emulation (no CPU fallback)."""
+    pat = re.compile(r"^\s*(from|import)\s+[\w.]*\b(oracle|hostemu|emu)\b", re.M)
+    for p in (ROOT / "track_mjx_amd").rglob("*.py"):
+        src = p.read_text()
+        assert not pat.search(src), p
+        assert "liboracle" not in src and "libhostemu" not in src, p

@@ -1,0 +1,123 @@
+"""CPU: the HIP kernel bodies (csrc/physics_core.h, csrc/env_core.h) compiled for the host by the TEST-ONLY emulation
+harness tests/hostemu/ and compared with the oracle.  This is how the kernel source is unit-tested in the GPU-less build
+container; the same checks run on the real GPU in test_gpu_parity.py.  Nothing in the product loads the emulation."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, str(Path(__file__).parent / "hostemu"))
+from emu import Emu  # noqa: E402
+
+from tests.common import default_blob, default_walker, make_oracle, rel_err  # noqa: E402
+from track_mjx_amd import clips as _clips  # noqa: E402
+
+G = np.load(Path(__file__).parent / "golden" / "task_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    w, cfg = default_walker()
+    blob = default_blob(w, cfg)
+    clip = _clips.make_synthetic_clips(w.model, 4, seed=0)
+    return w, blob, clip
+
+
+def _states(clip, n, rng, sink):
+    qpos = np.zeros((n, 74)); qvel = rng.uniform(-1e-3, 1e-3, size=(n, 73))
+    for e in range(n):
+        c, f = e % 4, (7 * e) % 44
+        qpos[e] = np.concatenate([clip.position[c, f], clip.quaternion[c, f], clip.joints[c, f]]) + rng.uniform(-1e-3, 1e-3, 74)
+        qpos[e, 2] -= sink * (e % 5)
+    return qpos, qvel
+
+
+def test_forward_intermediates_sparse_vs_dense(setup):
+    w, blob, clip = setup
+    n = 8
+    E = Emu(blob, n); O64 = make_oracle(blob, clip, "f64")
+    rng = np.random.default_rng(0)
+    qpos, qvel = _states(clip, n, rng, 0.012)
+    act = rng.uniform(-0.1, 0.1, size=(n, 38))
+    E.rows("qpos")[:] = qpos.T; E.rows("qvel")[:] = qvel.T; E.rows("act")[:] = act.T
+    E.physics(None, 1, do_euler=False)
+    ds = []
+    for e in range(n):
+        d = O64.new_data(qpos[e], qvel[e]); O64.set(d, "act", act[e]); O64.forward(d); ds.append(d)
+    for name, tol in (("xpos", 2e-6), ("cinert", 2e-6), ("cdof", 5e-6), ("qfrc_smooth", 2e-5), ("con_dist", 5e-6), ("con_frame", 5e-6),
+                      ("efc_D", 5e-5), ("efc_aref", 2e-5), ("qacc_smooth", 2e-4), ("qacc", 2e-4), ("efc_force", 2e-4)):
+        ref = np.stack([O64.get(d, name) for d in ds], 1)
+        assert rel_err(E.rows(name), ref) < tol, (name, rel_err(E.rows(name), ref))
+    assert (E.rows("con_dist") < 0).sum() > 0
+    assert np.array_equal(E.rows("con_dist") < 0, np.stack([O64.get(d, "con_dist") < 0 for d in ds], 1))
+
+
+def test_substeps_teacher_forced(setup):
+    w, blob, clip = setup
+    n = 8
+    E = Emu(blob, n); O32 = make_oracle(blob, clip, "f32"); O64 = make_oracle(blob, clip, "f64")
+    rng = np.random.default_rng(1)
+    qpos, qvel = _states(clip, n, rng, 0.001)
+    d32 = [O32.new_data(qpos[e], qvel[e]) for e in range(n)]; d64 = [O64.new_data(qpos[e], qvel[e]) for e in range(n)]
+    names = ("qpos", "qvel", "act", "qacc_warmstart", "time")
+    for sub in range(30):
+        a = np.clip(rng.normal(size=(n, 38)) * 0.03, -1, 1)
+        st = {k: np.stack([O64.get(d, k) for d in d64], 1) for k in names}
+        for k, v in st.items():
+            E.rows(k)[:] = v
+            for e in range(n):
+                O32.set(d32[e], k, v[:, e])
+        E.physics(a.T.astype(np.float32).copy(), 1, True)
+        for e in range(n):
+            O32.step(d32[e], a[e]); O64.step(d64[e], a[e])
+        for k in ("qpos", "qvel"):
+            ref = np.stack([O64.get(d, k) for d in d64], 1); r32 = np.stack([O32.get(d, k) for d in d32], 1)
+            e_emu, e_32 = rel_err(E.rows(k), ref, axis=0), rel_err(r32, ref, axis=0)
+            assert np.median(e_emu) <= 1e-5, (sub, k, e_emu)
+            assert e_emu.max() <= 4 * e_32.max() + 2e-5, (sub, k, e_emu.max(), e_32.max())
+    assert sum((O64.get(d, "con_dist") < 0).sum() for d in d64) > 0
+
+
+def test_env_step_and_golden_post(setup):
+    w, blob, clip = setup
+    n = 4
+    E = Emu(blob, n); O = make_oracle(blob, clip, "f32")
+    E.set_clips(clip.as_dict())
+    rng = np.random.default_rng(3)
+    ci = (np.arange(n) % 4).astype(np.int32); sf = ((np.arange(n) * 11) % 44).astype(np.int32)
+    qn = rng.uniform(-1e-3, 1e-3, (74, n)).astype(np.float32); vn = rng.uniform(-1e-3, 1e-3, (73, n)).astype(np.float32)
+    E.reset(ci, sf, qn, vn)
+    envs = O.new_envs(n)
+    for e in range(n):
+        O.env_reset(envs, e, ci[e], sf[e], qn[:, e], vn[:, e])
+    assert np.abs(E.obs - np.stack([O.env_get(envs, e, "obs") for e in range(n)], 1)).max() < 1e-6
+    for s in range(2):
+        a = np.clip(rng.normal(size=(38, n)) * 0.03, -1, 1).astype(np.float32)
+        E.step(a)
+        for e in range(n):
+            O.env_step(envs, e, a[:, e])
+        assert rel_err(E.obs, np.stack([O.env_get(envs, e, "obs") for e in range(n)], 1)) < 1e-4
+        assert np.abs(E.reward - np.array([O.env_get(envs, e, "reward")[0] for e in range(n)])).max() < 1e-5
+    # K3 alone on the golden cases (clips of the golden file: seed 123, 3 clips)
+    gclip = _clips.make_synthetic_clips(w.model, 3, seed=123)
+    m = G["in_qpos"].shape[0]
+    E2 = Emu(blob, m); E2.set_clips(gclip.as_dict())
+    z = np.zeros((74, m), np.float32)
+    E2.reset(G["in_clip_idx"].astype(np.int32), G["in_start_frame"].astype(np.int32), z, z[:73])
+    first_obs = E2.obs.copy()
+    for k in ("qpos", "qvel", "xpos", "xmat_torso", "qfrc_actuator"):
+        E2.rows(k)[:] = G["in_" + k].T
+    E2.rows("time")[:] = G["in_time"][None]
+    lay_buf = E2.st  # action buffer rows follow prev_ctrl: locate through a write/read of the kernel itself
+    E2.ist[2] = G["in_buffer_index"]
+    # action_buffer offset = rows("qfrc_actuator") end + nu (layout: ..., qfrc_actuator, prev_ctrl, action_buffer)
+    off = 259 + 204 + 9 + 73 + 38
+    E2.st[off:off + 1900] = G["in_action_buffer"].T
+    E2.post(G["in_action"].T.astype(np.float32).copy())
+    np.testing.assert_allclose(E2.metrics.T, G["out_metrics"], rtol=3e-5, atol=3e-6)
+    np.testing.assert_allclose(E2.reward, G["out_reward"], rtol=3e-5, atol=3e-6)
+    assert np.array_equal(E2.done, G["out_done"]) and np.array_equal(E2.ist[2], G["out_buffer_index"])
+    keep = G["out_done"] == 0
+    np.testing.assert_allclose(E2.obs.T[keep], G["out_obs"][keep], rtol=3e-5, atol=3e-6)
+    assert np.array_equal(E2.obs.T[~keep], first_obs.T[~keep])   # auto-reset returns the snapshot bit-exactly

@@ -1,0 +1,92 @@
+"""CPU: learner-side maths against independent formulations (the reference's own modules are not importable here)."""
+import math
+
+import numpy as np
+import torch
+
+from track_mjx_amd import config as _config
+from track_mjx_amd.agent import losses
+from track_mjx_amd.agent.networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet
+
+
+def _gae_torch(trunc, term, rew, val, boot, lam, disc):
+    """plain fp32 torch reference of losses.py:39-100 (reverse python loop)"""
+    T = rew.shape[0]
+    tm = 1 - trunc
+    v1 = torch.cat([val[1:], boot[None]], 0)
+    deltas = (rew + disc * (1 - term) * v1 - val) * tm
+    acc = torch.zeros_like(boot); out = []
+    for t in range(T - 1, -1, -1):
+        acc = deltas[t] + disc * (1 - term[t]) * tm[t] * lam * acc
+        out.append(acc)
+    vs = torch.stack(out[::-1]) + val
+    adv = (rew + disc * (1 - term) * torch.cat([vs[1:], boot[None]], 0) - val) * tm
+    return vs, adv
+
+
+def test_normal_tanh_matches_torch_distributions():
+    torch.manual_seed(0)
+    logits = torch.randn(5, 76)
+    raw = torch.randn(5, 38)
+    loc, scale = NormalTanh.params(logits)
+    base = torch.distributions.Normal(loc, scale)
+    td = torch.distributions.TransformedDistribution(base, [torch.distributions.transforms.TanhTransform(cache_size=1)])
+    lp_ref = td.log_prob(torch.tanh(raw).clamp(-1 + 1e-7, 1 - 1e-7)).sum(-1)
+    assert torch.allclose(NormalTanh.log_prob(logits, raw), lp_ref, atol=2e-3)
+    assert (scale > 0.001).all() and torch.allclose(NormalTanh.mode(logits), torch.tanh(loc))
+
+
+def test_running_statistics_two_batches():
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(size=(100, 7)).astype(np.float32) * 3 + 1, rng.normal(size=(50, 7)).astype(np.float32)
+    rs = RunningStatistics(7, "cpu")
+    rs.update(torch.from_numpy(a)); rs.update(torch.from_numpy(b))
+    allx = np.concatenate([a, b])
+    np.testing.assert_allclose(rs.mean.numpy(), allx.mean(0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rs.std.numpy(), allx.std(0), rtol=1e-4)
+    rs2 = RunningStatistics(3, "cpu"); rs2.update(torch.zeros(10, 3))
+    assert (rs2.std == 1e-6).all()                       # std clip floor (masked_running_statistics.py:203-206)
+
+
+def test_network_shapes_and_parameter_counts():
+    cfg = _config.default_config()["network_config"]
+    pol = IntentionPolicy(696, 470, 38, 60, [256, 256], [256, 256]); val = ValueNet(696, [256, 256])
+    n = sum(p.numel() for p in pol.parameters()) + sum(p.numel() for p in val.parameters())
+    assert n == 622533                                     # 2x256 nets
+    pol2 = IntentionPolicy(696, 470, 38, 60, cfg["encoder_layer_sizes"], cfg["decoder_layer_sizes"]); val2 = ValueNet(696, cfg["critic_layer_sizes"])
+    assert sum(p.numel() for p in pol2.parameters()) + sum(p.numel() for p in val2.parameters()) == 4294853
+    logits, mu, lv = pol(torch.randn(3, 696))
+    assert logits.shape == (3, 76) and mu.shape == (3, 60) and val(torch.randn(3, 696)).shape == (3,)
+    # LayerNorm comes after the activation (intention_network.py:38-39): the block output is normalised
+    h = pol.encoder[0](torch.randn(4, 470))
+    assert torch.allclose(h.mean(-1), torch.zeros(4), atol=1e-5)
+
+
+def test_ppo_loss_pieces_with_torch_gae():
+    torch.manual_seed(0)
+    T, B = 5, 6
+    pol = IntentionPolicy(30, 20, 4, 8, [16], [16]); val = ValueNet(30, [16]); rs = RunningStatistics(30, "cpu")
+    data = {"observation": torch.randn(T, B, 30), "next_observation_last": torch.randn(B, 30), "reward": torch.randn(T, B),
+            "discount": (torch.rand(T, B) > 0.1).float(), "truncation": (torch.rand(T, B) > 0.9).float(),
+            "raw_action": torch.randn(T, B, 4), "log_prob": torch.randn(T, B) - 4}
+    total, m = losses.compute_ppo_loss(pol, val, rs, data, entropy_cost=1e-2, kl_weight=0.1, discounting=0.98, clipping_epsilon=0.2, gae_fn=_gae_torch)
+    assert torch.isfinite(total)
+    assert abs(float(m["total_loss"]) - float(m["policy_loss"] + m["v_loss"] + m["entropy_loss"] + m["kl_latent_loss"])) < 1e-5
+    total.backward()
+    assert all(p.grad is not None for p in pol.parameters())
+    # KL term by hand for T = 2 (losses.py:200-235)
+    mu = torch.tensor([[[0.5]], [[0.2]]]); lv = torch.tensor([[[0.1]], [[-0.3]]])
+    kl0 = -0.5 * (1 + 0.1 - 0.25 - math.exp(0.1))
+    pv = 1 - 0.95 ** 2
+    klt = 0.5 * (math.exp(-0.3) / pv + (0.95 * 0.5 - 0.2) ** 2 / pv - 1 + math.log(pv) + 0.3)
+    expect = 0.1 * ((kl0 + klt * 1) / 2)
+
+    class P(torch.nn.Module):
+        def forward(self, obs):
+            return torch.zeros(2, 1, 8), mu, lv
+    d2 = {"observation": torch.zeros(2, 1, 30), "next_observation_last": torch.zeros(1, 30), "reward": torch.zeros(2, 1), "discount": torch.ones(2, 1),
+          "truncation": torch.zeros(2, 1), "raw_action": torch.zeros(2, 1, 4), "log_prob": torch.zeros(2, 1)}
+    _, m2 = losses.compute_ppo_loss(P(), val, rs, d2, kl_weight=0.1, gae_fn=_gae_torch)
+    assert abs(float(m2["kl_latent_loss"]) - expect) < 1e-6
+    sch = losses.create_ramp_schedule(max_value=0.1, ramp_steps=37)
+    assert abs(sch(0) - 1e-5) < 1e-12 and abs(sch(18.5) - 0.05) < 1e-9 and sch(100) == 0.1

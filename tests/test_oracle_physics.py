@@ -1,0 +1,120 @@
+"""CPU: physics invariants of the oracle: the reference pins nothing at the mjx boundary, so the
+restatement is checked against analytic properties and against independent formulations."""
+import numpy as np
+import pytest
+
+from tests.common import default_blob, default_walker, make_oracle
+from track_mjx_amd import clips as _clips
+
+
+def _free_model_blob(timestep):
+    w, cfg = default_walker()
+    w.model["dof_damping"][:] = 0; w.model["jnt_stiffness"][:] = 0
+    w.model["jnt_range"] = np.tile([-100.0, 100.0], 68)
+    return default_blob(w, cfg, timestep=timestep), w
+
+
+def _energy(O, d, mass):
+    O.forward(d)
+    M = O.get(d, "qM").reshape(73, 73); v = O.get(d, "qvel"); xi = O.get(d, "xipos").reshape(-1, 3)
+    return 0.5 * v @ M @ v + 9.81 * (mass * xi[:, 2]).sum()
+
+
+def test_energy_drift_is_first_order_in_timestep():
+    drift = []
+    for h in (1e-4, 5e-5):
+        blob, w = _free_model_blob(h)
+        O = make_oracle(blob, None, "f64")
+        rng = np.random.default_rng(0)
+        qpos = w.model["qpos0"].copy(); qpos[2] = 5.0; qpos[7:] = 0.3 * (rng.random(67) - 0.5)
+        qvel = rng.normal(size=73); qvel[:3] *= 0.1
+        d = O.new_data(qpos, qvel)
+        e0 = _energy(O, d, w.model["body_mass"])
+        for _ in range(int(0.1 / h)):
+            O.step(d)
+        drift.append(_energy(O, d, w.model["body_mass"]) - e0)
+    assert abs(drift[0]) < 1e-3 and abs(drift[1] / drift[0] - 0.5) < 0.05   # semi-implicit Euler: error ∝ h
+
+
+def test_free_fall_closed_form_and_momentum():
+    blob, w = _free_model_blob(0.002)
+    O = make_oracle(blob, None, "f64")
+    qpos = w.model["qpos0"].copy(); qpos[2] = 3.0
+    d = O.new_data(qpos, np.zeros(73))
+    n, h = 100, 0.002
+    for _ in range(n):
+        O.step(d)
+    # semi-implicit Euler: v_n = -g h n ; z_n = z0 - g h^2 n(n+1)/2 ; no relative motion
+    assert abs(O.get(d, "qvel")[2] + 9.81 * h * n) < 1e-9
+    assert abs(O.get(d, "qpos")[2] - (3.0 - 9.81 * h * h * n * (n + 1) / 2)) < 1e-9
+    assert np.abs(O.get(d, "qvel")[6:]).max() < 1e-6
+
+
+def test_mass_matrix_spd_and_inverse_dynamics_consistency():
+    w, cfg = default_walker()
+    O = make_oracle(default_blob(w, cfg), None, "f64")
+    rng = np.random.default_rng(1)
+    qpos = w.model["qpos0"].copy(); qpos[2] = 1.0; qpos[7:] = 0.2 * (rng.random(67) - 0.5)
+    q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q)
+    d = O.new_data(qpos, rng.normal(size=73) * 0.3)
+    O.forward(d)
+    M = O.get(d, "qM").reshape(73, 73)
+    assert np.abs(M - M.T).max() == 0 and np.linalg.eigvalsh(M).min() > 0
+    assert abs(np.trace(M) / 73 - 0.0110020) < 2e-3   # meaninertia is M's mean diagonal at qpos0 (pose dependence is small)
+    # unconstrained dynamics: M qacc_smooth = passive - bias + actuator; the CG iterate obeys the same equation up to its
+    # (un-converged, 5 iterations) gradient: M qacc - qfrc_smooth - qfrc_constraint = grad
+    resid = M @ O.get(d, "qacc_smooth") - (O.get(d, "qfrc_passive") - O.get(d, "qfrc_bias") + O.get(d, "qfrc_actuator"))
+    assert np.abs(resid).max() < 1e-9
+    assert abs(w.model["body_mass"].sum() - 0.2639283527) < 1e-9
+
+
+def test_contact_jacobian_matches_finite_differences_and_rest_force():
+    w, cfg = default_walker()
+    O = make_oracle(default_blob(w, cfg, iterations=50), None, "f64")
+    qpos = w.model["qpos0"].copy(); qpos[2] = 0.02
+    d = O.new_data(qpos, np.zeros(73))
+    mg = w.model["body_mass"].sum() * 9.81
+    ratios = []
+    for i in range(600):
+        O.step(d, np.zeros(38))
+        if i >= 300 and i % 50 == 0:
+            ratios.append(O.get(d, "efc_force")[67:].sum() / mg)
+    assert abs(np.mean(ratios) - 1.0) < 0.03     # sum of the pyramid edge forces balances the weight at rest
+    # every slot's geom pair is the static MJX order (bit-exact integer path)
+    assert list(w.model["con_geom2"][:4]) == [13, 13, 14, 14] and int(w.model["con_geom1"].max()) == 0
+    # efc_J rows of active contacts: J qvel equals the finite-difference rate of the contact distance along the normal
+    O.forward(d)
+    J = O.get(d, "efc_J").reshape(-1, 73); dist = O.get(d, "con_dist")
+    act = np.where(dist < 0)[0]
+    assert len(act) > 0
+    c = int(act[0]); rows = J[67 + 4 * c: 67 + 4 * c + 4]
+    normal_row = rows.sum(0) / 4            # (d0+mu d1)+(d0-mu d1)+(d0+mu d2)+(d0-mu d2) = 4 d0
+    rng = np.random.default_rng(0); v = rng.normal(size=73) * 0.1
+    eps = 1e-6
+    q0 = O.get(d, "qpos").copy()
+    d2 = O.new_data(q0, np.zeros(73))
+    # integrate q0 by eps*v (hinges additive; root translation additive; tiny root rotation via quaternion)
+    q1 = q0.copy(); q1[:3] += eps * v[:3]; q1[7:] += eps * v[6:]
+    wq = v[3:6] * eps; dq = np.concatenate([[1.0], 0.5 * wq]); qa = q0[3:7]
+    q1[3:7] = np.array([qa[0]*dq[0]-qa[1]*dq[1]-qa[2]*dq[2]-qa[3]*dq[3], qa[0]*dq[1]+qa[1]*dq[0]+qa[2]*dq[3]-qa[3]*dq[2],
+                        qa[0]*dq[2]-qa[1]*dq[3]+qa[2]*dq[0]+qa[3]*dq[1], qa[0]*dq[3]+qa[1]*dq[2]-qa[2]*dq[1]+qa[3]*dq[0]])
+    d2 = O.new_data(q1, np.zeros(73)); O.forward(d2)
+    fd = (O.get(d2, "con_dist")[c] - dist[c]) / eps
+    assert abs(fd - normal_row @ v) < 2e-3 * max(1.0, abs(fd))
+
+
+def test_f32_oracle_tracks_f64_over_one_control_step():
+    w, cfg = default_walker()
+    blob = default_blob(w, cfg)
+    clip = _clips.make_synthetic_clips(w.model, 2, seed=0)
+    O32, O64 = make_oracle(blob, clip, "f32"), make_oracle(blob, clip, "f64")
+    rng = np.random.default_rng(0)
+    qpos = np.concatenate([clip.position[0, 3], clip.quaternion[0, 3], clip.joints[0, 3]]) + rng.uniform(-1e-3, 1e-3, 74)
+    qvel = rng.uniform(-1e-3, 1e-3, 73)
+    a, b = O32.new_data(qpos, qvel), O64.new_data(qpos, qvel)
+    ctrl = rng.normal(size=38) * 0.03
+    for _ in range(10):
+        O32.step(a, ctrl); O64.step(b, ctrl)
+    assert np.abs(O32.get(a, "qpos") - O64.get(b, "qpos")).max() < 1e-5
+    q = O32.get(a, "qpos")[3:7]
+    assert abs(np.linalg.norm(q) - 1) < 1e-6
