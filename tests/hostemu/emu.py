@@ -80,6 +80,15 @@ class Emu:
         a = None if action is None else np.ascontiguousarray(action, np.float32)
         self.L.emu_physics(self.m, _f(self.st), _f(a) if a is not None else None, nsub, int(do_euler), _f(self.ws), self.n)
 
+    def physics_wave(self, action, nsub, do_euler=True, dump=True):
+        """The wave-per-env kernel body (64 emulated lanes, LDS image per env)."""
+        a = None if action is None else np.ascontiguousarray(action, np.float32)
+        self.L.emu_physics_wave(self.m, _f(self.st), _f(a) if a is not None else None, nsub, int(do_euler),
+                                _f(self.ws) if dump else None, self.n)
+
+    def lds_bytes(self):
+        return 4 * self.L.emu_lds_floats(self.m)
+
     def post(self, action):
         a = np.ascontiguousarray(action, np.float32)
         self.L.emu_post(self.m, _f(self.st), _i(self.ist), _f(a), _f(self.obs), _f(self.reward), _f(self.done),

@@ -14,6 +14,8 @@
 
 #include "../../track_mjx_amd/csrc/env_core.h"
 #include "../../track_mjx_amd/csrc/model_host.h"
+#include "../../track_mjx_amd/csrc/wave_physics.h"
+#include <vector>
 
 struct EmuModel { DModel h; float *clips[5]; };
 static std::string g_err;
@@ -63,6 +65,20 @@ void emu_physics(EmuModel *mm, float *st, const float *action, int nsub, int do_
     for (int f = 0; f < nsub; f++) { tm_forward(m, r); if (do_euler) tm_euler(m, r); }
   }
 }
+// wave-per-env kernel body (csrc/wave_physics.h): one emulated 64-lane wavefront + an LDS image per env
+void emu_physics_wave(EmuModel *mm, float *st, const float *action, int nsub, int do_euler, float *ws_dump, int n) {
+  std::vector<float> lds(mm->h.lds_floats + 64);
+  for (int e = 0; e < n; e++) {
+    for (auto &v : lds) v = 0.f;
+    WCtx c{&mm->h, lds.data(), st, n, e, 0, nullptr, 0ull};
+    const WLayout K = tmjx_host::make_wave_layout(mm->h);
+    float time = tmw_load_state(c, K, action);
+    for (int f = 0; f < nsub; f++) { tmw_forward(c, K, f == nsub - 1); if (do_euler) time = tmw_euler(c, K, time); }
+    if (ws_dump) tmw_dump(c, K, ws_dump);
+    tmw_store_state(c, K, time);
+  }
+}
+int emu_lds_floats(const EmuModel *m) { return m->h.lds_floats; }
 void emu_post(EmuModel *mm, float *st, int *is, const float *action, float *obs, float *rew, float *done, float *trunc, float *metrics, int n) {
   const DModel &m = mm->h;
   for (int e = 0; e < n; e++) { EnvRef r{st, nullptr, n, e}; tm_step_prologue(m, r); tm_step_post(m, r, is, action, obs, rew, done, trunc, metrics); }

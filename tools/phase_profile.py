@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""In-kernel phase profile of the wave-per-env physics kernel (s_memtime stamps; TMW_PROFILE build).
+Run on the GPU box:  TMJX_SO=track_mjx_amd/libtmjx_hip_prof.so python tools/phase_profile.py"""
+import os, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from tests.common import make_env_and_oracle
+
+NAMES = ["position", "velocity+M", "factor", "invert_L", "make_constraint", "solve(qacc_smooth)", "cg init (3 cost evals + grad)",
+         "cg linesearch", "cg update (+euler rhs)", "euler factor", "euler invert_L", "euler solve", "load/store/other"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+env, _, _ = make_env_and_oracle(num_envs=n, n_clips=64, wrappers=True)
+g = torch.Generator().manual_seed(0)
+st = env.reset(g)
+a = (torch.randn((38, n), generator=g) * 0.3).clamp(-1, 1).cuda()
+for _ in range(3):
+    st = env.step(st, a)
+env.workspace.zero_()
+torch.cuda.synchronize()
+env.physics(a, 10)
+torch.cuda.synchronize()
+prof = env.workspace.flatten().view(torch.int64)[: n * 16].view(n, 16).double()
+tot = prof[:, :13].sum(1)
+print(f"envs={n} substeps=10: mean cycles/env-step {tot.mean().item():.0f} (min {tot.min().item():.0f} max {tot.max().item():.0f}); s_memtime ticks at 100 MHz")
+for i, nm in enumerate(NAMES):
+    print(f"  {nm:34s} {prof[:, i].mean().item() / 10:10.0f} ticks/substep  {100 * prof[:, i].mean().item() / tot.mean().item():5.1f} %")

@@ -61,6 +61,33 @@ struct DModel {
       w_cfrc, w_qfrc_smooth, w_qacc_smooth, w_act_dot, w_con_dist, w_con_off, w_con_frame, w_efc_D, w_efc_aref,
       w_efc_Jaref, w_efc_jv, w_lim_sign, w_qacc, w_Ma, w_grad, w_Mgrad, w_search, w_mv, w_qfrc_constraint, w_tmp,
       w_efc_force, w_com, w_rows;
+
+  // ================= tables and LDS map of the wave-per-env physics kernel (csrc/wave_physics.h) =================
+  // bodies
+  int scan_parent[TM_MAXB];   // ancestor pointer for the transform scan (-1: transform is already absolute)
+  int body_lastdof[TM_MAXB];  // last dof on the path world -> body (own dofs included), -1 if none
+  int child_adr[TM_MAXB + 1], child_ids[TM_MAXB];
+  int nlevel, lvl_adr[TM_MAXB + 1], lvl_parents[TM_MAXB];  // level L (deepest first): parents that own children
+  int nround_body, nround_dof;
+  // dofs
+  int dof_jntid[TM_MAXV], dof_vpar[TM_MAXV], dof_ndesc[TM_MAXV], dof_limrow[TM_MAXV], dof_freetrans[TM_MAXV];
+  int dof_act_adr[TM_MAXV + 1], dof_act_id[128];
+  float dof_act_coef[128], dof_stiffness[TM_MAXV], dof_qspring[TM_MAXV];
+  int dof_qposadr[TM_MAXV];
+  int dof_grp_adr[TM_MAXV + 1], dof_grp_ids[TM_MAXV * TM_MAXG];
+  int con_grp[TM_MAXC];
+  // tree-sparse rows: ancestor tables, one entry per stored non-zero (entry k of row i = k-th ancestor of dof i)
+  uint8_t anc_dof[1280];
+  uint16_t anc_Madr[1280];
+  // column access: for dof i, entries (descendant k ascending) = offset of M(k,i) inside the sparse storage
+  int dof_coladr[TM_MAXV + 1];
+  uint16_t col_off[1280];
+  float total_mass;
+  // per-dof packed words kept in LDS: [2i] = Madr | depth << 16 ; [2i+1] = chain_start | (jump + 1) << 8
+  // (ancestors of dof i: i-1 .. chain_start, then jump, jump-1, .. 0 — checked on the host)
+  int tdof[TM_MAXV * 2];
+  int body_nsub[TM_MAXB];  // subtree size (bodies are numbered depth-first: subtree = [b, b + nsub))
+  int lds_floats;
 };
 
 enum { RW_TOO_FAR, RW_BAD_POSE, RW_BAD_QUAT, RW_CTRL_W, RW_CTRL_DIFF_W, RW_ENERGY_W, RW_POS_W, RW_QUAT_W, RW_JOINT_W,

@@ -9,8 +9,13 @@
 #include <vector>
 
 #include "dmodel.h"
+#include "wave_layout.h"
 
 namespace tmjx_host {
+
+inline WLayout make_wave_layout(const DModel &m) {
+  return WLayout(m.nbody, m.njnt, m.nq, m.nv, m.nu, m.ncon, m.nlim, m.nnz, m.ngroup, m.nround_body, m.nround_dof);
+}
 
 struct BlobEntry { int code = -1, count = 0; const unsigned char *data = nullptr; };
 
@@ -183,6 +188,119 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
   WROW(w_qfrc_constraint, m.nv); WROW(w_tmp, m.nefc > m.nv ? m.nefc : m.nv); WROW(w_efc_force, m.nefc); WROW(w_com, 3);
 #undef WROW
   m.w_rows = w;
+
+  // ================= wave-per-env kernel tables =================
+  if (m.nnz > 1280 || m.nbody > 128 || m.nv > 128) { err = "model too large for the wave kernel tables"; return false; }
+  std::vector<int> blevel(m.nbody, 0);
+  int maxlevel = 0;
+  for (int b = 1; b < m.nbody; b++) { blevel[b] = blevel[m.body_parentid[b]] + 1; if (blevel[b] > maxlevel) maxlevel = blevel[b]; }
+  for (int b = 0; b < m.nbody; b++) {
+    bool has_free = false;
+    for (int jj = 0; jj < m.body_jntnum[b]; jj++) if (m.jnt_type[m.body_jntadr[b] + jj] == 0) has_free = true;
+    m.scan_parent[b] = (b == 0 || has_free || m.body_parentid[b] == 0) ? -1 : m.body_parentid[b];
+    int last = -1;
+    for (int c = b; c > 0 && last < 0; c = m.body_parentid[c]) if (m.body_dofnum[c]) last = m.body_dofadr[c] + m.body_dofnum[c] - 1;
+    m.body_lastdof[b] = last;
+  }
+  {  // children lists (body ids ascending)
+    int a = 0;
+    for (int p = 0; p < m.nbody; p++) {
+      m.child_adr[p] = a;
+      for (int c = 1; c < m.nbody; c++) if (m.body_parentid[c] == p && c != p) m.child_ids[a++] = c;
+    }
+    m.child_adr[m.nbody] = a;
+    // up-sweep levels: deepest parents first; world (level 0) is never a target
+    int nl = 0, la = 0;
+    for (int L = maxlevel - 1; L >= 1; L--) {
+      m.lvl_adr[nl] = la;
+      for (int p = 1; p < m.nbody; p++) if (blevel[p] == L && m.child_adr[p + 1] > m.child_adr[p]) m.lvl_parents[la++] = p;
+      if (la > m.lvl_adr[nl]) nl++;
+    }
+    m.lvl_adr[nl] = la;
+    m.nlevel = nl;
+  }
+  int scan_depth = 0;
+  for (int b = 0; b < m.nbody; b++) { int d = 0; for (int c = b; m.scan_parent[c] >= 0; c = m.scan_parent[c]) d++; if (d > scan_depth) scan_depth = d; }
+  m.nround_body = 0; while ((1 << m.nround_body) < scan_depth + 1) m.nround_body++;
+  int maxdd = 0;
+  for (int i = 0; i < m.nv; i++) if (m.dof_depth[i] > maxdd) maxdd = m.dof_depth[i];
+  m.nround_dof = 0; while ((1 << m.nround_dof) < maxdd + 1) m.nround_dof++;
+  for (int j = 0; j < m.njnt; j++) {
+    int nd = m.jnt_type[j] == 0 ? 6 : 1;
+    for (int k = 0; k < nd; k++) {
+      int i = m.jnt_dofadr[j] + k;
+      m.dof_jntid[i] = j;
+      m.dof_freetrans[i] = (m.jnt_type[j] == 0 && k < 3) ? 1 : 0;
+      // velocity prefix seen by cdof_dot: free rotational dofs all use the prefix after the 3 translations
+      m.dof_vpar[i] = (m.jnt_type[j] == 0 && k >= 3) ? m.jnt_dofadr[j] + 2 : m.dof_parentid[i];
+      m.dof_stiffness[i] = m.jnt_type[j] == 3 ? m.jnt_stiffness[j] : 0.f;
+      m.dof_qposadr[i] = m.jnt_type[j] == 3 ? m.jnt_qposadr[j] : 0;
+      m.dof_qspring[i] = m.jnt_type[j] == 3 ? m.qpos_spring[m.jnt_qposadr[j]] : 0.f;
+      m.dof_limrow[i] = -1;
+    }
+  }
+  for (int l = 0; l < m.nlim; l++) m.dof_limrow[m.jnt_dofadr[m.lim_jnt[l]]] = l;
+  for (int i = 0; i < m.nv; i++) {  // descendants are a contiguous dof range (depth-first numbering)
+    int nd = 0;
+    for (int k = i + 1; k < m.nv; k++) { bool desc = false; for (int a = m.dof_parentid[k]; a >= 0; a = m.dof_parentid[a]) if (a == i) desc = true; if (desc) nd++; else break; }
+    m.dof_ndesc[i] = nd;
+    int total = 0;
+    for (int k = i + 1; k < m.nv; k++) for (int a = m.dof_parentid[k]; a >= 0; a = m.dof_parentid[a]) if (a == i) total++;
+    if (total != nd) { err = "dof numbering is not depth-first"; return false; }
+    int k = 0;
+    for (int j = i; j >= 0; j = m.dof_parentid[j], k++) { m.anc_dof[m.dof_Madr[i] + k] = (uint8_t)j; m.anc_Madr[m.dof_Madr[i] + k] = (uint16_t)m.dof_Madr[j]; }
+  }
+  {  // column access table: M(k,i) for every descendant k of i, k ascending
+    int a = 0;
+    for (int i = 0; i < m.nv; i++) {
+      m.dof_coladr[i] = a;
+      for (int k = i + 1; k <= i + m.dof_ndesc[i]; k++) m.col_off[a++] = (uint16_t)(m.dof_Madr[k] + m.dof_depth[k] - m.dof_depth[i]);
+    }
+    m.dof_coladr[m.nv] = a;
+    m.total_mass = 0.f;
+    for (int b = 0; b < m.nbody; b++) if (m.body_moving[b]) m.total_mass += m.body_mass[b];
+  }
+  {  // per-dof actuator gather lists (transpose of the sparse moment)
+    int a = 0;
+    for (int i = 0; i < m.nv; i++) {
+      m.dof_act_adr[i] = a;
+      for (int u = 0; u < m.nu; u++) for (int e = m.act_madr[u]; e < m.act_madr[u + 1]; e++) if (m.act_mdof[e] == i) {
+        if (a >= 128) { err = "too many actuator couplings"; return false; }
+        m.dof_act_id[a] = u; m.dof_act_coef[a] = m.act_mval[e]; a++;
+      }
+    }
+    m.dof_act_adr[m.nv] = a;
+    int g = 0;
+    for (int i = 0; i < m.nv; i++) {
+      m.dof_grp_adr[i] = g;
+      for (int gg = 0; gg < m.ngroup; gg++) for (int d = m.grp_lastdof[gg]; d >= 0; d = m.dof_parentid[d]) if (d == i) m.dof_grp_ids[g++] = gg;
+    }
+    m.dof_grp_adr[m.nv] = g;
+    for (int gg = 0; gg < m.ngroup; gg++) for (int c = m.grp_start[gg]; c < m.grp_start[gg] + m.grp_count[gg]; c++) m.con_grp[c] = gg;
+  }
+  for (int i = 0; i < m.nv; i++) {  // two-segment ancestor structure (chain below a trunk chain)
+    int sgm = i;
+    while (sgm > 0 && m.dof_parentid[sgm] == sgm - 1) sgm--;
+    int jump = m.dof_parentid[sgm];
+    m.tdof[2 * i] = m.dof_Madr[i] | (m.dof_depth[i] << 16);
+    m.tdof[2 * i + 1] = sgm | ((jump + 1) << 8);
+    int r = i - sgm;
+    for (int q = 0; q <= m.dof_depth[i]; q++) {
+      int a = q <= r ? i - q : jump + 1 + r - q;
+      if (a != (int)m.anc_dof[m.dof_Madr[i] + q]) { err = "kinematic tree is not 'chains hanging off one trunk chain' (wave kernel limitation)"; return false; }
+    }
+    if (m.dof_depth[i] >= 64) { err = "dof depth exceeds the wavefront width"; return false; }
+  }
+  for (int b = 0; b < m.nbody; b++) {
+    int nsub = 1;
+    for (int cb = b + 1; cb < m.nbody; cb++) { bool desc = false; for (int a = m.body_parentid[cb]; a > 0 || a == b; a = m.body_parentid[a]) { if (a == b) { desc = true; break; } if (a == 0) break; } if (desc) nsub++; else break; }
+    m.body_nsub[b] = nsub;
+    int total = 1;
+    for (int cb = 1; cb < m.nbody; cb++) if (cb != b) for (int a = m.body_parentid[cb];; a = m.body_parentid[a]) { if (a == b) { total++; break; } if (a == 0) break; }
+    if (b > 0 && total != nsub) { err = "body numbering is not depth-first"; return false; }
+  }
+  // LDS map of the wave kernel: one source of truth (wave_layout.h); only the total is kept in the model
+  m.lds_floats = make_wave_layout(m).lds_floats;
   return true;
 }
 

@@ -12,13 +12,17 @@
 #include "../../include/tmjx.h"
 #include "env_core.h"
 #include "model_host.h"
+#include "wave_physics.h"
 
 struct tmjx_model {
   DModel h;           // host copy (clip pointers are device pointers)
   DModel *d = nullptr;  // device copy
   float *clips[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int block = 16;     // lanes per workgroup for the per-env kernels
+  int block = 64;     // lanes per workgroup for the lane-per-env kernels (K1/K3 and the v1 physics)
+  int wave = 1;       // 1: wave-per-env LDS physics kernel (default); 0: lane-per-env reference implementation
+  bool rodent = false;  // dims match the compile-time specialisation of the wave kernel
 };
+static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -71,6 +75,46 @@ __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const 
   tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics);
 }
 
+// K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
+// STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
+template <bool STATIC>
+__global__ __launch_bounds__(64) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
+                                                     int do_euler, float *ws_dump, int n) {
+  extern __shared__ float tmw_lds[];
+  WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x, (int)threadIdx.x, nullptr, 0ull};
+#ifdef TMW_PROFILE
+  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)blockIdx.x * 16; c.tlast = __builtin_amdgcn_s_memtime(); }
+#endif
+  constexpr WLayout ks(TMW_RODENT_DIMS);
+  const WLayout kd = STATIC ? ks : WLayout(mp->nbody, mp->njnt, mp->nq, mp->nv, mp->nu, mp->ncon, mp->nlim, mp->nnz, mp->ngroup,
+                                           mp->nround_body, mp->nround_dof);
+  const WLayout &K = STATIC ? ks : kd;
+  float time = tmw_load_state(c, K, action);
+  for (int f = 0; f < nsub; f++) {
+    tmw_forward(c, K, f == nsub - 1);
+    if (do_euler) time = tmw_euler(c, K, time);
+  }
+#ifndef TMW_PROFILE
+  if (ws_dump) tmw_dump(c, K, ws_dump);
+#endif
+  tmw_store_state(c, K, time);
+  TMW_TICK(12);
+}
+
+__global__ void k_reset_pre(const DModel *__restrict__ mp, float *st, int *is, const int *clip, const int *start, const float *qn,
+                            const float *vn, float *ws, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  EnvRef r{st, ws, n, e};
+  tm_reset_pre(*mp, r, is, clip[e], start[e], qn, vn);
+}
+__global__ void k_reset_post(const DModel *__restrict__ mp, float *st, int *is, float *obs, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  EnvRef r{st, nullptr, n, e};
+  tm_reset_post(*mp, r, is, obs);
+}
+
 // compute_gae (losses.py:39-100): one lane per batch column, reverse scan over T then the advantage pass
 __global__ void k_gae(const float *__restrict__ trunc, const float *__restrict__ term, const float *__restrict__ rew,
                       const float *__restrict__ val, const float *__restrict__ boot, float lam, float disc, float *vs,
@@ -100,7 +144,7 @@ __global__ void k_gae(const float *__restrict__ trunc, const float *__restrict__
 extern "C" {
 
 const char *tmjx_last_error(void) { return g_err.c_str(); }
-const char *tmjx_version(void) { return "tmjx-hip 0.1 (gfx950, lane-per-env)"; }
+const char *tmjx_version(void) { return "tmjx-hip 0.2 (gfx950, wave-per-env LDS physics)"; }
 
 int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
   if (!blob || !out) return fail(TMJX_EINVAL, "null argument");
@@ -109,6 +153,18 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
   if (!tmjx_host::build_dmodel(blob, nbytes, m->h, err)) { delete m; return fail(TMJX_EINVAL, err); }
   const char *bs = getenv("TMJX_BLOCK");
   if (bs) { int v = atoi(bs); if (v >= 1 && v <= 256) m->block = v; }
+  const char *impl = getenv("TMJX_IMPL");
+  if (impl && !strcmp(impl, "lane")) m->wave = 0;
+  if (m->wave) {
+    size_t lds_bytes = (size_t)m->h.lds_floats * sizeof(float);
+    if (lds_bytes > 160 * 1024) { delete m; return fail(TMJX_EINVAL, "model does not fit the 160 KiB LDS of a CU"); }
+    if (lds_bytes > 64 * 1024) { delete m; return fail(TMJX_EINVAL, "model needs more than 64 KiB of LDS per env"); }
+    constexpr WLayout ks(TMW_RODENT_DIMS);
+    const WLayout kd = tmjx_host::make_wave_layout(m->h);
+    m->rodent = !getenv("TMJX_WAVE_DYNAMIC") && kd.nbody == ks.nbody && kd.njnt == ks.njnt && kd.nq == ks.nq && kd.nv == ks.nv &&
+                kd.nu == ks.nu && kd.ncon == ks.ncon && kd.nlim == ks.nlim && kd.nnz == ks.nnz && kd.ngroup == ks.ngroup &&
+                kd.nround_body == ks.nround_body && kd.nround_dof == ks.nround_dof && kd.lds_floats == ks.lds_floats;
+  }
   hipError_t e = hipMalloc((void **)&m->d, sizeof(DModel));
   if (e != hipSuccess) { delete m; return fail(TMJX_ENOMEM, std::string("hipMalloc(DModel): ") + hipGetErrorString(e)); }
   e = hipMemcpy(m->d, &m->h, sizeof(DModel), hipMemcpyHostToDevice);
@@ -158,18 +214,31 @@ int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quatern
   return TMJX_OK;
 }
 
+static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream) {
+  size_t lds = (size_t)m->h.lds_floats * sizeof(float);
+  if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(n_env), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env);
+  else hipLaunchKernelGGL(k_physics_wave<false>, dim3(n_env), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env);
+}
 static int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(TMJX_EHIP, std::string(what) + ": " + hipGetErrorString(e));
   return TMJX_OK;
 }
 #define GRID(m, n) dim3(((n) + (m)->block - 1) / (m)->block), dim3((m)->block)
+#define WAVE_LDS(m) ((size_t)(m)->h.lds_floats * sizeof(float))
 
 int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip_idx, const int32_t *start_frame,
                const float *qpos_noise, const float *qvel_noise, float *obs, float *workspace, int n_env, void *stream) {
   if (!m || !state || !istate || !clip_idx || !start_frame || !qpos_noise || !qvel_noise || !obs || !workspace) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
+  if (m->wave) {
+    hipLaunchKernelGGL(k_reset_pre, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, clip_idx, start_frame, qpos_noise,
+                       qvel_noise, workspace, n_env);
+    launch_wave(m, state, (const float *)nullptr, 1, 0, (float *)nullptr, n_env, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_reset_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, obs, n_env);
+    return check_launch("k_reset(wave)");
+  }
   hipLaunchKernelGGL(k_reset, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, clip_idx, start_frame, qpos_noise,
                      qvel_noise, obs, workspace, n_env);
   return check_launch("k_reset");
@@ -180,6 +249,12 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
   if (!m || !state || !istate || !action || !obs || !reward || !done || !truncation || !metrics || !workspace) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
+  if (m->wave) {
+    launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
+                       metrics, n_env);
+    return check_launch("k_step(wave)");
+  }
   hipLaunchKernelGGL(k_step, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
                      metrics, workspace, n_env);
   return check_launch("k_step");
@@ -188,6 +263,10 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
 int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substeps, float *workspace, int n_env, void *stream) {
   if (!m || !state || !workspace) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1 || n_substeps < 0) return fail(TMJX_EINVAL, "bad n_env / n_substeps");
+  if (m->wave) {
+    launch_wave(m, state, action, n_substeps, 1, workspace, n_env, (hipStream_t)stream);
+    return check_launch("k_physics_wave");
+  }
   hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, action, n_substeps, 1, workspace, n_env);
   return check_launch("k_physics");
 }
@@ -195,6 +274,10 @@ int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substep
 int tmjx_forward(tmjx_model *m, float *state, float *workspace, int n_env, void *stream) {
   if (!m || !state || !workspace) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+  if (m->wave) {
+    launch_wave(m, state, (const float *)nullptr, 1, 0, workspace, n_env, (hipStream_t)stream);
+    return check_launch("k_forward(wave)");
+  }
   hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, (const float *)nullptr, 1, 0, workspace, n_env);
   return check_launch("k_forward");
 }

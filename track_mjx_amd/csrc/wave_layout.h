@@ -1,0 +1,56 @@
+// csrc/wave_layout.h — dimensions and LDS map of the wave-per-env physics kernel as ONE constexpr-constructible value.
+//
+// The kernel is instantiated twice: with `constexpr WLayout k(rodent dims)` every LDS offset and loop bound folds into
+// an instruction immediate (no scalar loads of layout fields inside the pivot / mat-vec loops — each such s_load also
+// forces an lgkmcnt(0) wait that serialises the LDS pipeline), and with a run-time WLayout built from the model's
+// dims for any other model.  The host picks the specialised kernel when the dims match (tmjx_hip.hip).
+#pragma once
+
+struct WLayout {
+  int nbody, njnt, nq, nv, nu, ncon, nlim, nefc, ngroup, nnz, nphys, nround_body, nround_dof;
+  // persistent part
+  int l_qpos, l_qvel, l_act, l_warm, l_ctrl, l_cdof, l_M, l_con_dist, l_con_off, l_con_frame, l_lim_sign, l_qfrc_smooth,
+      l_qfrc_actuator, l_act_dot, l_com, l_sv, l_wr, l_tdof, l_tgrp, l_dummy, l_alias0;
+  // aliased region A (solver stage)
+  int l_LD, l_Dinv, l_efc_D, l_efc_aref, l_Jaref, l_jv, l_qacc_smooth, l_qacc, l_Ma, l_grad, l_Mgrad, l_search, l_mv,
+      l_qfrc_constraint, l_tmp;
+  // aliased region B (position / velocity stage), same base as region A
+  int l_scanA, l_scanB, l_jl_anchor, l_jl_axis, l_xipos, l_cinert, l_cfrc, l_dscanA, l_dscanB;
+  int lds_floats;
+
+  constexpr WLayout(int nb, int nj, int nq_, int nv_, int nu_, int nc, int nl, int nnz_, int ng, int rb, int rd)
+      : nbody(nb), njnt(nj), nq(nq_), nv(nv_), nu(nu_), ncon(nc), nlim(nl), nefc(nl + 4 * nc), ngroup(ng), nnz(nnz_),
+        nphys(nq_ + nv_ + nu_ + nv_ + 1), nround_body(rb), nround_dof(rd),
+        l_qpos(0), l_qvel(0), l_act(0), l_warm(0), l_ctrl(0), l_cdof(0), l_M(0), l_con_dist(0), l_con_off(0), l_con_frame(0),
+        l_lim_sign(0), l_qfrc_smooth(0), l_qfrc_actuator(0), l_act_dot(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_dummy(0),
+        l_alias0(0), l_LD(0), l_Dinv(0), l_efc_D(0), l_efc_aref(0), l_Jaref(0), l_jv(0), l_qacc_smooth(0), l_qacc(0), l_Ma(0),
+        l_grad(0), l_Mgrad(0), l_search(0), l_mv(0), l_qfrc_constraint(0), l_tmp(0), l_scanA(0), l_scanB(0), l_jl_anchor(0),
+        l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0) {
+    int l = 0;
+    l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += nu; l_warm = l; l += nv; l_ctrl = l; l += nu;
+    l_cdof = l; l += nv * 6; l_M = l; l += nnz; l_con_dist = l; l += ncon; l_con_off = l; l += ncon * 3;
+    l_con_frame = l; l += ncon * 9; l_lim_sign = l; l += nlim; l_qfrc_smooth = l; l += nv; l_qfrc_actuator = l; l += nv;
+    l_act_dot = l; l += nu; l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_wr = l; l += ncon * 6; l_tdof = l; l += nv * 2;
+    l_tgrp = l; l += ngroup * 4; l_dummy = l; l += 64;  // per-lane sink for branch-free masked LDS accesses
+    l = (l + 3) & ~3;
+    l_alias0 = l;
+    l_LD = l; l += nnz; l_Dinv = l; l += nv; l_efc_D = l; l += nefc; l_efc_aref = l; l += nefc; l_Jaref = l; l += nefc;
+    l_jv = l; l += nefc; l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
+    l_Mgrad = l; l += nv; l_search = l; l += nv; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
+    int endA = l;
+    l = l_alias0;
+    l_scanA = l; l += nbody * 8; l_scanB = l; l += nbody * 8; l_jl_anchor = l; l += njnt * 3; l_jl_axis = l; l += njnt * 3;
+    l_xipos = l; l += nbody * 3;
+    int endB1 = l;
+    // velocity stage: behind scanA (which still holds the world transforms); scanB / joint frames / xipos are dead by then
+    l = l_alias0 + nbody * 8;
+    l_cinert = l; l += nbody * 10; l_cfrc = l; l += nbody * 6; l_dscanA = l; l += nv * 8; l_dscanB = l; l += nv * 8;
+    int endB2 = l;
+    lds_floats = endA > endB1 ? endA : endB1;
+    if (endB2 > lds_floats) lds_floats = endB2;
+  }
+};
+
+// the rodent walker of the reference (track_mjx/environment/walker/assets/rodent/rodent.xml): 68 bodies, 68 joints,
+// nq 74, nv 73, 38 actuators, 30 contact slots, 67 joint limits, 1119 non-zeros in the tree-sparse M, 8 paw bodies
+#define TMW_RODENT_DIMS 68, 68, 74, 73, 38, 30, 67, 1119, 8, 6, 6

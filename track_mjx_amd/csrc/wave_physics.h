@@ -1,0 +1,958 @@
+// csrc/wave_physics.h — K2, wave-per-env: one 64-lane wavefront integrates one env; every per-env array of a
+// substep lives in LDS (DModel::l_* map, ~22 KB per env => 7 envs per CU), the 64 lanes split bodies / dofs /
+// constraint rows / matrix columns between them.
+//
+// Same maths as physics_core.h (MJX `mjx.step`, reference call site
+// track_mjx/environment/task/single_clip_tracking.py:219) re-organised for the wavefront:
+//   * kinematics and velocity/acceleration prefixes by POINTER JUMPING over the tree (log2(depth) = 6 rounds
+//     instead of a 39-level walk),
+//   * composite inertias / body forces by a level-synchronous up-sweep,
+//   * tree-sparse M; L^T D L with one lane per row-k column and scalar-broadcast pivots; L is then inverted in
+//     place (the inverse has the same ancestor sparsity) so that every M^-1 apply in the CG loop is two parallel
+//     sparse mat-vecs instead of two 73-step dependent sweeps,
+//   * matrix-free constraint Jacobian (spatial velocity per paw body, wrench accumulation),
+//   * dot products / line-search sums by DPP wave reductions.
+//
+// Single source for the GPU and for the TEST-ONLY host emulation: a block of lane code is written as
+//   TMW_FOR { ... uses `lane` ... }  TMW_SYNC();
+// On the GPU TMW_FOR is empty (the wave executes the block once, lane = threadIdx.x) and TMW_SYNC is a workgroup
+// barrier (one wave per workgroup, so it only orders LDS traffic); under TM_HOST_EMU TMW_FOR loops lane = 0..63.
+// Lane-private values that live across blocks are declared with TMW_REG (one slot on the GPU, 64 in emulation).
+#pragma once
+#include "physics_core.h"
+#include "wave_layout.h"
+
+#ifdef TM_HOST_EMU
+#define TMW_NL 64
+#define TMW_FOR for (int lane = 0; lane < 64; lane++)
+#define TMW_SYNC() do { } while (0)
+#define TMW_LI lane
+#define TMW_LANE_DECL
+#else
+#define TMW_NL 1
+#define TMW_FOR if (true)
+#define TMW_SYNC() __syncthreads()
+#define TMW_LI 0
+#define TMW_LANE_DECL const int lane = c.lane;
+#endif
+#define TMW_REG(type, name) type name[TMW_NL]
+
+struct WCtx {
+  const DModel *mp;
+  float *L;          // LDS
+  float *st;         // global float state [rows][n]
+  int n, e;
+  int lane;
+  unsigned long long *prof;   // TMW_PROFILE builds only: per-env phase cycle counters
+  unsigned long long tlast;
+};
+#if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
+#define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
+#else
+#define TMW_TICK(idx) do { } while (0)
+#endif
+#define WST(off, i) c.st[(size_t)((off) + (i)) * (size_t)c.n + (size_t)c.e]
+
+TM_DEV int tm_f2i(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
+TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
+
+// ---- wave reductions / broadcasts
+#ifdef TM_HOST_EMU
+TM_DEV float tmw_sum(const float *v) { float s = 0.f; for (int i = 0; i < 64; i++) s += v[i]; return s; }
+TM_DEV float tmw_readlane(const float *v, int src) { return v[src]; }
+#else
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+TM_DEV float tmw_dpp_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, tm_f2i(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return v + tm_i2f(moved);
+}
+#ifdef TMW_SHFL_REDUCE
+TM_DEV float tmw_sum(const float *vp) {
+  float v = vp[0];
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+TM_DEV float tmw_readlane(const float *v, int src) { return __shfl(v[0], src); }
+#define tmw_sum_dpp tmw_sum_unused
+#define tmw_readlane_dpp tmw_readlane_unused
+#else
+#define tmw_sum_dpp tmw_sum
+#define tmw_readlane_dpp tmw_readlane
+#endif
+TM_DEV float tmw_sum_dpp(const float *vp) {
+  float v = vp[0];
+  v = tmw_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+  v = tmw_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+  v = tmw_dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4
+  v = tmw_dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8
+  v = tmw_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15
+  v = tmw_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31
+  return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 63));  // the builtin is typed int: pass the BITS, not the value
+}
+TM_DEV float tmw_readlane_dpp(const float *v, int src) { return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v[0]), src)); }
+#endif
+
+// ------------------------------------------------------------------------------------------ state in / out
+TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    for (int i = lane; i < K.nphys - 1; i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);
+    for (int a = lane; a < K.nu; a += 64) L[K.l_ctrl + a] = action ? action[(size_t)a * c.n + c.e] : 0.f;
+    for (int i = lane; i < 2 * K.nv; i += 64) L[K.l_tdof + i] = tm_i2f(m.tdof[i]);  // index table of the sparse rows
+    for (int g = lane; g < K.ngroup; g += 64) { L[K.l_tgrp + 4 * g] = tm_i2f(m.grp_lastdof[g]); L[K.l_tgrp + 4 * g + 1] = tm_i2f(m.grp_start[g]); L[K.l_tgrp + 4 * g + 2] = tm_i2f(m.grp_count[g]); }
+  }
+  TMW_SYNC();
+  return WST(m.s_time, 0);
+}
+// packed per-dof words in LDS: w0 = Madr | depth << 16, w1 = chain_start | (jump + 1) << 8
+#define TMW_W0(i) tm_f2i(L[K.l_tdof + 2 * (i)])
+#define TMW_W1(i) tm_f2i(L[K.l_tdof + 2 * (i) + 1])
+// q-th ancestor of dof i (q = 0: i itself): the chain i, i-1, .., chain_start, then jump, jump-1, .., 0
+TM_DEV int tmw_anc(int i, int q, int w1) {
+  int r = i - (w1 & 0xff);
+  return q <= r ? i - q : ((w1 >> 8) & 0xff) + r - q;
+}
+TM_DEV void tmw_store_state(WCtx &c, const WLayout &K, float time) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    for (int i = lane; i < K.nphys - 1; i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];
+    for (int i = lane; i < K.nv; i += 64) WST(m.s_qfrc_actuator, i) = L[K.l_qfrc_actuator + i];
+    if (lane == 0) WST(m.s_time, 0) = time;
+  }
+  TMW_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ fwd_position
+// kinematics by pointer jumping; com; collision; cdof; cinert.  `emit`: also write xpos / torso xmat to global.
+TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  // (1) local transform of every body relative to its parent (absolute for the free-joint body)
+  TMW_FOR {
+    for (int b = lane; b < K.nbody; b += 64) {
+      float t[3] = {m.body_pos[b][0], m.body_pos[b][1], m.body_pos[b][2]};
+      float q[4] = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
+      for (int jj = 0; jj < m.body_jntnum[b]; jj++) {
+        int j = m.body_jntadr[b] + jj, qa = m.jnt_qposadr[j];
+        if (m.jnt_type[j] == 0) {
+          for (int k = 0; k < 3; k++) t[k] = L[K.l_qpos + qa + k];
+          for (int k = 0; k < 4; k++) q[k] = L[K.l_qpos + qa + 3 + k];
+          tm_normalize4(q);
+          for (int k = 0; k < 4; k++) L[K.l_qpos + qa + 3 + k] = q[k];
+          for (int k = 0; k < 3; k++) { L[K.l_jl_anchor + j * 3 + k] = t[k]; L[K.l_jl_axis + j * 3 + k] = (k == 2) ? 1.f : 0.f; }
+        } else {
+          float r[3], an[3], ax[3], ql[4], q2[4];
+          tm_rotate(r, m.jnt_pos[j], q);
+          for (int k = 0; k < 3; k++) an[k] = t[k] + r[k];
+          tm_rotate(ax, m.jnt_axis[j], q);
+          float ang = (L[K.l_qpos + qa] - m.qpos0[qa]) * 0.5f, sn = sinf(ang), cs = cosf(ang);
+          ql[0] = cs; ql[1] = m.jnt_axis[j][0] * sn; ql[2] = m.jnt_axis[j][1] * sn; ql[3] = m.jnt_axis[j][2] * sn;
+          tm_quat_mul(q2, q, ql);
+          for (int k = 0; k < 4; k++) q[k] = q2[k];
+          tm_rotate(r, m.jnt_pos[j], q);
+          for (int k = 0; k < 3; k++) { t[k] = an[k] - r[k]; L[K.l_jl_anchor + j * 3 + k] = an[k]; L[K.l_jl_axis + j * 3 + k] = ax[k]; }
+        }
+      }
+      float *o = L + K.l_scanA + b * 8;
+      o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3]; o[7] = tm_i2f(m.scan_parent[b]);
+    }
+  }
+  TMW_SYNC();
+  // (2) pointer jumping: T_b <- T_anc(b) o T_b ; anc(b) <- anc(anc(b)).  Even round count => result in scanA.
+  int R = K.nround_body + (K.nround_body & 1);
+  for (int r = 0; r < R; r++) {
+    const float *cur = L + ((r & 1) ? K.l_scanB : K.l_scanA);
+    float *nxt = L + ((r & 1) ? K.l_scanA : K.l_scanB);
+    TMW_FOR {
+      for (int b = lane; b < K.nbody; b += 64) {
+        const float *s = cur + b * 8;
+        float t[3] = {s[0], s[1], s[2]}, q[4] = {s[3], s[4], s[5], s[6]};
+        int a = tm_f2i(s[7]);
+        if (a >= 0) {
+          const float *sa = cur + a * 8;
+          float qa[4] = {sa[3], sa[4], sa[5], sa[6]}, rt[3], q2[4];
+          tm_rotate(rt, t, qa);
+          for (int k = 0; k < 3; k++) t[k] = sa[k] + rt[k];
+          tm_quat_mul(q2, qa, q);
+          for (int k = 0; k < 4; k++) q[k] = q2[k];
+          a = tm_f2i(sa[7]);
+        }
+        float *o = nxt + b * 8;
+        o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3]; o[7] = tm_i2f(a);
+      }
+    }
+    TMW_SYNC();
+  }
+  // (3) inertial frame origins and the tree's centre of mass
+  TMW_REG(float, s0); TMW_REG(float, s1); TMW_REG(float, s2);
+  TMW_FOR {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int b = lane; b < K.nbody; b += 64) {
+      const float *s = L + K.l_scanA + b * 8;
+      float r[3];
+      tm_rotate(r, m.body_ipos[b], s + 3);
+      float x0 = s[0] + r[0], x1 = s[1] + r[1], x2 = s[2] + r[2];
+      L[K.l_xipos + b * 3] = x0; L[K.l_xipos + b * 3 + 1] = x1; L[K.l_xipos + b * 3 + 2] = x2;
+      if (m.body_moving[b]) { float mb = m.body_mass[b]; a0 += x0 * mb; a1 += x1 * mb; a2 += x2 * mb; }
+      if (emit) {
+        for (int k = 0; k < 3; k++) WST(m.s_xpos, b * 3 + k) = s[k];
+        if (b == m.torso_idx) { float X[9]; tm_quat_to_mat(X, s + 3); for (int k = 0; k < 9; k++) WST(m.s_xmat_torso, k) = X[k]; }
+      }
+    }
+    s0[TMW_LI] = a0; s1[TMW_LI] = a1; s2[TMW_LI] = a2;
+  }
+  float com[3] = {tmw_sum(s0) / m.total_mass, tmw_sum(s1) / m.total_mass, tmw_sum(s2) / m.total_mass};
+  TMW_FOR { if (lane < 3) L[K.l_com + lane] = com[lane]; }
+  // (4) collision: one lane per contact slot (plane vs paw capsule end / ellipsoid)
+  TMW_FOR {
+    for (int cc = lane; cc < K.ncon; cc += 64) {
+      int b1 = m.con_body1[cc], b2 = m.con_body2[cc];
+      const float *s1p = L + K.l_scanA + b1 * 8, *s2p = L + K.l_scanA + b2 * 8;
+      float t[3], pp[3], pq[4], pm[9], gp[3], gq[4], gm[9];
+      tm_rotate(t, m.con_g1_pos[cc], s1p + 3);
+      for (int k = 0; k < 3; k++) pp[k] = s1p[k] + t[k];
+      tm_quat_mul(pq, s1p + 3, m.con_g1_quat[cc]); tm_quat_to_mat(pm, pq);
+      tm_rotate(t, m.con_g2_pos[cc], s2p + 3);
+      for (int k = 0; k < 3; k++) gp[k] = s2p[k] + t[k];
+      tm_quat_mul(gq, s2p + 3, m.con_g2_quat[cc]); tm_quat_to_mat(gm, gq);
+      float nrm[3] = {pm[2], pm[5], pm[8]}, fr[9], pos[3], dist;
+      const float *size = m.con_g2_size[cc];
+      if (m.con_type[cc] == 3) {
+        float axis[3] = {gm[2], gm[5], gm[8]}, bb[3], na = tm_dot3(nrm, axis), cr[3];
+        for (int k = 0; k < 3; k++) bb[k] = axis[k] - nrm[k] * na;
+        float bn = tm_normalize3(bb);
+        if (bn < 0.5f) { bool yy = (-0.5f < nrm[1]) && (nrm[1] < 0.5f); bb[0] = 0.f; bb[1] = yy ? 1.f : 0.f; bb[2] = yy ? 0.f : 1.f; }
+        tm_cross(cr, nrm, bb);
+        for (int k = 0; k < 3; k++) { fr[k] = nrm[k]; fr[3 + k] = bb[k]; fr[6 + k] = cr[k]; }
+        float sg = m.con_sub[cc] == 0 ? 1.f : -1.f, end[3];
+        for (int k = 0; k < 3; k++) end[k] = gp[k] + sg * (axis[k] * size[1]);
+        tm_plane_sphere(nrm, pp, end, size[0], dist, pos);
+      } else if (m.con_type[cc] == 4) {
+        float loc[3], sup[3], w[3], df[3];
+        for (int k = 0; k < 3; k++) loc[k] = gm[k] * nrm[0] + gm[3 + k] * nrm[1] + gm[6 + k] * nrm[2];
+        for (int k = 0; k < 3; k++) sup[k] = loc[k] * size[k];
+        tm_normalize3(sup);
+        for (int k = 0; k < 3; k++) sup[k] = -sup[k] * size[k];
+        for (int k = 0; k < 3; k++) w[k] = gm[k * 3] * sup[0] + gm[k * 3 + 1] * sup[1] + gm[k * 3 + 2] * sup[2];
+        for (int k = 0; k < 3; k++) { pos[k] = gp[k] + w[k]; df[k] = pos[k] - pp[k]; }
+        dist = tm_dot3(nrm, df);
+        for (int k = 0; k < 3; k++) pos[k] = pos[k] - nrm[k] * dist * 0.5f;
+        tm_make_frame(nrm, fr);
+      } else {
+        tm_plane_sphere(nrm, pp, gp, size[0], dist, pos);
+        tm_make_frame(nrm, fr);
+      }
+      L[K.l_con_dist + cc] = dist;
+      for (int k = 0; k < 3; k++) L[K.l_con_off + cc * 3 + k] = pos[k] - com[k];
+      for (int k = 0; k < 9; k++) L[K.l_con_frame + cc * 9 + k] = fr[k];
+    }
+  }
+  // (5) cdof: one lane per dof (joint anchors / axes are stored in the parent frame)
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      int j = m.dof_jntid[i], b = m.jnt_bodyid[j];
+      float cd[6];
+      if (m.jnt_type[j] == 0) {
+        int k = i - m.jnt_dofadr[j];
+        const float *s = L + K.l_scanA + b * 8;
+        if (k < 3) { for (int r = 0; r < 6; r++) cd[r] = (r == 3 + k) ? 1.f : 0.f; }
+        else {
+          float X[9], off[3] = {com[0] - s[0], com[1] - s[1], com[2] - s[2]};
+          tm_quat_to_mat(X, s + 3);
+          float ax[3] = {X[k - 3], X[3 + k - 3], X[6 + k - 3]}, cr[3];
+          tm_cross(cr, ax, off);
+          for (int r = 0; r < 3; r++) { cd[r] = ax[r]; cd[3 + r] = cr[r]; }
+        }
+      } else {
+        int p = m.body_parentid[b];
+        const float *sp = L + K.l_scanA + p * 8;
+        float an[3], ax[3], off[3], cr[3];
+        tm_rotate(an, L + K.l_jl_anchor + j * 3, sp + 3);
+        tm_rotate(ax, L + K.l_jl_axis + j * 3, sp + 3);
+        for (int r = 0; r < 3; r++) off[r] = com[r] - (sp[r] + an[r]);
+        tm_cross(cr, ax, off);
+        for (int r = 0; r < 3; r++) { cd[r] = ax[r]; cd[3 + r] = cr[r]; }
+      }
+      for (int r = 0; r < 6; r++) L[K.l_cdof + i * 6 + r] = cd[r];
+    }
+  }
+  TMW_SYNC();
+  // (6) cinert (overwrites the dead scanB / joint-frame scratch)
+  TMW_FOR {
+    for (int b = lane; b < K.nbody; b += 64) {
+      float ci[10];
+      if (!m.body_moving[b]) { for (int k = 0; k < 10; k++) ci[k] = 0.f; }
+      else {
+        const float *s = L + K.l_scanA + b * 8;
+        float q[4], X[9], off[3];
+        tm_quat_mul(q, s + 3, m.body_iquat[b]);
+        tm_quat_to_mat(X, q);
+        float mass = m.body_mass[b];
+        for (int k = 0; k < 3; k++) off[k] = L[K.l_xipos + b * 3 + k] - com[k];
+        const float *in = m.body_inertia[b];
+        float oo = tm_dot3(off, off);
+        ci[0] = X[0] * in[0] * X[0] + X[1] * in[1] * X[1] + X[2] * in[2] * X[2] + (oo - off[0] * off[0]) * mass;
+        ci[1] = X[3] * in[0] * X[3] + X[4] * in[1] * X[4] + X[5] * in[2] * X[5] + (oo - off[1] * off[1]) * mass;
+        ci[2] = X[6] * in[0] * X[6] + X[7] * in[1] * X[7] + X[8] * in[2] * X[8] + (oo - off[2] * off[2]) * mass;
+        ci[3] = X[0] * in[0] * X[3] + X[1] * in[1] * X[4] + X[2] * in[2] * X[5] - off[0] * off[1] * mass;
+        ci[4] = X[0] * in[0] * X[6] + X[1] * in[1] * X[7] + X[2] * in[2] * X[8] - off[0] * off[2] * mass;
+        ci[5] = X[3] * in[0] * X[6] + X[4] * in[1] * X[7] + X[5] * in[2] * X[8] - off[1] * off[2] * mass;
+        ci[6] = off[0] * mass; ci[7] = off[1] * mass; ci[8] = off[2] * mass; ci[9] = mass;
+      }
+      // NOTE: written after every lane has read its xipos/xquat inputs above in this block only for its OWN body;
+      // cinert rows never overlap scanA or xipos (model_host.h LDS map), so no cross-lane hazard.
+      for (int k = 0; k < 10; k++) L[K.l_cinert + b * 10 + k] = ci[k];
+    }
+  }
+  TMW_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ fwd_velocity + smooth forces
+// com_vel / rne prefixes by pointer jumping over dofs, body forces, up-sweep (crb, cfrc), M, qfrc_smooth, act_dot
+TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  int R = K.nround_dof + (K.nround_dof & 1);
+  // inclusive prefix P_i = sum over ancestors-or-self of cdof * qvel
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      float qv = L[K.l_qvel + i];
+      float *o = L + K.l_dscanA + i * 8;
+      for (int k = 0; k < 6; k++) o[k] = L[K.l_cdof + i * 6 + k] * qv;
+      o[6] = tm_i2f(m.dof_parentid[i]);
+    }
+  }
+  TMW_SYNC();
+  for (int r = 0; r < R; r++) {
+    const float *cur = L + ((r & 1) ? K.l_dscanB : K.l_dscanA);
+    float *nxt = L + ((r & 1) ? K.l_dscanA : K.l_dscanB);
+    TMW_FOR {
+      for (int i = lane; i < K.nv; i += 64) {
+        const float *s = cur + i * 8;
+        float v[6] = {s[0], s[1], s[2], s[3], s[4], s[5]};
+        int a = tm_f2i(s[6]);
+        if (a >= 0) { const float *sa = cur + a * 8; for (int k = 0; k < 6; k++) v[k] += sa[k]; a = tm_f2i(sa[6]); }
+        float *o = nxt + i * 8;
+        for (int k = 0; k < 6; k++) o[k] = v[k];
+        o[6] = tm_i2f(a);
+      }
+    }
+    TMW_SYNC();
+  }
+  // cdof_dot (kept in registers, two dof slots per lane) and body velocities
+  float dd0[TMW_NL][6], dd1[TMW_NL][6], cv0[TMW_NL][6], cv1[TMW_NL][6];
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) {
+      int i = lane + 64 * slot;
+      float *dd = slot ? dd1[TMW_LI] : dd0[TMW_LI];
+      for (int k = 0; k < 6; k++) dd[k] = 0.f;
+      if (i < K.nv && !m.dof_freetrans[i]) {
+        int vp = m.dof_vpar[i];
+        float E[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cd[6];
+        if (vp >= 0) for (int k = 0; k < 6; k++) E[k] = L[K.l_dscanA + vp * 8 + k];
+        for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
+        tm_motion_cross(dd, E, cd);
+      }
+      int b = lane + 64 * slot;
+      float *cv = slot ? cv1[TMW_LI] : cv0[TMW_LI];
+      for (int k = 0; k < 6; k++) cv[k] = 0.f;
+      if (b < K.nbody) { int ld = m.body_lastdof[b]; if (ld >= 0) for (int k = 0; k < 6; k++) cv[k] = L[K.l_dscanA + ld * 8 + k]; }
+    }
+  }
+  TMW_SYNC();
+  // inclusive prefix Q_i = sum of cdof_dot * qvel
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) {
+      int i = lane + 64 * slot;
+      if (i >= K.nv) continue;
+      const float *dd = slot ? dd1[TMW_LI] : dd0[TMW_LI];
+      float qv = L[K.l_qvel + i];
+      float *o = L + K.l_dscanA + i * 8;
+      for (int k = 0; k < 6; k++) o[k] = dd[k] * qv;
+      o[6] = tm_i2f(m.dof_parentid[i]);
+    }
+  }
+  TMW_SYNC();
+  for (int r = 0; r < R; r++) {
+    const float *cur = L + ((r & 1) ? K.l_dscanB : K.l_dscanA);
+    float *nxt = L + ((r & 1) ? K.l_dscanA : K.l_dscanB);
+    TMW_FOR {
+      for (int i = lane; i < K.nv; i += 64) {
+        const float *s = cur + i * 8;
+        float v[6] = {s[0], s[1], s[2], s[3], s[4], s[5]};
+        int a = tm_f2i(s[6]);
+        if (a >= 0) { const float *sa = cur + a * 8; for (int k = 0; k < 6; k++) v[k] += sa[k]; a = tm_f2i(sa[6]); }
+        float *o = nxt + i * 8;
+        for (int k = 0; k < 6; k++) o[k] = v[k];
+        o[6] = tm_i2f(a);
+      }
+    }
+    TMW_SYNC();
+  }
+  // body forces: cfrc_b = I_b cacc_b + cvel_b x* (I_b cvel_b)
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) {
+      int b = lane + 64 * slot;
+      if (b >= K.nbody) continue;
+      const float *cv = slot ? cv1[TMW_LI] : cv0[TMW_LI];
+      float ca[6] = {0.f, 0.f, 0.f, -m.gravity[0], -m.gravity[1], -m.gravity[2]}, I[10], f1[6], t[6], f2[6];
+      int ld = m.body_lastdof[b];
+      if (ld >= 0) for (int k = 0; k < 6; k++) ca[k] += L[K.l_dscanA + ld * 8 + k];
+      for (int k = 0; k < 10; k++) I[k] = L[K.l_cinert + b * 10 + k];
+      tm_inert_mul(f1, I, ca);
+      tm_inert_mul(t, I, cv);
+      tm_motion_cross_force(f2, cv, t);
+      for (int k = 0; k < 6; k++) L[K.l_cfrc + b * 6 + k] = (b == 0) ? 0.f : f1[k] + f2[k];
+    }
+  }
+  TMW_SYNC();
+  // composite inertia and accumulated body force of the body carrying each dof: bodies are numbered depth-first, so a
+  // subtree is the contiguous range [b, b + nsub); every dof lane sums its own range (no level-by-level dependency)
+  // M rows, bias, passive, actuation -> qfrc_smooth; act_dot
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      int b = m.dof_bodyid[i], nsub = m.body_nsub[b];
+      float I[10], fb[6], cd[6], buf[6];
+      for (int k = 0; k < 10; k++) I[k] = 0.f;
+      for (int k = 0; k < 6; k++) fb[k] = 0.f;
+#pragma unroll 2
+      for (int cb = b; cb < b + nsub; cb++) {
+        for (int k = 0; k < 10; k++) I[k] += L[K.l_cinert + cb * 10 + k];
+        for (int k = 0; k < 6; k++) fb[k] += L[K.l_cfrc + cb * 6 + k];
+      }
+      for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
+      tm_inert_mul(buf, I, cd);
+      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16;
+#pragma unroll 4
+      for (int k = 0; k <= d; k++) {
+        const float *cj = L + K.l_cdof + tmw_anc(i, k, w1) * 6;
+        float s = buf[0] * cj[0] + buf[1] * cj[1] + buf[2] * cj[2] + buf[3] * cj[3] + buf[4] * cj[4] + buf[5] * cj[5];
+        if (k == 0) s += m.dof_armature[i];
+        L[K.l_M + adr + k] = s;
+      }
+      float bias = 0.f;
+      for (int k = 0; k < 6; k++) bias += cd[k] * fb[k];
+      float fa = 0.f;
+      for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[K.l_act + u]); }
+      L[K.l_qfrc_actuator + i] = fa;
+      float f = -m.dof_damping[i] * L[K.l_qvel + i] - bias + fa;
+      if (m.dof_stiffness[i] != 0.f) f += -m.dof_stiffness[i] * (L[K.l_qpos + m.dof_qposadr[i]] - m.dof_qspring[i]);
+      L[K.l_qfrc_smooth + i] = f;
+    }
+    for (int a = lane; a < K.nu; a += 64) {
+      float ctrl = fminf(fmaxf(L[K.l_ctrl + a], m.act_ctrlrange[a][0]), m.act_ctrlrange[a][1]);
+      L[K.l_act_dot + a] = (ctrl - L[K.l_act + a]) / fmaxf(TM_MINVAL, m.act_tau[a]);
+    }
+  }
+  TMW_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ factorisation, L^-1, solves
+// LD <- L^T D L of (M + hdamp diag(damping)); pivots leaf -> root; lane q owns column q of pivot row k
+TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    for (int i = lane; i < K.nnz; i += 64) L[K.l_LD + i] = L[K.l_M + i];
+  }
+  TMW_SYNC();
+  if (hdamp != 0.f) {
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_LD + m.dof_Madr[i]] += hdamp * m.dof_damping[i]; }
+    TMW_SYNC();
+  }
+  TMW_REG(float, x); TMW_REG(float, arow);
+  for (int k = K.nv - 1; k >= 0; k--) {
+    int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = w0k & 0xffff, d = w0k >> 16;
+    TMW_FOR {
+      x[TMW_LI] = (lane <= d) ? L[K.l_LD + ak + lane] : 0.f;
+      // lane q also keeps the row address of the q-th ancestor; the pivot loop fetches it with a scalar readlane
+      arow[TMW_LI] = (lane <= d) ? tm_i2f(TMW_W0(tmw_anc(k, lane, w1k)) & 0xffff) : 0.f;
+    }
+    float inv = 1.f / tmw_readlane(x, 0);
+    // ancestors in chunks of 8: the 8 LDS reads of a chunk are issued back to back (their rows are distinct, which the
+    // compiler cannot know), then the 8 FMAs, then the 8 writes — one LDS round trip per chunk instead of per ancestor
+    for (int mm0 = 1; mm0 <= d; mm0 += 8) {
+      float a[8]; int ai[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int mc = mm0 + u <= d ? mm0 + u : d;
+        a[u] = tmw_readlane(x, mc) * inv;
+        ai[u] = tm_f2i(tmw_readlane(arow, mc)) - (mm0 + u);
+      }
+      TMW_FOR {
+        // branch-free: masked-off (lane, ancestor) pairs read and re-write the lane's private sink word instead
+        float v[8]; int ad[8]; bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          ok[u] = mm0 + u <= d && lane >= mm0 + u && lane <= d;
+          ad[u] = ok[u] ? K.l_LD + ai[u] + lane : K.l_dummy + lane;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = L[ad[u]];
+#pragma unroll
+        for (int u = 0; u < 8; u++) L[ad[u]] = ok[u] ? v[u] - a[u] * x[TMW_LI] : 0.f;
+      }
+    }
+    TMW_FOR {
+      if (lane >= 1 && lane <= d) L[K.l_LD + ak + lane] = x[TMW_LI] * inv;
+      if (lane == 0) L[K.l_Dinv + k] = inv;
+    }
+    TMW_SYNC();
+  }
+}
+// in place: strict part of every row of LD becomes the corresponding row of L^-1 (same ancestor sparsity)
+TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_REG(float, x); TMW_REG(float, arow);
+  for (int k = 1; k < K.nv; k++) {
+    int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = w0k & 0xffff, d = w0k >> 16;
+    if (d == 0) continue;
+    TMW_FOR {
+      x[TMW_LI] = (lane >= 1 && lane <= d) ? L[K.l_LD + ak + lane] : 0.f;
+      arow[TMW_LI] = (lane <= d) ? tm_i2f(TMW_W0(tmw_anc(k, lane, w1k)) & 0xffff) : 0.f;
+    }
+    TMW_REG(float, acc);
+    TMW_FOR { acc[TMW_LI] = x[TMW_LI]; }
+    for (int mm0 = 1; mm0 < d; mm0 += 8) {
+      float lm[8]; int ai[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int mc = mm0 + u < d ? mm0 + u : d - 1;
+        lm[u] = tmw_readlane(x, mc);
+        ai[u] = tm_f2i(tmw_readlane(arow, mc)) - (mm0 + u);
+      }
+      TMW_FOR {
+        float v[8]; int ad[8]; bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          ok[u] = mm0 + u < d && lane > mm0 + u && lane <= d;
+          ad[u] = ok[u] ? K.l_LD + ai[u] + lane : K.l_dummy + lane;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = L[ad[u]];
+        float s = acc[TMW_LI];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += ok[u] ? lm[u] * v[u] : 0.f;
+        acc[TMW_LI] = s;
+      }
+    }
+    TMW_FOR { if (lane >= 1 && lane <= d) L[K.l_LD + ak + lane] = -acc[TMW_LI]; }
+    TMW_SYNC();
+  }
+}
+// x <- M^-1 x using N = L^-1:  x = N D^-1 N^T x   (two sparse mat-vecs; `x` is an LDS vector offset)
+TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_REG(float, z0); TMW_REG(float, z1);
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) {
+      int i = lane + 64 * slot;
+      if (i >= K.nv) continue;
+      float acc = L[x + i];
+      int nd = m.dof_ndesc[i], di = TMW_W0(i) >> 16;
+#pragma unroll 4
+      for (int k = i + 1; k <= i + nd; k++) {  // column i: entry of descendant row k sits at Madr_k + depth_k - depth_i
+        int w0 = TMW_W0(k);
+        acc += L[K.l_LD + (w0 & 0xffff) + (w0 >> 16) - di] * L[x + k];
+      }
+      (slot ? z1 : z0)[TMW_LI] = acc * L[K.l_Dinv + i];
+    }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) { int i = lane + 64 * slot; if (i < K.nv) L[x + i] = (slot ? z1 : z0)[TMW_LI]; }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) {
+      int i = lane + 64 * slot;
+      if (i >= K.nv) continue;
+      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16;
+      float acc = L[x + i];
+#pragma unroll 4
+      for (int q = 1; q <= d; q++) acc += L[K.l_LD + adr + q] * L[x + tmw_anc(i, q, w1)];
+      (slot ? z1 : z0)[TMW_LI] = acc;
+    }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) { int i = lane + 64 * slot; if (i < K.nv) L[x + i] = (slot ? z1 : z0)[TMW_LI]; }
+  }
+  TMW_SYNC();
+}
+// y = M x
+TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16, nd = m.dof_ndesc[i];
+      float acc = 0.f;
+#pragma unroll 4
+      for (int q = 0; q <= d; q++) acc += L[K.l_M + adr + q] * L[x + tmw_anc(i, q, w1)];
+#pragma unroll 4
+      for (int k = i + 1; k <= i + nd; k++) { int wk = TMW_W0(k); acc += L[K.l_M + (wk & 0xffff) + (wk >> 16) - d] * L[x + k]; }
+      L[y + i] = acc;
+    }
+  }
+  TMW_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ matrix-free J
+TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    for (int l = lane; l < K.nlim; l += 64) L[out + l] = L[K.l_lim_sign + l] * L[v + m.jnt_dofadr[m.lim_jnt[l]]];
+    if (lane < K.ngroup * 6) {  // spatial velocity of each paw body, one lane per (group, component)
+      int g = lane / 6, k = lane - g * 6, ld = tm_f2i(L[K.l_tgrp + 4 * g]);
+      float s = 0.f;
+      if (ld >= 0) {
+        int w1 = TMW_W1(ld), d = TMW_W0(ld) >> 16;
+#pragma unroll 4
+        for (int q = 0; q <= d; q++) { int i = tmw_anc(ld, q, w1); s += L[K.l_cdof + i * 6 + k] * L[v + i]; }
+      }
+      L[K.l_sv + lane] = s;
+    }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    for (int cc = lane; cc < K.ncon; cc += 64) {
+      int r0 = K.nlim + 4 * cc;
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+      if (L[K.l_con_dist + cc] < 0.f) {
+        const float *sv = L + K.l_sv + m.con_grp[cc] * 6, *off = L + K.l_con_off + cc * 3, *fr = L + K.l_con_frame + cc * 9;
+        float cr[3], vel[3];
+        tm_cross(cr, sv, off);
+        for (int k = 0; k < 3; k++) vel[k] = sv[3 + k] + cr[k];
+        float mu = m.con_mu[cc], a0 = tm_dot3(fr, vel), a1 = tm_dot3(fr + 3, vel) * mu, a2 = tm_dot3(fr + 6, vel) * mu;
+        o0 = a0 + a1; o1 = a0 - a1; o2 = a0 + a2; o3 = a0 - a2;
+      }
+      L[out + r0] = o0; L[out + r0 + 1] = o1; L[out + r0 + 2] = o2; L[out + r0 + 3] = o3;
+    }
+  }
+  TMW_SYNC();
+}
+// out = J^T f where f_r = active ? -D_r Jaref_r : 0 is formed on the fly (efc_force is never stored)
+TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    for (int cc = lane; cc < K.ncon; cc += 64) {
+      float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (L[K.l_con_dist + cc] < 0.f) {
+        int r0 = K.nlim + 4 * cc;
+        float f[4];
+        for (int e = 0; e < 4; e++) { float ja = L[K.l_Jaref + r0 + e]; f[e] = ja < 0.f ? -L[K.l_efc_D + r0 + e] * ja : 0.f; }
+        float mu = m.con_mu[cc], c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
+        const float *off = L + K.l_con_off + cc * 3, *fr = L + K.l_con_frame + cc * 9;
+        float F[3], T[3];
+        for (int k = 0; k < 3; k++) F[k] = c0 * fr[k] + c1 * fr[3 + k] + c2 * fr[6 + k];
+        tm_cross(T, off, F);
+        for (int k = 0; k < 3; k++) { w[k] = T[k]; w[3 + k] = F[k]; }
+      }
+      for (int k = 0; k < 6; k++) L[K.l_wr + cc * 6 + k] = w[k];
+    }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    if (lane < K.ngroup * 6) {
+      int g = lane / 6, k = lane - g * 6;
+      float s = 0.f;
+      for (int cc = tm_f2i(L[K.l_tgrp + 4 * g + 1]), ce = cc + tm_f2i(L[K.l_tgrp + 4 * g + 2]); cc < ce; cc++) s += L[K.l_wr + cc * 6 + k];
+      L[K.l_sv + lane] = s;
+    }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      float s = 0.f;
+      int lr = m.dof_limrow[i];
+      if (lr >= 0) { float ja = L[K.l_Jaref + lr]; if (ja < 0.f) s = L[K.l_lim_sign + lr] * (-L[K.l_efc_D + lr] * ja); }
+      for (int g = 0; g < K.ngroup; g++) {  // dof i feels the wrench of paw body g iff i is on the body's dof chain
+        int ld = tm_f2i(L[K.l_tgrp + 4 * g]), w1 = TMW_W1(ld);
+        bool on_chain = (i <= ld && i >= (w1 & 0xff)) || (i < ((w1 >> 8) & 0xff));
+        if (on_chain) { const float *w = L + K.l_sv + g * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
+      }
+      L[out + i] = s;
+    }
+  }
+  TMW_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ make_constraint
+TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    for (int l = lane; l < K.nlim; l += 64) {
+      int j = m.lim_jnt[l];
+      float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
+      float pos = fminf(dmin, dmax) - m.jnt_margin[j];
+      L[K.l_lim_sign + l] = pos < 0.f ? (dmin < dmax ? 1.f : -1.f) : 0.f;
+    }
+  }
+  TMW_SYNC();
+  tmw_jmul(c, K, K.l_qvel, K.l_jv);
+  TMW_FOR {
+    for (int l = lane; l < K.nlim; l += 64) {
+      int j = m.lim_jnt[l];
+      float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
+      float pos = fminf(dmin, dmax) - m.jnt_margin[j], k, b, imp;
+      tm_kbi(m, m.jnt_solref[j], m.jnt_solimp[j], pos, k, b, imp);
+      float Rr = fmaxf(m.dof_invweight0[m.jnt_dofadr[j]] * (1.f - imp) / imp, TM_MINVAL);
+      L[K.l_efc_D + l] = 1.f / Rr;
+      L[K.l_efc_aref + l] = -b * L[K.l_jv + l] - k * imp * pos;
+    }
+    for (int cc = lane; cc < K.ncon; cc += 64) {
+      float k, b, imp, pos = L[K.l_con_dist + cc];
+      tm_kbi(m, m.con_solref[cc], m.con_solimp[cc], pos, k, b, imp);
+      float Rr = fmaxf(m.con_invweight[cc] * (1.f - imp) / imp, TM_MINVAL), D = 1.f / Rr;
+      int r0 = K.nlim + 4 * cc;
+      for (int e = 0; e < 4; e++) { L[K.l_efc_D + r0 + e] = D; L[K.l_efc_aref + r0 + e] = -b * L[K.l_jv + r0 + e] - k * imp * pos; }
+    }
+  }
+  TMW_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ CG solver
+TM_DEV float tmw_dot(WCtx &c, const WLayout &K, int a, int b) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_REG(float, p);
+  TMW_FOR { float s = 0.f; for (int i = lane; i < K.nv; i += 64) s += L[a + i] * L[b + i]; p[TMW_LI] = s; }
+  return tmw_sum(p);
+}
+// Jaref <- J q - aref ; Ma <- M q ; returns cost and gauss for qacc vector `q`
+TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  tmw_mul_m(c, K, q, K.l_Ma);
+  tmw_jmul(c, K, q, K.l_Jaref);
+  TMW_REG(float, pc); TMW_REG(float, pg);
+  TMW_FOR {
+    float sc = 0.f, sg = 0.f;
+    for (int e = lane; e < K.nefc; e += 64) {
+      float ja = L[K.l_Jaref + e] - L[K.l_efc_aref + e];
+      L[K.l_Jaref + e] = ja;
+      if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja;
+    }
+    for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - L[K.l_qfrc_smooth + i]) * (L[q + i] - L[K.l_qacc_smooth + i]);
+    pc[TMW_LI] = sc; pg[TMW_LI] = sg;
+  }
+  TMW_SYNC();
+  gauss = 0.5f * tmw_sum(pg);
+  return 0.5f * tmw_sum(pc) + gauss;
+}
+// cost/gauss from the current Jaref, Ma, qacc (no mat-vecs)
+TM_DEV float tmw_cost_from_state(WCtx &c, const WLayout &K, float &gauss) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_REG(float, pc); TMW_REG(float, pg);
+  TMW_FOR {
+    float sc = 0.f, sg = 0.f;
+    for (int e = lane; e < K.nefc; e += 64) { float ja = L[K.l_Jaref + e]; if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja; }
+    for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - L[K.l_qfrc_smooth + i]) * (L[K.l_qacc + i] - L[K.l_qacc_smooth + i]);
+    pc[TMW_LI] = sc; pg[TMW_LI] = sg;
+  }
+  gauss = 0.5f * tmw_sum(pg);
+  return 0.5f * tmw_sum(pc) + gauss;
+}
+TM_DEV void tmw_update_gradient(WCtx &c, const WLayout &K) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  tmw_jt_force(c, K, K.l_qfrc_constraint);
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      float g = L[K.l_Ma + i] - L[K.l_qfrc_smooth + i] - L[K.l_qfrc_constraint + i];
+      L[K.l_grad + i] = g; L[K.l_Mgrad + i] = g;
+    }
+  }
+  TMW_SYNC();
+  tmw_solve(c, K, K.l_Mgrad);
+}
+struct TmwLS { float alpha, cost, d0, d1; };
+// three line-search points evaluated together (alphas a[0..2]): 9 partial sums, one pass over the rows
+TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const float *a, int np, float g0, float g1, float g2, TmwLS *out) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  float q[TMW_NL][9];
+  TMW_FOR {
+    float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = lane; e < K.nefc; e += 64) {
+      float ja = L[K.l_Jaref + e], jv = L[K.l_jv + e], D = L[K.l_efc_D + e];
+      float t0 = 0.5f * ja * ja * D, t1 = jv * ja * D, t2 = 0.5f * jv * jv * D;
+      for (int p = 0; p < 3; p++) if (p < np && ja + a[p] * jv < 0.f) { s[3 * p] += t0; s[3 * p + 1] += t1; s[3 * p + 2] += t2; }
+    }
+    for (int k = 0; k < 9; k++) q[TMW_LI][k] = s[k];
+  }
+  for (int p = 0; p < np; p++) {
+    TMW_REG(float, t);
+    float qq[3];
+    for (int k = 0; k < 3; k++) { TMW_FOR { t[TMW_LI] = q[TMW_LI][3 * p + k]; } qq[k] = tmw_sum(t); }
+    float q0 = g0 + qq[0], q1 = g1 + qq[1], q2 = g2 + qq[2], al = a[p];
+    out[p].alpha = al;
+    out[p].cost = al * al * q2 + al * q1 + q0;
+    out[p].d0 = 2.f * al * q2 + q1;
+    out[p].d1 = 2.f * q2 + (q2 == 0.f ? TM_MINVAL : 0.f);
+  }
+}
+TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  float scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
+  float smag = sqrtf(tmw_dot(c, K, K.l_search, K.l_search)) * scale;
+  float gtol = m.tolerance * m.ls_tolerance * smag;
+  tmw_mul_m(c, K, K.l_search, K.l_mv);
+  tmw_jmul(c, K, K.l_search, K.l_jv);
+  float g0 = gauss, g1 = tmw_dot(c, K, K.l_search, K.l_Ma) - tmw_dot(c, K, K.l_search, K.l_qfrc_smooth), g2 = 0.5f * tmw_dot(c, K, K.l_search, K.l_mv);
+  TmwLS pt[3];
+  float al[3] = {0.f, 0.f, 0.f};
+  tmw_ls_points(c, K, al, 1, g0, g1, g2, pt);
+  TmwLS p0 = pt[0];
+  al[0] = p0.alpha - p0.d0 / p0.d1;
+  tmw_ls_points(c, K, al, 1, g0, g1, g2, pt);
+  TmwLS lo0 = pt[0];
+  bool lesser = lo0.d0 < p0.d0;
+  TmwLS hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
+  bool swap = true;
+  for (int it = 0; it < m.ls_iterations; it++) {
+    bool done = !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
+    if (done) break;
+    al[0] = lo.alpha - lo.d0 / lo.d1; al[1] = hi.alpha - hi.d0 / hi.d1; al[2] = 0.5f * (lo.alpha + hi.alpha);
+    tmw_ls_points(c, K, al, 3, g0, g1, g2, pt);
+    TmwLS lo_next = pt[0], hi_next = pt[1], mid = pt[2];
+    bool s1 = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
+    if (s1) lo = lo_next;
+    bool s2 = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
+    if (s2) lo = mid;
+    bool s3 = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
+    if (s3) hi = hi_next;
+    bool s4 = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
+    if (s4) hi = mid;
+    swap = s1 || s2 || s3 || s4;
+  }
+  bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+  float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  float ia = improved ? alpha : 0.f;
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] += L[K.l_search + i] * ia; L[K.l_Ma + i] += L[K.l_mv + i] * ia; }
+    for (int e = lane; e < K.nefc; e += 64) L[K.l_Jaref + e] += L[K.l_jv + e] * ia;
+  }
+  TMW_SYNC();
+}
+TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  float gauss, scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc + i] = L[K.l_warm + i]; }
+  TMW_SYNC();
+  float cw = tmw_eval_cost(c, K, K.l_qacc, gauss);
+  float cs = tmw_eval_cost(c, K, K.l_qacc_smooth, gauss);
+  float cost;
+  if (cw < cs) cost = tmw_eval_cost(c, K, K.l_qacc, gauss);
+  else {
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc + i] = L[K.l_qacc_smooth + i]; }
+    TMW_SYNC();
+    cost = cs;
+  }
+  float prev_cost = INFINITY;
+  tmw_update_gradient(c, K);
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_search + i] = -L[K.l_Mgrad + i]; }
+  TMW_SYNC();
+  TMW_TICK(6);
+  for (int it = 0; it < m.iterations; it++) {
+    if (m.iterations != 1) {
+      float improvement = (prev_cost - cost) / scale;
+      float gradient = sqrtf(tmw_dot(c, K, K.l_grad, K.l_grad)) / scale;
+      if (improvement < m.tolerance || gradient < m.tolerance) break;
+    }
+    tmw_linesearch(c, K, gauss);
+    TMW_TICK(7);
+    float den = tmw_dot(c, K, K.l_grad, K.l_Mgrad);
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_Mgrad + i]; }
+    TMW_SYNC();
+    prev_cost = cost;
+    cost = tmw_cost_from_state(c, K, gauss);
+    tmw_update_gradient(c, K);
+    TMW_REG(float, pn);
+    TMW_FOR { float s = 0.f; for (int i = lane; i < K.nv; i += 64) s += L[K.l_grad + i] * (L[K.l_Mgrad + i] - L[K.l_tmp + i]); pn[TMW_LI] = s; }
+    float beta = fmaxf(0.f, tmw_sum(pn) / fmaxf(TM_MINVAL, den));
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_search + i] = -L[K.l_Mgrad + i] + beta * L[K.l_search + i]; }
+    TMW_SYNC();
+    TMW_TICK(8);
+  }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_warm + i] = L[K.l_qacc + i]; }
+  TMW_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ forward / euler
+TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_TICK(12);
+  tmw_position(c, K, emit);
+  TMW_TICK(0);
+  tmw_velocity_inertia(c, K);
+  TMW_TICK(1);
+  tmw_factor(c, K, 0.f);
+  TMW_TICK(2);
+  tmw_invert_l(c, K);
+  TMW_TICK(3);
+  tmw_make_constraint(c, K);
+  TMW_TICK(4);
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = L[K.l_qfrc_smooth + i]; }
+  TMW_SYNC();
+  tmw_solve(c, K, K.l_qacc_smooth);
+  TMW_TICK(5);
+  tmw_solve_cg(c, K);
+}
+TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  float h = m.timestep;
+  // qfrc_constraint of the final iterate is in LDS (last tmw_update_gradient); keep the rhs out of the LD alias
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_qfrc_smooth + i] + L[K.l_qfrc_constraint + i]; }
+  TMW_SYNC();
+  TMW_TICK(8);
+  tmw_factor(c, K, h);
+  TMW_TICK(9);
+  tmw_invert_l(c, K);
+  TMW_TICK(10);
+  tmw_solve(c, K, K.l_tmp);
+  TMW_TICK(11);
+  TMW_FOR {
+    for (int a = lane; a < K.nu; a += 64) L[K.l_act + a] += L[K.l_act_dot + a] * h;
+    for (int i = lane; i < K.nv; i += 64) L[K.l_qvel + i] += L[K.l_tmp + i] * h;
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    for (int j = lane; j < K.njnt; j += 64) {
+      int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+      if (m.jnt_type[j] == 0) {
+        for (int k = 0; k < 3; k++) L[K.l_qpos + qa + k] += h * L[K.l_qvel + da + k];
+        float v[3] = {L[K.l_qvel + da + 3], L[K.l_qvel + da + 4], L[K.l_qvel + da + 5]}, q[4], qr[4], q2[4];
+        for (int k = 0; k < 4; k++) q[k] = L[K.l_qpos + qa + 3 + k];
+        float nn = tm_normalize3(v), ang = h * nn * 0.5f, sn = sinf(ang), cs = cosf(ang);
+        qr[0] = cs; qr[1] = v[0] * sn; qr[2] = v[1] * sn; qr[3] = v[2] * sn;
+        tm_quat_mul(q2, q, qr);
+        tm_normalize4(q2);
+        for (int k = 0; k < 4; k++) L[K.l_qpos + qa + 3 + k] = q2[k];
+      } else {
+        L[K.l_qpos + qa] += h * L[K.l_qvel + da];
+      }
+    }
+  }
+  TMW_SYNC();
+  return time + h;
+}
+
+// ------------------------------------------------------------------------------------------ debug dump (tests)
+// copies solver-stage intermediates of the last forward from LDS to the lane-per-env workspace rows so that the same
+// named arrays (tmjx_debug_rows) can be compared with the oracle; never called on the timed path
+TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+#define WDUMP(row, i) ws[(size_t)((row) + (i)) * (size_t)c.n + (size_t)c.e]
+  TMW_FOR {
+    for (int i = lane; i < K.nnz; i += 64) WDUMP(m.w_M, i) = L[K.l_M + i];
+    for (int i = lane; i < K.nv * 6; i += 64) WDUMP(m.w_cdof, i) = L[K.l_cdof + i];
+    for (int i = lane; i < K.nv; i += 64) {
+      WDUMP(m.w_qfrc_smooth, i) = L[K.l_qfrc_smooth + i]; WDUMP(m.w_qacc_smooth, i) = L[K.l_qacc_smooth + i];
+      WDUMP(m.w_qacc, i) = L[K.l_qacc + i]; WDUMP(m.w_qfrc_constraint, i) = L[K.l_qfrc_constraint + i];
+    }
+    for (int i = lane; i < K.ncon; i += 64) WDUMP(m.w_con_dist, i) = L[K.l_con_dist + i];
+    for (int i = lane; i < K.ncon * 9; i += 64) WDUMP(m.w_con_frame, i) = L[K.l_con_frame + i];
+    for (int i = lane; i < K.nefc; i += 64) {
+      WDUMP(m.w_efc_D, i) = L[K.l_efc_D + i]; WDUMP(m.w_efc_aref, i) = L[K.l_efc_aref + i];
+      float ja = L[K.l_Jaref + i];
+      WDUMP(m.w_efc_force, i) = ja < 0.f ? -L[K.l_efc_D + i] * ja : 0.f;
+    }
+    if (lane < 3) WDUMP(m.w_com, lane) = L[K.l_com + lane];
+  }
+#undef WDUMP
+  TMW_SYNC();
+}

@@ -12,7 +12,7 @@ import subprocess
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-SO_PATH = _PKG / "libtmjx_hip.so"
+SO_PATH = Path(os.environ.get("TMJX_SO", str(_PKG / "libtmjx_hip.so")))  # TMJX_SO: alternative build (profiling)
 CSRC = _PKG / "csrc"
 
 
