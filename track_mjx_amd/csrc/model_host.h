@@ -283,7 +283,7 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
     while (sgm > 0 && m.dof_parentid[sgm] == sgm - 1) sgm--;
     int jump = m.dof_parentid[sgm];
     m.tdof[2 * i] = m.dof_Madr[i] | (m.dof_depth[i] << 16);
-    m.tdof[2 * i + 1] = sgm | ((jump + 1) << 8);
+    m.tdof[2 * i + 1] = sgm | ((jump + 1) << 8) | (m.dof_ndesc[i] << 16);
     int r = i - sgm;
     for (int q = 0; q <= m.dof_depth[i]; q++) {
       int a = q <= r ? i - q : jump + 1 + r - q;

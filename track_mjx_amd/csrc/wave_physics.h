@@ -48,8 +48,10 @@ struct WCtx {
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
+#define TMW_TICK2(idx) TMW_TICK(idx)
 #else
 #define TMW_TICK(idx) do { } while (0)
+#define TMW_TICK2(idx) do { } while (0)
 #endif
 #define WST(off, i) c.st[(size_t)((off) + (i)) * (size_t)c.n + (size_t)c.e]
 
@@ -447,7 +449,13 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
 
 // ------------------------------------------------------------------------------------------ factorisation, L^-1, solves
 // LD <- L^T D L of (M + hdamp diag(damping)); pivots leaf -> root; lane q owns column q of pivot row k
-TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp) {
+// LD <- L^T D L of (M + hdamp diag(damping)), LEFT-LOOKING: rows are finished leaf -> root; row i gathers, in registers,
+// the rank-1 contributions of all its (already final) descendant rows k:  row_i -= (M'(k,i) / D_k) * M'(k, anc(i)).
+// Lane q owns column q of row i; lane t pre-computes multiplier and row address of descendant t, the inner loop fetches
+// them with scalar readlanes: per (row, descendant) pair one LDS read and one FMA per lane, no LDS write, no masks.
+// `rhs` >= 0: an LDS vector eliminated alongside (x <- L^-T x, the leaf -> root sweep of mj_solveLD), so that one more
+// root -> leaf pass (tmw_subst_down) completes (M + hD)^-1 rhs without inverting L.
+TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     for (int i = lane; i < K.nnz; i += 64) L[K.l_LD + i] = L[K.l_M + i];
@@ -457,79 +465,117 @@ TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp) {
     TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_LD + m.dof_Madr[i]] += hdamp * m.dof_damping[i]; }
     TMW_SYNC();
   }
-  TMW_REG(float, x); TMW_REG(float, arow);
-  for (int k = K.nv - 1; k >= 0; k--) {
-    int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = w0k & 0xffff, d = w0k >> 16;
+  TMW_REG(float, a0); TMW_REG(float, a1); TMW_REG(float, b0); TMW_REG(float, b1); TMW_REG(float, acc); TMW_REG(float, pr);
+  for (int i = K.nv - 1; i >= 0; i--) {
+    int w0 = TMW_W0(i), adr = w0 & 0xffff, d = w0 >> 16, nd = (TMW_W1(i) >> 16) & 0xff;
     TMW_FOR {
-      x[TMW_LI] = (lane <= d) ? L[K.l_LD + ak + lane] : 0.f;
-      // lane q also keeps the row address of the q-th ancestor; the pivot loop fetches it with a scalar readlane
-      arow[TMW_LI] = (lane <= d) ? tm_i2f(TMW_W0(tmw_anc(k, lane, w1k)) & 0xffff) : 0.f;
-    }
-    float inv = 1.f / tmw_readlane(x, 0);
-    // ancestors in chunks of 8: the 8 LDS reads of a chunk are issued back to back (their rows are distinct, which the
-    // compiler cannot know), then the 8 FMAs, then the 8 writes — one LDS round trip per chunk instead of per ancestor
-    for (int mm0 = 1; mm0 <= d; mm0 += 8) {
-      float a[8]; int ai[8];
+      float rsum = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        int mc = mm0 + u <= d ? mm0 + u : d;
-        a[u] = tmw_readlane(x, mc) * inv;
-        ai[u] = tm_f2i(tmw_readlane(arow, mc)) - (mm0 + u);
-      }
-      TMW_FOR {
-        // branch-free: masked-off (lane, ancestor) pairs read and re-write the lane's private sink word instead
-        float v[8]; int ad[8]; bool ok[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          ok[u] = mm0 + u <= d && lane >= mm0 + u && lane <= d;
-          ad[u] = ok[u] ? K.l_LD + ai[u] + lane : K.l_dummy + lane;
+      for (int slot = 0; slot < 2; slot++) {
+        int t = lane + 64 * slot;
+        float a = 0.f; int base = K.l_LD;
+        if (t < nd) {
+          // farthest descendant first: the small contributions of the leaves are summed before the large ones of the
+          // near descendants (same order as the right-looking elimination; measurably more accurate in fp32)
+          int kk = i + nd - t, wk = TMW_W0(kk);
+          base = K.l_LD + (wk & 0xffff) + (wk >> 16) - d;      // M'(k, i) sits at Madr_k + depth_k - depth_i
+          a = L[base] * L[K.l_Dinv + kk];                       // = L(k, i)
+          if (rhs >= 0) rsum += a * L[rhs + kk];
         }
+        (slot ? a1 : a0)[TMW_LI] = a; (slot ? b1 : b0)[TMW_LI] = tm_i2f(base);
+      }
+      acc[TMW_LI] = (lane <= d) ? L[K.l_LD + adr + lane] : 0.f;
+      pr[TMW_LI] = rsum;
+    }
+    TMW_TICK2(13);
+    if (rhs >= 0 && nd > 0) { float s = tmw_sum(pr); TMW_FOR { if (lane == 0) L[rhs + i] -= s; } }
+    for (int slot = 0; slot < 2; slot++) {       // descendants 0..63 live in (a0, b0), 64.. in (a1, b1): no per-item select
+      const float *ar = slot ? a1 : a0, *br = slot ? b1 : b0;
+      int cnt = nd - 64 * slot; if (cnt > 64) cnt = 64;
+      for (int t0 = 0; t0 < cnt; t0 += 8) {
+        float a[8]; int bb[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = L[ad[u]];
+        for (int u = 0; u < 8; u++) {             // t >= cnt within the last chunk: multiplier 0, address = start of LD
+          int t = t0 + u < 64 ? t0 + u : 63;    // lanes t >= cnt hold multiplier 0 and a valid address: no branch needed
+          a[u] = tmw_readlane(ar, t);
+          bb[u] = tm_f2i(tmw_readlane(br, t));
+        }
+        TMW_FOR {
+          float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) L[ad[u]] = ok[u] ? v[u] - a[u] * x[TMW_LI] : 0.f;
+          for (int u = 0; u < 8; u++) v[u] = L[bb[u] + lane];
+          float s = acc[TMW_LI];
+#pragma unroll
+          for (int u = 0; u < 8; u++) s -= a[u] * v[u];
+          acc[TMW_LI] = s;
+        }
       }
     }
+    TMW_TICK2(14);
+    float inv = 1.f / tmw_readlane(acc, 0);
     TMW_FOR {
-      if (lane >= 1 && lane <= d) L[K.l_LD + ak + lane] = x[TMW_LI] * inv;
-      if (lane == 0) L[K.l_Dinv + k] = inv;
+      if (lane <= d) L[K.l_LD + adr + lane] = acc[TMW_LI];
+      if (lane == 0) L[K.l_Dinv + i] = inv;
     }
+    TMW_SYNC();
+    TMW_TICK2(15);
+  }
+  // rows still hold M' = D L: scale the strict part to the unit-lower L
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      int w0 = TMW_W0(i), adr = w0 & 0xffff, d = w0 >> 16;
+      float inv = L[K.l_Dinv + i];
+      for (int q = 1; q <= d; q++) L[K.l_LD + adr + q] *= inv;
+    }
+  }
+  TMW_SYNC();
+}
+// root -> leaf pass after tmw_factor(.., rhs): x_i <- x_i / D_i - sum_q L(i,q) x_anc_q(i)   (ancestors are final first)
+TM_DEV void tmw_subst_down(WCtx &c, const WLayout &K, int x) {
+  float *L = c.L; TMW_LANE_DECL
+  TMW_REG(float, t);
+  for (int i = 0; i < K.nv; i++) {
+    int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16;
+    TMW_FOR { t[TMW_LI] = (lane >= 1 && lane <= d) ? L[K.l_LD + adr + lane] * L[x + tmw_anc(i, lane, w1)] : 0.f; }
+    float s = d > 0 ? tmw_sum(t) : 0.f;
+    TMW_FOR { if (lane == 0) L[x + i] = L[x + i] * L[K.l_Dinv + i] - s; }
     TMW_SYNC();
   }
 }
-// in place: strict part of every row of LD becomes the corresponding row of L^-1 (same ancestor sparsity)
+// in place: strict part of every row of LD becomes the corresponding row of N = L^-1 (same ancestor sparsity), rows
+// root -> leaf:  N(k,q) = -( L(k,q) + sum_{m<q} L(k,m) N(anc_m, q-m) ).  Lane q owns column q; lane m pre-computes the
+// row address of ancestor m; the loop over m is scalar-broadcast (readlane), one LDS read + one FMA per lane per m.
 TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
-  TMW_REG(float, x); TMW_REG(float, arow);
+  float *L = c.L; TMW_LANE_DECL
+  TMW_REG(float, x); TMW_REG(float, arow); TMW_REG(float, acc);
   for (int k = 1; k < K.nv; k++) {
     int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = w0k & 0xffff, d = w0k >> 16;
     if (d == 0) continue;
     TMW_FOR {
-      x[TMW_LI] = (lane >= 1 && lane <= d) ? L[K.l_LD + ak + lane] : 0.f;
-      arow[TMW_LI] = (lane <= d) ? tm_i2f(TMW_W0(tmw_anc(k, lane, w1k)) & 0xffff) : 0.f;
+      float xv = (lane >= 1 && lane <= d) ? L[K.l_LD + ak + lane] : 0.f;
+      x[TMW_LI] = (lane < d) ? xv : 0.f;   // multipliers L(k,m), m < d only (lane d contributes nothing: zero, no branch)
+      acc[TMW_LI] = xv;
+      // address such that  L[arow_m + lane]  is entry (lane - m) of ancestor m's row
+      int am = tmw_anc(k, lane <= d ? lane : 0, w1k);
+      arow[TMW_LI] = tm_i2f(K.l_LD + (TMW_W0(am) & 0xffff) - lane);
     }
-    TMW_REG(float, acc);
-    TMW_FOR { acc[TMW_LI] = x[TMW_LI]; }
-    for (int mm0 = 1; mm0 < d; mm0 += 8) {
-      float lm[8]; int ai[8];
+    for (int m0 = 1; m0 < d; m0 += 8) {
+      float lm[8]; int ab[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        int mc = mm0 + u < d ? mm0 + u : d - 1;
+        int mc = m0 + u < 64 ? m0 + u : 63;
         lm[u] = tmw_readlane(x, mc);
-        ai[u] = tm_f2i(tmw_readlane(arow, mc)) - (mm0 + u);
+        ab[u] = tm_f2i(tmw_readlane(arow, mc));
       }
       TMW_FOR {
-        float v[8]; int ad[8]; bool ok[8];
+        float v[8]; int ad[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          ok[u] = mm0 + u < d && lane > mm0 + u && lane <= d;
-          ad[u] = ok[u] ? K.l_LD + ai[u] + lane : K.l_dummy + lane;
-        }
+        for (int u = 0; u < 8; u++) ad[u] = lane > m0 + u ? ab[u] + lane : K.l_dummy + lane;   // q <= m: not a column of that row
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = L[ad[u]];
         float s = acc[TMW_LI];
 #pragma unroll
-        for (int u = 0; u < 8; u++) s += ok[u] ? lm[u] * v[u] : 0.f;
+        for (int u = 0; u < 8; u++) s += lane > m0 + u ? lm[u] * v[u] : 0.f;
         acc[TMW_LI] = s;
       }
     }
@@ -899,11 +945,9 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_qfrc_smooth + i] + L[K.l_qfrc_constraint + i]; }
   TMW_SYNC();
   TMW_TICK(8);
-  tmw_factor(c, K, h);
+  tmw_factor(c, K, h, K.l_tmp);
   TMW_TICK(9);
-  tmw_invert_l(c, K);
-  TMW_TICK(10);
-  tmw_solve(c, K, K.l_tmp);
+  tmw_subst_down(c, K, K.l_tmp);
   TMW_TICK(11);
   TMW_FOR {
     for (int a = lane; a < K.nu; a += 64) L[K.l_act + a] += L[K.l_act_dot + a] * h;
