@@ -80,9 +80,10 @@ int tmjx_forward(tmjx_model *m, float *state, float *workspace, int n_env, void 
 
 /* K3 alone: everything in step() except the physics substeps: frame index, clip gather, rewards,
  * observation, done/NaN guard, episode + auto-reset wrappers (task/single_clip_tracking.py:220-320,
- * task/reward.py:359-485, wrappers.py:104-144). */
+ * task/reward.py:359-485, wrappers.py:104-144).
+ * `workspace` (>= 2*nu rows) receives the per-(action dim, env) window partials; NULL computes them inline. */
 int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward,
-                    float *done, float *truncation, float *metrics, int n_env, void *stream);
+                    float *done, float *truncation, float *metrics, float *workspace, int n_env, void *stream);
 
 /* GAE reverse scan: compute_gae (track_mjx/agent/mlp_ppo/losses.py:39-100). All arrays [T][B] row-major
  * (B contiguous), bootstrap [B]; outputs vs, advantages [T][B]. */

@@ -103,8 +103,30 @@ TM_DEV void tm_step_prologue(const DModel &m, EnvRef r) {
   if (ST(m.s_done, 0) != 0.f) ST(m.s_steps, 0) = 0.f;
   ST(m.s_done, 0) = 0.f;
 }
+// Windowed action statistics of ONE action dimension i of one env (reward.py:314-356): writes the action into the ring
+// buffer row `bi`, then returns the variance term and the jerk term of column i with the advanced index.
+TM_DEV void tm_window_dim(const DModel &m, EnvRef r, int i, int bi, float a, float &var_i, float &jerk_i) {
+  int nu = m.nu, W = m.window;
+  ST(m.s_action_buffer, bi * nu + i) = a;
+  bi = (bi + 1) % W;
+  float mean = 0.f, var = 0.f, jerk = 0.f;
+  for (int rr = 0; rr < W; rr++) mean += ST(m.s_action_buffer, rr * nu + i);
+  mean /= (float)W;
+  for (int rr = 0; rr < W; rr++) { float df = ST(m.s_action_buffer, rr * nu + i) - mean; var += df * df; }
+  int i0 = bi % W, i1 = (bi + 1) % W;
+  float o0 = ST(m.s_action_buffer, i0 * nu + i), o1 = ST(m.s_action_buffer, i1 * nu + i);
+  for (int rr = 0; rr + 2 < W; rr++) {
+    int i2 = (bi + rr + 2) % W;
+    float o2 = ST(m.s_action_buffer, i2 * nu + i), j = o2 - 2.f * o1 + o0;
+    jerk += j * j;
+    o0 = o1; o1 = o2;
+  }
+  var_i = var / (float)W; jerk_i = jerk;
+}
+// `win`: per-(dim, env) partials [2*nu][n] produced by the (env x action-dim)-parallel window kernel, or nullptr to
+// compute the window terms inline (lane-per-env path).
 TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *action, float *obs, float *reward, float *done_out,
-                         float *trunc_out, float *metrics) {
+                         float *trunc_out, float *metrics, const float *win = nullptr) {
   int nu = m.nu, W = m.window, nj = m.nq - 7, nbp = m.nbody - 1;
   int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame), bi = IS(m.i_buffer_index);
   int frame = tm_cur_frame(m, ST(m.s_time, 0), start);
@@ -117,11 +139,11 @@ TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *acti
   for (int i = 0; i < nu; i++) {
     float a = OUTROW(action, i);
     ST(m.s_prev_ctrl, i) = a;
-    ST(m.s_action_buffer, bi * nu + i) = a;
     ctrl_sq += a * a;
     float df = a - a;  // prev_ctrl == action at this point (reference quirk); keeps NaN/inf propagation
     ctrl_diff += df * df;
   }
+  int bi_old = bi;
   bi = (bi + 1) % W;
   IS(m.i_buffer_index) = bi;
   float pd[3], s = 0.f;
@@ -165,19 +187,10 @@ TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *acti
   // action-variance and jerk costs over the ring buffer (reward.py:314-356)
   float var_sum = 0.f, jerk = 0.f;
   for (int i = 0; i < nu; i++) {
-    float mean = 0.f, var = 0.f;
-    for (int rr = 0; rr < W; rr++) mean += ST(m.s_action_buffer, rr * nu + i);
-    mean /= (float)W;
-    for (int rr = 0; rr < W; rr++) { float df = ST(m.s_action_buffer, rr * nu + i) - mean; var += df * df; }
-    var_sum += var / (float)W;
-    int i0 = bi % W, i1 = (bi + 1) % W;
-    float o0 = ST(m.s_action_buffer, i0 * nu + i), o1 = ST(m.s_action_buffer, i1 * nu + i);
-    for (int rr = 0; rr + 2 < W; rr++) {
-      int i2 = (bi + rr + 2) % W;
-      float o2 = ST(m.s_action_buffer, i2 * nu + i), j = o2 - 2.f * o1 + o0;
-      jerk += j * j;
-      o0 = o1; o1 = o2;
-    }
+    float vi, ji;
+    if (win) { vi = OUTROW(win, i); ji = OUTROW(win, nu + i); }
+    else tm_window_dim(m, r, i, bi_old, OUTROW(action, i), vi, ji);
+    var_sum += vi; jerk += ji;
   }
   float var_cost = w[RW_VAR_COEFF] * var_sum, jerk_cost = w[RW_JERK_COEFF] * jerk;
   tm_get_obs(m, r, clip, frame, obs, true);

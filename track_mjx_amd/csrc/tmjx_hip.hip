@@ -65,14 +65,25 @@ __global__ void k_physics(const DModel *__restrict__ mp, float *st, const float 
   for (int f = 0; f < nsub; f++) { tm_forward(m, r); if (do_euler) tm_euler(m, r); }
 }
 
+// window statistics, one lane per (action dim, env): 38x more parallelism than lane-per-env for the 50x38 ring buffer
+__global__ void k_window(const DModel *__restrict__ mp, float *st, const int *is, const float *action, float *win, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, nullptr, n, e};
+  float vi, ji;
+  tm_window_dim(m, r, i, is[(size_t)m.i_buffer_index * n + e], action[(size_t)i * n + e], vi, ji);
+  win[(size_t)i * n + e] = vi;
+  win[(size_t)(m.nu + i) * n + e] = ji;
+}
 __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const float *action, float *obs, float *reward,
-                       float *done, float *trunc, float *metrics, int n) {
+                       float *done, float *trunc, float *metrics, const float *win, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const DModel &m = *mp;
   EnvRef r{st, nullptr, n, e};
   tm_step_prologue(m, r);
-  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics);
+  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win);
 }
 
 // K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
@@ -251,8 +262,10 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
   if (m->wave) {
     launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_window, dim3((n_env + 255) / 256, m->h.nu), dim3(256), 0, (hipStream_t)stream, m->d, state, istate, action,
+                       workspace, n_env);
     hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
-                       metrics, n_env);
+                       metrics, (const float *)workspace, n_env);
     return check_launch("k_step(wave)");
   }
   hipLaunchKernelGGL(k_step, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
@@ -283,12 +296,16 @@ int tmjx_forward(tmjx_model *m, float *state, float *workspace, int n_env, void 
 }
 
 int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
-                    float *truncation, float *metrics, int n_env, void *stream) {
+                    float *truncation, float *metrics, float *workspace, int n_env, void *stream) {
   if (!m || !state || !istate || !action || !obs || !reward || !done || !truncation || !metrics) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
+  if (workspace) {
+    hipLaunchKernelGGL(k_window, dim3((n_env + 255) / 256, m->h.nu), dim3(256), 0, (hipStream_t)stream, m->d, state, istate, action,
+                       workspace, n_env);
+  }
   hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
-                     metrics, n_env);
+                     metrics, (const float *)workspace, n_env);
   return check_launch("k_post");
 }
 

@@ -248,7 +248,7 @@ class MultiClipTracking:
         with torch.cuda.device(self.device):
             _hip.check(self._L.tmjx_reward_obs(self._handle, _ptr(self.state_buf), _ptr(self.istate_buf), _ptr(action_rows),
                                                _ptr(self.obs_buf), _ptr(self.reward_buf), _ptr(self.done_buf), _ptr(self.trunc_buf),
-                                               _ptr(self.metrics_buf), self.num_envs, self._stream()), "tmjx_reward_obs")
+                                               _ptr(self.metrics_buf), _ptr(self.workspace), self.num_envs, self._stream()), "tmjx_reward_obs")
         return self._state()
 
     def rows(self, name: str) -> torch.Tensor:

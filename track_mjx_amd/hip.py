@@ -68,7 +68,7 @@ def lib():
     L.tmjx_step.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
     L.tmjx_physics.argtypes = [vp, fp, fp, C.c_int, fp, C.c_int, vp]
     L.tmjx_forward.argtypes = [vp, fp, fp, C.c_int, vp]
-    L.tmjx_reward_obs.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
+    L.tmjx_reward_obs.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
     L.tmjx_gae.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, vp]
     L.tmjx_debug_rows.argtypes = [vp, C.c_char_p, ip, ip]
     L.tmjx_last_error.restype = C.c_char_p
