@@ -274,7 +274,7 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
 }
 
 int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substeps, float *workspace, int n_env, void *stream) {
-  if (!m || !state || !workspace) return fail(TMJX_EINVAL, "null argument");
+  if (!m || !state || (!workspace && !m->wave)) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1 || n_substeps < 0) return fail(TMJX_EINVAL, "bad n_env / n_substeps");
   if (m->wave) {
     launch_wave(m, state, action, n_substeps, 1, workspace, n_env, (hipStream_t)stream);

@@ -102,6 +102,7 @@ class MultiClipTracking:
         self._n_clips = int(reference_clip.position.shape[0]) if reference_clip is not None else 0
         self._L = _hip.lib()  # raises loudly if the HIP extension is missing
         self._handle = C.c_void_p()
+        self._physics_events = None   # list => step() records (start, end) HIP events around the physics kernel
         self._episode_length = int(episode_length) if episode_length is not None else (1 << 30)
         self._auto_reset = bool(auto_reset)
         self._create_handle()
@@ -226,6 +227,20 @@ class MultiClipTracking:
         else:
             raise ValueError(f"action must be [{n},{L.nu}] or [{L.nu},{n}]")
         a = a.to(device=self.device, dtype=torch.float32)
+        if self._physics_events is not None:
+            # measurement mode (bench.py): the same kernels as tmjx_step, issued as K2 then K3 so that HIP events on the
+            # launch stream bracket the physics kernel alone
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.device(self.device):
+                e0.record(torch.cuda.current_stream(self.device))
+                _hip.check(self._L.tmjx_physics(self._handle, _ptr(self.state_buf), _ptr(a), self._n_frames, None, n, self._stream()), "tmjx_physics")
+                e1.record(torch.cuda.current_stream(self.device))
+                _hip.check(self._L.tmjx_reward_obs(self._handle, _ptr(self.state_buf), _ptr(self.istate_buf), _ptr(a), _ptr(self.obs_buf),
+                                                   _ptr(self.reward_buf), _ptr(self.done_buf), _ptr(self.trunc_buf), _ptr(self.metrics_buf),
+                                                   _ptr(self.workspace), n, self._stream()), "tmjx_reward_obs")
+            self._physics_events.append((e0, e1))
+            self._keep_a = a
+            return self._state()
         with torch.cuda.device(self.device):
             _hip.check(self._L.tmjx_step(self._handle, _ptr(self.state_buf), _ptr(self.istate_buf), _ptr(a), _ptr(self.obs_buf),
                                          _ptr(self.reward_buf), _ptr(self.done_buf), _ptr(self.trunc_buf), _ptr(self.metrics_buf),
