@@ -280,3 +280,15 @@ def test_error_paths():
     h = C.c_void_p()
     assert hip.lib().tmjx_model_create(b"garbage", 7, C.byref(h)) != 0
     assert b"" != hip.lib().tmjx_last_error()
+
+
+def test_train_entrypoint_smoke():
+    """python -m track_mjx_amd.train key=value ... (mirror of track_mjx/train.py:56) runs one PPO training step."""
+    from track_mjx_amd import train
+    overrides = ["train_setup.train_config.num_envs=256", "train_setup.train_config.batch_size=64",
+                 "train_setup.train_config.num_minibatches=4", "train_setup.train_config.unroll_length=5",
+                 "train_setup.train_config.num_updates_per_batch=2", "network_config.encoder_layer_sizes=[64,64]",
+                 "network_config.decoder_layer_sizes=[64,64]", "network_config.critic_layer_sizes=[64,64]",
+                 "train_setup.train_config.num_timesteps=100000", "train_setup.eval_every=50000", "train_setup.reset_every=50000",
+                 "max_training_steps=2", "n_synthetic_clips=4"]
+    train.main(overrides)
