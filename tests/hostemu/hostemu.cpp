@@ -70,7 +70,7 @@ void emu_physics_wave(EmuModel *mm, float *st, const float *action, int nsub, in
   std::vector<float> lds(mm->h.lds_floats + 64);
   for (int e = 0; e < n; e++) {
     for (auto &v : lds) v = 0.f;
-    WCtx c{&mm->h, lds.data(), st, n, e, 0, nullptr, 0ull};
+    WCtx c{&mm->h, lds.data(), st, n, e, 0, nullptr, 0ull, ws_dump};
     const WLayout K = tmjx_host::make_wave_layout(mm->h);
     float time = tmw_load_state(c, K, action);
     for (int f = 0; f < nsub; f++) { tmw_forward(c, K, f == nsub - 1); if (do_euler) time = tmw_euler(c, K, time); }

@@ -92,7 +92,10 @@ template <bool STATIC>
 __global__ __launch_bounds__(64) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
                                                      int do_euler, float *ws_dump, int n) {
   extern __shared__ float tmw_lds[];
-  WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x, (int)threadIdx.x, nullptr, 0ull};
+  WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x, (int)threadIdx.x, nullptr, 0ull, nullptr};
+#ifndef TMW_PROFILE
+  c.dump = ws_dump;
+#endif
 #ifdef TMW_PROFILE
   if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)blockIdx.x * 16; c.tlast = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -227,6 +230,7 @@ int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quatern
 
 static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream) {
   size_t lds = (size_t)m->h.lds_floats * sizeof(float);
+  if (const char *pad = getenv("TMJX_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;  // occupancy experiments only
   if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(n_env), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env);
   else hipLaunchKernelGGL(k_physics_wave<false>, dim3(n_env), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env);
 }

@@ -29,14 +29,18 @@ struct WLayout {
     int l = 0;
     l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += nu; l_warm = l; l += nv; l_ctrl = l; l += nu;
     l_cdof = l; l += nv * 6; l_M = l; l += nnz; l_con_dist = l; l += ncon; l_con_off = l; l += ncon * 3;
-    l_con_frame = l; l += ncon * 9; l_lim_sign = l; l += nlim; l_qfrc_smooth = l; l += nv; l_qfrc_actuator = l; l += nv;
-    l_act_dot = l; l += nu; l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_wr = l; l += ncon * 6; l_tdof = l; l += nv * 2;
-    l_tgrp = l; l += ngroup * 4; l_dummy = l; l += 64;  // per-lane sink for branch-free masked LDS accesses
+    l_con_frame = l; l += ncon * 6; l_lim_sign = l; l += nlim; l_qfrc_smooth = l; l += nv; l_qfrc_actuator = l; l += nv;
+    l_act_dot = l; l += nu; l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_tdof = l; l += nv * 2;
+    l_tgrp = l; l += ngroup * 4;
     l = (l + 3) & ~3;
     l_alias0 = l;
     l_LD = l; l += nnz; l_Dinv = l; l += nv; l_efc_D = l; l += nefc; l_efc_aref = l; l += nefc; l_Jaref = l; l += nefc;
-    l_jv = l; l += nefc; l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
+    // liveness-based sharing: aref is dead once the CG start point is chosen -> J*search (jv) re-uses it; the per-contact
+    // wrenches of J^T f (wr, 6*ncon <= nefc) are only live inside tmw_jt_force, never together with jv
+    l_jv = l_efc_aref; l_wr = l_efc_aref;
+    l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
     l_Mgrad = l; l += nv; l_search = l; l += nv; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
+    l_dummy = l_mv;   // per-lane sink of masked LDS reads (needs 64 <= nv words; mv is only live inside the line search)
     int endA = l;
     l = l_alias0;
     l_scanA = l; l += nbody * 8; l_scanB = l; l += nbody * 8; l_jl_anchor = l; l += njnt * 3; l_jl_axis = l; l += njnt * 3;
@@ -44,7 +48,8 @@ struct WLayout {
     int endB1 = l;
     // velocity stage: behind scanA (which still holds the world transforms); scanB / joint frames / xipos are dead by then
     l = l_alias0 + nbody * 8;
-    l_cinert = l; l += nbody * 10; l_cfrc = l; l += nbody * 6; l_dscanA = l; l += nv * 8; l_dscanB = l; l += nv * 8;
+    l_cinert = l; l += nbody * 10; l_cfrc = l; l += nbody * 6; l_dscanB = l; l += nv * 7;
+    l_dscanA = l_alias0;   // dof-scan buffer A overlays the (by then dead) body transforms: needs nv*7 <= nbody*8
     int endB2 = l;
     lds_floats = endA > endB1 ? endA : endB1;
     if (endB2 > lds_floats) lds_floats = endB2;

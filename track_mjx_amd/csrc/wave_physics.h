@@ -36,6 +36,7 @@
 #define TMW_LANE_DECL const int lane = c.lane;
 #endif
 #define TMW_REG(type, name) type name[TMW_NL]
+#define TMW_DS 7   // floats per dof-scan entry: 6-vector + ancestor pointer
 
 struct WCtx {
   const DModel *mp;
@@ -45,6 +46,7 @@ struct WCtx {
   int lane;
   unsigned long long *prof;   // TMW_PROFILE builds only: per-env phase cycle counters
   unsigned long long tlast;
+  float *dump;                // tests only: lane-per-env workspace that receives intermediates (tmw_dump)
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
@@ -245,7 +247,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
       }
       L[K.l_con_dist + cc] = dist;
       for (int k = 0; k < 3; k++) L[K.l_con_off + cc * 3 + k] = pos[k] - com[k];
-      for (int k = 0; k < 9; k++) L[K.l_con_frame + cc * 9 + k] = fr[k];
+      for (int k = 0; k < 6; k++) L[K.l_con_frame + cc * 6 + k] = fr[k];   // rows n and b; the third row is n x b
     }
   }
   // (5) cdof: one lane per dof (joint anchors / axes are stored in the parent frame)
@@ -317,7 +319,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       float qv = L[K.l_qvel + i];
-      float *o = L + K.l_dscanA + i * 8;
+      float *o = L + K.l_dscanA + i * TMW_DS;
       for (int k = 0; k < 6; k++) o[k] = L[K.l_cdof + i * 6 + k] * qv;
       o[6] = tm_i2f(m.dof_parentid[i]);
     }
@@ -328,11 +330,11 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
     float *nxt = L + ((r & 1) ? K.l_dscanA : K.l_dscanB);
     TMW_FOR {
       for (int i = lane; i < K.nv; i += 64) {
-        const float *s = cur + i * 8;
+        const float *s = cur + i * TMW_DS;
         float v[6] = {s[0], s[1], s[2], s[3], s[4], s[5]};
         int a = tm_f2i(s[6]);
-        if (a >= 0) { const float *sa = cur + a * 8; for (int k = 0; k < 6; k++) v[k] += sa[k]; a = tm_f2i(sa[6]); }
-        float *o = nxt + i * 8;
+        if (a >= 0) { const float *sa = cur + a * TMW_DS; for (int k = 0; k < 6; k++) v[k] += sa[k]; a = tm_f2i(sa[6]); }
+        float *o = nxt + i * TMW_DS;
         for (int k = 0; k < 6; k++) o[k] = v[k];
         o[6] = tm_i2f(a);
       }
@@ -349,14 +351,14 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       if (i < K.nv && !m.dof_freetrans[i]) {
         int vp = m.dof_vpar[i];
         float E[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cd[6];
-        if (vp >= 0) for (int k = 0; k < 6; k++) E[k] = L[K.l_dscanA + vp * 8 + k];
+        if (vp >= 0) for (int k = 0; k < 6; k++) E[k] = L[K.l_dscanA + vp * TMW_DS + k];
         for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
         tm_motion_cross(dd, E, cd);
       }
       int b = lane + 64 * slot;
       float *cv = slot ? cv1[TMW_LI] : cv0[TMW_LI];
       for (int k = 0; k < 6; k++) cv[k] = 0.f;
-      if (b < K.nbody) { int ld = m.body_lastdof[b]; if (ld >= 0) for (int k = 0; k < 6; k++) cv[k] = L[K.l_dscanA + ld * 8 + k]; }
+      if (b < K.nbody) { int ld = m.body_lastdof[b]; if (ld >= 0) for (int k = 0; k < 6; k++) cv[k] = L[K.l_dscanA + ld * TMW_DS + k]; }
     }
   }
   TMW_SYNC();
@@ -367,7 +369,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       if (i >= K.nv) continue;
       const float *dd = slot ? dd1[TMW_LI] : dd0[TMW_LI];
       float qv = L[K.l_qvel + i];
-      float *o = L + K.l_dscanA + i * 8;
+      float *o = L + K.l_dscanA + i * TMW_DS;
       for (int k = 0; k < 6; k++) o[k] = dd[k] * qv;
       o[6] = tm_i2f(m.dof_parentid[i]);
     }
@@ -378,11 +380,11 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
     float *nxt = L + ((r & 1) ? K.l_dscanA : K.l_dscanB);
     TMW_FOR {
       for (int i = lane; i < K.nv; i += 64) {
-        const float *s = cur + i * 8;
+        const float *s = cur + i * TMW_DS;
         float v[6] = {s[0], s[1], s[2], s[3], s[4], s[5]};
         int a = tm_f2i(s[6]);
-        if (a >= 0) { const float *sa = cur + a * 8; for (int k = 0; k < 6; k++) v[k] += sa[k]; a = tm_f2i(sa[6]); }
-        float *o = nxt + i * 8;
+        if (a >= 0) { const float *sa = cur + a * TMW_DS; for (int k = 0; k < 6; k++) v[k] += sa[k]; a = tm_f2i(sa[6]); }
+        float *o = nxt + i * TMW_DS;
         for (int k = 0; k < 6; k++) o[k] = v[k];
         o[6] = tm_i2f(a);
       }
@@ -397,7 +399,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       const float *cv = slot ? cv1[TMW_LI] : cv0[TMW_LI];
       float ca[6] = {0.f, 0.f, 0.f, -m.gravity[0], -m.gravity[1], -m.gravity[2]}, I[10], f1[6], t[6], f2[6];
       int ld = m.body_lastdof[b];
-      if (ld >= 0) for (int k = 0; k < 6; k++) ca[k] += L[K.l_dscanA + ld * 8 + k];
+      if (ld >= 0) for (int k = 0; k < 6; k++) ca[k] += L[K.l_dscanA + ld * TMW_DS + k];
       for (int k = 0; k < 10; k++) I[k] = L[K.l_cinert + b * 10 + k];
       tm_inert_mul(f1, I, ca);
       tm_inert_mul(t, I, cv);
@@ -662,7 +664,10 @@ TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
       int r0 = K.nlim + 4 * cc;
       float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
       if (L[K.l_con_dist + cc] < 0.f) {
-        const float *sv = L + K.l_sv + m.con_grp[cc] * 6, *off = L + K.l_con_off + cc * 3, *fr = L + K.l_con_frame + cc * 9;
+        const float *sv = L + K.l_sv + m.con_grp[cc] * 6, *off = L + K.l_con_off + cc * 3;
+        float fr[9];
+        for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
+        tm_cross(fr + 6, fr, fr + 3);
         float cr[3], vel[3];
         tm_cross(cr, sv, off);
         for (int k = 0; k < 3; k++) vel[k] = sv[3 + k] + cr[k];
@@ -685,7 +690,10 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
         float f[4];
         for (int e = 0; e < 4; e++) { float ja = L[K.l_Jaref + r0 + e]; f[e] = ja < 0.f ? -L[K.l_efc_D + r0 + e] * ja : 0.f; }
         float mu = m.con_mu[cc], c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
-        const float *off = L + K.l_con_off + cc * 3, *fr = L + K.l_con_frame + cc * 9;
+        const float *off = L + K.l_con_off + cc * 3;
+        float fr[9];
+        for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
+        tm_cross(fr + 6, fr, fr + 3);
         float F[3], T[3];
         for (int k = 0; k < 3; k++) F[k] = c0 * fr[k] + c1 * fr[3 + k] + c2 * fr[6 + k];
         tm_cross(T, off, F);
@@ -931,6 +939,9 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   tmw_invert_l(c, K);
   TMW_TICK(3);
   tmw_make_constraint(c, K);
+  if (c.dump) {   // efc_aref shares its LDS words with jv / wr later on: copy it out now (tests only)
+    TMW_FOR { for (int i = lane; i < K.nefc; i += 64) c.dump[(size_t)(m.w_efc_aref + i) * (size_t)c.n + (size_t)c.e] = L[K.l_efc_aref + i]; }
+  }
   TMW_TICK(4);
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = L[K.l_qfrc_smooth + i]; }
   TMW_SYNC();
@@ -989,9 +1000,14 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
       WDUMP(m.w_qacc, i) = L[K.l_qacc + i]; WDUMP(m.w_qfrc_constraint, i) = L[K.l_qfrc_constraint + i];
     }
     for (int i = lane; i < K.ncon; i += 64) WDUMP(m.w_con_dist, i) = L[K.l_con_dist + i];
-    for (int i = lane; i < K.ncon * 9; i += 64) WDUMP(m.w_con_frame, i) = L[K.l_con_frame + i];
+    for (int cc = lane; cc < K.ncon; cc += 64) {
+      float fr[9];
+      for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
+      tm_cross(fr + 6, fr, fr + 3);
+      for (int k = 0; k < 9; k++) WDUMP(m.w_con_frame, cc * 9 + k) = fr[k];
+    }
     for (int i = lane; i < K.nefc; i += 64) {
-      WDUMP(m.w_efc_D, i) = L[K.l_efc_D + i]; WDUMP(m.w_efc_aref, i) = L[K.l_efc_aref + i];
+      WDUMP(m.w_efc_D, i) = L[K.l_efc_D + i];
       float ja = L[K.l_Jaref + i];
       WDUMP(m.w_efc_force, i) = ja < 0.f ? -L[K.l_efc_D + i] * ja : 0.f;
     }
