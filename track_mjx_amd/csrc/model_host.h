@@ -282,7 +282,7 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
     int sgm = i;
     while (sgm > 0 && m.dof_parentid[sgm] == sgm - 1) sgm--;
     int jump = m.dof_parentid[sgm];
-    m.tdof[2 * i] = m.dof_Madr[i] | (m.dof_depth[i] << 16);
+    m.tdof[2 * i] = (m.dof_Madr[i] + m.dof_depth[i]) | (m.dof_depth[i] << 16);
     m.tdof[2 * i + 1] = sgm | ((jump + 1) << 8) | (m.dof_ndesc[i] << 16);
     int r = i - sgm;
     for (int q = 0; q <= m.dof_depth[i]; q++) {

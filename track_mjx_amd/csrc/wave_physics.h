@@ -31,7 +31,14 @@
 #else
 #define TMW_NL 1
 #define TMW_FOR if (true)
+// One wave per workgroup: the LDS unit executes a wave's DS instructions in issue order, so a ds_read issued after a
+// ds_write of another lane of the SAME wave already sees the data — no s_waitcnt / s_barrier is needed, only a compiler
+// barrier that keeps the program order of the LDS accesses (TMW_HARD_SYNC restores __syncthreads() for A/B checks).
+#ifdef TMW_HARD_SYNC
 #define TMW_SYNC() __syncthreads()
+#else
+#define TMW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 #define TMW_LI 0
 #define TMW_LANE_DECL const int lane = c.lane;
 #endif
@@ -108,7 +115,9 @@ TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
   TMW_SYNC();
   return WST(m.s_time, 0);
 }
-// packed per-dof words in LDS: w0 = Madr | depth << 16, w1 = chain_start | (jump + 1) << 8
+// packed per-dof words in LDS: w0 = (Madr + depth) | depth << 16, w1 = chain_start | (jump + 1) << 8 | ndesc << 16
+#define TMW_MEND(w0) ((w0) & 0xffff)              /* address of the LAST entry of the row = Madr + depth */
+#define TMW_ADR(w0) (((w0) & 0xffff) - ((w0) >> 16)) /* Madr: address of the diagonal entry */
 #define TMW_W0(i) tm_f2i(L[K.l_tdof + 2 * (i)])
 #define TMW_W1(i) tm_f2i(L[K.l_tdof + 2 * (i) + 1])
 // q-th ancestor of dof i (q = 0: i itself): the chain i, i-1, .., chain_start, then jump, jump-1, .., 0
@@ -424,7 +433,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       }
       for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
       tm_inert_mul(buf, I, cd);
-      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16;
+      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = w0 >> 16;
 #pragma unroll 4
       for (int k = 0; k <= d; k++) {
         const float *cj = L + K.l_cdof + tmw_anc(i, k, w1) * 6;
@@ -469,7 +478,7 @@ TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
   }
   TMW_REG(float, a0); TMW_REG(float, a1); TMW_REG(float, b0); TMW_REG(float, b1); TMW_REG(float, acc); TMW_REG(float, pr);
   for (int i = K.nv - 1; i >= 0; i--) {
-    int w0 = TMW_W0(i), adr = w0 & 0xffff, d = w0 >> 16, nd = (TMW_W1(i) >> 16) & 0xff;
+    int w0 = TMW_W0(i), adr = TMW_ADR(w0), d = w0 >> 16, nd = (TMW_W1(i) >> 16) & 0xff;
     TMW_FOR {
       float rsum = 0.f;
 #pragma unroll
@@ -480,7 +489,7 @@ TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
           // farthest descendant first: the small contributions of the leaves are summed before the large ones of the
           // near descendants (same order as the right-looking elimination; measurably more accurate in fp32)
           int kk = i + nd - t, wk = TMW_W0(kk);
-          base = K.l_LD + (wk & 0xffff) + (wk >> 16) - d;      // M'(k, i) sits at Madr_k + depth_k - depth_i
+          base = K.l_LD + TMW_MEND(wk) - d;      // M'(k, i) sits at Madr_k + depth_k - depth_i
           a = L[base] * L[K.l_Dinv + kk];                       // = L(k, i)
           if (rhs >= 0) rsum += a * L[rhs + kk];
         }
@@ -525,7 +534,7 @@ TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
   // rows still hold M' = D L: scale the strict part to the unit-lower L
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
-      int w0 = TMW_W0(i), adr = w0 & 0xffff, d = w0 >> 16;
+      int w0 = TMW_W0(i), adr = TMW_ADR(w0), d = w0 >> 16;
       float inv = L[K.l_Dinv + i];
       for (int q = 1; q <= d; q++) L[K.l_LD + adr + q] *= inv;
     }
@@ -537,7 +546,7 @@ TM_DEV void tmw_subst_down(WCtx &c, const WLayout &K, int x) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, t);
   for (int i = 0; i < K.nv; i++) {
-    int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16;
+    int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = w0 >> 16;
     TMW_FOR { t[TMW_LI] = (lane >= 1 && lane <= d) ? L[K.l_LD + adr + lane] * L[x + tmw_anc(i, lane, w1)] : 0.f; }
     float s = d > 0 ? tmw_sum(t) : 0.f;
     TMW_FOR { if (lane == 0) L[x + i] = L[x + i] * L[K.l_Dinv + i] - s; }
@@ -551,7 +560,7 @@ TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, x); TMW_REG(float, arow); TMW_REG(float, acc);
   for (int k = 1; k < K.nv; k++) {
-    int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = w0k & 0xffff, d = w0k >> 16;
+    int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = TMW_ADR(w0k), d = w0k >> 16;
     if (d == 0) continue;
     TMW_FOR {
       float xv = (lane >= 1 && lane <= d) ? L[K.l_LD + ak + lane] : 0.f;
@@ -559,7 +568,7 @@ TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
       acc[TMW_LI] = xv;
       // address such that  L[arow_m + lane]  is entry (lane - m) of ancestor m's row
       int am = tmw_anc(k, lane <= d ? lane : 0, w1k);
-      arow[TMW_LI] = tm_i2f(K.l_LD + (TMW_W0(am) & 0xffff) - lane);
+      arow[TMW_LI] = tm_i2f(K.l_LD + TMW_ADR(TMW_W0(am)) - lane);
     }
     for (int m0 = 1; m0 < d; m0 += 8) {
       float lm[8]; int ab[8];
@@ -585,22 +594,40 @@ TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
     TMW_SYNC();
   }
 }
+// Lean sparse row / column products shared by tmw_solve and tmw_mul_m.  Row i of the ancestor-sparse storage `A` is
+// [A(i,i), A(i,i-1), .., A(i,chain_start), A(i,jump), .., A(i,0)]; column i is { A(k,i) : k = i+1 .. i+ndesc },
+// entry (k,i) sitting at Mend_k - depth_i.  No per-iteration ancestor arithmetic: two pointer runs for the row, one table
+// word per descendant for the column.  `diag`: include q = 0.
+TM_DEV float tmw_row_dot(const float *L, const WLayout &K, int A, int x, int i, bool diag) {
+  int w0 = tm_f2i(L[K.l_tdof + 2 * i]), w1 = tm_f2i(L[K.l_tdof + 2 * i + 1]);
+  int d = w0 >> 16, adr = TMW_ADR(w0), r = i - (w1 & 0xff), jp1 = (w1 >> 8) & 0xff;
+  const float *Ap = L + A + adr, *xp = L + x;
+  float acc = diag ? Ap[0] * xp[i] : 0.f;
+#pragma unroll 4
+  for (int q = 1; q <= r; q++) acc += Ap[q] * xp[i - q];
+  const float *Aq = Ap + r + 1;
+#pragma unroll 4
+  for (int t = 0; t < d - r; t++) acc += Aq[t] * xp[jp1 - 1 - t];
+  return acc;
+}
+TM_DEV float tmw_col_dot(const float *L, const WLayout &K, int A, int x, int i) {
+  int w0 = tm_f2i(L[K.l_tdof + 2 * i]), nd = (tm_f2i(L[K.l_tdof + 2 * i + 1]) >> 16) & 0xff, d = w0 >> 16;
+  const float *Ap = L + A - d, *xp = L + x + i + 1;
+  const float *tw = L + K.l_tdof + 2 * (i + 1);
+  float acc = 0.f;
+#pragma unroll 4
+  for (int t = 0; t < nd; t++) acc += Ap[TMW_MEND(tm_f2i(tw[2 * t]))] * xp[t];
+  return acc;
+}
 // x <- M^-1 x using N = L^-1:  x = N D^-1 N^T x   (two sparse mat-vecs; `x` is an LDS vector offset)
 TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, z0); TMW_REG(float, z1);
   TMW_FOR {
     for (int slot = 0; slot < 2; slot++) {
       int i = lane + 64 * slot;
       if (i >= K.nv) continue;
-      float acc = L[x + i];
-      int nd = m.dof_ndesc[i], di = TMW_W0(i) >> 16;
-#pragma unroll 4
-      for (int k = i + 1; k <= i + nd; k++) {  // column i: entry of descendant row k sits at Madr_k + depth_k - depth_i
-        int w0 = TMW_W0(k);
-        acc += L[K.l_LD + (w0 & 0xffff) + (w0 >> 16) - di] * L[x + k];
-      }
-      (slot ? z1 : z0)[TMW_LI] = acc * L[K.l_Dinv + i];
+      (slot ? z1 : z0)[TMW_LI] = (L[x + i] + tmw_col_dot(L, K, K.l_LD, x, i)) * L[K.l_Dinv + i];
     }
   }
   TMW_SYNC();
@@ -612,11 +639,7 @@ TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
     for (int slot = 0; slot < 2; slot++) {
       int i = lane + 64 * slot;
       if (i >= K.nv) continue;
-      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16;
-      float acc = L[x + i];
-#pragma unroll 4
-      for (int q = 1; q <= d; q++) acc += L[K.l_LD + adr + q] * L[x + tmw_anc(i, q, w1)];
-      (slot ? z1 : z0)[TMW_LI] = acc;
+      (slot ? z1 : z0)[TMW_LI] = L[x + i] + tmw_row_dot(L, K, K.l_LD, x, i, false);
     }
   }
   TMW_SYNC();
@@ -627,17 +650,9 @@ TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
 }
 // y = M x
 TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) {
-      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = w0 & 0xffff, d = w0 >> 16, nd = m.dof_ndesc[i];
-      float acc = 0.f;
-#pragma unroll 4
-      for (int q = 0; q <= d; q++) acc += L[K.l_M + adr + q] * L[x + tmw_anc(i, q, w1)];
-#pragma unroll 4
-      for (int k = i + 1; k <= i + nd; k++) { int wk = TMW_W0(k); acc += L[K.l_M + (wk & 0xffff) + (wk >> 16) - d] * L[x + k]; }
-      L[y + i] = acc;
-    }
+    for (int i = lane; i < K.nv; i += 64) L[y + i] = tmw_row_dot(L, K, K.l_M, x, i, true) + tmw_col_dot(L, K, K.l_M, x, i);
   }
   TMW_SYNC();
 }
