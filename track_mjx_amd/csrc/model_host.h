@@ -13,8 +13,28 @@
 
 namespace tmjx_host {
 
-inline WLayout make_wave_layout(const DModel &m) {
-  return WLayout(m.nbody, m.njnt, m.nq, m.nv, m.nu, m.ncon, m.nlim, m.nnz, m.ngroup, m.nround_body, m.nround_dof);
+// does the dof tree equal the compile-time chain table of the rodent (wave_layout.h)?  Required by the register-resident
+// factorisation: dofs 0..TRUNK-1 one chain from the root, every leaf chain X(first, n, d0) = consecutive dofs hanging off
+// trunk dof d0-1, M rows stored back to back in dof order.
+inline bool rodent_chains_match(const DModel &m) {
+  constexpr WLayout ks(TMW_RODENT_DIMS);
+  if (m.nv != ks.nv || m.nnz != ks.nnz) return false;
+  std::vector<int> parent(m.nv, -2);
+  for (int i = 0; i < TMW_RODENT_TRUNK; i++) parent[i] = i - 1;
+#define TMW_X(first, n, d0) for (int k = 0; k < n; k++) parent[first + k] = k ? first + k - 1 : d0 - 1;
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  int adr = 0;
+  for (int i = 0; i < m.nv; i++) {
+    if (parent[i] != m.dof_parentid[i] || m.dof_Madr[i] != adr) return false;
+    if (m.dof_depth[i] != (parent[i] < 0 ? 0 : m.dof_depth[parent[i]] + 1)) return false;
+    adr += m.dof_depth[i] + 1;
+  }
+  return adr == m.nnz;
+}
+inline WLayout make_wave_layout(const DModel &m, bool allow_chains = true) {
+  return WLayout(m.nbody, m.njnt, m.nq, m.nv, m.nu, m.ncon, m.nlim, m.nnz, m.ngroup, m.nround_body, m.nround_dof,
+                 allow_chains && rodent_chains_match(m) ? 1 : 0);
 }
 
 struct BlobEntry { int code = -1, count = 0; const unsigned char *data = nullptr; };

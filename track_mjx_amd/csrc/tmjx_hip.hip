@@ -89,7 +89,7 @@ __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const 
 // K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
 // STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
 template <bool STATIC>
-__global__ __launch_bounds__(64) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
+__global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
                                                      int do_euler, float *ws_dump, int n) {
   extern __shared__ float tmw_lds[];
   WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x, (int)threadIdx.x, nullptr, 0ull, nullptr};
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void k_physics_wave(const DModel *__restrict__ 
 #ifdef TMW_PROFILE
   if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)blockIdx.x * 16; c.tlast = __builtin_amdgcn_s_memtime(); }
 #endif
-  constexpr WLayout ks(TMW_RODENT_DIMS);
+  constexpr WLayout ks(TMW_RODENT_DIMS, 1);
   const WLayout kd = STATIC ? ks : WLayout(mp->nbody, mp->njnt, mp->nq, mp->nv, mp->nu, mp->ncon, mp->nlim, mp->nnz, mp->ngroup,
                                            mp->nround_body, mp->nround_dof);
   const WLayout &K = STATIC ? ks : kd;
@@ -177,7 +177,7 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
     const WLayout kd = tmjx_host::make_wave_layout(m->h);
     m->rodent = !getenv("TMJX_WAVE_DYNAMIC") && kd.nbody == ks.nbody && kd.njnt == ks.njnt && kd.nq == ks.nq && kd.nv == ks.nv &&
                 kd.nu == ks.nu && kd.ncon == ks.ncon && kd.nlim == ks.nlim && kd.nnz == ks.nnz && kd.ngroup == ks.ngroup &&
-                kd.nround_body == ks.nround_body && kd.nround_dof == ks.nround_dof && kd.lds_floats == ks.lds_floats;
+                kd.nround_body == ks.nround_body && kd.nround_dof == ks.nround_dof && kd.lds_floats == ks.lds_floats && kd.chains == 1;
   }
   hipError_t e = hipMalloc((void **)&m->d, sizeof(DModel));
   if (e != hipSuccess) { delete m; return fail(TMJX_ENOMEM, std::string("hipMalloc(DModel): ") + hipGetErrorString(e)); }

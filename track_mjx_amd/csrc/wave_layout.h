@@ -17,15 +17,16 @@ struct WLayout {
   // aliased region B (position / velocity stage), same base as region A
   int l_scanA, l_scanB, l_jl_anchor, l_jl_axis, l_xipos, l_cinert, l_cfrc, l_dscanA, l_dscanB;
   int lds_floats;
+  int chains;   // 0: any tree (LDS-resident sparse factorisation); 1: the rodent's dof chains (register-resident, wave_physics.h)
 
-  constexpr WLayout(int nb, int nj, int nq_, int nv_, int nu_, int nc, int nl, int nnz_, int ng, int rb, int rd)
+  constexpr WLayout(int nb, int nj, int nq_, int nv_, int nu_, int nc, int nl, int nnz_, int ng, int rb, int rd, int ch = 0)
       : nbody(nb), njnt(nj), nq(nq_), nv(nv_), nu(nu_), ncon(nc), nlim(nl), nefc(nl + 4 * nc), ngroup(ng), nnz(nnz_),
         nphys(nq_ + nv_ + nu_ + nv_ + 1), nround_body(rb), nround_dof(rd),
         l_qpos(0), l_qvel(0), l_act(0), l_warm(0), l_ctrl(0), l_cdof(0), l_M(0), l_con_dist(0), l_con_off(0), l_con_frame(0),
         l_lim_sign(0), l_qfrc_smooth(0), l_qfrc_actuator(0), l_act_dot(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_dummy(0),
         l_alias0(0), l_LD(0), l_Dinv(0), l_efc_D(0), l_efc_aref(0), l_Jaref(0), l_jv(0), l_qacc_smooth(0), l_qacc(0), l_Ma(0),
         l_grad(0), l_Mgrad(0), l_search(0), l_mv(0), l_qfrc_constraint(0), l_tmp(0), l_scanA(0), l_scanB(0), l_jl_anchor(0),
-        l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0) {
+        l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0), chains(ch) {
     int l = 0;
     l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += nu; l_warm = l; l += nv; l_ctrl = l; l += nu;
     l_cdof = l; l += nv * 6; l_M = l; l += nnz; l_con_dist = l; l += ncon; l_con_off = l; l += ncon * 3;
@@ -59,3 +60,7 @@ struct WLayout {
 // the rodent walker of the reference (track_mjx/environment/walker/assets/rodent/rodent.xml): 68 bodies, 68 joints,
 // nq 74, nv 73, 38 actuators, 30 contact slots, 67 joint limits, 1119 non-zeros in the tree-sparse M, 8 paw bodies
 #define TMW_RODENT_DIMS 68, 68, 74, 73, 38, 30, 67, 1119, 8, 6, 6
+// its dof tree: a trunk chain (dofs 0..11: the free joint, then the 6 dofs up to the pelvis/lumbar branch point) and six leaf
+// chains X(first dof, length, depth of the first dof) of consecutive dofs; listed in the order they are eliminated
+#define TMW_RODENT_TRUNK 12
+#define TMW_RODENT_LEAF_CHAINS(X) X(65, 8, 6) X(57, 8, 6) X(48, 9, 6) X(24, 24, 12) X(18, 6, 12) X(12, 6, 12)

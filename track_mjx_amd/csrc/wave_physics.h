@@ -594,6 +594,165 @@ TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
     TMW_SYNC();
   }
 }
+// ---- register-resident variants for a tree made of CHAINS (WLayout::chains: the rodent, wave_layout.h).
+// A chain = N consecutive dofs FIRST.., dof FIRST+k at depth D0+k, whose ancestors above the chain are the trunk dofs
+// 0..D0-1 (depth j <-> dof j).  Lane q owns the column of the ancestor at DEPTH q, so that the rows of one root->leaf path
+// line up lane by lane: row k of the chain is ONE register (r[k], lane q = M'(k, anc_q)), the trunk rows are 12 more, and a
+// rank-1 update / a row of L^-1 is  `s_a = v_readlane(row, j);  target = fma(-s_a, row', target)`  — two instructions per
+// (dof, ancestor) pair, no LDS traffic, no address arithmetic, no dependent-load chain.  Everything is unrolled at compile
+// time (register arrays cannot be indexed dynamically).  Lane TMW_RL carries the right-hand side of the fused solve.
+#define TMW_RL 63
+// The unrolled chain code compares `lane` with ~36 compile-time depths.  Left alone, LLVM hoists every such lane mask (an
+// SGPR pair each) out of the substep loop and keeps it alive across the whole kernel — SGPRs overflow into VGPR lanes and
+// those into scratch.  An opaque copy of the lane id per function keeps the masks local: one v_cmp at the point of use.
+#ifdef TM_HOST_EMU
+#define TMW_LANE_OPAQUE
+#define TMW_SCHED_FENCE() do { } while (0)
+#define TMW_PIN(x) do { } while (0)
+#else
+// ... and from sinking every rank-1 update down to the pivot step of its target row (which turns the elimination into a
+// left-looking one whose ~600 multipliers all stay live in SGPRs): an empty volatile asm that "modifies" the target pins
+// the FMA to its place in program order
+#define TMW_PIN(x) asm volatile("" : "+v"(x))
+// also: keep the scheduler from batching hundreds of independent v_readlane results (SGPRs) ahead of the FMAs using them
+#define TMW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+TM_DEV int tmw_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+#define TMW_LANE_OPAQUE const int lane = tmw_opaque(c.lane);
+#endif
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float hdamp, int rhs) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_OPAQUE
+  const int adr0 = K.l_M + TMW_ADR(TMW_W0(FIRST));
+  TMW_REG(float, hd);   // hdamp * damping of the chain dof whose DIAGONAL sits in this lane (depth = lane)
+  TMW_FOR { hd[TMW_LI] = (hdamp != 0.f && lane >= D0 && lane < D0 + N) ? hdamp * m.dof_damping[FIRST + lane - D0] : 0.f; }
+  TMW_FOR {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;   // Madr(FIRST + k) - Madr(FIRST): rows are stored back to back
+      float v = L[adr0 - lane + (off + dk)];   // lanes beyond the row read (and discard) whatever precedes it in LDS
+      v = lane < dk ? v : (lane == dk ? v + hd[TMW_LI] : 0.f);
+      if (rhs >= 0) v = lane == TMW_RL ? L[rhs + FIRST + k] : v;
+      r[k][TMW_LI] = v;
+    }
+  }
+}
+// eliminate the chain leaf -> root: finished rows go to LD (strict part = L, entry 0 = D) / Dinv / rhs; the Schur
+// complement lands in the remaining chain rows and in the trunk rows `tr` (registers, shared by all chains)
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float (*tr)[TMW_NL], int rhs) {
+  float *L = c.L; TMW_LANE_OPAQUE
+  const int adr0 = K.l_LD + TMW_ADR(TMW_W0(FIRST));
+  TMW_REG(float, rs); TMW_REG(float, dv);
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
+    float piv = tmw_readlane(r[k], dk), inv = 1.f / piv;
+    TMW_FOR { rs[TMW_LI] = r[k][TMW_LI] * inv; }
+#pragma unroll
+    for (int j = dk - 1; j >= 0; j--) {
+      float a = tmw_readlane(rs, j);                 // L(k, anc_j)
+      float *tgt = j >= D0 ? r[j >= D0 ? j - D0 : 0] : tr[j < D0 ? j : 0];
+      TMW_FOR { tgt[TMW_LI] -= a * r[k][TMW_LI]; TMW_PIN(tgt[TMW_LI]); }
+    }
+    TMW_FOR {
+      if (lane <= dk) L[adr0 - lane + (off + dk)] = lane == dk ? piv : rs[TMW_LI];
+      dv[TMW_LI] = lane == dk ? inv : dv[TMW_LI];
+      if (rhs >= 0 && lane == TMW_RL) L[rhs + FIRST + k] = r[k][TMW_LI];
+    }
+  }
+  TMW_FOR { if (lane >= D0 && lane < D0 + N) L[K.l_Dinv + FIRST - D0 + lane] = dv[TMW_LI]; }
+}
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, float (*tr)[TMW_NL], float hdamp, int rhs) {
+  float r[N][TMW_NL];
+  tmw_rows_load<FIRST, N, D0>(c, K, r, hdamp, rhs);
+  tmw_rows_factor<FIRST, N, D0>(c, K, r, tr, rhs);
+}
+// LD <- L^T D L of (M + hdamp diag(damping)) read straight from l_M; same outputs as tmw_factor
+TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
+  float tr[TMW_RODENT_TRUNK][TMW_NL];
+  tmw_rows_load<0, TMW_RODENT_TRUNK, 0>(c, K, tr, hdamp, rhs);
+#define TMW_X(first, n, d0) tmw_chain_factor<first, n, d0>(c, K, tr, hdamp, rhs);
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  tmw_rows_factor<0, TMW_RODENT_TRUNK, 0>(c, K, tr, tr, rhs);
+  TMW_SYNC();
+}
+// rows of N = L^-1, root -> leaf:  N(k,:) = e_k - sum_{j < depth_k} L(k, anc_j) N(anc_j, :).  `tn`: the finished trunk rows
+// (with their unit diagonal); chain rows are kept in `n` the same way.  Lanes beyond a row's depth hold exact zeros.
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, float (*n)[TMW_NL], float (*tn)[TMW_NL]) {
+  float *L = c.L; TMW_LANE_OPAQUE
+  const int adr0 = K.l_LD + TMW_ADR(TMW_W0(FIRST));
+  TMW_REG(float, l); TMW_REG(float, acc0); TMW_REG(float, acc1);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
+    TMW_FOR {
+      float v = L[adr0 - lane + (off + dk)];
+      l[TMW_LI] = lane < dk ? v : 0.f;
+      acc0[TMW_LI] = lane == dk ? 1.f : 0.f; acc1[TMW_LI] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < dk; j++) {
+      float a = tmw_readlane(l, j);
+      const float *src = j >= D0 ? n[j >= D0 ? j - D0 : 0] : tn[j < D0 ? j : 0];
+      float *acc = (j & 1) ? acc1 : acc0;
+      TMW_FOR { acc[TMW_LI] -= a * src[TMW_LI]; }
+    }
+    TMW_FOR {
+      float v = acc0[TMW_LI] + acc1[TMW_LI];
+      n[k][TMW_LI] = v;
+      if (lane < dk) L[adr0 - lane + (off + dk)] = v;
+    }
+  }
+}
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_chain_invert(WCtx &c, const WLayout &K, float (*tn)[TMW_NL]) {
+  float n[N][TMW_NL];
+  tmw_rows_invert<FIRST, N, D0>(c, K, n, tn);
+}
+TM_DEV void tmw_invert_chains(WCtx &c, const WLayout &K) {
+  float tn[TMW_RODENT_TRUNK][TMW_NL];
+  tmw_rows_invert<0, TMW_RODENT_TRUNK, 0>(c, K, tn, tn);
+#define TMW_X(first, n, d0) tmw_chain_invert<first, n, d0>(c, K, tn);
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  TMW_SYNC();
+}
+// root -> leaf pass after tmw_factor_chains(.., rhs):  x_k = y_k / D_k - sum_j L(k, anc_j) x_anc_j.  Lane q of `xv` holds
+// the solution at depth q of the current path; one wave reduction per dof.
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_rows_subst(WCtx &c, const WLayout &K, float *xv, int x) {
+  float *L = c.L; TMW_LANE_OPAQUE
+  const int adr0 = K.l_LD + TMW_ADR(TMW_W0(FIRST));
+  TMW_REG(float, t);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
+    TMW_FOR {
+      float v = L[adr0 - lane + (off + dk)];
+      t[TMW_LI] = lane < dk ? v * xv[TMW_LI] : (lane == TMW_RL ? -L[x + FIRST + k] * L[K.l_Dinv + FIRST + k] : 0.f);
+    }
+    float xk = -tmw_sum(t);
+    TMW_FOR {
+      xv[TMW_LI] = lane == dk ? xk : xv[TMW_LI];
+      if (lane == 0) L[x + FIRST + k] = xk;
+    }
+  }
+}
+TM_DEV void tmw_subst_chains(WCtx &c, const WLayout &K, int x) {
+  TMW_LANE_DECL
+  TMW_REG(float, xv);
+  TMW_FOR { xv[TMW_LI] = 0.f; }
+  tmw_rows_subst<0, TMW_RODENT_TRUNK, 0>(c, K, xv, x);
+  TMW_REG(float, xt);     // the trunk part of the solution: every chain restarts from it (chains overwrite lanes >= d0)
+  TMW_FOR { xt[TMW_LI] = xv[TMW_LI]; }
+#define TMW_X(first, n, d0) TMW_FOR { xv[TMW_LI] = xt[TMW_LI]; } tmw_rows_subst<first, n, d0>(c, K, xv, x);
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  TMW_SYNC();
+}
 // Lean sparse row / column products shared by tmw_solve and tmw_mul_m.  Row i of the ancestor-sparse storage `A` is
 // [A(i,i), A(i,i-1), .., A(i,chain_start), A(i,jump), .., A(i,0)]; column i is { A(k,i) : k = i+1 .. i+ndesc },
 // entry (k,i) sitting at Mend_k - depth_i.  No per-iteration ancestor arithmetic: two pointer runs for the row, one table
@@ -949,9 +1108,9 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   TMW_TICK(0);
   tmw_velocity_inertia(c, K);
   TMW_TICK(1);
-  tmw_factor(c, K, 0.f);
+  if (K.chains) tmw_factor_chains(c, K, 0.f); else tmw_factor(c, K, 0.f);
   TMW_TICK(2);
-  tmw_invert_l(c, K);
+  if (K.chains) tmw_invert_chains(c, K); else tmw_invert_l(c, K);
   TMW_TICK(3);
   tmw_make_constraint(c, K);
   if (c.dump) {   // efc_aref shares its LDS words with jv / wr later on: copy it out now (tests only)
@@ -971,9 +1130,9 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_qfrc_smooth + i] + L[K.l_qfrc_constraint + i]; }
   TMW_SYNC();
   TMW_TICK(8);
-  tmw_factor(c, K, h, K.l_tmp);
+  if (K.chains) tmw_factor_chains(c, K, h, K.l_tmp); else tmw_factor(c, K, h, K.l_tmp);
   TMW_TICK(9);
-  tmw_subst_down(c, K, K.l_tmp);
+  if (K.chains) tmw_subst_chains(c, K, K.l_tmp); else tmw_subst_down(c, K, K.l_tmp);
   TMW_TICK(11);
   TMW_FOR {
     for (int a = lane; a < K.nu; a += 64) L[K.l_act + a] += L[K.l_act_dot + a] * h;
