@@ -87,6 +87,10 @@ struct DModel {
   // (ancestors of dof i: i-1 .. chain_start, then jump, jump-1, .. 0 — checked on the host)
   int tdof[TM_MAXV * 2];
   int body_nsub[TM_MAXB];  // subtree size (bodies are numbered depth-first: subtree = [b, b + nsub))
+  // subtree sums (wave kernel): a RUN is a maximal chain b, b+1, .. with parent[b+1] == b.  After the per-run suffix sums,
+  // every branch body p (more than one child), taken in DESCENDING order, adds the finished sums of its non-first children
+  // (run heads fix_child[fix_adr[f] .. fix_adr[f+1])) to the bodies fix_r0[f] .. fix_p[f] of its own run.
+  int n_fix, fix_p[TM_MAXB], fix_r0[TM_MAXB], fix_adr[TM_MAXB + 1], fix_child[TM_MAXB];
   int lds_floats;
 };
 

@@ -319,6 +319,15 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
     for (int cb = 1; cb < m.nbody; cb++) if (cb != b) for (int a = m.body_parentid[cb];; a = m.body_parentid[a]) { if (a == b) { total++; break; } if (a == 0) break; }
     if (b > 0 && total != nsub) { err = "body numbering is not depth-first"; return false; }
   }
+  m.n_fix = 0; m.fix_adr[0] = 0;
+  for (int p = m.nbody - 1; p >= 1; p--) {
+    int nch = 0, first = m.fix_adr[m.n_fix];
+    for (int cb = p + 1; cb < p + m.body_nsub[p]; cb += m.body_nsub[cb]) if (cb != p + 1) m.fix_child[first + nch++] = cb;
+    if (!nch) continue;
+    int r0 = p;
+    while (r0 > 1 && m.body_parentid[r0] == r0 - 1) r0--;
+    m.fix_p[m.n_fix] = p; m.fix_r0[m.n_fix] = r0; m.fix_adr[++m.n_fix] = first + nch;
+  }
   // LDS map of the wave kernel: one source of truth (wave_layout.h); only the total is kept in the model
   m.lds_floats = make_wave_layout(m).lds_floats;
   return true;

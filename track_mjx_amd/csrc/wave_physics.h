@@ -43,6 +43,13 @@
 #define TMW_LANE_DECL const int lane = c.lane;
 #endif
 #define TMW_REG(type, name) type name[TMW_NL]
+// may lanes that merely duplicate another lane's work also duplicate its (identical) LDS store?  Yes on the GPU (same word,
+// same value, one instruction); not in the emulation, where the lanes of a block run one after the other
+#ifdef TM_HOST_EMU
+#define TMW_DUP_LANES_OK 0
+#else
+#define TMW_DUP_LANES_OK 1
+#endif
 #define TMW_DS 7   // floats per dof-scan entry: 6-vector + ancestor pointer
 
 struct WCtx {
@@ -101,6 +108,13 @@ TM_DEV float tmw_sum_dpp(const float *vp) {
   return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 63));  // the builtin is typed int: pass the BITS, not the value
 }
 TM_DEV float tmw_readlane_dpp(const float *v, int src) { return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v[0]), src)); }
+#endif
+
+// element `idx` (uniform) of a 128-entry table kept as two lane vectors
+#ifdef TM_HOST_EMU
+TM_DEV int tmw_table2(const float *a0, const float *a1, int idx) { return tm_f2i(idx < 64 ? a0[idx] : a1[idx - 64]); }
+#else
+TM_DEV int tmw_table2(const float *a0, const float *a1, int idx) { return __builtin_amdgcn_readlane(tm_f2i(idx < 64 ? a0[0] : a1[0]), idx & 63); }
 #endif
 
 // ------------------------------------------------------------------------------------------ state in / out
@@ -350,6 +364,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
     }
     TMW_SYNC();
   }
+  TMW_TICK2(20);
   // cdof_dot (kept in registers, two dof slots per lane) and body velocities
   float dd0[TMW_NL][6], dd1[TMW_NL][6], cv0[TMW_NL][6], cv1[TMW_NL][6];
   TMW_FOR {
@@ -400,6 +415,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
     }
     TMW_SYNC();
   }
+  TMW_TICK2(21);
   // body forces: cfrc_b = I_b cacc_b + cvel_b x* (I_b cvel_b)
   TMW_FOR {
     for (int slot = 0; slot < 2; slot++) {
@@ -417,20 +433,53 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
     }
   }
   TMW_SYNC();
-  // composite inertia and accumulated body force of the body carrying each dof: bodies are numbered depth-first, so a
-  // subtree is the contiguous range [b, b + nsub); every dof lane sums its own range (no level-by-level dependency)
+  TMW_TICK2(22);
+  // composite inertia / accumulated body force of every subtree, in place (cinert[b], cfrc[b] <- sum over the subtree of b).
+  // Bodies are numbered depth-first; a RUN is a maximal chain b, b+1, .. with parent[b+1] == b.  (1) One branch-free reverse
+  // sweep, lane & 15 = component (10 + 6), gives the suffix sums of every run: the running sum is kept or reset by the
+  // "has a first child" flag, values are fetched 8 bodies ahead.  (2) The few branch bodies then add the finished sums of
+  // their other children to their own run (DModel::fix_*, descending).  All 64 lanes run the sweep, lanes 16.. as copies,
+  // and store the same words (no exec-mask branch per store).  This replaces per-dof range sums in which the six root-dof
+  // lanes each added up all 67 bodies x 16 components.
+  TMW_REG(float, ns0); TMW_REG(float, ns1);
+  TMW_FOR { ns0[TMW_LI] = tm_i2f(lane < K.nbody ? m.body_nsub[lane] : 1); ns1[TMW_LI] = tm_i2f(lane + 64 < K.nbody ? m.body_nsub[lane + 64] : 1); }
+  TMW_FOR {
+    const int comp = lane & 15;
+    const int base = comp < 10 ? K.l_cinert + comp : K.l_cfrc + comp - 10, stride = comp < 10 ? 10 : 6;
+    float run = 0.f;
+    for (int b0 = K.nbody - 1; b0 >= 1; b0 -= 8) {
+      float vb[8]; int nb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { int b = b0 - u > 0 ? b0 - u : 0; vb[u] = L[base + b * stride]; nb[u] = tmw_table2(ns0, ns1, b); }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int b = b0 - u > 0 ? b0 - u : 0;       // b == 0 (the world body) only pads the last block: its sum is never used
+        run = vb[u] + (nb[u] > 1 ? run : 0.f);
+        if (TMW_DUP_LANES_OK || lane < 16) L[base + b * stride] = run;
+      }
+    }
+  }
+  TMW_SYNC();
+  for (int f = 0; f < m.n_fix; f++) {
+    int p = m.fix_p[f], r0 = m.fix_r0[f];
+    TMW_FOR {
+      const int comp = lane & 15;
+      const int base = comp < 10 ? K.l_cinert + comp : K.l_cfrc + comp - 10, stride = comp < 10 ? 10 : 6;
+      float delta = 0.f;
+      for (int e = m.fix_adr[f]; e < m.fix_adr[f + 1]; e++) delta += L[base + m.fix_child[e] * stride];
+      for (int b = r0 + (lane >> 4); b <= p; b += 4) L[base + b * stride] += delta;
+    }
+    TMW_SYNC();
+  }
+  TMW_SYNC();
+  TMW_TICK2(23);
   // M rows, bias, passive, actuation -> qfrc_smooth; act_dot
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
-      int b = m.dof_bodyid[i], nsub = m.body_nsub[b];
+      int b = m.dof_bodyid[i];
       float I[10], fb[6], cd[6], buf[6];
-      for (int k = 0; k < 10; k++) I[k] = 0.f;
-      for (int k = 0; k < 6; k++) fb[k] = 0.f;
-#pragma unroll 2
-      for (int cb = b; cb < b + nsub; cb++) {
-        for (int k = 0; k < 10; k++) I[k] += L[K.l_cinert + cb * 10 + k];
-        for (int k = 0; k < 6; k++) fb[k] += L[K.l_cfrc + cb * 6 + k];
-      }
+      for (int k = 0; k < 10; k++) I[k] = L[K.l_cinert + b * 10 + k];
+      for (int k = 0; k < 6; k++) fb[k] = L[K.l_cfrc + b * 6 + k];
       for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
       tm_inert_mul(buf, I, cd);
       int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = w0 >> 16;
@@ -602,6 +651,16 @@ TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
 // (dof, ancestor) pair, no LDS traffic, no address arithmetic, no dependent-load chain.  Everything is unrolled at compile
 // time (register arrays cannot be indexed dynamically).  Lane TMW_RL carries the right-hand side of the fused solve.
 #define TMW_RL 63
+// 1/x: hardware reciprocal (1 ulp) + one Newton step — the pivots are positive, normal numbers (D of an SPD matrix); the IEEE
+// division sequence costs ~12 dependent instructions on the critical path of every pivot
+TM_DEV float tmw_rcp(float x) {
+#ifdef TM_HOST_EMU
+  return 1.f / x;
+#else
+  float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.f), r, r);
+#endif
+}
 // The unrolled chain code compares `lane` with ~36 compile-time depths.  Left alone, LLVM hoists every such lane mask (an
 // SGPR pair each) out of the substep loop and keeps it alive across the whole kernel — SGPRs overflow into VGPR lanes and
 // those into scratch.  An opaque copy of the lane id per function keeps the masks local: one v_cmp at the point of use.
@@ -646,7 +705,7 @@ TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float
 #pragma unroll
   for (int k = N - 1; k >= 0; k--) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
-    float piv = tmw_readlane(r[k], dk), inv = 1.f / piv;
+    float piv = tmw_readlane(r[k], dk), inv = tmw_rcp(piv);
     TMW_FOR { rs[TMW_LI] = r[k][TMW_LI] * inv; }
 #pragma unroll
     for (int j = dk - 1; j >= 0; j--) {
@@ -726,20 +785,24 @@ template <int FIRST, int N, int D0>
 TM_DEV void tmw_rows_subst(WCtx &c, const WLayout &K, float *xv, int x) {
   float *L = c.L; TMW_LANE_OPAQUE
   const int adr0 = K.l_LD + TMW_ADR(TMW_W0(FIRST));
-  TMW_REG(float, t);
+  TMW_REG(float, t); TMW_REG(float, yv);
+  // y_k / D_k of the chain dofs, lane = depth; nothing is stored inside the row loop, so the row loads can all be issued early
+  TMW_FOR {
+    bool mine = lane >= D0 && lane < D0 + N;
+    int idx = mine ? FIRST - D0 + lane : 0;
+    yv[TMW_LI] = mine ? L[x + idx] * L[K.l_Dinv + idx] : 0.f;
+  }
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
     TMW_FOR {
       float v = L[adr0 - lane + (off + dk)];
-      t[TMW_LI] = lane < dk ? v * xv[TMW_LI] : (lane == TMW_RL ? -L[x + FIRST + k] * L[K.l_Dinv + FIRST + k] : 0.f);
+      t[TMW_LI] = lane < dk ? v * xv[TMW_LI] : (lane == dk ? -yv[TMW_LI] : 0.f);
     }
     float xk = -tmw_sum(t);
-    TMW_FOR {
-      xv[TMW_LI] = lane == dk ? xk : xv[TMW_LI];
-      if (lane == 0) L[x + FIRST + k] = xk;
-    }
+    TMW_FOR { xv[TMW_LI] = lane == dk ? xk : xv[TMW_LI]; }
   }
+  TMW_FOR { if (lane >= D0 && lane < D0 + N) L[x + FIRST - D0 + lane] = xv[TMW_LI]; }
 }
 TM_DEV void tmw_subst_chains(WCtx &c, const WLayout &K, int x) {
   TMW_LANE_DECL
@@ -751,6 +814,49 @@ TM_DEV void tmw_subst_chains(WCtx &c, const WLayout &K, int x) {
 #define TMW_X(first, n, d0) TMW_FOR { xv[TMW_LI] = xt[TMW_LI]; } tmw_rows_subst<first, n, d0>(c, K, xv, x);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
 #undef TMW_X
+  TMW_SYNC();
+}
+// column part of a product with ancestor-sparse storage `A`:  c_i = sum_{k descendant of i} A(k,i) x_k  for every dof, rows
+// streamed once through a register in the lane = depth layout (per row: one ds_read, one readlane of x_k, one masked FMA;
+// the lane-per-column loop it replaces walked up to 72 descendants with two dependent LDS reads each).
+//   SOLVE = false:  out_i = c_i                          (out may not alias x)
+//   SOLVE = true :  out_i = (x_i + c_i) * Dinv_i         (first half of M^-1 x with A = L^-1; out == x is fine: a chain reads
+//                                                         only its own part of x, and before it writes)
+template <int FIRST, int N, int D0, bool SOLVE>
+TM_DEV void tmw_rows_colpart(WCtx &c, const WLayout &K, int A, int x, int out, float *tacc) {
+  float *L = c.L; TMW_LANE_OPAQUE
+  const int adr0 = A + TMW_ADR(TMW_W0(FIRST));
+  TMW_REG(float, xv); TMW_REG(float, acc);
+  TMW_FOR {
+    bool mine = lane >= D0 && lane < D0 + N;
+    xv[TMW_LI] = mine ? L[x + (mine ? FIRST - D0 + lane : 0)] : 0.f;
+    acc[TMW_LI] = D0 == 0 ? tacc[TMW_LI] : 0.f;
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 1 - (D0 > 0); k--) {
+    const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
+    float xk = tmw_readlane(xv, dk);
+    TMW_FOR { float v = L[adr0 - lane + (off + dk)]; acc[TMW_LI] += lane < dk ? v * xk : 0.f; }
+  }
+  TMW_FOR {
+    bool mine = lane >= D0 && lane < D0 + N;
+    if (mine) {
+      float v = acc[TMW_LI];
+      if (SOLVE) v = (xv[TMW_LI] + v) * L[K.l_Dinv + FIRST - D0 + lane];
+      L[out + FIRST - D0 + lane] = v;
+    }
+    if (D0 > 0) tacc[TMW_LI] += lane < D0 ? acc[TMW_LI] : 0.f;
+  }
+}
+template <bool SOLVE>
+TM_DEV void tmw_colpart_chains(WCtx &c, const WLayout &K, int A, int x, int out) {
+  TMW_LANE_DECL
+  TMW_REG(float, tacc);
+  TMW_FOR { tacc[TMW_LI] = 0.f; }
+#define TMW_X(first, n, d0) tmw_rows_colpart<first, n, d0, SOLVE>(c, K, A, x, out, tacc);
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  tmw_rows_colpart<0, TMW_RODENT_TRUNK, 0, SOLVE>(c, K, A, x, out, tacc);
   TMW_SYNC();
 }
 // Lean sparse row / column products shared by tmw_solve and tmw_mul_m.  Row i of the ancestor-sparse storage `A` is
@@ -782,18 +888,22 @@ TM_DEV float tmw_col_dot(const float *L, const WLayout &K, int A, int x, int i) 
 TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, z0); TMW_REG(float, z1);
-  TMW_FOR {
-    for (int slot = 0; slot < 2; slot++) {
-      int i = lane + 64 * slot;
-      if (i >= K.nv) continue;
-      (slot ? z1 : z0)[TMW_LI] = (L[x + i] + tmw_col_dot(L, K, K.l_LD, x, i)) * L[K.l_Dinv + i];
+  if (K.chains) {
+    tmw_colpart_chains<true>(c, K, K.l_LD, x, x);
+  } else {
+    TMW_FOR {
+      for (int slot = 0; slot < 2; slot++) {
+        int i = lane + 64 * slot;
+        if (i >= K.nv) continue;
+        (slot ? z1 : z0)[TMW_LI] = (L[x + i] + tmw_col_dot(L, K, K.l_LD, x, i)) * L[K.l_Dinv + i];
+      }
     }
+    TMW_SYNC();
+    TMW_FOR {
+      for (int slot = 0; slot < 2; slot++) { int i = lane + 64 * slot; if (i < K.nv) L[x + i] = (slot ? z1 : z0)[TMW_LI]; }
+    }
+    TMW_SYNC();
   }
-  TMW_SYNC();
-  TMW_FOR {
-    for (int slot = 0; slot < 2; slot++) { int i = lane + 64 * slot; if (i < K.nv) L[x + i] = (slot ? z1 : z0)[TMW_LI]; }
-  }
-  TMW_SYNC();
   TMW_FOR {
     for (int slot = 0; slot < 2; slot++) {
       int i = lane + 64 * slot;
@@ -810,8 +920,13 @@ TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
 // y = M x
 TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
   float *L = c.L; TMW_LANE_DECL
-  TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) L[y + i] = tmw_row_dot(L, K, K.l_M, x, i, true) + tmw_col_dot(L, K, K.l_M, x, i);
+  if (K.chains) {
+    tmw_colpart_chains<false>(c, K, K.l_M, x, y);
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[y + i] += tmw_row_dot(L, K, K.l_M, x, i, true); }
+  } else {
+    TMW_FOR {
+      for (int i = lane; i < K.nv; i += 64) L[y + i] = tmw_row_dot(L, K, K.l_M, x, i, true) + tmw_col_dot(L, K, K.l_M, x, i);
+    }
   }
   TMW_SYNC();
 }
@@ -946,8 +1061,11 @@ TM_DEV float tmw_dot(WCtx &c, const WLayout &K, int a, int b) {
 // Jaref <- J q - aref ; Ma <- M q ; returns cost and gauss for qacc vector `q`
 TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_TICK2(15);
   tmw_mul_m(c, K, q, K.l_Ma);
+  TMW_TICK2(18);
   tmw_jmul(c, K, q, K.l_Jaref);
+  TMW_TICK2(19);
   TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
     float sc = 0.f, sg = 0.f;
@@ -978,7 +1096,9 @@ TM_DEV float tmw_cost_from_state(WCtx &c, const WLayout &K, float &gauss) {
 }
 TM_DEV void tmw_update_gradient(WCtx &c, const WLayout &K) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_TICK2(15);
   tmw_jt_force(c, K, K.l_qfrc_constraint);
+  TMW_TICK2(16);
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       float g = L[K.l_Ma + i] - L[K.l_qfrc_smooth + i] - L[K.l_qfrc_constraint + i];
@@ -986,7 +1106,9 @@ TM_DEV void tmw_update_gradient(WCtx &c, const WLayout &K) {
     }
   }
   TMW_SYNC();
+  TMW_TICK2(15);
   tmw_solve(c, K, K.l_Mgrad);
+  TMW_TICK2(17);
 }
 struct TmwLS { float alpha, cost, d0, d1; };
 // three line-search points evaluated together (alphas a[0..2]): 9 partial sums, one pass over the rows
@@ -1021,6 +1143,7 @@ TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
   tmw_mul_m(c, K, K.l_search, K.l_mv);
   tmw_jmul(c, K, K.l_search, K.l_jv);
   float g0 = gauss, g1 = tmw_dot(c, K, K.l_search, K.l_Ma) - tmw_dot(c, K, K.l_search, K.l_qfrc_smooth), g2 = 0.5f * tmw_dot(c, K, K.l_search, K.l_mv);
+  TMW_TICK2(13);
   TmwLS pt[3];
   float al[3] = {0.f, 0.f, 0.f};
   tmw_ls_points(c, K, al, 1, g0, g1, g2, pt);
@@ -1047,6 +1170,7 @@ TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
     if (s4) hi = mid;
     swap = s1 || s2 || s3 || s4;
   }
+  TMW_TICK2(14);
   bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
   float ia = improved ? alpha : 0.f;
