@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict
   c.dump = ws_dump;
 #endif
 #ifdef TMW_PROFILE
-  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)blockIdx.x * 24; c.tlast = __builtin_amdgcn_s_memtime(); }
+  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)blockIdx.x * 32; c.tlast = __builtin_amdgcn_s_memtime(); }
 #endif
   constexpr WLayout ks(TMW_RODENT_DIMS, 1);
   const WLayout kd = STATIC ? ks : WLayout(mp->nbody, mp->njnt, mp->nq, mp->nv, mp->nu, mp->ncon, mp->nlim, mp->nnz, mp->ngroup,
@@ -173,6 +173,7 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
     size_t lds_bytes = (size_t)m->h.lds_floats * sizeof(float);
     if (lds_bytes > 160 * 1024) { delete m; return fail(TMJX_EINVAL, "model does not fit the 160 KiB LDS of a CU"); }
     if (lds_bytes > 64 * 1024) { delete m; return fail(TMJX_EINVAL, "model needs more than 64 KiB of LDS per env"); }
+    if (m->h.nefc > 64 * TMW_LS_SLOTS) { delete m; return fail(TMJX_EINVAL, "more than 256 constraint rows (wave kernel keeps the line-search rows in 4 registers per lane)"); }
     constexpr WLayout ks(TMW_RODENT_DIMS);
     const WLayout kd = tmjx_host::make_wave_layout(m->h);
     m->rodent = !getenv("TMJX_WAVE_DYNAMIC") && kd.nbody == ks.nbody && kd.njnt == ks.njnt && kd.nq == ks.nq && kd.nv == ks.nv &&

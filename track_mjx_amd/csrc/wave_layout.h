@@ -64,3 +64,24 @@ struct WLayout {
 // chains X(first dof, length, depth of the first dof) of consecutive dofs; listed in the order they are eliminated
 #define TMW_RODENT_TRUNK 12
 #define TMW_RODENT_LEAF_CHAINS(X) X(65, 8, 6) X(57, 8, 6) X(48, 9, 6) X(24, 24, 12) X(18, 6, 12) X(12, 6, 12)
+#define TMW_RODENT_NCHAIN 6
+// depth of a dof and address of its row in the tree-sparse storage (rows back to back in dof order, row i = depth+1 words),
+// folded at compile time from the chain table; model_host.h checks the loaded model against it
+constexpr int tmw_chain_depth(int i) {
+  if (i < TMW_RODENT_TRUNK) return i;
+#define TMW_X(first, n, d0) if (i >= first && i < first + n) return d0 + i - first;
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  return 0;
+}
+constexpr int tmw_chain_madr(int i) { int a = 0; for (int j = 0; j < i; j++) a += tmw_chain_depth(j) + 1; return a; }
+constexpr int tmw_chain_maxdepth(int i0, int i1) { int d = 0; for (int i = i0; i < i1; i++) if (tmw_chain_depth(i) > d) d = tmw_chain_depth(i); return d; }
+constexpr int tmw_chain_first(int i) {
+  if (i < TMW_RODENT_TRUNK) return 0;
+#define TMW_X(first, n, d0) if (i >= first && i < first + n) return first;
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  return 0;
+}
+// longest run of in-chain ancestors (i - chain start) among dofs i0 .. i1-1
+constexpr int tmw_chain_maxrun(int i0, int i1) { int r = 0; for (int i = i0; i < i1; i++) if (i - tmw_chain_first(i) > r) r = i - tmw_chain_first(i); return r; }

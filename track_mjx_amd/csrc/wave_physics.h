@@ -661,46 +661,50 @@ TM_DEV float tmw_rcp(float x) {
   return fmaf(fmaf(-x, r, 1.f), r, r);
 #endif
 }
-// The unrolled chain code compares `lane` with ~36 compile-time depths.  Left alone, LLVM hoists every such lane mask (an
-// SGPR pair each) out of the substep loop and keeps it alive across the whole kernel — SGPRs overflow into VGPR lanes and
-// those into scratch.  An opaque copy of the lane id per function keeps the masks local: one v_cmp at the point of use.
+// Lane predicates of the unrolled chain code are COMPILE-TIME lane masks (lane < depth, lane == depth, ..): on the GPU they
+// become 64-bit literals moved into an SGPR pair (llvm.amdgcn.inverse.ballot) — no v_cmp, nothing for LICM to hoist and
+// keep alive across the substep loop (an earlier version compared `lane` with the ~36 depths and drowned in SGPR spills).
 #ifdef TM_HOST_EMU
-#define TMW_LANE_OPAQUE
+#define TMW_MASK(m64) (((((unsigned long long)(m64)) >> lane) & 1ull) != 0ull)
 #define TMW_SCHED_FENCE() do { } while (0)
 #define TMW_PIN(x) do { } while (0)
 #else
-// ... and from sinking every rank-1 update down to the pivot step of its target row (which turns the elimination into a
+#define TMW_MASK(m64) __builtin_amdgcn_inverse_ballot_w64((unsigned long long)(m64))
+// keep LLVM from sinking every rank-1 update down to the pivot step of its target row (which turns the elimination into a
 // left-looking one whose ~600 multipliers all stay live in SGPRs): an empty volatile asm that "modifies" the target pins
 // the FMA to its place in program order
 #define TMW_PIN(x) asm volatile("" : "+v"(x))
-// also: keep the scheduler from batching hundreds of independent v_readlane results (SGPRs) ahead of the FMAs using them
 #define TMW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-TM_DEV int tmw_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
-#define TMW_LANE_OPAQUE const int lane = tmw_opaque(c.lane);
 #endif
-template <int FIRST, int N, int D0>
+#define TMW_M_LT(n) ((n) >= 64 ? ~0ull : ((1ull << (n)) - 1ull))
+#define TMW_M_EQ(n) (1ull << (n))
+#define TMW_M_RANGE(a, b) (TMW_M_LT(b) & ~TMW_M_LT(a))
+// EULER = false: plain M (no damping term, no right-hand side)
+template <int FIRST, int N, int D0, bool EULER>
 TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float hdamp, int rhs) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_OPAQUE
-  const int adr0 = K.l_M + TMW_ADR(TMW_W0(FIRST));
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  const int adr0 = K.l_M + tmw_chain_madr(FIRST);
   TMW_REG(float, hd);   // hdamp * damping of the chain dof whose DIAGONAL sits in this lane (depth = lane)
-  TMW_FOR { hd[TMW_LI] = (hdamp != 0.f && lane >= D0 && lane < D0 + N) ? hdamp * m.dof_damping[FIRST + lane - D0] : 0.f; }
+  if (EULER) { TMW_FOR { bool mine = TMW_MASK(TMW_M_RANGE(D0, D0 + N)); hd[TMW_LI] = mine ? hdamp * m.dof_damping[mine ? FIRST + lane - D0 : 0] : 0.f; } }
   TMW_FOR {
 #pragma unroll
     for (int k = 0; k < N; k++) {
       const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;   // Madr(FIRST + k) - Madr(FIRST): rows are stored back to back
       float v = L[adr0 - lane + (off + dk)];   // lanes beyond the row read (and discard) whatever precedes it in LDS
-      v = lane < dk ? v : (lane == dk ? v + hd[TMW_LI] : 0.f);
-      if (rhs >= 0) v = lane == TMW_RL ? L[rhs + FIRST + k] : v;
+      if (EULER) v += TMW_MASK(TMW_M_EQ(dk)) ? hd[TMW_LI] : 0.f;
+      v = TMW_MASK(TMW_M_LT(dk + 1)) ? v : 0.f;
+      if (EULER) v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? L[rhs + FIRST + k] : v;
       r[k][TMW_LI] = v;
     }
   }
 }
-// eliminate the chain leaf -> root: finished rows go to LD (strict part = L, entry 0 = D) / Dinv / rhs; the Schur
-// complement lands in the remaining chain rows and in the trunk rows `tr` (registers, shared by all chains)
-template <int FIRST, int N, int D0>
+// eliminate the chain leaf -> root: finished rows go to LD (strict part = L; the diagonal word is not written, D^-1 goes to
+// Dinv) and the eliminated rhs; the Schur complement lands in the remaining chain rows and in the trunk rows `tr`
+// (registers, shared by all chains)
+template <int FIRST, int N, int D0, bool EULER>
 TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float (*tr)[TMW_NL], int rhs) {
-  float *L = c.L; TMW_LANE_OPAQUE
-  const int adr0 = K.l_LD + TMW_ADR(TMW_W0(FIRST));
+  float *L = c.L; TMW_LANE_DECL
+  const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
   TMW_REG(float, rs); TMW_REG(float, dv);
 #pragma unroll
   for (int k = N - 1; k >= 0; k--) {
@@ -714,43 +718,45 @@ TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float
       TMW_FOR { tgt[TMW_LI] -= a * r[k][TMW_LI]; TMW_PIN(tgt[TMW_LI]); }
     }
     TMW_FOR {
-      if (lane <= dk) L[adr0 - lane + (off + dk)] = lane == dk ? piv : rs[TMW_LI];
-      dv[TMW_LI] = lane == dk ? inv : dv[TMW_LI];
-      if (rhs >= 0 && lane == TMW_RL) L[rhs + FIRST + k] = r[k][TMW_LI];
+      if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = rs[TMW_LI];
+      dv[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? inv : dv[TMW_LI];
+      if (EULER && TMW_MASK(TMW_M_EQ(TMW_RL))) L[rhs + FIRST + k] = r[k][TMW_LI];
     }
   }
-  TMW_FOR { if (lane >= D0 && lane < D0 + N) L[K.l_Dinv + FIRST - D0 + lane] = dv[TMW_LI]; }
+  TMW_FOR { if (TMW_MASK(TMW_M_RANGE(D0, D0 + N))) L[K.l_Dinv + FIRST - D0 + lane] = dv[TMW_LI]; }
 }
-template <int FIRST, int N, int D0>
+template <int FIRST, int N, int D0, bool EULER>
 TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, float (*tr)[TMW_NL], float hdamp, int rhs) {
   float r[N][TMW_NL];
-  tmw_rows_load<FIRST, N, D0>(c, K, r, hdamp, rhs);
-  tmw_rows_factor<FIRST, N, D0>(c, K, r, tr, rhs);
+  tmw_rows_load<FIRST, N, D0, EULER>(c, K, r, hdamp, rhs);
+  tmw_rows_factor<FIRST, N, D0, EULER>(c, K, r, tr, rhs);
 }
-// LD <- L^T D L of (M + hdamp diag(damping)) read straight from l_M; same outputs as tmw_factor
-TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
+// LD <- L^T D L of M (EULER = false) or of M + hdamp diag(damping) with the rhs eliminated alongside (EULER = true),
+// read straight from l_M; same outputs as tmw_factor except that the diagonal words of LD are left alone
+template <bool EULER>
+TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs) {
   float tr[TMW_RODENT_TRUNK][TMW_NL];
-  tmw_rows_load<0, TMW_RODENT_TRUNK, 0>(c, K, tr, hdamp, rhs);
-#define TMW_X(first, n, d0) tmw_chain_factor<first, n, d0>(c, K, tr, hdamp, rhs);
+  tmw_rows_load<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, hdamp, rhs);
+#define TMW_X(first, n, d0) tmw_chain_factor<first, n, d0, EULER>(c, K, tr, hdamp, rhs);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
 #undef TMW_X
-  tmw_rows_factor<0, TMW_RODENT_TRUNK, 0>(c, K, tr, tr, rhs);
+  tmw_rows_factor<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, tr, rhs);
   TMW_SYNC();
 }
 // rows of N = L^-1, root -> leaf:  N(k,:) = e_k - sum_{j < depth_k} L(k, anc_j) N(anc_j, :).  `tn`: the finished trunk rows
 // (with their unit diagonal); chain rows are kept in `n` the same way.  Lanes beyond a row's depth hold exact zeros.
 template <int FIRST, int N, int D0>
 TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, float (*n)[TMW_NL], float (*tn)[TMW_NL]) {
-  float *L = c.L; TMW_LANE_OPAQUE
-  const int adr0 = K.l_LD + TMW_ADR(TMW_W0(FIRST));
+  float *L = c.L; TMW_LANE_DECL
+  const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
   TMW_REG(float, l); TMW_REG(float, acc0); TMW_REG(float, acc1);
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
     TMW_FOR {
       float v = L[adr0 - lane + (off + dk)];
-      l[TMW_LI] = lane < dk ? v : 0.f;
-      acc0[TMW_LI] = lane == dk ? 1.f : 0.f; acc1[TMW_LI] = 0.f;
+      l[TMW_LI] = TMW_MASK(TMW_M_LT(dk)) ? v : 0.f;
+      acc0[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? 1.f : 0.f; acc1[TMW_LI] = 0.f;
     }
 #pragma unroll
     for (int j = 0; j < dk; j++) {
@@ -762,7 +768,7 @@ TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, float (*n)[TMW_NL], float
     TMW_FOR {
       float v = acc0[TMW_LI] + acc1[TMW_LI];
       n[k][TMW_LI] = v;
-      if (lane < dk) L[adr0 - lane + (off + dk)] = v;
+      if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = v;
     }
   }
 }
@@ -779,16 +785,16 @@ TM_DEV void tmw_invert_chains(WCtx &c, const WLayout &K) {
 #undef TMW_X
   TMW_SYNC();
 }
-// root -> leaf pass after tmw_factor_chains(.., rhs):  x_k = y_k / D_k - sum_j L(k, anc_j) x_anc_j.  Lane q of `xv` holds
+// root -> leaf pass after tmw_factor_chains<true>:  x_k = y_k / D_k - sum_j L(k, anc_j) x_anc_j.  Lane q of `xv` holds
 // the solution at depth q of the current path; one wave reduction per dof.
 template <int FIRST, int N, int D0>
 TM_DEV void tmw_rows_subst(WCtx &c, const WLayout &K, float *xv, int x) {
-  float *L = c.L; TMW_LANE_OPAQUE
-  const int adr0 = K.l_LD + TMW_ADR(TMW_W0(FIRST));
+  float *L = c.L; TMW_LANE_DECL
+  const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
   TMW_REG(float, t); TMW_REG(float, yv);
   // y_k / D_k of the chain dofs, lane = depth; nothing is stored inside the row loop, so the row loads can all be issued early
   TMW_FOR {
-    bool mine = lane >= D0 && lane < D0 + N;
+    bool mine = TMW_MASK(TMW_M_RANGE(D0, D0 + N));
     int idx = mine ? FIRST - D0 + lane : 0;
     yv[TMW_LI] = mine ? L[x + idx] * L[K.l_Dinv + idx] : 0.f;
   }
@@ -797,12 +803,12 @@ TM_DEV void tmw_rows_subst(WCtx &c, const WLayout &K, float *xv, int x) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
     TMW_FOR {
       float v = L[adr0 - lane + (off + dk)];
-      t[TMW_LI] = lane < dk ? v * xv[TMW_LI] : (lane == dk ? -yv[TMW_LI] : 0.f);
+      t[TMW_LI] = TMW_MASK(TMW_M_LT(dk)) ? v * xv[TMW_LI] : (TMW_MASK(TMW_M_EQ(dk)) ? -yv[TMW_LI] : 0.f);
     }
     float xk = -tmw_sum(t);
-    TMW_FOR { xv[TMW_LI] = lane == dk ? xk : xv[TMW_LI]; }
+    TMW_FOR { xv[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? xk : xv[TMW_LI]; }
   }
-  TMW_FOR { if (lane >= D0 && lane < D0 + N) L[x + FIRST - D0 + lane] = xv[TMW_LI]; }
+  TMW_FOR { if (TMW_MASK(TMW_M_RANGE(D0, D0 + N))) L[x + FIRST - D0 + lane] = xv[TMW_LI]; }
 }
 TM_DEV void tmw_subst_chains(WCtx &c, const WLayout &K, int x) {
   TMW_LANE_DECL
@@ -820,43 +826,41 @@ TM_DEV void tmw_subst_chains(WCtx &c, const WLayout &K, int x) {
 // streamed once through a register in the lane = depth layout (per row: one ds_read, one readlane of x_k, one masked FMA;
 // the lane-per-column loop it replaces walked up to 72 descendants with two dependent LDS reads each).
 //   SOLVE = false:  out_i = c_i                          (out may not alias x)
-//   SOLVE = true :  out_i = (x_i + c_i) * Dinv_i         (first half of M^-1 x with A = L^-1; out == x is fine: a chain reads
-//                                                         only its own part of x, and before it writes)
-template <int FIRST, int N, int D0, bool SOLVE>
-TM_DEV void tmw_rows_colpart(WCtx &c, const WLayout &K, int A, int x, int out, float *tacc) {
-  float *L = c.L; TMW_LANE_OPAQUE
-  const int adr0 = A + TMW_ADR(TMW_W0(FIRST));
-  TMW_REG(float, xv); TMW_REG(float, acc);
-  TMW_FOR {
-    bool mine = lane >= D0 && lane < D0 + N;
-    xv[TMW_LI] = mine ? L[x + (mine ? FIRST - D0 + lane : 0)] : 0.f;
-    acc[TMW_LI] = D0 == 0 ? tacc[TMW_LI] : 0.f;
-  }
+//   SOLVE = true :  out_i = (x_i + c_i) * Dinv_i         (first half of M^-1 x with A = L^-1; out == x is fine: every x is
+//                                                         read before the first store)
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_rows_colacc(WCtx &c, const WLayout &K, int A, const float *xv, float *acc) {
+  float *L = c.L; TMW_LANE_DECL
+  const int adr0 = A + tmw_chain_madr(FIRST);
 #pragma unroll
   for (int k = N - 1; k >= 1 - (D0 > 0); k--) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
     float xk = tmw_readlane(xv, dk);
-    TMW_FOR { float v = L[adr0 - lane + (off + dk)]; acc[TMW_LI] += lane < dk ? v * xk : 0.f; }
-  }
-  TMW_FOR {
-    bool mine = lane >= D0 && lane < D0 + N;
-    if (mine) {
-      float v = acc[TMW_LI];
-      if (SOLVE) v = (xv[TMW_LI] + v) * L[K.l_Dinv + FIRST - D0 + lane];
-      L[out + FIRST - D0 + lane] = v;
-    }
-    if (D0 > 0) tacc[TMW_LI] += lane < D0 ? acc[TMW_LI] : 0.f;
+    TMW_FOR { float v = L[adr0 - lane + (off + dk)]; acc[TMW_LI] += (TMW_MASK(TMW_M_LT(dk)) ? v : 0.f) * xk; }
   }
 }
+// all loads of x first, all stores last: the 73 row loads in between have no LDS store to be ordered against
 template <bool SOLVE>
 TM_DEV void tmw_colpart_chains(WCtx &c, const WLayout &K, int A, int x, int out) {
-  TMW_LANE_DECL
-  TMW_REG(float, tacc);
-  TMW_FOR { tacc[TMW_LI] = 0.f; }
-#define TMW_X(first, n, d0) tmw_rows_colpart<first, n, d0, SOLVE>(c, K, A, x, out, tacc);
+  float *L = c.L; TMW_LANE_DECL
+  float xv[TMW_RODENT_NCHAIN + 1][TMW_NL], acc[TMW_RODENT_NCHAIN + 1][TMW_NL];
+  { int ci = 0;
+#define TMW_X(first, n, d0) TMW_FOR { bool mine = TMW_MASK(TMW_M_RANGE(d0, d0 + n)); xv[ci][TMW_LI] = mine ? L[x + (mine ? first - d0 + lane : 0)] : 0.f; acc[ci][TMW_LI] = 0.f; } ci++;
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+  TMW_X(0, TMW_RODENT_TRUNK, 0)
+#undef TMW_X
+  }
+  { int ci = 0;
+#define TMW_X(first, n, d0) tmw_rows_colacc<first, n, d0>(c, K, A, xv[ci], acc[ci]); TMW_FOR { acc[TMW_RODENT_NCHAIN][TMW_LI] += TMW_MASK(TMW_M_LT(d0)) ? acc[ci][TMW_LI] : 0.f; } ci++;
   TMW_RODENT_LEAF_CHAINS(TMW_X)
 #undef TMW_X
-  tmw_rows_colpart<0, TMW_RODENT_TRUNK, 0, SOLVE>(c, K, A, x, out, tacc);
+  tmw_rows_colacc<0, TMW_RODENT_TRUNK, 0>(c, K, A, xv[ci], acc[ci]); }
+  { int ci = 0;
+#define TMW_STORE(first, n, d0) TMW_FOR { if (TMW_MASK(TMW_M_RANGE(d0, d0 + n))) { float v = acc[ci][TMW_LI]; if (SOLVE) v = (xv[ci][TMW_LI] + v) * L[K.l_Dinv + first - d0 + lane]; L[out + first - d0 + lane] = v; } } ci++;
+  TMW_RODENT_LEAF_CHAINS(TMW_STORE)
+  TMW_STORE(0, TMW_RODENT_TRUNK, 0)
+#undef TMW_STORE
+  }
   TMW_SYNC();
 }
 // Lean sparse row / column products shared by tmw_solve and tmw_mul_m.  Row i of the ancestor-sparse storage `A` is
@@ -884,26 +888,65 @@ TM_DEV float tmw_col_dot(const float *L, const WLayout &K, int A, int x, int i) 
   for (int t = 0; t < nd; t++) acc += Ap[TMW_MEND(tm_f2i(tw[2 * t]))] * xp[t];
   return acc;
 }
+// row part for the chain layout, lane = dof: the two pointer runs of tmw_row_dot (ancestors inside the dof's own chain, then
+// on the trunk) as counted loops with a trip count common to the whole slot and a predicate per entry — no divergent loop
+// exits, one wait per 6 entries.  The bounds are made opaque so that the loops stay loops: fully unrolled, every
+// `q <= r(lane)` would be a loop-invariant lane mask that LLVM hoists out of the substep loop and spills.
+#ifdef TM_HOST_EMU
+TM_DEV int tmw_opaque_s(int x) { return x; }
+#else
+TM_DEV int tmw_opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+#endif
+template <int MAXR, int MAXT>
+TM_DEV float tmw_row_runs(const float *L, const WLayout &K, int A, int x, int i, bool diag) {
+  int w0 = tm_f2i(L[K.l_tdof + 2 * i]), w1 = tm_f2i(L[K.l_tdof + 2 * i + 1]);
+  int d = w0 >> 16, r = i - (w1 & 0xff), jp1 = (w1 >> 8) & 0xff;
+  const float *Ap = L + A + TMW_ADR(w0), *xp = L + x + i;
+  float acc = diag ? Ap[0] * xp[0] : 0.f;
+  const int maxr = tmw_opaque_s(MAXR), maxt = tmw_opaque_s(MAXT);
+#pragma unroll 6
+  for (int q = 1; q <= maxr; q++) { float a = Ap[q], xx = xp[-q]; acc += q <= r ? a * xx : 0.f; }
+  const float *Aq = Ap + r + 1, *xq = L + x + jp1 - 1;
+  const int nt = d - r;
+#pragma unroll 6
+  for (int t = 0; t < maxt; t++) { float a = Aq[t], xx = xq[-t]; acc += t < nt ? a * xx : 0.f; }
+  return acc;
+}
+// (A x)_i over the ancestors of i (+ diagonal) for every dof, kept in two lane registers
+TM_DEV void tmw_rowpart_chains(WCtx &c, const WLayout &K, int A, int x, bool diag, float *z0, float *z1) {
+  float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    z0[TMW_LI] = tmw_row_runs<tmw_chain_maxrun(0, 64), TMW_RODENT_TRUNK>(L, K, A, x, lane, diag);
+    z1[TMW_LI] = tmw_row_runs<tmw_chain_maxrun(64, 73), TMW_RODENT_TRUNK>(L, K, A, x, lane + 64 < K.nv ? lane + 64 : 64, diag);
+  }
+}
 // x <- M^-1 x using N = L^-1:  x = N D^-1 N^T x   (two sparse mat-vecs; `x` is an LDS vector offset)
 TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, z0); TMW_REG(float, z1);
   if (K.chains) {
+    TMW_TICK2(15);
     tmw_colpart_chains<true>(c, K, K.l_LD, x, x);
-  } else {
-    TMW_FOR {
-      for (int slot = 0; slot < 2; slot++) {
-        int i = lane + 64 * slot;
-        if (i >= K.nv) continue;
-        (slot ? z1 : z0)[TMW_LI] = (L[x + i] + tmw_col_dot(L, K, K.l_LD, x, i)) * L[K.l_Dinv + i];
-      }
-    }
+    TMW_TICK2(26);
+    tmw_rowpart_chains(c, K, K.l_LD, x, false, z0, z1);
+    TMW_FOR { z0[TMW_LI] += L[x + lane]; if (lane + 64 < K.nv) z1[TMW_LI] += L[x + lane + 64]; }
     TMW_SYNC();
-    TMW_FOR {
-      for (int slot = 0; slot < 2; slot++) { int i = lane + 64 * slot; if (i < K.nv) L[x + i] = (slot ? z1 : z0)[TMW_LI]; }
-    }
+    TMW_FOR { L[x + lane] = z0[TMW_LI]; if (lane + 64 < K.nv) L[x + lane + 64] = z1[TMW_LI]; }
     TMW_SYNC();
+    return;
   }
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) {
+      int i = lane + 64 * slot;
+      if (i >= K.nv) continue;
+      (slot ? z1 : z0)[TMW_LI] = (L[x + i] + tmw_col_dot(L, K, K.l_LD, x, i)) * L[K.l_Dinv + i];
+    }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    for (int slot = 0; slot < 2; slot++) { int i = lane + 64 * slot; if (i < K.nv) L[x + i] = (slot ? z1 : z0)[TMW_LI]; }
+  }
+  TMW_SYNC();
   TMW_FOR {
     for (int slot = 0; slot < 2; slot++) {
       int i = lane + 64 * slot;
@@ -921,14 +964,20 @@ TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
 TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
   float *L = c.L; TMW_LANE_DECL
   if (K.chains) {
+    TMW_REG(float, z0); TMW_REG(float, z1);
+    TMW_TICK2(15);
+    tmw_rowpart_chains(c, K, K.l_M, x, true, z0, z1);
+    TMW_SCHED_FENCE();
     tmw_colpart_chains<false>(c, K, K.l_M, x, y);
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[y + i] += tmw_row_dot(L, K, K.l_M, x, i, true); }
+    TMW_FOR { L[y + lane] += z0[TMW_LI]; if (lane + 64 < K.nv) L[y + lane + 64] += z1[TMW_LI]; }
+    TMW_SYNC();
+    TMW_TICK2(24);
   } else {
     TMW_FOR {
       for (int i = lane; i < K.nv; i += 64) L[y + i] = tmw_row_dot(L, K, K.l_M, x, i, true) + tmw_col_dot(L, K, K.l_M, x, i);
     }
+    TMW_SYNC();
   }
-  TMW_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------ matrix-free J
@@ -1111,24 +1160,37 @@ TM_DEV void tmw_update_gradient(WCtx &c, const WLayout &K) {
   TMW_TICK2(17);
 }
 struct TmwLS { float alpha, cost, d0, d1; };
-// three line-search points evaluated together (alphas a[0..2]): 9 partial sums, one pass over the rows
-TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const float *a, int np, float g0, float g1, float g2, TmwLS *out) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
-  float q[TMW_NL][9];
+// The constraint rows of a line search live in registers: per row e = lane + 64 s the three quadratic coefficients
+// t0 = D ja^2 / 2, t1 = D ja jv, t2 = D jv^2 / 2 and (ja, jv) for the activity test ja + alpha jv < 0.
+#define TMW_LS_SLOTS 4        // up to 256 constraint rows
+struct TmwLSRows { float ja[TMW_NL][TMW_LS_SLOTS], jv[TMW_NL][TMW_LS_SLOTS], t0[TMW_NL][TMW_LS_SLOTS], t1[TMW_NL][TMW_LS_SLOTS], t2[TMW_NL][TMW_LS_SLOTS]; };
+// NP line-search points evaluated together (alphas a[0..NP-1]): 3 NP partial sums over the rows, reduced together
+template <int NP>
+TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const float *a, float g0, float g1, float g2, TmwLS *out) {
+  TMW_LANE_DECL
+  float q[3 * NP][TMW_NL];
+  const int nslot = (K.nefc + 63) / 64;
   TMW_FOR {
-    float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int e = lane; e < K.nefc; e += 64) {
-      float ja = L[K.l_Jaref + e], jv = L[K.l_jv + e], D = L[K.l_efc_D + e];
-      float t0 = 0.5f * ja * ja * D, t1 = jv * ja * D, t2 = 0.5f * jv * jv * D;
-      for (int p = 0; p < 3; p++) if (p < np && ja + a[p] * jv < 0.f) { s[3 * p] += t0; s[3 * p + 1] += t1; s[3 * p + 2] += t2; }
+    float s[3 * NP];
+    for (int k = 0; k < 3 * NP; k++) s[k] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
+      if (sl >= nslot) break;
+      float ja = R.ja[TMW_LI][sl], jv = R.jv[TMW_LI][sl];
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        bool act = ja + a[p] * jv < 0.f;
+        s[3 * p] += act ? R.t0[TMW_LI][sl] : 0.f; s[3 * p + 1] += act ? R.t1[TMW_LI][sl] : 0.f; s[3 * p + 2] += act ? R.t2[TMW_LI][sl] : 0.f;
+      }
     }
-    for (int k = 0; k < 9; k++) q[TMW_LI][k] = s[k];
+    for (int k = 0; k < 3 * NP; k++) q[k][TMW_LI] = s[k];
   }
-  for (int p = 0; p < np; p++) {
-    TMW_REG(float, t);
-    float qq[3];
-    for (int k = 0; k < 3; k++) { TMW_FOR { t[TMW_LI] = q[TMW_LI][3 * p + k]; } qq[k] = tmw_sum(t); }
-    float q0 = g0 + qq[0], q1 = g1 + qq[1], q2 = g2 + qq[2], al = a[p];
+  float qq[3 * NP];
+#pragma unroll
+  for (int k = 0; k < 3 * NP; k++) qq[k] = tmw_sum(q[k]);
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    float q0 = g0 + qq[3 * p], q1 = g1 + qq[3 * p + 1], q2 = g2 + qq[3 * p + 2], al = a[p];
     out[p].alpha = al;
     out[p].cost = al * al * q2 + al * q1 + q0;
     out[p].d0 = 2.f * al * q2 + q1;
@@ -1143,13 +1205,24 @@ TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
   tmw_mul_m(c, K, K.l_search, K.l_mv);
   tmw_jmul(c, K, K.l_search, K.l_jv);
   float g0 = gauss, g1 = tmw_dot(c, K, K.l_search, K.l_Ma) - tmw_dot(c, K, K.l_search, K.l_qfrc_smooth), g2 = 0.5f * tmw_dot(c, K, K.l_search, K.l_mv);
+  TmwLSRows R;
+  TMW_FOR {
+#pragma unroll
+    for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
+      int e = lane + 64 * sl;
+      bool ok = e < K.nefc;
+      float ja = ok ? L[K.l_Jaref + (ok ? e : 0)] : 1.f, jv = ok ? L[K.l_jv + (ok ? e : 0)] : 0.f, D = ok ? L[K.l_efc_D + (ok ? e : 0)] : 0.f;   // padding rows: never active
+      R.ja[TMW_LI][sl] = ja; R.jv[TMW_LI][sl] = jv;
+      R.t0[TMW_LI][sl] = 0.5f * ja * ja * D; R.t1[TMW_LI][sl] = jv * ja * D; R.t2[TMW_LI][sl] = 0.5f * jv * jv * D;
+    }
+  }
   TMW_TICK2(13);
   TmwLS pt[3];
   float al[3] = {0.f, 0.f, 0.f};
-  tmw_ls_points(c, K, al, 1, g0, g1, g2, pt);
+  tmw_ls_points<1>(c, K, R, al, g0, g1, g2, pt);
   TmwLS p0 = pt[0];
   al[0] = p0.alpha - p0.d0 / p0.d1;
-  tmw_ls_points(c, K, al, 1, g0, g1, g2, pt);
+  tmw_ls_points<1>(c, K, R, al, g0, g1, g2, pt);
   TmwLS lo0 = pt[0];
   bool lesser = lo0.d0 < p0.d0;
   TmwLS hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
@@ -1158,7 +1231,7 @@ TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
     bool done = !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
     if (done) break;
     al[0] = lo.alpha - lo.d0 / lo.d1; al[1] = hi.alpha - hi.d0 / hi.d1; al[2] = 0.5f * (lo.alpha + hi.alpha);
-    tmw_ls_points(c, K, al, 3, g0, g1, g2, pt);
+    tmw_ls_points<3>(c, K, R, al, g0, g1, g2, pt);
     TmwLS lo_next = pt[0], hi_next = pt[1], mid = pt[2];
     bool s1 = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
     if (s1) lo = lo_next;
@@ -1176,7 +1249,8 @@ TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
   float ia = improved ? alpha : 0.f;
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] += L[K.l_search + i] * ia; L[K.l_Ma + i] += L[K.l_mv + i] * ia; }
-    for (int e = lane; e < K.nefc; e += 64) L[K.l_Jaref + e] += L[K.l_jv + e] * ia;
+#pragma unroll
+    for (int sl = 0; sl < TMW_LS_SLOTS; sl++) { int e = lane + 64 * sl; if (e < K.nefc) L[K.l_Jaref + e] = R.ja[TMW_LI][sl] + R.jv[TMW_LI][sl] * ia; }
   }
   TMW_SYNC();
 }
@@ -1232,7 +1306,7 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   TMW_TICK(0);
   tmw_velocity_inertia(c, K);
   TMW_TICK(1);
-  if (K.chains) tmw_factor_chains(c, K, 0.f); else tmw_factor(c, K, 0.f);
+  if (K.chains) tmw_factor_chains<false>(c, K, 0.f, -1); else tmw_factor(c, K, 0.f);
   TMW_TICK(2);
   if (K.chains) tmw_invert_chains(c, K); else tmw_invert_l(c, K);
   TMW_TICK(3);
@@ -1254,7 +1328,7 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_qfrc_smooth + i] + L[K.l_qfrc_constraint + i]; }
   TMW_SYNC();
   TMW_TICK(8);
-  if (K.chains) tmw_factor_chains(c, K, h, K.l_tmp); else tmw_factor(c, K, h, K.l_tmp);
+  if (K.chains) tmw_factor_chains<true>(c, K, h, K.l_tmp); else tmw_factor(c, K, h, K.l_tmp);
   TMW_TICK(9);
   if (K.chains) tmw_subst_chains(c, K, K.l_tmp); else tmw_subst_down(c, K, K.l_tmp);
   TMW_TICK(11);
