@@ -76,6 +76,10 @@ struct DModel {
   int dof_qposadr[TM_MAXV];
   int dof_grp_adr[TM_MAXV + 1], dof_grp_ids[TM_MAXV * TM_MAXG];
   int con_grp[TM_MAXC];
+  // J^T f by wrench SUBSETS: every dof feels the summed wrench of the paw bodies below it; dofs with the same set of paw
+  // groups share one sum.  wsub_cmask[s]: contacts (bit c of word c / 32) of subset s; dof_wsub[i]: subset of dof i or -1
+  int n_wsub, dof_wsub[TM_MAXV];
+  unsigned wsub_cmask[TM_MAXV][2];
   // tree-sparse rows: ancestor tables, one entry per stored non-zero (entry k of row i = k-th ancestor of dof i)
   uint8_t anc_dof[1280];
   uint16_t anc_Madr[1280];

@@ -297,6 +297,23 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
     }
     m.dof_grp_adr[m.nv] = g;
     for (int gg = 0; gg < m.ngroup; gg++) for (int c = m.grp_start[gg]; c < m.grp_start[gg] + m.grp_count[gg]; c++) m.con_grp[c] = gg;
+    {  // wrench subsets
+      if (m.ncon > 64) { err = "more than 64 contact slots"; return false; }
+      std::vector<unsigned long long> masks;
+      m.n_wsub = 0;
+      for (int i = 0; i < m.nv; i++) {
+        unsigned long long cm = 0;
+        for (int e = m.dof_grp_adr[i]; e < m.dof_grp_adr[i + 1]; e++) { int gg = m.dof_grp_ids[e]; for (int c = m.grp_start[gg]; c < m.grp_start[gg] + m.grp_count[gg]; c++) cm |= 1ull << c; }
+        m.dof_wsub[i] = -1;
+        if (!cm) continue;
+        size_t s = 0;
+        while (s < masks.size() && masks[s] != cm) s++;
+        if (s == masks.size()) { masks.push_back(cm); m.wsub_cmask[s][0] = (unsigned)cm; m.wsub_cmask[s][1] = (unsigned)(cm >> 32); }
+        m.dof_wsub[i] = (int)s;
+      }
+      m.n_wsub = (int)masks.size();
+      if (m.n_wsub * 6 > 128) { err = "more than 21 distinct paw-wrench subsets (wave kernel limitation)"; return false; }
+    }
   }
   for (int i = 0; i < m.nv; i++) {  // two-segment ancestor structure (chain below a trunk chain)
     int sgm = i;

@@ -679,9 +679,37 @@ TM_DEV float tmw_rcp(float x) {
 #define TMW_M_LT(n) ((n) >= 64 ? ~0ull : ((1ull << (n)) - 1ull))
 #define TMW_M_EQ(n) (1ull << (n))
 #define TMW_M_RANGE(a, b) (TMW_M_LT(b) & ~TMW_M_LT(a))
+// Two rows per 64-bit register pair: v_pk_fma_f32 updates both with ONE instruction — the two multipliers come as an SGPR
+// pair (two v_readlane), the pivot row is broadcast by op_sel.  1.5 instead of 2 instructions per (dof, ancestor) pair.
+#ifdef TM_HOST_EMU
+struct tmw_f2 { float x, y; };
+TM_DEV tmw_f2 tmw_fnma2(float ax, float ay, float bx, float by, tmw_f2 c) { tmw_f2 r; r.x = c.x - ax * bx; r.y = c.y - ay * by; return r; }
+#define TMW_PIN2(v) do { } while (0)
+#else
+typedef float tmw_f2 __attribute__((ext_vector_type(2)));
+TM_DEV tmw_f2 tmw_fnma2(float ax, float ay, float bx, float by, tmw_f2 c) { tmw_f2 a = {ax, ay}, b = {bx, by}; return __builtin_elementwise_fma(-a, b, c); }
+#define TMW_PIN2(v) asm volatile("" : "+v"(v))
+#endif
+#define TMW_ROW(arr, k) (((k) & 1) ? arr[(k) >> 1][TMW_LI].y : arr[(k) >> 1][TMW_LI].x)
+#define TMW_SET_ROW(arr, k, v) do { if ((k) & 1) arr[(k) >> 1][TMW_LI].y = (v); else arr[(k) >> 1][TMW_LI].x = (v); } while (0)
+// rows [0, CNT) of the paired register array T -= L(k, .) * (pivot row): multipliers are lanes BASE + row of `rs`
+template <typename F>
+TM_DEV void tmw_rank1_rows(tmw_f2 (*T)[TMW_NL], const int CNT, const int BASE, const float *rs, const float *rk, F after_top) {
+#pragma unroll
+  for (int p = (CNT - 1) / 2; p >= 0; p--) {
+    if (2 * p + 1 < CNT) {
+      float alo = tmw_readlane(rs, BASE + 2 * p), ahi = tmw_readlane(rs, BASE + 2 * p + 1);
+      TMW_FOR { T[p][TMW_LI] = tmw_fnma2(alo, ahi, rk[TMW_LI], rk[TMW_LI], T[p][TMW_LI]); TMW_PIN2(T[p][TMW_LI]); }
+    } else {
+      float alo = tmw_readlane(rs, BASE + 2 * p);
+      TMW_FOR { T[p][TMW_LI].x -= alo * rk[TMW_LI]; TMW_PIN2(T[p][TMW_LI]); }
+    }
+    if (p == (CNT - 1) / 2) after_top();
+  }
+}
 // EULER = false: plain M (no damping term, no right-hand side)
 template <int FIRST, int N, int D0, bool EULER>
-TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float hdamp, int rhs) {
+TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float hdamp, int rhs) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_M + tmw_chain_madr(FIRST);
   TMW_REG(float, hd);   // hdamp * damping of the chain dof whose DIAGONAL sits in this lane (depth = lane)
@@ -694,40 +722,46 @@ TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float h
       if (EULER) v += TMW_MASK(TMW_M_EQ(dk)) ? hd[TMW_LI] : 0.f;
       v = TMW_MASK(TMW_M_LT(dk + 1)) ? v : 0.f;
       if (EULER) v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? L[rhs + FIRST + k] : v;
-      r[k][TMW_LI] = v;
+      TMW_SET_ROW(r, k, v);
     }
+    if (N & 1) r[N >> 1][TMW_LI].y = 0.f;
   }
 }
 // eliminate the chain leaf -> root: finished rows go to LD (strict part = L; the diagonal word is not written, D^-1 goes to
 // Dinv) and the eliminated rhs; the Schur complement lands in the remaining chain rows and in the trunk rows `tr`
-// (registers, shared by all chains)
+// (registers, shared by all chains).  Software-pipelined by hand: as soon as the first update of step k has finished row
+// k-1, the pivot chain of step k-1 (readlane -> rcp -> scale) is issued and the remaining updates of step k cover it.
 template <int FIRST, int N, int D0, bool EULER>
-TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, float (*r)[TMW_NL], float (*tr)[TMW_NL], int rhs) {
+TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], tmw_f2 (*tr)[TMW_NL], int rhs) {
   float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
-  TMW_REG(float, rs); TMW_REG(float, dv);
+  float rs[2][TMW_NL], rk[2][TMW_NL], inv[2];
+  TMW_REG(float, dv);
+  TMW_FOR { rk[(N - 1) & 1][TMW_LI] = TMW_ROW(r, N - 1); }
+  inv[(N - 1) & 1] = tmw_rcp(tmw_readlane(rk[(N - 1) & 1], D0 + N - 1));
+  TMW_FOR { rs[(N - 1) & 1][TMW_LI] = rk[(N - 1) & 1][TMW_LI] * inv[(N - 1) & 1]; }
 #pragma unroll
   for (int k = N - 1; k >= 0; k--) {
-    const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
-    float piv = tmw_readlane(r[k], dk), inv = tmw_rcp(piv);
-    TMW_FOR { rs[TMW_LI] = r[k][TMW_LI] * inv; }
-#pragma unroll
-    for (int j = dk - 1; j >= 0; j--) {
-      float a = tmw_readlane(rs, j);                 // L(k, anc_j)
-      float *tgt = j >= D0 ? r[j >= D0 ? j - D0 : 0] : tr[j < D0 ? j : 0];
-      TMW_FOR { tgt[TMW_LI] -= a * r[k][TMW_LI]; TMW_PIN(tgt[TMW_LI]); }
+    const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k, b = k & 1;
+    if (k > 0) {
+      tmw_rank1_rows(r, k, D0, rs[b], rk[b], [&]() {
+        TMW_FOR { rk[b ^ 1][TMW_LI] = TMW_ROW(r, k - 1); }
+        inv[b ^ 1] = tmw_rcp(tmw_readlane(rk[b ^ 1], dk - 1));
+        TMW_FOR { rs[b ^ 1][TMW_LI] = rk[b ^ 1][TMW_LI] * inv[b ^ 1]; TMW_PIN(rs[b ^ 1][TMW_LI]); }
+      });
     }
+    if (D0 > 0) tmw_rank1_rows(tr, D0, 0, rs[b], rk[b], []() {});
     TMW_FOR {
-      if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = rs[TMW_LI];
-      dv[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? inv : dv[TMW_LI];
-      if (EULER && TMW_MASK(TMW_M_EQ(TMW_RL))) L[rhs + FIRST + k] = r[k][TMW_LI];
+      if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = rs[b][TMW_LI];
+      dv[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? inv[b] : dv[TMW_LI];
+      if (EULER && TMW_MASK(TMW_M_EQ(TMW_RL))) L[rhs + FIRST + k] = rk[b][TMW_LI];
     }
   }
   TMW_FOR { if (TMW_MASK(TMW_M_RANGE(D0, D0 + N))) L[K.l_Dinv + FIRST - D0 + lane] = dv[TMW_LI]; }
 }
 template <int FIRST, int N, int D0, bool EULER>
-TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, float (*tr)[TMW_NL], float hdamp, int rhs) {
-  float r[N][TMW_NL];
+TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, tmw_f2 (*tr)[TMW_NL], float hdamp, int rhs) {
+  tmw_f2 r[(N + 1) / 2][TMW_NL];
   tmw_rows_load<FIRST, N, D0, EULER>(c, K, r, hdamp, rhs);
   tmw_rows_factor<FIRST, N, D0, EULER>(c, K, r, tr, rhs);
 }
@@ -735,7 +769,7 @@ TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, float (*tr)[TMW_NL], flo
 // read straight from l_M; same outputs as tmw_factor except that the diagonal words of LD are left alone
 template <bool EULER>
 TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs) {
-  float tr[TMW_RODENT_TRUNK][TMW_NL];
+  tmw_f2 tr[(TMW_RODENT_TRUNK + 1) / 2][TMW_NL];
   tmw_rows_load<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, hdamp, rhs);
 #define TMW_X(first, n, d0) tmw_chain_factor<first, n, d0, EULER>(c, K, tr, hdamp, rhs);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
@@ -749,18 +783,24 @@ template <int FIRST, int N, int D0>
 TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, float (*n)[TMW_NL], float (*tn)[TMW_NL]) {
   float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
-  TMW_REG(float, l); TMW_REG(float, acc0); TMW_REG(float, acc1);
+  float l[N][TMW_NL];
+  TMW_REG(float, acc0); TMW_REG(float, acc1);
+  // all rows of L first: the loads of later rows must not queue behind the stores of the finished rows of N
+  TMW_FOR {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
+      float v = L[adr0 - lane + (off + dk)];
+      l[k][TMW_LI] = TMW_MASK(TMW_M_LT(dk)) ? v : 0.f;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
-    TMW_FOR {
-      float v = L[adr0 - lane + (off + dk)];
-      l[TMW_LI] = TMW_MASK(TMW_M_LT(dk)) ? v : 0.f;
-      acc0[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? 1.f : 0.f; acc1[TMW_LI] = 0.f;
-    }
+    TMW_FOR { acc0[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? 1.f : 0.f; acc1[TMW_LI] = 0.f; }
 #pragma unroll
     for (int j = 0; j < dk; j++) {
-      float a = tmw_readlane(l, j);
+      float a = tmw_readlane(l[k], j);
       const float *src = j >= D0 ? n[j >= D0 ? j - D0 : 0] : tn[j < D0 ? j : 0];
       float *acc = (j & 1) ? acc1 : acc0;
       TMW_FOR { acc[TMW_LI] -= a * src[TMW_LI]; }
@@ -785,39 +825,39 @@ TM_DEV void tmw_invert_chains(WCtx &c, const WLayout &K) {
 #undef TMW_X
   TMW_SYNC();
 }
-// root -> leaf pass after tmw_factor_chains<true>:  x_k = y_k / D_k - sum_j L(k, anc_j) x_anc_j.  Lane q of `xv` holds
-// the solution at depth q of the current path; one wave reduction per dof.
+// root -> leaf pass after tmw_factor_chains<true>:  x_k = y_k / D_k - sum_j L(k, anc_j) x_anc_j.  TRANSPOSED lane layout:
+// lane k = row k of the chain, the loop runs over the ancestor depth q, the already final x_q is a scalar broadcast
+// (v_readlane) — one load + one FMA per (chain, depth) for all rows at once and no wave reduction (the lane = depth
+// layout needed one 6-step DPP reduction per dof).  `xt`: lane j = solution of trunk dof j.
 template <int FIRST, int N, int D0>
-TM_DEV void tmw_rows_subst(WCtx &c, const WLayout &K, float *xv, int x) {
+TM_DEV void tmw_rows_subst(WCtx &c, const WLayout &K, const float *xt, float *z, int x) {
   float *L = c.L; TMW_LANE_DECL
-  const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
-  TMW_REG(float, t); TMW_REG(float, yv);
-  // y_k / D_k of the chain dofs, lane = depth; nothing is stored inside the row loop, so the row loads can all be issued early
+  constexpr int QMAX = D0 + N - 1;
+  TMW_REG(float, bv);
   TMW_FOR {
-    bool mine = TMW_MASK(TMW_M_RANGE(D0, D0 + N));
-    int idx = mine ? FIRST - D0 + lane : 0;
-    yv[TMW_LI] = mine ? L[x + idx] * L[K.l_Dinv + idx] : 0.f;
+    int k = lane < N ? lane : N - 1;                                    // lanes beyond the chain shadow its last row
+    int base = K.l_LD + tmw_chain_madr(FIRST) + k * D0 + k * (k - 1) / 2 + k + D0 + k - QMAX;   // entry of depth q: base + (QMAX - q)
+    bv[TMW_LI] = tm_i2f(base);
+    z[TMW_LI] = L[x + FIRST + k] * L[K.l_Dinv + FIRST + k];
   }
 #pragma unroll
-  for (int k = 0; k < N; k++) {
-    const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
-    TMW_FOR {
-      float v = L[adr0 - lane + (off + dk)];
-      t[TMW_LI] = TMW_MASK(TMW_M_LT(dk)) ? v * xv[TMW_LI] : (TMW_MASK(TMW_M_EQ(dk)) ? -yv[TMW_LI] : 0.f);
-    }
-    float xk = -tmw_sum(t);
-    TMW_FOR { xv[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? xk : xv[TMW_LI]; }
+  for (int q = 0; q < D0; q++) {
+    float xq = tmw_readlane(xt, q);
+    TMW_FOR { z[TMW_LI] -= L[tm_f2i(bv[TMW_LI]) + (QMAX - q)] * xq; }
   }
-  TMW_FOR { if (TMW_MASK(TMW_M_RANGE(D0, D0 + N))) L[x + FIRST - D0 + lane] = xv[TMW_LI]; }
+#pragma unroll
+  for (int q = D0; q < QMAX; q++) {
+    float xq = tmw_readlane(z, q - D0);                                 // row q - D0 is final: rows below it take its term
+    TMW_FOR { float v = L[tm_f2i(bv[TMW_LI]) + (QMAX - q)]; z[TMW_LI] = TMW_MASK(~TMW_M_LT(q - D0 + 1)) ? z[TMW_LI] - v * xq : z[TMW_LI]; }
+  }
+  TMW_FOR { if (TMW_MASK(TMW_M_LT(N))) L[x + FIRST + lane] = z[TMW_LI]; }
 }
 TM_DEV void tmw_subst_chains(WCtx &c, const WLayout &K, int x) {
   TMW_LANE_DECL
-  TMW_REG(float, xv);
-  TMW_FOR { xv[TMW_LI] = 0.f; }
-  tmw_rows_subst<0, TMW_RODENT_TRUNK, 0>(c, K, xv, x);
-  TMW_REG(float, xt);     // the trunk part of the solution: every chain restarts from it (chains overwrite lanes >= d0)
-  TMW_FOR { xt[TMW_LI] = xv[TMW_LI]; }
-#define TMW_X(first, n, d0) TMW_FOR { xv[TMW_LI] = xt[TMW_LI]; } tmw_rows_subst<first, n, d0>(c, K, xv, x);
+  TMW_REG(float, xt); TMW_REG(float, z);
+  TMW_FOR { xt[TMW_LI] = 0.f; }
+  tmw_rows_subst<0, TMW_RODENT_TRUNK, 0>(c, K, xt, xt, x);
+#define TMW_X(first, n, d0) tmw_rows_subst<first, n, d0>(c, K, xt, z, x);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
 #undef TMW_X
   TMW_SYNC();
@@ -897,28 +937,37 @@ TM_DEV int tmw_opaque_s(int x) { return x; }
 #else
 TM_DEV int tmw_opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 #endif
-template <int MAXR, int MAXT>
-TM_DEV float tmw_row_runs(const float *L, const WLayout &K, int A, int x, int i, bool diag) {
-  int w0 = tm_f2i(L[K.l_tdof + 2 * i]), w1 = tm_f2i(L[K.l_tdof + 2 * i + 1]);
-  int d = w0 >> 16, r = i - (w1 & 0xff), jp1 = (w1 >> 8) & 0xff;
-  const float *Ap = L + A + TMW_ADR(w0), *xp = L + x + i;
-  float acc = diag ? Ap[0] * xp[0] : 0.f;
-  const int maxr = tmw_opaque_s(MAXR), maxt = tmw_opaque_s(MAXT);
-#pragma unroll 6
-  for (int q = 1; q <= maxr; q++) { float a = Ap[q], xx = xp[-q]; acc += q <= r ? a * xx : 0.f; }
-  const float *Aq = Ap + r + 1, *xq = L + x + jp1 - 1;
-  const int nt = d - r;
-#pragma unroll 6
-  for (int t = 0; t < maxt; t++) { float a = Aq[t], xx = xq[-t]; acc += t < nt ? a * xx : 0.f; }
-  return acc;
+// both dof slots of a lane (i and i + 64) advance in the same loops, so that their loads share the LDS round trips
+template <int MAXR0, int MAXR1, int MAXT>
+TM_DEV void tmw_row_runs2(const float *L, const WLayout &K, int A, int x, int lane, bool diag, float &z0, float &z1) {
+  const int i0 = lane, i1 = lane + 64 < K.nv ? lane + 64 : 64;
+  int w00 = tm_f2i(L[K.l_tdof + 2 * i0]), w01 = tm_f2i(L[K.l_tdof + 2 * i0 + 1]);
+  int w10 = tm_f2i(L[K.l_tdof + 2 * i1]), w11 = tm_f2i(L[K.l_tdof + 2 * i1 + 1]);
+  int d0 = w00 >> 16, r0 = i0 - (w01 & 0xff), j0 = (w01 >> 8) & 0xff;
+  int d1 = w10 >> 16, r1 = i1 - (w11 & 0xff), j1 = (w11 >> 8) & 0xff;
+  const float *A0 = L + A + TMW_ADR(w00), *x0 = L + x + i0, *A1 = L + A + TMW_ADR(w10), *x1 = L + x + i1;
+  float a0 = diag ? A0[0] * x0[0] : 0.f, a1 = diag ? A1[0] * x1[0] : 0.f;
+  const int maxr0 = tmw_opaque_s(MAXR0), maxr1 = tmw_opaque_s(MAXR1), maxt = tmw_opaque_s(MAXT);
+#pragma unroll 4
+  for (int q = 1; q <= maxr1; q++) {
+    float u0 = A0[q], v0 = x0[-q], u1 = A1[q], v1 = x1[-q];
+    a0 += q <= r0 ? u0 * v0 : 0.f; a1 += q <= r1 ? u1 * v1 : 0.f;
+  }
+#pragma unroll 8
+  for (int q = maxr1 + 1; q <= maxr0; q++) { float u0 = A0[q], v0 = x0[-q]; a0 += q <= r0 ? u0 * v0 : 0.f; }
+  const float *B0 = A0 + r0 + 1, *y0 = L + x + j0 - 1, *B1 = A1 + r1 + 1, *y1 = L + x + j1 - 1;
+  const int n0 = d0 - r0, n1 = d1 - r1;
+#pragma unroll 4
+  for (int t = 0; t < maxt; t++) {
+    float u0 = B0[t], v0 = y0[-t], u1 = B1[t], v1 = y1[-t];
+    a0 += t < n0 ? u0 * v0 : 0.f; a1 += t < n1 ? u1 * v1 : 0.f;
+  }
+  z0 = a0; z1 = a1;
 }
 // (A x)_i over the ancestors of i (+ diagonal) for every dof, kept in two lane registers
 TM_DEV void tmw_rowpart_chains(WCtx &c, const WLayout &K, int A, int x, bool diag, float *z0, float *z1) {
   float *L = c.L; TMW_LANE_DECL
-  TMW_FOR {
-    z0[TMW_LI] = tmw_row_runs<tmw_chain_maxrun(0, 64), TMW_RODENT_TRUNK>(L, K, A, x, lane, diag);
-    z1[TMW_LI] = tmw_row_runs<tmw_chain_maxrun(64, 73), TMW_RODENT_TRUNK>(L, K, A, x, lane + 64 < K.nv ? lane + 64 : 64, diag);
-  }
+  TMW_FOR { tmw_row_runs2<tmw_chain_maxrun(0, 64), tmw_chain_maxrun(64, 73), TMW_RODENT_TRUNK>(L, K, A, x, lane, diag, z0[TMW_LI], z1[TMW_LI]); }
 }
 // x <- M^-1 x using N = L^-1:  x = N D^-1 N^T x   (two sparse mat-vecs; `x` is an LDS vector offset)
 TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
@@ -1041,25 +1090,35 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
     }
   }
   TMW_SYNC();
+  // wrench of every SUBSET of paw groups that some dof feels (DModel::wsub_*): lane = (subset, component), all contacts
+  // streamed past a per-lane contact bit mask; the sums replace the contact wrenches in l_wr
+  TMW_REG(float, W0); TMW_REG(float, W1);
   TMW_FOR {
-    if (lane < K.ngroup * 6) {
-      int g = lane / 6, k = lane - g * 6;
-      float s = 0.f;
-      for (int cc = tm_f2i(L[K.l_tgrp + 4 * g + 1]), ce = cc + tm_f2i(L[K.l_tgrp + 4 * g + 2]); cc < ce; cc++) s += L[K.l_wr + cc * 6 + k];
-      L[K.l_sv + lane] = s;
+    for (int slot = 0; slot < 2; slot++) {
+      int idx = lane + 64 * slot;
+      float sacc = 0.f;
+      if (idx < m.n_wsub * 6) {
+        int su = idx / 6, k = idx - su * 6;
+        unsigned m0 = m.wsub_cmask[su][0], m1 = m.wsub_cmask[su][1];
+#pragma unroll 8
+        for (int cc = 0; cc < K.ncon; cc++) { float w = L[K.l_wr + cc * 6 + k]; bool in = ((cc < 32 ? m0 >> cc : m1 >> (cc - 32)) & 1u) != 0u; sacc += in ? w : 0.f; }
+      }
+      (slot ? W1 : W0)[TMW_LI] = sacc;
+      if (m.n_wsub * 6 <= 64) break;
     }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    if (lane < m.n_wsub * 6) L[K.l_wr + lane] = W0[TMW_LI];
+    if (lane + 64 < m.n_wsub * 6) L[K.l_wr + lane + 64] = W1[TMW_LI];
   }
   TMW_SYNC();
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       float s = 0.f;
-      int lr = m.dof_limrow[i];
+      int lr = m.dof_limrow[i], su = m.dof_wsub[i];
       if (lr >= 0) { float ja = L[K.l_Jaref + lr]; if (ja < 0.f) s = L[K.l_lim_sign + lr] * (-L[K.l_efc_D + lr] * ja); }
-      for (int g = 0; g < K.ngroup; g++) {  // dof i feels the wrench of paw body g iff i is on the body's dof chain
-        int ld = tm_f2i(L[K.l_tgrp + 4 * g]), w1 = TMW_W1(ld);
-        bool on_chain = (i <= ld && i >= (w1 & 0xff)) || (i < ((w1 >> 8) & 0xff));
-        if (on_chain) { const float *w = L + K.l_sv + g * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
-      }
+      if (su >= 0) { const float *w = L + K.l_wr + su * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
       L[out + i] = s;
     }
   }
@@ -1259,14 +1318,16 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   float gauss, scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc + i] = L[K.l_warm + i]; }
   TMW_SYNC();
+  // start from the warm start unless the unconstrained acceleration has the lower cost (MJX evaluates warm, smooth and
+  // then the winner again; evaluating smooth FIRST leaves Ma / Jaref of the warm start — the usual winner — in place, the
+  // same numbers with one evaluation less)
+  float gs, cs = tmw_eval_cost(c, K, K.l_qacc_smooth, gs);
   float cw = tmw_eval_cost(c, K, K.l_qacc, gauss);
-  float cs = tmw_eval_cost(c, K, K.l_qacc_smooth, gauss);
-  float cost;
-  if (cw < cs) cost = tmw_eval_cost(c, K, K.l_qacc, gauss);
-  else {
+  float cost = cw;
+  if (!(cw < cs)) {
     TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc + i] = L[K.l_qacc_smooth + i]; }
     TMW_SYNC();
-    cost = cs;
+    cost = tmw_eval_cost(c, K, K.l_qacc, gauss);
   }
   float prev_cost = INFINITY;
   tmw_update_gradient(c, K);
