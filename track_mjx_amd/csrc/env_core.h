@@ -41,8 +41,9 @@ TM_DEV float tm_nan_to_num(float x) {
   return x;
 }
 
-// _get_obs -> obs[obs_size][n]; applies nan_to_num when `sanitize`
-TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *obs, bool sanitize) {
+// _get_obs -> obs[obs_size][n]; applies nan_to_num when `sanitize`.  `part` < 0: everything; 0 .. T-1: the four reference
+// segments of trajectory frame `part`; T: the proprioceptive tail (the split kernel k_obs runs one part per blockIdx.y).
+TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *obs, bool sanitize, int part = -1) {
   int nj = m.nq - 7, nbp = m.nbody - 1, T = m.traj_length, o = 0;
   int start = tm_clampi(frame + 1, 0, m.n_frames_clip - T);
   float root[3], quat[4];
@@ -50,30 +51,31 @@ TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *ob
   TM_LD(quat, ST, m.s_qpos, 3, 4);
 #define PUT(v) do { float v_ = (v); OUTROW(obs, o) = sanitize ? tm_nan_to_num(v_) : v_; o++; } while (0)
   for (int t = 0; t < T; t++) {
+    if (part >= 0 && part != t) continue;
+    o = 3 * t;
     const float *rp = m.clip_pos + tm_clip_row(m, clip, start + t) * 3;
     float v[3] = {rp[0] - root[0], rp[1] - root[1], rp[2] - root[2]}, w[3];
     tm_rotate(w, v, quat);
     PUT(w[0]); PUT(w[1]); PUT(w[2]);
-  }
-  for (int t = 0; t < T; t++) {
+    o = 3 * T + 4 * t;
     const float *rq = m.clip_quat + tm_clip_row(m, clip, start + t) * 4;
-    float inv[4] = {rq[0], -rq[1], -rq[2], -rq[3]}, w[4];
-    tm_quat_mul(w, quat, inv);
-    PUT(w[0]); PUT(w[1]); PUT(w[2]); PUT(w[3]);
-  }
-  for (int t = 0; t < T; t++) {
+    float inv[4] = {rq[0], -rq[1], -rq[2], -rq[3]}, wq[4];
+    tm_quat_mul(wq, quat, inv);
+    PUT(wq[0]); PUT(wq[1]); PUT(wq[2]); PUT(wq[3]);
+    o = 7 * T + m.n_joint_idx * t;
     const float *rj = m.clip_joints + tm_clip_row(m, clip, start + t) * nj;
     for (int k = 0; k < m.n_joint_idx; k++) { int i = tm_clampi(m.joint_idxs[k] - 1, 0, nj - 1); PUT(rj[i] - ST(m.s_qpos, 7 + i)); }
-  }
-  for (int t = 0; t < T; t++) {
+    o = 7 * T + m.n_joint_idx * T + 3 * m.n_body_idx * t;
     const float *rb = m.clip_bodypos + tm_clip_row(m, clip, start + t) * (size_t)(nbp * 3);
     for (int k = 0; k < m.n_body_idx; k++) {
       int i = tm_clampi(m.body_idxs[k], 0, nbp - 1);
-      float v[3] = {rb[i * 3] - ST(m.s_xpos, (1 + i) * 3), rb[i * 3 + 1] - ST(m.s_xpos, (1 + i) * 3 + 1), rb[i * 3 + 2] - ST(m.s_xpos, (1 + i) * 3 + 2)}, w[3];
-      tm_rotate(w, v, quat);
-      PUT(w[0]); PUT(w[1]); PUT(w[2]);
+      float vb[3] = {rb[i * 3] - ST(m.s_xpos, (1 + i) * 3), rb[i * 3 + 1] - ST(m.s_xpos, (1 + i) * 3 + 1), rb[i * 3 + 2] - ST(m.s_xpos, (1 + i) * 3 + 2)}, wb[3];
+      tm_rotate(wb, vb, quat);
+      PUT(wb[0]); PUT(wb[1]); PUT(wb[2]);
     }
   }
+  if (part >= 0 && part != T) return;
+  o = T * (7 + m.n_joint_idx + 3 * m.n_body_idx);
   for (int i = 7; i < m.nq; i++) PUT(ST(m.s_qpos, i));
   for (int i = 6; i < m.nv; i++) PUT(ST(m.s_qvel, i));
   for (int i = 0; i < m.nv; i++) PUT(ST(m.s_qfrc_actuator, i));
@@ -125,8 +127,9 @@ TM_DEV void tm_window_dim(const DModel &m, EnvRef r, int i, int bi, float a, flo
 }
 // `win`: per-(dim, env) partials [2*nu][n] produced by the (env x action-dim)-parallel window kernel, or nullptr to
 // compute the window terms inline (lane-per-env path).
+// `split`: the observation was written by k_obs and the auto-reset copies are left to k_autoreset (tmjx_hip.hip).
 TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *action, float *obs, float *reward, float *done_out,
-                         float *trunc_out, float *metrics, const float *win = nullptr) {
+                         float *trunc_out, float *metrics, const float *win = nullptr, bool split = false) {
   int nu = m.nu, W = m.window, nj = m.nq - 7, nbp = m.nbody - 1;
   int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame), bi = IS(m.i_buffer_index);
   int frame = tm_cur_frame(m, ST(m.s_time, 0), start);
@@ -193,7 +196,7 @@ TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *acti
     var_sum += vi; jerk += ji;
   }
   float var_cost = w[RW_VAR_COEFF] * var_sum, jerk_cost = w[RW_JERK_COEFF] * jerk;
-  tm_get_obs(m, r, clip, frame, obs, true);
+  if (!split) tm_get_obs(m, r, clip, frame, obs, true);
   float rew = joint_reward + pos_reward + quat_reward + angvel_reward + bodypos_reward + endeff_reward - ctrl_cost -
               ctrl_diff_cost - energy_cost - var_cost - jerk_cost;
   float done = fmaxf(fmaxf(fall, too_far), fmaxf(bad_pose, bad_quat));
@@ -215,7 +218,7 @@ TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *acti
   ST(m.s_done, 0) = done;
   reward[r.e] = rew; done_out[r.e] = done; trunc_out[r.e] = trunc;
   // auto-reset: pipeline_state, obs, prev_ctrl <- snapshot taken at reset
-  if (done != 0.f && m.auto_reset) {
+  if (done != 0.f && m.auto_reset && !split) {
     for (int i = 0; i < m.nphys; i++) ST(m.s_qpos, i) = ST(m.s_first_phys, i);
     for (int i = 0; i < m.obs_size; i++) OUTROW(obs, i) = ST(m.s_first_obs, i);
     for (int i = 0; i < nu; i++) ST(m.s_prev_ctrl, i) = ST(m.s_first_prev_ctrl, i);

@@ -77,13 +77,37 @@ __global__ void k_window(const DModel *__restrict__ mp, float *st, const int *is
   win[(size_t)(m.nu + i) * n + e] = ji;
 }
 __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const float *action, float *obs, float *reward,
-                       float *done, float *trunc, float *metrics, const float *win, int n) {
+                       float *done, float *trunc, float *metrics, const float *win, int split, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const DModel &m = *mp;
   EnvRef r{st, nullptr, n, e};
   tm_step_prologue(m, r);
-  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win);
+  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win, split != 0);
+}
+// observation, one lane per (env, part): parts 0 .. T-1 = the reference segments of one trajectory frame, part T = the
+// proprioceptive tail (6x the parallelism of lane-per-env; rows of obs stay coalesced over envs)
+__global__ void k_obs(const DModel *__restrict__ mp, float *st, const int *is, float *obs, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x, part = blockIdx.y;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, nullptr, n, e};
+  int clip = is[(size_t)m.i_clip_idx * n + e], start = is[(size_t)m.i_start_frame * n + e];
+  tm_get_obs(m, r, clip, tm_cur_frame(m, ST(m.s_time, 0), start), obs, true, part);
+}
+// auto-reset of the envs that are done: physics state, observation and prev_ctrl <- the snapshot taken at reset
+// (wrappers.py:104-144), one lane per (env, block of 16 rows)
+__global__ void k_autoreset(const DModel *__restrict__ mp, float *st, float *obs, const float *done, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || done[e] == 0.f) return;
+  const DModel &m = *mp;
+  EnvRef r{st, nullptr, n, e};
+  int total = m.nphys + m.obs_size + m.nu;
+  for (int k = blockIdx.y * 16; k < total && k < (int)blockIdx.y * 16 + 16; k++) {
+    if (k < m.nphys) ST(m.s_qpos, k) = ST(m.s_first_phys, k);
+    else if (k < m.nphys + m.obs_size) OUTROW(obs, k - m.nphys) = ST(m.s_first_obs, k - m.nphys);
+    else ST(m.s_prev_ctrl, k - m.nphys - m.obs_size) = ST(m.s_first_prev_ctrl, k - m.nphys - m.obs_size);
+  }
 }
 
 // K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
@@ -260,6 +284,19 @@ int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip
   return check_launch("k_reset");
 }
 
+// K3 as four launches: observation parts, reward / termination, auto-reset copies (the window statistics were launched before)
+static void launch_post_split(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
+                              float *truncation, float *metrics, float *workspace, int n_env, hipStream_t stream) {
+  const DModel &h = m->h;
+  hipLaunchKernelGGL(k_obs, dim3((n_env + 63) / 64, h.traj_length + 1), dim3(64), 0, stream, m->d, state, istate, obs, n_env);
+  hipLaunchKernelGGL(k_post, dim3((n_env + 63) / 64), dim3(64), 0, stream, m->d, state, istate, action, obs, reward, done, truncation, metrics,
+                     (const float *)workspace, 1, n_env);
+  if (h.auto_reset) {
+    int total = h.nphys + h.obs_size + h.nu;
+    hipLaunchKernelGGL(k_autoreset, dim3((n_env + 63) / 64, (total + 15) / 16), dim3(64), 0, stream, m->d, state, obs, done, n_env);
+  }
+}
+
 int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
               float *truncation, float *metrics, float *workspace, int n_env, void *stream) {
   if (!m || !state || !istate || !action || !obs || !reward || !done || !truncation || !metrics || !workspace) return fail(TMJX_EINVAL, "null argument");
@@ -269,8 +306,7 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
     launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream);
     hipLaunchKernelGGL(k_window, dim3((n_env + 255) / 256, m->h.nu), dim3(256), 0, (hipStream_t)stream, m->d, state, istate, action,
                        workspace, n_env);
-    hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
-                       metrics, (const float *)workspace, n_env);
+    launch_post_split(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
     return check_launch("k_step(wave)");
   }
   hipLaunchKernelGGL(k_step, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
@@ -309,8 +345,9 @@ int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *a
     hipLaunchKernelGGL(k_window, dim3((n_env + 255) / 256, m->h.nu), dim3(256), 0, (hipStream_t)stream, m->d, state, istate, action,
                        workspace, n_env);
   }
-  hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
-                     metrics, (const float *)workspace, n_env);
+  if (workspace) launch_post_split(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
+  else hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
+                          metrics, (const float *)nullptr, 0, n_env);
   return check_launch("k_post");
 }
 

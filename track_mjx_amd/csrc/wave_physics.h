@@ -184,6 +184,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
     }
   }
   TMW_SYNC();
+  TMW_TICK2(27);
   // (2) pointer jumping: T_b <- T_anc(b) o T_b ; anc(b) <- anc(anc(b)).  Even round count => result in scanA.
   int R = K.nround_body + (K.nround_body & 1);
   for (int r = 0; r < R; r++) {
@@ -209,6 +210,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
     }
     TMW_SYNC();
   }
+  TMW_TICK2(28);
   // (3) inertial frame origins and the tree's centre of mass
   TMW_REG(float, s0); TMW_REG(float, s1); TMW_REG(float, s2);
   TMW_FOR {
@@ -229,6 +231,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
   }
   float com[3] = {tmw_sum(s0) / m.total_mass, tmw_sum(s1) / m.total_mass, tmw_sum(s2) / m.total_mass};
   TMW_FOR { if (lane < 3) L[K.l_com + lane] = com[lane]; }
+  TMW_TICK2(29);
   // (4) collision: one lane per contact slot (plane vs paw capsule end / ellipsoid)
   TMW_FOR {
     for (int cc = lane; cc < K.ncon; cc += 64) {
@@ -273,6 +276,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
       for (int k = 0; k < 6; k++) L[K.l_con_frame + cc * 6 + k] = fr[k];   // rows n and b; the third row is n x b
     }
   }
+  TMW_TICK2(30);
   // (5) cdof: one lane per dof (joint anchors / axes are stored in the parent frame)
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
@@ -303,6 +307,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
     }
   }
   TMW_SYNC();
+  TMW_TICK2(31);
   // (6) cinert (overwrites the dead scanB / joint-frame scratch)
   TMW_FOR {
     for (int b = lane; b < K.nbody; b += 64) {
@@ -779,12 +784,20 @@ TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs) {
 }
 // rows of N = L^-1, root -> leaf:  N(k,:) = e_k - sum_{j < depth_k} L(k, anc_j) N(anc_j, :).  `tn`: the finished trunk rows
 // (with their unit diagonal); chain rows are kept in `n` the same way.  Lanes beyond a row's depth hold exact zeros.
+// acc -= L(k, rows [0, CNT) of S): multipliers are lanes BASE + row of `l`; two rows per v_pk_fma_f32
+TM_DEV void tmw_rows_accum(tmw_f2 &acc, const tmw_f2 (*S)[TMW_NL], const int CNT, const int BASE, const float *l, int li) {
+#pragma unroll
+  for (int p = 0; 2 * p < CNT; p++) {
+    float alo = tmw_readlane(l, BASE + 2 * p), ahi = 2 * p + 1 < CNT ? tmw_readlane(l, BASE + 2 * p + 1) : 0.f;
+    acc = tmw_fnma2(alo, ahi, S[p][li].x, S[p][li].y, acc);
+  }
+}
 template <int FIRST, int N, int D0>
-TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, float (*n)[TMW_NL], float (*tn)[TMW_NL]) {
+TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, tmw_f2 (*n)[TMW_NL], tmw_f2 (*tn)[TMW_NL]) {
   float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
   float l[N][TMW_NL];
-  TMW_REG(float, acc0); TMW_REG(float, acc1);
+  tmw_f2 acc[TMW_NL];
   // all rows of L first: the loads of later rows must not queue behind the stores of the finished rows of N
   TMW_FOR {
 #pragma unroll
@@ -793,32 +806,30 @@ TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, float (*n)[TMW_NL], float
       float v = L[adr0 - lane + (off + dk)];
       l[k][TMW_LI] = TMW_MASK(TMW_M_LT(dk)) ? v : 0.f;
     }
+    // (rows not yet computed enter the odd tail of a pair with a zero multiplier: they must hold numbers)
+#pragma unroll
+    for (int p = 0; p < (N + 1) / 2; p++) { n[p][TMW_LI].x = 0.f; n[p][TMW_LI].y = 0.f; }
   }
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
-    TMW_FOR { acc0[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? 1.f : 0.f; acc1[TMW_LI] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < dk; j++) {
-      float a = tmw_readlane(l[k], j);
-      const float *src = j >= D0 ? n[j >= D0 ? j - D0 : 0] : tn[j < D0 ? j : 0];
-      float *acc = (j & 1) ? acc1 : acc0;
-      TMW_FOR { acc[TMW_LI] -= a * src[TMW_LI]; }
-    }
+    TMW_FOR { acc[TMW_LI].x = TMW_MASK(TMW_M_EQ(dk)) ? 1.f : 0.f; acc[TMW_LI].y = 0.f; }
+    if (D0 > 0) { TMW_FOR { tmw_rows_accum(acc[TMW_LI], tn, D0, 0, l[k], TMW_LI); } }
+    if (k > 0) { TMW_FOR { tmw_rows_accum(acc[TMW_LI], n, k, D0, l[k], TMW_LI); } }
     TMW_FOR {
-      float v = acc0[TMW_LI] + acc1[TMW_LI];
-      n[k][TMW_LI] = v;
+      float v = acc[TMW_LI].x + acc[TMW_LI].y;
+      TMW_SET_ROW(n, k, v);
       if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = v;
     }
   }
 }
 template <int FIRST, int N, int D0>
-TM_DEV void tmw_chain_invert(WCtx &c, const WLayout &K, float (*tn)[TMW_NL]) {
-  float n[N][TMW_NL];
+TM_DEV void tmw_chain_invert(WCtx &c, const WLayout &K, tmw_f2 (*tn)[TMW_NL]) {
+  tmw_f2 n[(N + 1) / 2][TMW_NL];
   tmw_rows_invert<FIRST, N, D0>(c, K, n, tn);
 }
 TM_DEV void tmw_invert_chains(WCtx &c, const WLayout &K) {
-  float tn[TMW_RODENT_TRUNK][TMW_NL];
+  tmw_f2 tn[(TMW_RODENT_TRUNK + 1) / 2][TMW_NL];
   tmw_rows_invert<0, TMW_RODENT_TRUNK, 0>(c, K, tn, tn);
 #define TMW_X(first, n, d0) tmw_chain_invert<first, n, d0>(c, K, tn);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
