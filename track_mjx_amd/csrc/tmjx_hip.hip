@@ -129,6 +129,9 @@ __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict
   const WLayout &K = STATIC ? ks : kd;
   float time = tmw_load_state(c, K, action);
   for (int f = 0; f < nsub; f++) {
+    // fresh, opaque copies of the lane id and the model pointer per substep: LICM otherwise hoists every lane-derived LDS /
+    // global address of the substep body (cheap adds) out of this loop, and the register allocator then SPILLS them
+    { int l = threadIdx.x; asm volatile("" : "+v"(l)); c.lane = l; const DModel *q = mp; asm volatile("" : "+s"(q)); c.mp = q; }
     tmw_forward(c, K, f == nsub - 1);
     if (do_euler) time = tmw_euler(c, K, time);
   }
