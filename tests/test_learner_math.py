@@ -90,3 +90,19 @@ def test_ppo_loss_pieces_with_torch_gae():
     assert abs(float(m2["kl_latent_loss"]) - expect) < 1e-6
     sch = losses.create_ramp_schedule(max_value=0.1, ramp_steps=37)
     assert abs(sch(0) - 1e-5) < 1e-12 and abs(sch(18.5) - 0.05) < 1e-9 and sch(100) == 0.1
+
+
+def test_splitk_linear_matches_autograd_linear():
+    """The split-K weight-gradient path of agent/networks.py:_SplitKLinearFn against torch's own Linear backward."""
+    import torch
+    import torch.nn.functional as F
+    from track_mjx_amd.agent.networks import _SplitKLinearFn
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 12, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(5, 12, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(5, generator=g, dtype=torch.float64, requires_grad=True)
+    up = torch.randn(64, 5, generator=g, dtype=torch.float64)
+    got = torch.autograd.grad((_SplitKLinearFn.apply(x, w, b) * up).sum(), (x, w, b))
+    ref = torch.autograd.grad((F.linear(x, w, b) * up).sum(), (x, w, b))
+    for a, r in zip(got, ref):
+        assert torch.allclose(a, r, rtol=1e-12, atol=1e-12)

@@ -35,8 +35,40 @@ def _lecun_normal_(w: torch.Tensor) -> None:
         nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std)
 
 
+class _SplitKLinearFn(torch.autograd.Function):
+    """y = x W^T + b with a weight gradient computed as a split-K batched GEMM.
+
+    dW = dy^T x contracts over the ROWS (T*B = 20 480 per minibatch) into a small [out, in] matrix: as one GEMM it has
+    too few output tiles for 256 CUs and no split-K in the library heuristics (25 TFLOP/s measured on MI355X); cut into
+    SPLIT row slabs -> one batched GEMM + a tiny sum it runs ~3x faster (tools/scratch/gemm_bench2.py)."""
+    SPLIT = 8
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        m, s = x.shape[0], _SplitKLinearFn.SPLIT
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = torch.bmm(dy.view(s, m // s, dy.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).sum(0)
+        return dx, dw, dy.sum(0)
+
+
+class _Dense(nn.Linear):
+    def forward(self, x):
+        rows = x.numel() // x.shape[-1]
+        if torch.is_grad_enabled() and self.weight.requires_grad and rows >= 4096 and rows % _SplitKLinearFn.SPLIT == 0 and x.is_cuda:
+            y = _SplitKLinearFn.apply(x.reshape(rows, x.shape[-1]), self.weight, self.bias)
+            return y.view(*x.shape[:-1], self.out_features)
+        return F.linear(x, self.weight, self.bias)
+
+
 def _dense(i: int, o: int, init=_lecun_uniform_) -> nn.Linear:
-    lin = nn.Linear(i, o)
+    lin = _Dense(i, o)
     init(lin.weight)
     nn.init.zeros_(lin.bias)
     return lin
@@ -65,8 +97,8 @@ class IntentionPolicy(nn.Module):
         for h in encoder_layers:
             enc.append(_Block(d, h)); d = h
         self.encoder = nn.Sequential(*enc)
-        self.fc2_mean = _dense(d, latents, _lecun_normal_)
-        self.fc2_logvar = _dense(d, latents, _lecun_normal_)
+        # fc2_mean and fc2_logvar of the reference (two Dense(latents), lecun_normal) as the two halves of ONE GEMM
+        self.fc2 = _dense(d, 2 * latents, _lecun_normal_)
         dec, d = [], latents + (obs_size - reference_obs_size)
         for h in decoder_layers:
             dec.append(_Block(d, h)); d = h
@@ -77,7 +109,7 @@ class IntentionPolicy(nn.Module):
         """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar)."""
         traj = obs[..., :self.reference_obs_size]
         h = self.encoder(traj)
-        mean, logvar = self.fc2_mean(h), self.fc2_logvar(h)
+        mean, logvar = torch.chunk(self.fc2(h), 2, dim=-1)
         if deterministic:
             z = mean
         else:

@@ -38,6 +38,11 @@ class FlatGrads:
     def zero(self):
         self.flat.zero_()
 
+    def assign(self, grads):
+        """Write freshly computed gradients (torch.autograd.grad) into the flat buffer with one multi-tensor copy: no
+        zero-fill and no per-parameter `grad += new` kernels as with loss.backward() into pre-existing .grad views."""
+        torch._foreach_copy_([p.grad for p in self.params], list(grads))
+
     def all_reduce_mean(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -86,7 +91,7 @@ class PPOLearner:
         self.value = ValueNet(obs, critic_layers).to(dev)
         self.params = list(self.policy.parameters()) + list(self.value.parameters())
         self.grads = FlatGrads(self.params)
-        self.opt = torch.optim.Adam(self.params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
+        self.opt = torch.optim.Adam(self.params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, fused=bool(dev.type == "cuda"))
         self.normalizer = RunningStatistics(obs, dev)
         self.gen = torch.Generator(device=dev).manual_seed(seed * 1000 + 17 + self.rank)
         rows = self.unrolls * n_local
@@ -147,10 +152,9 @@ class PPOLearner:
             for mb in range(self.num_minibatches):
                 idx = perm[mb * self.local_batch:(mb + 1) * self.local_batch]
                 data = {k: (v.index_select(1, idx) if k != "next_observation_last" else v.index_select(0, idx)) for k, v in self.buf.items()}
-                self.grads.zero()
                 with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
                     loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
-                loss.backward()
+                self.grads.assign(torch.autograd.grad(loss, self.grads.params))
                 self.grads.all_reduce_mean(self.group)       # C1: one RCCL all-reduce per minibatch step
                 self.grads.clip_by_global_norm(10.0)          # optax.clip_by_global_norm(10.0) -> adam (ppo.py:517-520)
                 self.opt.step()
