@@ -91,6 +91,24 @@ int tmjx_gae(const float *truncation, const float *termination, const float *rew
              const float *bootstrap, float lambda_, float discount, float *vs, float *advantages, int T, int B,
              void *stream);
 
+/* PPO loss head, forward and gradients w.r.t. the network outputs in one call: compute_ppo_loss
+ * (track_mjx/agent/mlp_ppo/losses.py:103-245) from the policy logits on: NormalTanh log-prob / entropy, GAE
+ * (losses.py:39-100), advantage normalisation, clipped surrogate, value loss, AR(1)-prior latent KL.
+ * Row-major device arrays: logits [T][B][2A], raw_action / noise [T][B][A], behaviour_logp / baseline / reward /
+ * discount / truncation [T][B], bootstrap [B], fc2 = latent mean | logvar [T][B][2Z]; outputs dlogits, dbaseline,
+ * dfc2 (same shapes as their inputs) = d total / d input; out[8] = total, policy_loss, v_loss, entropy_loss,
+ * kl_latent_loss, advantage mean, advantage std, entropy; scratch >= tmjx_ppo_scratch_floats(T, B) floats. */
+typedef struct {
+  int32_t T, B, A, Z;
+  float reward_scaling, discounting, gae_lambda, clip_eps, entropy_cost, kl_weight;
+  int32_t normalize_advantage;
+} tmjx_ppo_cfg_t;
+int tmjx_ppo_scratch_floats(int T, int B);
+int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *raw_action, const float *behaviour_logp,
+                  const float *noise, const float *baseline, const float *bootstrap, const float *reward, const float *discount,
+                  const float *truncation, const float *fc2, float *dlogits, float *dbaseline, float *dfc2, float *scratch,
+                  float *out, void *stream);
+
 /* Debug/test access: copy a named per-env workspace/intermediate array of the last tmjx_forward /
  * tmjx_physics call into `out` (device pointer, [count][n_env]); returns count or a negative code.
  * Names: "qM" (sparse rows), "qfrc_smooth", "qacc", "qacc_smooth", "efc_D", "efc_aref", "con_dist", ... */

@@ -292,3 +292,45 @@ def test_train_entrypoint_smoke():
                  "train_setup.train_config.num_timesteps=100000", "train_setup.eval_every=50000", "train_setup.reset_every=50000",
                  "max_training_steps=2", "n_synthetic_clips=4"]
     train.main(overrides)
+
+
+@pytest.mark.gpu
+def test_fused_ppo_loss_head_matches_torch_reference():
+    """tmjx_ppo_loss (csrc/ppo_kernels.h) against the plain-torch restatement of losses.py:103-245: loss terms and the
+    gradient of every network parameter (fp32 both; tolerance 2e-4 of the largest gradient entry)."""
+    import torch
+    from track_mjx_amd.agent import losses
+    from track_mjx_amd.agent.networks import IntentionPolicy, RunningStatistics, ValueNet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    obs, ref, nu, Z, T, B = 96, 40, 38, 60, 7, 96
+    policy = IntentionPolicy(obs, ref, nu, Z, (64, 64), (64, 64)).to(dev)
+    value = ValueNet(obs, (64, 64)).to(dev)
+    with torch.no_grad():
+        policy.head.weight.mul_(0.05)   # keeps the importance ratios O(1) although the latent noise differs between calls
+    norm = RunningStatistics(obs, dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=dev)
+    data = {"observation": rnd(T, B, obs), "next_observation_last": rnd(B, obs), "raw_action": rnd(T, B, nu) * 0.7,
+            "log_prob": rnd(T, B) * 0.3 - 20.0, "reward": rnd(T, B).abs(),
+            "discount": (torch.rand(T, B, generator=g, device=dev) > 0.1).float(),
+            "truncation": (torch.rand(T, B, generator=g, device=dev) > 0.9).float()}
+    # behaviour log-probs close to the current policy's so that rho is O(1) and both clip branches occur
+    with torch.no_grad():
+        from track_mjx_amd.agent.networks import NormalTanh
+        lg, _, _ = policy(norm.normalize(data["observation"]))
+        data["log_prob"] = NormalTanh.log_prob(lg, data["raw_action"]) + rnd(T, B) * 0.3
+    hp = dict(entropy_cost=1e-2, kl_weight=0.1, discounting=0.95, reward_scaling=1.0, gae_lambda=0.95, clipping_epsilon=0.2)
+    params = list(policy.parameters()) + list(value.parameters())
+    torch.manual_seed(99)
+    l_ref, m_ref = losses.compute_ppo_loss(policy, value, norm, data, **hp)
+    g_ref = torch.autograd.grad(l_ref, params)
+    torch.manual_seed(99)
+    l_fus, m_fus = losses.compute_ppo_loss_fused(policy, value, norm, data, **hp)
+    g_fus = torch.autograd.grad(l_fus, params)
+    for k in ("total_loss", "policy_loss", "v_loss", "kl_latent_loss", "entropy_loss"):
+        a, b = float(m_fus[k]), float(m_ref[k])
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (k, a, b)
+    for a, b in zip(g_fus, g_ref):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-7, (a.shape, float((a - b).abs().max()), scale)

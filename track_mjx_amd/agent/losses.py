@@ -41,6 +41,55 @@ def create_ramp_schedule(max_value: float = 0.1, min_value: float = 0.0001, ramp
     return schedule_fn
 
 
+class _FusedLossHead(torch.autograd.Function):
+    """tmjx_ppo_loss (csrc/ppo_kernels.h): the scalar loss and its gradients w.r.t. logits / baseline / fc2 in four
+    launches; backward only scales the stored gradients by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, logits, baseline, fc2, raw_action, behaviour_logp, noise, bootstrap, reward, discount, truncation, cfg):
+        T, B = reward.shape
+        dev = logits.device
+        args = [a.detach().contiguous().float() for a in (logits, raw_action, behaviour_logp, noise, baseline, bootstrap, reward,
+                                                          discount, truncation, fc2)]
+        dlogits, dbaseline, dfc2 = torch.empty_like(args[0]), torch.empty_like(args[4]), torch.empty_like(args[9])
+        L = _hip.lib()
+        scratch = torch.empty(L.tmjx_ppo_scratch_floats(T, B), dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        c = _hip.PpoCfg(T, B, raw_action.shape[-1], fc2.shape[-1] // 2, cfg["reward_scaling"], cfg["discounting"], cfg["gae_lambda"],
+                        cfg["clipping_epsilon"], cfg["entropy_cost"], cfg["kl_weight"], int(cfg["normalize_advantage"]))
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            ptr = [C.c_void_p(a.data_ptr()) for a in args + [dlogits, dbaseline, dfc2, scratch, out]]
+            _hip.check(L.tmjx_ppo_loss(C.byref(c), *ptr, stream), "tmjx_ppo_loss")
+        ctx.save_for_backward(dlogits, dbaseline, dfc2)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_out):
+        dlogits, dbaseline, dfc2 = ctx.saved_tensors
+        return (dlogits * g_total, dbaseline * g_total, dfc2 * g_total) + (None,) * 8
+
+
+def compute_ppo_loss_fused(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
+                           discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
+                           clipping_epsilon: float = 0.3, normalize_advantage: bool = True):
+    """compute_ppo_loss with the loss head (everything after the network outputs) in the HIP kernels of
+    csrc/ppo_kernels.h.  Same inputs, same outputs; GPU only (the product path of PPOLearner.update)."""
+    obs = normalizer.normalize(data["observation"])
+    logits, fc2 = policy(obs, return_fc2=True)
+    baseline = value(obs)
+    with torch.no_grad():
+        bootstrap_value = value(normalizer.normalize(data["next_observation_last"]))
+        noise = torch.randn(data["raw_action"].shape, dtype=torch.float32, device=logits.device)   # entropy sample (randn_like(loc))
+    cfg = dict(reward_scaling=reward_scaling, discounting=discounting, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
+               entropy_cost=entropy_cost, kl_weight=kl_weight, normalize_advantage=normalize_advantage)
+    total, out = _FusedLossHead.apply(logits, baseline, fc2, data["raw_action"], data["log_prob"], noise, bootstrap_value, data["reward"],
+                                      data["discount"], data["truncation"], cfg)
+    return total, {"total_loss": out[0], "policy_loss": out[1], "v_loss": out[2], "kl_latent_loss": out[4], "entropy_loss": out[3],
+                   "kl_weight": torch.as_tensor(kl_weight)}
+
+
 def compute_ppo_loss(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
                      discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
                      clipping_epsilon: float = 0.3, normalize_advantage: bool = True, gae_fn=compute_gae):

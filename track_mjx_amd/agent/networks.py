@@ -105,11 +105,13 @@ class IntentionPolicy(nn.Module):
         self.decoder = nn.Sequential(*dec)
         self.head = _dense(d, 2 * action_size)
 
-    def forward(self, obs: torch.Tensor, eps: torch.Tensor | None = None, deterministic: bool = False):
-        """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar)."""
+    def forward(self, obs: torch.Tensor, eps: torch.Tensor | None = None, deterministic: bool = False, return_fc2: bool = False):
+        """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar), or (logits, mean | logvar as
+        one [.., 2*latents] tensor) with `return_fc2` (what the fused loss head consumes)."""
         traj = obs[..., :self.reference_obs_size]
         h = self.encoder(traj)
-        mean, logvar = torch.chunk(self.fc2(h), 2, dim=-1)
+        fc2 = self.fc2(h)
+        mean, logvar = torch.chunk(fc2, 2, dim=-1)
         if deterministic:
             z = mean
         else:
@@ -117,7 +119,10 @@ class IntentionPolicy(nn.Module):
                 eps = torch.randn_like(mean)
             z = mean + eps * torch.exp(0.5 * logvar)
         x = torch.cat([z, obs[..., self.reference_obs_size:]], dim=-1)
-        return self.head(self.decoder(x)), mean, logvar
+        logits = self.head(self.decoder(x))
+        if return_fc2:
+            return logits, fc2
+        return logits, mean, logvar
 
 
 class ValueNet(nn.Module):

@@ -153,7 +153,8 @@ class PPOLearner:
                 idx = perm[mb * self.local_batch:(mb + 1) * self.local_batch]
                 data = {k: (v.index_select(1, idx) if k != "next_observation_last" else v.index_select(0, idx)) for k, v in self.buf.items()}
                 with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
-                    loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
+                    loss_fn = _losses.compute_ppo_loss_fused if self.dev.type == "cuda" else _losses.compute_ppo_loss
+                    loss, m = loss_fn(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
                 self.grads.assign(torch.autograd.grad(loss, self.grads.params))
                 self.grads.all_reduce_mean(self.group)       # C1: one RCCL all-reduce per minibatch step
                 self.grads.clip_by_global_norm(10.0)          # optax.clip_by_global_norm(10.0) -> adam (ppo.py:517-520)

@@ -1,0 +1,191 @@
+// csrc/ppo_kernels.h — the PPO loss head as four kernels: everything of compute_ppo_loss
+// (track_mjx/agent/mlp_ppo/losses.py:103-245) between the network outputs and the scalar loss, forward AND the
+// gradients w.r.t. the network outputs (the loss is a scalar, so the backward pass only scales what is stored here).
+// Replaces ~170 tiny element-wise / reduction launches per minibatch step.  Deterministic: block partials + a final
+// single-block reduction, no atomics.
+//
+//   logits  [T][B][2A]  loc | raw_scale of the NormalTanh policy (brax NormalTanhDistribution, min_std 0.001)
+//   fc2     [T][B][2Z]  latent_mean | latent_logvar of the intention encoder
+//   scratch [4 T B + 4 nblk + 16] floats, nblk = ceil(T B / 256)
+//   out     [8]: total, policy_loss, v_loss, entropy_loss, kl_latent_loss, adv_mean, adv_std, entropy
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+struct PpoCfg {
+  int T, B, A, Z;
+  float reward_scaling, discounting, gae_lambda, clip_eps, entropy_cost, kl_weight;
+  int normalize_advantage;
+};
+
+#define PPO_BLOCK 256
+#define PPO_ALPHA 0.95f
+__device__ __forceinline__ float ppo_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float ppo_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float ppo_fldj(float x) { return 2.f * (0.69314718055994531f - x - ppo_softplus(-2.f * x)); }
+
+// block-wide sum of NV values per thread; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void ppo_block_sum(float *v, float *lds) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    float x = v[k];
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    if (lane == 0) lds[k * 16 + w] = x;
+  }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) { float s = 0.f; for (int i = 0; i < nw; i++) s += lds[k * 16 + i]; v[k] = s; }
+  }
+  __syncthreads();
+}
+
+// A: per (t, b): log-prob of the stored action, entropy sample, latent-KL sums
+__global__ __launch_bounds__(PPO_BLOCK) void k_ppo_a(PpoCfg c, const float *__restrict__ logits, const float *__restrict__ raw_action,
+                                                     const float *__restrict__ noise, const float *__restrict__ fc2, float *scratch) {
+  __shared__ float lds[64];
+  const int N = c.T * c.B, i = blockIdx.x * PPO_BLOCK + threadIdx.x;
+  float acc[3] = {0.f, 0.f, 0.f};   // entropy, kl0 inner sum, klt inner sum
+  if (i < N) {
+    const int t = i / c.B;
+    const float *lg = logits + (size_t)i * 2 * c.A, *xa = raw_action + (size_t)i * c.A, *nz = noise + (size_t)i * c.A;
+    float logp = 0.f, ent = 0.f;
+    for (int a = 0; a < c.A; a++) {
+      float loc = lg[a], scale = ppo_softplus(lg[c.A + a]) + 0.001f, x = xa[a], d = (x - loc) / scale;
+      logp += -0.5f * d * d - logf(scale) - 0.91893853320467274f - ppo_fldj(x);
+      float xs = loc + scale * nz[a];
+      ent += 0.5f + 0.91893853320467274f + logf(scale) + ppo_fldj(xs);
+    }
+    scratch[i] = logp;
+    acc[0] = ent;
+    const float *f = fc2 + (size_t)i * 2 * c.Z;
+    const float pv = 1.f - PPO_ALPHA * PPO_ALPHA;
+    if (t == 0) {
+      float s = 0.f;
+      for (int z = 0; z < c.Z; z++) { float m = f[z], lv = f[c.Z + z]; s += 1.f + lv - m * m - expf(lv); }
+      acc[1] = s;
+    } else {
+      const float *fp = f - (size_t)c.B * 2 * c.Z;
+      float s = 0.f;
+      for (int z = 0; z < c.Z; z++) { float m = f[z], lv = f[c.Z + z], e = PPO_ALPHA * fp[z] - m; s += expf(lv) / pv + e * e / pv - 1.f + logf(pv) - lv; }
+      acc[2] = s;
+    }
+  }
+  ppo_block_sum<3>(acc, lds);
+  if (threadIdx.x == 0) { float *p = scratch + (size_t)4 * N + (size_t)blockIdx.x * 4; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; }
+}
+
+// B: one block: GAE per column (losses.py:39-100), advantage statistics, value loss, reduction of A's partials
+__global__ __launch_bounds__(1024) void k_ppo_b(PpoCfg c, const float *__restrict__ baseline, const float *__restrict__ bootstrap,
+                                                const float *__restrict__ reward, const float *__restrict__ discount,
+                                                const float *__restrict__ truncation, float *scratch, int nblk) {
+  __shared__ float lds[96];
+  const int N = c.T * c.B;
+  float *vs = scratch + N, *adv = scratch + 2 * (size_t)N, *part = scratch + 4 * (size_t)N, *scal = part + (size_t)4 * nblk;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // sum adv, sum adv^2 (shifted later), sum v_err^2, ent, kl0, klt
+  for (int b = threadIdx.x; b < c.B; b += blockDim.x) {
+    float a = 0.f, bv = bootstrap[b], vnext = bv;
+    for (int t = c.T - 1; t >= 0; t--) {
+      size_t i = (size_t)t * c.B + b;
+      float tr = truncation[i], te = (1.f - discount[i]) * (1.f - tr), tm = 1.f - tr, v = baseline[i];
+      float delta = (reward[i] * c.reward_scaling + c.discounting * (1.f - te) * vnext - v) * tm;
+      a = delta + c.discounting * (1.f - te) * tm * c.gae_lambda * a;
+      vs[i] = a + v;
+      vnext = v;
+    }
+    float vsn = bv;
+    for (int t = c.T - 1; t >= 0; t--) {
+      size_t i = (size_t)t * c.B + b;
+      float tr = truncation[i], te = (1.f - discount[i]) * (1.f - tr), tm = 1.f - tr, cur = vs[i], v = baseline[i];
+      float ad = (reward[i] * c.reward_scaling + c.discounting * (1.f - te) * vsn - v) * tm;
+      adv[i] = ad;
+      acc[0] += ad;
+      float ve = cur - v;
+      acc[2] += ve * ve;
+      vsn = cur;
+    }
+  }
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) { acc[3] += part[4 * k]; acc[4] += part[4 * k + 1]; acc[5] += part[4 * k + 2]; }
+  ppo_block_sum<6>(acc, lds);
+  __shared__ float mean_s;
+  if (threadIdx.x == 0) mean_s = acc[0] / (float)N;
+  __syncthreads();
+  float mean = mean_s, ss[1] = {0.f};
+  for (int b = threadIdx.x; b < c.B; b += blockDim.x)
+    for (int t = 0; t < c.T; t++) { float d = adv[(size_t)t * c.B + b] - mean; ss[0] += d * d; }
+  ppo_block_sum<1>(ss, lds);
+  if (threadIdx.x == 0) {
+    const float Nf = (float)N;
+    scal[0] = mean;                                   // advantage mean
+    scal[1] = sqrtf(ss[0] / Nf);                      // population std
+    scal[2] = acc[2] / Nf * 0.25f;                    // v_loss = mean(err^2) * 0.5 * 0.5
+    scal[3] = acc[3] / Nf;                            // entropy
+    float kl0 = -0.5f * acc[4] / (float)(c.B * c.Z);
+    float kl = kl0;
+    if (c.T > 1) { float klt = 0.5f * acc[5] / (float)((c.T - 1) * c.B * c.Z); kl = (kl0 + klt * (float)(c.T - 1)) / (float)c.T; }
+    scal[4] = c.kl_weight * kl;
+  }
+}
+
+// C: per (t, b): surrogate loss term and every gradient w.r.t. logits, baseline, fc2
+__global__ __launch_bounds__(PPO_BLOCK) void k_ppo_c(PpoCfg c, const float *__restrict__ logits, const float *__restrict__ raw_action,
+                                                     const float *__restrict__ behaviour_logp, const float *__restrict__ noise,
+                                                     const float *__restrict__ baseline, const float *__restrict__ fc2, float *dlogits,
+                                                     float *dbaseline, float *dfc2, float *scratch, int nblk) {
+  __shared__ float lds[32];
+  const int N = c.T * c.B, i = blockIdx.x * PPO_BLOCK + threadIdx.x;
+  const float *vs = scratch + N, *adv = scratch + 2 * (size_t)N, *scal = scratch + 4 * (size_t)N + (size_t)4 * nblk;
+  float acc[1] = {0.f};
+  if (i < N) {
+    const float Nf = (float)N;
+    float ad = adv[i];
+    if (c.normalize_advantage) ad = (ad - scal[0]) / (scal[1] + 1e-8f);
+    float rho = expf(scratch[i] - behaviour_logp[i]), lo = 1.f - c.clip_eps, hi = 1.f + c.clip_eps;
+    float rc = fminf(fmaxf(rho, lo), hi), s1 = rho * ad, s2 = rc * ad;
+    acc[0] = fminf(s1, s2);
+    // d(-mean min(s1, s2)) / d logp: s1 taken (ties included: both sides then have the same derivative) or unclipped s2
+    float glp = (s1 <= s2 || (rho >= lo && rho <= hi)) ? -ad * rho / Nf : 0.f;
+    const float ce = -c.entropy_cost / Nf;   // entropy_loss = -entropy_cost * mean(ent)
+    const float *lg = logits + (size_t)i * 2 * c.A, *xa = raw_action + (size_t)i * c.A, *nz = noise + (size_t)i * c.A;
+    float *dl = dlogits + (size_t)i * 2 * c.A;
+    for (int a = 0; a < c.A; a++) {
+      float loc = lg[a], raw = lg[c.A + a], scale = ppo_softplus(raw) + 0.001f, sig = ppo_sigmoid(raw), x = xa[a], d = x - loc;
+      float inv = 1.f / scale, dlp_loc = d * inv * inv, dlp_scale = d * d * inv * inv * inv - inv;
+      float n = nz[a], th = tanhf(loc + scale * n), de_loc = -2.f * th, de_scale = inv - 2.f * th * n;
+      dl[a] = glp * dlp_loc + ce * de_loc;
+      dl[c.A + a] = (glp * dlp_scale + ce * de_scale) * sig;
+    }
+    dbaseline[i] = -0.5f * (vs[i] - baseline[i]) / Nf;
+    // latent KL
+    const int t = i / c.B;
+    const float pv = 1.f - PPO_ALPHA * PPO_ALPHA, kw = c.kl_weight;
+    const float c0 = kw / (float)c.T / (float)(c.B * c.Z), c1 = c.T > 1 ? kw * (float)(c.T - 1) / (float)c.T / (float)((c.T - 1) * c.B * c.Z) : 0.f;
+    const float *f = fc2 + (size_t)i * 2 * c.Z, *fp = f - (size_t)c.B * 2 * c.Z, *fn = f + (size_t)c.B * 2 * c.Z;
+    float *df = dfc2 + (size_t)i * 2 * c.Z;
+    for (int z = 0; z < c.Z; z++) {
+      float m = f[z], lv = f[c.Z + z], dm, dlv;
+      if (t == 0) { dm = c0 * m; dlv = -0.5f * c0 * (1.f - expf(lv)); }
+      else { float e = PPO_ALPHA * fp[z] - m; dm = -c1 * e / pv; dlv = 0.5f * c1 * (expf(lv) / pv - 1.f); }
+      if (t + 1 < c.T) { float e2 = PPO_ALPHA * m - fn[z]; dm += c1 * PPO_ALPHA * e2 / pv; }
+      df[z] = dm; df[c.Z + z] = dlv;
+    }
+  }
+  ppo_block_sum<1>(acc, lds);
+  if (threadIdx.x == 0) scratch[(size_t)4 * N + (size_t)blockIdx.x * 4 + 3] = acc[0];
+}
+
+// D: final scalars
+__global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk) {
+  __shared__ float lds[16];
+  const int N = c.T * c.B;
+  const float *part = scratch + 4 * (size_t)N, *scal = part + (size_t)4 * nblk;
+  float acc[1] = {0.f};
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) acc[0] += part[4 * k + 3];
+  ppo_block_sum<1>(acc, lds);
+  if (threadIdx.x == 0) {
+    float policy = -acc[0] / (float)N, v = scal[2], entl = -c.entropy_cost * scal[3], kl = scal[4];
+    out[0] = policy + v + entl + kl; out[1] = policy; out[2] = v; out[3] = entl; out[4] = kl; out[5] = scal[0]; out[6] = scal[1]; out[7] = scal[3];
+  }
+}

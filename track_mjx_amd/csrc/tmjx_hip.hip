@@ -181,6 +181,8 @@ __global__ void k_gae(const float *__restrict__ trunc, const float *__restrict__
   }
 }
 
+#include "ppo_kernels.h"
+
 // ----------------------------------------------------------------------------------------------- C-ABI
 extern "C" {
 
@@ -361,6 +363,27 @@ int tmjx_gae(const float *truncation, const float *termination, const float *rew
   hipLaunchKernelGGL(k_gae, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, truncation, termination, rewards, values,
                      bootstrap, lambda_, discount, vs, advantages, T, B);
   return check_launch("k_gae");
+}
+
+int tmjx_ppo_scratch_floats(int T, int B) { return 4 * T * B + 4 * ((T * B + PPO_BLOCK - 1) / PPO_BLOCK) + 16; }
+
+int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *raw_action, const float *behaviour_logp,
+                  const float *noise, const float *baseline, const float *bootstrap, const float *reward, const float *discount,
+                  const float *truncation, const float *fc2, float *dlogits, float *dbaseline, float *dfc2, float *scratch,
+                  float *out, void *stream) {
+  if (!cfg || !logits || !raw_action || !behaviour_logp || !noise || !baseline || !bootstrap || !reward || !discount || !truncation ||
+      !fc2 || !dlogits || !dbaseline || !dfc2 || !scratch || !out) return fail(TMJX_EINVAL, "null argument");
+  if (cfg->T < 1 || cfg->B < 1 || cfg->A < 1 || cfg->Z < 1) return fail(TMJX_EINVAL, "bad T / B / A / Z");
+  PpoCfg c{cfg->T, cfg->B, cfg->A, cfg->Z, cfg->reward_scaling, cfg->discounting, cfg->gae_lambda, cfg->clip_eps, cfg->entropy_cost,
+           cfg->kl_weight, cfg->normalize_advantage};
+  const int N = c.T * c.B, nblk = (N + PPO_BLOCK - 1) / PPO_BLOCK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ppo_a, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, noise, fc2, scratch);
+  hipLaunchKernelGGL(k_ppo_b, dim3(1), dim3(1024), 0, s, c, baseline, bootstrap, reward, discount, truncation, scratch, nblk);
+  hipLaunchKernelGGL(k_ppo_c, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, behaviour_logp, noise, baseline, fc2, dlogits, dbaseline,
+                     dfc2, scratch, nblk);
+  hipLaunchKernelGGL(k_ppo_d, dim3(1), dim3(256), 0, s, c, (const float *)scratch, out, nblk);
+  return check_launch("k_ppo");
 }
 
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {

@@ -29,8 +29,15 @@ class Layout(C.Structure):
 
 
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
-           "tmjx_physics", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_debug_rows", "tmjx_last_error",
-           "tmjx_version")
+           "tmjx_physics", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
+           "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
+
+
+class PpoCfg(C.Structure):
+    """tmjx_ppo_cfg_t (include/tmjx.h)."""
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("A", C.c_int32), ("Z", C.c_int32), ("reward_scaling", C.c_float),
+                ("discounting", C.c_float), ("gae_lambda", C.c_float), ("clip_eps", C.c_float), ("entropy_cost", C.c_float),
+                ("kl_weight", C.c_float), ("normalize_advantage", C.c_int32)]
 
 _lib = None
 
@@ -70,6 +77,8 @@ def lib():
     L.tmjx_forward.argtypes = [vp, fp, fp, C.c_int, vp]
     L.tmjx_reward_obs.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
     L.tmjx_gae.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, vp]
+    L.tmjx_ppo_scratch_floats.argtypes = [C.c_int, C.c_int]
+    L.tmjx_ppo_loss.argtypes = [C.POINTER(PpoCfg)] + [fp] * 15 + [vp]
     L.tmjx_debug_rows.argtypes = [vp, C.c_char_p, ip, ip]
     L.tmjx_last_error.restype = C.c_char_p
     L.tmjx_version.restype = C.c_char_p
