@@ -109,6 +109,16 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
                   const float *truncation, const float *fc2, float *dlogits, float *dbaseline, float *dfc2, float *scratch,
                   float *out, void *stream);
 
+/* Dense -> SiLU -> LayerNorm epilogue of the intention network's hidden layers (intention_network.py:14-88):
+ * y = LayerNorm_{gamma,beta,eps}(silu(z + bias)), z [rows][H] = the GEMM output, H in {64, 128, 256, 512, 1024}.
+ * fwd also writes stats [rows][2] = mean, rstd; bwd returns dz and grads [3][H] = d_gamma | d_beta | d_bias;
+ * partial >= tmjx_silu_ln_partial_floats(rows, H) floats of scratch. */
+int tmjx_silu_ln_partial_floats(int rows, int H);
+int tmjx_silu_ln_fwd(const float *z, const float *bias, const float *gamma, const float *beta, float *y, float *stats, int rows, int H,
+                     float eps, void *stream);
+int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, float *dz, float *grads,
+                     float *partial, int rows, int H, void *stream);
+
 /* Debug/test access: copy a named per-env workspace/intermediate array of the last tmjx_forward /
  * tmjx_physics call into `out` (device pointer, [count][n_env]); returns count or a negative code.
  * Names: "qM" (sparse rows), "qfrc_smooth", "qacc", "qacc_smooth", "efc_D", "efc_aref", "con_dist", ... */

@@ -334,3 +334,27 @@ def test_fused_ppo_loss_head_matches_torch_reference():
     for a, b in zip(g_fus, g_ref):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-7, (a.shape, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [64, 256, 1024])
+def test_fused_silu_layernorm_block_matches_torch(H):
+    """tmjx_silu_ln_fwd / _bwd against torch's linear -> silu -> layer_norm, outputs and all four gradients."""
+    import torch
+    import torch.nn.functional as F
+    from track_mjx_amd.agent.networks import _SiluLayerNormFn
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(H)
+    rows = 1000
+    z = torch.randn(rows, H, generator=g, device=dev, requires_grad=True)
+    bias = (torch.randn(H, generator=g, device=dev) * 0.3).requires_grad_()
+    gamma = (1 + 0.2 * torch.randn(H, generator=g, device=dev)).requires_grad_()
+    beta = (0.1 * torch.randn(H, generator=g, device=dev)).requires_grad_()
+    up = torch.randn(rows, H, generator=g, device=dev)
+    y_ref = F.layer_norm(F.silu(z + bias), (H,), gamma, beta, 1e-6)
+    g_ref = torch.autograd.grad((y_ref * up).sum(), (z, bias, gamma, beta))
+    y = _SiluLayerNormFn.apply(z, bias, gamma, beta, 1e-6)
+    g_fus = torch.autograd.grad((y * up).sum(), (z, bias, gamma, beta))
+    assert float((y - y_ref).abs().max()) < 2e-5
+    for a, b in zip(g_fus, g_ref):
+        assert float((a - b).abs().max()) <= 1e-4 * (float(b.abs().max()) + 1e-6), (a.shape, float((a - b).abs().max()), float(b.abs().max()))

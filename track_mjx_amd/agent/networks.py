@@ -74,8 +74,69 @@ def _dense(i: int, o: int, init=_lecun_uniform_) -> nn.Linear:
     return lin
 
 
+class _SplitKMatmulFn(torch.autograd.Function):
+    """z = x W^T (no bias) with the split-K weight gradient of _SplitKLinearFn."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        m, s = x.shape[0], _SplitKLinearFn.SPLIT
+        dx = dz @ w if ctx.needs_input_grad[0] else None
+        if m % s == 0 and m >= 4096:
+            dw = torch.bmm(dz.view(s, m // s, dz.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).sum(0)
+        else:
+            dw = dz.t() @ x
+        return dx, dw
+
+
+class _SiluLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(silu(z + bias)) through tmjx_silu_ln_fwd / _bwd (csrc/ppo_kernels.h): one launch forward, two
+    backward (dz plus d_gamma | d_beta | d_bias), instead of torch's bias-add, silu, layer_norm and five backward kernels."""
+
+    @staticmethod
+    def forward(ctx, z, bias, gamma, beta, eps):
+        import ctypes as C
+        from .. import hip as _hip
+        H = z.shape[-1]
+        rows = z.numel() // H
+        z = z.contiguous()
+        y = torch.empty_like(z)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=z.device)
+        L = _hip.lib()
+        with torch.cuda.device(z.device):
+            stream = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+            _hip.check(L.tmjx_silu_ln_fwd(*[C.c_void_p(t.data_ptr()) for t in (z, bias, gamma, beta, y, stats)], rows, H, float(eps), stream),
+                       "tmjx_silu_ln_fwd")
+        ctx.save_for_backward(z, bias, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from .. import hip as _hip
+        z, bias, gamma, stats = ctx.saved_tensors
+        H = z.shape[-1]
+        rows = z.numel() // H
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        grads = torch.empty((3, H), dtype=torch.float32, device=z.device)
+        L = _hip.lib()
+        partial = torch.empty(L.tmjx_silu_ln_partial_floats(rows, H), dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            stream = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+            _hip.check(L.tmjx_silu_ln_bwd(*[C.c_void_p(t.data_ptr()) for t in (dy, z, bias, gamma, stats, dz, grads, partial)], rows, H, stream),
+                       "tmjx_silu_ln_bwd")
+        return dz, grads[2], grads[0], grads[1], None
+
+
 class _Block(nn.Module):
     """Dense -> SiLU -> LayerNorm (flax LayerNorm defaults: eps 1e-6, scale + bias)."""
+    FUSED_WIDTHS = (64, 128, 256, 512, 1024)
 
     def __init__(self, i: int, o: int):
         super().__init__()
@@ -83,6 +144,11 @@ class _Block(nn.Module):
         self.norm = nn.LayerNorm(o, eps=1e-6)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.dense.out_features in self.FUSED_WIDTHS and not torch.is_autocast_enabled():
+            x2 = x.reshape(-1, x.shape[-1])
+            z = _SplitKMatmulFn.apply(x2, self.dense.weight) if torch.is_grad_enabled() else x2 @ self.dense.weight.t()
+            y = _SiluLayerNormFn.apply(z, self.dense.bias, self.norm.weight, self.norm.bias, self.norm.eps)
+            return y.view(*x.shape[:-1], self.dense.out_features)
         return self.norm(F.silu(self.dense(x)))
 
 

@@ -189,3 +189,85 @@ __global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk) {
     out[0] = policy + v + entl + kl; out[1] = policy; out[2] = v; out[3] = entl; out[4] = kl; out[5] = scal[0]; out[6] = scal[1]; out[7] = scal[3];
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dense -> SiLU -> LayerNorm block epilogue (intention_network.py:14-88: flax Dense, nn.silu, nn.LayerNorm eps 1e-6):
+//   y = gamma * (a - mean(a)) * rstd(a) + beta,  a = silu(z + bias),  z = x W^T from the library GEMM.
+// One wavefront per row, VPT = H / 64 consecutive columns per lane (H = 256: one float4), row statistics by wave
+// shuffles.  The backward kernel also produces the column sums d_gamma, d_beta, d_bias as per-block partials (rows are
+// dealt to blocks in contiguous slabs) that a second small kernel adds up: deterministic, no atomics.
+#define BLK_ROWS_PER_BLOCK 64
+__device__ __forceinline__ float wave_sum(float x) { for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off); return x; }
+
+template <int VPT>
+__global__ __launch_bounds__(256) void k_silu_ln_fwd(const float *__restrict__ z, const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ stats, int rows,
+                                                     float eps) {
+  constexpr int H = VPT * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float b[VPT], g[VPT], be[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; k++) { int c = lane * VPT + k; b[k] = bias[c]; g[k] = gamma[c]; be[k] = beta[c]; }
+  for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+    float a[VPT], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) { float v = z[(size_t)r * H + lane * VPT + k] + b[k]; a[k] = v / (1.f + expf(-v)); s += a[k]; }
+    float mean = wave_sum(s) / (float)H, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) { float d = a[k] - mean; q += d * d; }
+    float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int k = 0; k < VPT; k++) y[(size_t)r * H + lane * VPT + k] = (a[k] - mean) * rstd * g[k] + be[k];
+    if (lane == 0) { stats[2 * (size_t)r] = mean; stats[2 * (size_t)r + 1] = rstd; }
+  }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void k_silu_ln_bwd(const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ bias,
+                                                     const float *__restrict__ gamma, const float *__restrict__ stats, float *__restrict__ dz,
+                                                     float *__restrict__ partial, int rows) {
+  constexpr int H = VPT * 64;
+  __shared__ float lds[3 * H * 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float b[VPT], g[VPT], sg[VPT], sb[VPT], sz[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; k++) { int c = lane * VPT + k; b[k] = bias[c]; g[k] = gamma[c]; sg[k] = 0.f; sb[k] = 0.f; sz[k] = 0.f; }
+  const int r0 = blockIdx.x * BLK_ROWS_PER_BLOCK, r1 = min(rows, r0 + BLK_ROWS_PER_BLOCK);
+  for (int r = r0 + w; r < r1; r += 4) {
+    const float mean = stats[2 * (size_t)r], rstd = stats[2 * (size_t)r + 1];
+    float v[VPT], sig[VPT], ah[VPT], da[VPT], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      v[k] = z[(size_t)r * H + lane * VPT + k] + b[k];
+      sig[k] = 1.f / (1.f + expf(-v[k]));
+      ah[k] = (v[k] * sig[k] - mean) * rstd;
+      float d = dy[(size_t)r * H + lane * VPT + k];
+      sg[k] += d * ah[k]; sb[k] += d;
+      da[k] = d * g[k];
+      m1 += da[k]; m2 += da[k] * ah[k];
+    }
+    m1 = wave_sum(m1) / (float)H; m2 = wave_sum(m2) / (float)H;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      float dact = rstd * (da[k] - m1 - ah[k] * m2);
+      float o = dact * (sig[k] * (1.f + v[k] * (1.f - sig[k])));
+      dz[(size_t)r * H + lane * VPT + k] = o;
+      sz[k] += o;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VPT; k++) { int c = lane * VPT + k; lds[(0 * 4 + w) * H + c] = sg[k]; lds[(1 * 4 + w) * H + c] = sb[k]; lds[(2 * 4 + w) * H + c] = sz[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * H; i += 256) {
+    int which = i / H, c = i - which * H;
+    partial[(size_t)blockIdx.x * 3 * H + i] = lds[(which * 4 + 0) * H + c] + lds[(which * 4 + 1) * H + c] + lds[(which * 4 + 2) * H + c] + lds[(which * 4 + 3) * H + c];
+  }
+}
+// column sums of the per-block partials -> [3][H] = d_gamma | d_beta | d_bias
+__global__ void k_colsum(const float *__restrict__ partial, float *__restrict__ out, int nblk, int width) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= width) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; k++) s += partial[(size_t)k * width + i];
+  out[i] = s;
+}

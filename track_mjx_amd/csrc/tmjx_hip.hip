@@ -386,6 +386,35 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
   return check_launch("k_ppo");
 }
 
+int tmjx_silu_ln_partial_floats(int rows, int H) { return ((rows + BLK_ROWS_PER_BLOCK - 1) / BLK_ROWS_PER_BLOCK) * 3 * H; }
+
+int tmjx_silu_ln_fwd(const float *z, const float *bias, const float *gamma, const float *beta, float *y, float *stats, int rows, int H,
+                     float eps, void *stream) {
+  if (!z || !bias || !gamma || !beta || !y || !stats) return fail(TMJX_EINVAL, "null argument");
+  if (rows < 1) return fail(TMJX_EINVAL, "rows must be >= 1");
+  hipStream_t s = (hipStream_t)stream;
+  int grid = (rows + 3) / 4; if (grid > 4096) grid = 4096;
+#define TMJX_FWD(V) hipLaunchKernelGGL(k_silu_ln_fwd<V>, dim3(grid), dim3(256), 0, s, z, bias, gamma, beta, y, stats, rows, eps)
+  switch (H) { case 64: TMJX_FWD(1); break; case 128: TMJX_FWD(2); break; case 256: TMJX_FWD(4); break; case 512: TMJX_FWD(8); break;
+               case 1024: TMJX_FWD(16); break; default: return fail(TMJX_EINVAL, "H must be 64, 128, 256, 512 or 1024"); }
+#undef TMJX_FWD
+  return check_launch("k_silu_ln_fwd");
+}
+
+int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, float *dz, float *grads,
+                     float *partial, int rows, int H, void *stream) {
+  if (!dy || !z || !bias || !gamma || !stats || !dz || !grads || !partial) return fail(TMJX_EINVAL, "null argument");
+  if (rows < 1) return fail(TMJX_EINVAL, "rows must be >= 1");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = (rows + BLK_ROWS_PER_BLOCK - 1) / BLK_ROWS_PER_BLOCK;
+#define TMJX_BWD(V) hipLaunchKernelGGL(k_silu_ln_bwd<V>, dim3(nblk), dim3(256), 0, s, dy, z, bias, gamma, stats, dz, partial, rows)
+  switch (H) { case 64: TMJX_BWD(1); break; case 128: TMJX_BWD(2); break; case 256: TMJX_BWD(4); break; case 512: TMJX_BWD(8); break;
+               case 1024: TMJX_BWD(16); break; default: return fail(TMJX_EINVAL, "H must be 64, 128, 256, 512 or 1024"); }
+#undef TMJX_BWD
+  hipLaunchKernelGGL(k_colsum, dim3((3 * H + 255) / 256), dim3(256), 0, s, (const float *)partial, grads, nblk, 3 * H);
+  return check_launch("k_silu_ln_bwd");
+}
+
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {
   if (!m || !name || !row0 || !count) return fail(TMJX_EINVAL, "null argument");
   for (const auto &e : tmjx_host::debug_rows(m->h))

@@ -30,6 +30,7 @@ class Layout(C.Structure):
 
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
            "tmjx_physics", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
+           "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
 
@@ -79,6 +80,9 @@ def lib():
     L.tmjx_gae.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, vp]
     L.tmjx_ppo_scratch_floats.argtypes = [C.c_int, C.c_int]
     L.tmjx_ppo_loss.argtypes = [C.POINTER(PpoCfg)] + [fp] * 15 + [vp]
+    L.tmjx_silu_ln_partial_floats.argtypes = [C.c_int, C.c_int]
+    L.tmjx_silu_ln_fwd.argtypes = [fp] * 6 + [C.c_int, C.c_int, C.c_float, vp]
+    L.tmjx_silu_ln_bwd.argtypes = [fp] * 8 + [C.c_int, C.c_int, vp]
     L.tmjx_debug_rows.argtypes = [vp, C.c_char_p, ip, ip]
     L.tmjx_last_error.restype = C.c_char_p
     L.tmjx_version.restype = C.c_char_p
