@@ -277,9 +277,10 @@ class RunningStatistics:
         var_update = (diff_old * (flat - mean)).sum(0)
         if group is not None:
             dist.all_reduce(var_update, group=group)
-        self.summed_variance = self.summed_variance + var_update
-        self.mean, self.count = mean, count
-        self.std = torch.sqrt(torch.clamp(self.summed_variance, min=0) / count).clamp(self.std_min, self.std_max)
+        # in place: the SGD-loop graph (PPOLearner) holds pointers to these buffers
+        self.summed_variance.add_(var_update)
+        self.mean.copy_(mean); self.count.copy_(count)
+        self.std.copy_(torch.sqrt(torch.clamp(self.summed_variance, min=0) / count).clamp(self.std_min, self.std_max))
 
     def normalize(self, x: torch.Tensor) -> torch.Tensor:
         return (x - self.mean) / self.std

@@ -67,7 +67,7 @@ class PPOLearner:
                  entropy_cost: float = 1e-2, discounting: float = 0.98, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
                  clipping_epsilon: float = 0.2, unroll_length: int = 20, batch_size: int = 1024, num_minibatches: int = 16,
                  num_updates_per_batch: int = 4, normalize_observations: bool = True, kl_weight: float = 0.1,
-                 seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None):
+                 seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None, use_graph: bool = True):
         self.env, self.group = env, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -103,6 +103,8 @@ class PPOLearner:
                     "next_observation_last": torch.empty((rows, obs), **f32)}
         self.matmul_dtype = matmul_dtype
         self.state = None
+        self.use_graph, self._graph, self._graph_kl = use_graph, None, None
+        self._act_graph, self._act_key, self._act_out = None, None, None
 
     def n_params(self) -> int:
         return int(self.grads.flat.numel())
@@ -122,6 +124,34 @@ class PPOLearner:
         return NormalTanh.postprocess(raw), {"raw_action": raw, "log_prob": NormalTanh.log_prob(logits, raw), "logits": logits,
                                              "latent_mean": mean, "latent_logvar": logvar}
 
+    def _act_graphed(self, obs: torch.Tensor):
+        """act() replayed as one hipGraph (~45 launches of the policy inference per control step).  Valid while `obs` is the
+        env's persistent observation buffer (same pointer every step); falls back to eager launches otherwise."""
+        if not (self.use_graph and self.dev.type == "cuda"):
+            return self.act(obs)
+        key = (obs.data_ptr(), tuple(obs.shape), tuple(obs.stride()))
+        if self._act_graph is None or self._act_key != key:
+            try:
+                side = torch.cuda.Stream(device=self.dev)
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self.act(obs)
+                torch.cuda.current_stream(self.dev).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                graph.register_generator_state(self.gen)
+                with torch.cuda.graph(graph):
+                    action, extra = self.act(obs)
+                self._act_graph, self._act_key, self._act_out = graph, key, (action, extra)
+            except Exception as e:  # noqa: BLE001
+                print(f"[track_mjx_amd] hipGraph capture of the policy inference failed ({type(e).__name__}: {e}); running eagerly", flush=True)
+                self._act_graph, self._act_key = False, key
+                torch.cuda.synchronize(self.dev)
+        if self._act_graph is False:
+            return self.act(obs)
+        self._act_graph.replay()
+        return self._act_out
+
     @torch.no_grad()
     def collect(self) -> None:
         env, n, T = self.env, self.env.num_envs, self.T
@@ -130,10 +160,10 @@ class PPOLearner:
             sl = slice(u * n, (u + 1) * n)
             for t in range(T):
                 self.buf["observation"][t, sl] = st.obs
-                action, extra = self.act(st.obs)
-                st = env.step(st, action)
-                self.buf["raw_action"][t, sl] = extra["raw_action"]
+                action, extra = self._act_graphed(st.obs)
+                self.buf["raw_action"][t, sl] = extra["raw_action"]     # before env.step: the graph's outputs are re-used next step
                 self.buf["log_prob"][t, sl] = extra["log_prob"]
+                st = env.step(st, action)
                 self.buf["reward"][t, sl] = st.reward
                 self.buf["discount"][t, sl] = 1.0 - st.done
                 self.buf["truncation"][t, sl] = st.info["truncation"]
@@ -141,28 +171,65 @@ class PPOLearner:
         self.state = st
 
     # ---- learning
+    def _minibatch_grads(self, idx: torch.Tensor, kl_w: float) -> torch.Tensor:
+        """Gather one minibatch, loss, gradients into the flat buffer; returns the 5 loss terms as one tensor."""
+        data = {k: (v.index_select(1, idx) if k != "next_observation_last" else v.index_select(0, idx)) for k, v in self.buf.items()}
+        with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
+            loss_fn = _losses.compute_ppo_loss_fused if self.dev.type == "cuda" else _losses.compute_ppo_loss
+            loss, m = loss_fn(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
+        self.grads.assign(torch.autograd.grad(loss, self.grads.params))
+        return torch.stack([m[k].float() for k in self.METRIC_KEYS])
+
+    METRIC_KEYS = ("total_loss", "policy_loss", "v_loss", "kl_latent_loss", "entropy_loss")
+
+    def _capture(self, kl_w: float):
+        """hipGraph of _minibatch_grads (torch.cuda.graphs): ~250 launches of the SGD step replayed as one graph launch.
+        The minibatch row indices are a static device buffer; the optimiser and the gradient all-reduce stay eager, so the
+        same graph serves any world size."""
+        self._g_idx = torch.zeros(self.local_batch, dtype=torch.long, device=self.dev)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._minibatch_grads(self._g_idx, kl_w)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._g_out = self._minibatch_grads(self._g_idx, kl_w)
+        self._graph, self._graph_kl = graph, kl_w
+
     def update(self, it: int = 0, kl_schedule: Callable | None = None) -> dict:
         if self.normalize_observations:
             self.normalizer.update(self.buf["observation"], self.group if self.world > 1 else None)
         kl_w = kl_schedule(it) if kl_schedule is not None else self.kl_weight
         rows = self.buf["reward"].shape[1]
-        metrics_acc: dict = {}
+        use_graph = self.use_graph and self.dev.type == "cuda"
+        if use_graph and (self._graph is None or self._graph_kl != kl_w):
+            try:
+                self._capture(kl_w)
+            except Exception as e:  # noqa: BLE001 — capture is an optimisation: fall back to eager launches, loudly
+                print(f"[track_mjx_amd] hipGraph capture of the SGD step failed ({type(e).__name__}: {e}); running eagerly", flush=True)
+                self.use_graph = use_graph = False
+                torch.cuda.synchronize(self.dev)
+        acc = torch.zeros(len(self.METRIC_KEYS), dtype=torch.float32, device=self.dev)
         for _ in range(self.num_updates):
             perm = torch.randperm(rows, generator=self.gen, device=self.dev)  # one permutation for every leaf (ppo.py:306-311)
             for mb in range(self.num_minibatches):
                 idx = perm[mb * self.local_batch:(mb + 1) * self.local_batch]
-                data = {k: (v.index_select(1, idx) if k != "next_observation_last" else v.index_select(0, idx)) for k, v in self.buf.items()}
-                with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
-                    loss_fn = _losses.compute_ppo_loss_fused if self.dev.type == "cuda" else _losses.compute_ppo_loss
-                    loss, m = loss_fn(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
-                self.grads.assign(torch.autograd.grad(loss, self.grads.params))
+                if use_graph:
+                    self._g_idx.copy_(idx)
+                    self._graph.replay()
+                    out = self._g_out
+                else:
+                    out = self._minibatch_grads(idx, kl_w)
                 self.grads.all_reduce_mean(self.group)       # C1: one RCCL all-reduce per minibatch step
                 self.grads.clip_by_global_norm(10.0)          # optax.clip_by_global_norm(10.0) -> adam (ppo.py:517-520)
                 self.opt.step()
-                for k, v in m.items():
-                    metrics_acc[k] = metrics_acc.get(k, 0.0) + v.float()
-        denom = self.num_updates * self.num_minibatches
-        return {k: v / denom for k, v in metrics_acc.items()}
+                acc += out
+        acc /= self.num_updates * self.num_minibatches
+        res = {k: acc[i] for i, k in enumerate(self.METRIC_KEYS)}
+        res["kl_weight"] = torch.as_tensor(kl_w)
+        return res
 
     def training_step(self, it: int = 0, kl_schedule=None) -> dict:
         self.collect()
