@@ -75,7 +75,14 @@ def test_forward_intermediates():
     assert act_ref.sum() > 0, "test state must exercise contacts"
 
 
-def test_substep_teacher_forced():
+@pytest.mark.parametrize("variant", ["product", "generic-tree", "lane-per-env"])
+def test_substep_teacher_forced(variant, monkeypatch):
+    """product: the static rodent kernel (register-resident chain path); generic-tree: TMJX_WAVE_DYNAMIC=1, the run-time-layout
+    wave kernel any other model gets (LDS-resident sparse factorisation); lane-per-env: TMJX_IMPL=lane (csrc/physics_core.h)."""
+    if variant == "generic-tree":
+        monkeypatch.setenv("TMJX_WAVE_DYNAMIC", "1")
+    elif variant == "lane-per-env":
+        monkeypatch.setenv("TMJX_IMPL", "lane")
     n = 64
     env, O32, cl = make_env_and_oracle(num_envs=n, wrappers=False)
     O64 = make_oracle(env._blob, cl, "f64")
@@ -84,7 +91,7 @@ def test_substep_teacher_forced():
     d32 = [O32.new_data(qpos[e], qvel[e]) for e in range(n)]
     d64 = [O64.new_data(qpos[e], qvel[e]) for e in range(n)]
     worst = []
-    for sub in range(40):
+    for sub in range(40 if variant == "product" else 12):
         a = np.clip(rng.normal(size=(n, 38)) * 0.03, -1, 1)
         st = _oracle_states(O64, d64)
         _push(env, st)

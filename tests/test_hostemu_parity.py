@@ -57,8 +57,12 @@ def test_forward_intermediates_sparse_vs_dense(setup, impl):
     assert np.array_equal(E.rows("con_dist") < 0, np.stack([O64.get(d, "con_dist") < 0 for d in ds], 1))
 
 
-@pytest.mark.parametrize("impl", ["lane", "wave"])
-def test_substeps_teacher_forced(setup, impl):
+@pytest.mark.parametrize("impl", ["lane", "wave", "wave-generic"])
+def test_substeps_teacher_forced(setup, impl, monkeypatch):
+    """wave: the rodent's register-resident chain path (what the static GPU kernel runs); wave-generic: TMJX_EMU_GENERIC=1, the
+    LDS-resident sparse path any other tree takes."""
+    if impl == "wave-generic":
+        monkeypatch.setenv("TMJX_EMU_GENERIC", "1")
     w, blob, clip = setup
     n = 8
     E = Emu(blob, n); O32 = make_oracle(blob, clip, "f32"); O64 = make_oracle(blob, clip, "f64")
@@ -83,7 +87,9 @@ def test_substeps_teacher_forced(setup, impl):
             ref = np.stack([O64.get(d, k) for d in d64], 1); r32 = np.stack([O32.get(d, k) for d in d32], 1)
             e_emu, e_32 = rel_err(E.rows(k), ref, axis=0), rel_err(r32, ref, axis=0)
             assert np.median(e_emu) <= 1e-5, (sub, k, e_emu)
-            assert e_emu.max() <= 4 * e_32.max() + 2e-5, (sub, k, e_emu.max(), e_32.max())
+            # worst env of the step: 4x the fp32 oracle's own worst error plus a floor for steps where that happens to be tiny
+            # (8 envs only; the generic path's longer LDS-resident reductions sit ~20 % above the chain path)
+            assert e_emu.max() <= 4 * e_32.max() + (3e-5 if impl == "wave-generic" else 2e-5), (sub, k, e_emu.max(), e_32.max())
     assert sum((O64.get(d, "con_dist") < 0).sum() for d in d64) > 0
 
 
