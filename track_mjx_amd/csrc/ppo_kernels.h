@@ -6,7 +6,7 @@
 //
 //   logits  [T][B][2A]  loc | raw_scale of the NormalTanh policy (brax NormalTanhDistribution, min_std 0.001)
 //   fc2     [T][B][2Z]  latent_mean | latent_logvar of the intention encoder
-//   scratch [4 T B + 4 nblk + 16] floats, nblk = ceil(T B / 256)
+//   scratch [4 T B + 4 nblk + 16] floats, nblk = ceil(8 T B / 256)
 //   out     [8]: total, policy_loss, v_loss, entropy_loss, kl_latent_loss, adv_mean, adv_std, entropy
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,34 +42,37 @@ __device__ __forceinline__ void ppo_block_sum(float *v, float *lds) {
   __syncthreads();
 }
 
-// A: per (t, b): log-prob of the stored action, entropy sample, latent-KL sums
+// A: per (t, b): log-prob of the stored action, entropy sample, latent-KL sums.  PPO_G = 8 lanes share one (t, b): lane s takes
+// the action / latent dims s, s + 8, .. (8 consecutive floats per load instead of one float per 304-byte row per lane)
+#define PPO_G 8
+__device__ __forceinline__ float ppo_group_sum(float x) { x += __shfl_xor(x, 4); x += __shfl_xor(x, 2); x += __shfl_xor(x, 1); return x; }
 __global__ __launch_bounds__(PPO_BLOCK) void k_ppo_a(PpoCfg c, const float *__restrict__ logits, const float *__restrict__ raw_action,
-                                                     const float *__restrict__ noise, const float *__restrict__ fc2, float *scratch) {
+                                                     const float *__restrict__ noise, const float *__restrict__ fc2, float *scratch, int nblk) {
   __shared__ float lds[64];
-  const int N = c.T * c.B, i = blockIdx.x * PPO_BLOCK + threadIdx.x;
+  const int N = c.T * c.B, gid = blockIdx.x * PPO_BLOCK + threadIdx.x, i = gid / PPO_G, sub = gid % PPO_G;
   float acc[3] = {0.f, 0.f, 0.f};   // entropy, kl0 inner sum, klt inner sum
   if (i < N) {
     const int t = i / c.B;
     const float *lg = logits + (size_t)i * 2 * c.A, *xa = raw_action + (size_t)i * c.A, *nz = noise + (size_t)i * c.A;
     float logp = 0.f, ent = 0.f;
-    for (int a = 0; a < c.A; a++) {
+    for (int a = sub; a < c.A; a += PPO_G) {
       float loc = lg[a], scale = ppo_softplus(lg[c.A + a]) + 0.001f, x = xa[a], d = (x - loc) / scale;
       logp += -0.5f * d * d - logf(scale) - 0.91893853320467274f - ppo_fldj(x);
       float xs = loc + scale * nz[a];
       ent += 0.5f + 0.91893853320467274f + logf(scale) + ppo_fldj(xs);
     }
-    scratch[i] = logp;
+    logp = ppo_group_sum(logp);
+    if (sub == 0) scratch[i] = logp;
     acc[0] = ent;
     const float *f = fc2 + (size_t)i * 2 * c.Z;
     const float pv = 1.f - PPO_ALPHA * PPO_ALPHA;
+    float s = 0.f;
     if (t == 0) {
-      float s = 0.f;
-      for (int z = 0; z < c.Z; z++) { float m = f[z], lv = f[c.Z + z]; s += 1.f + lv - m * m - expf(lv); }
+      for (int z = sub; z < c.Z; z += PPO_G) { float m = f[z], lv = f[c.Z + z]; s += 1.f + lv - m * m - expf(lv); }
       acc[1] = s;
     } else {
       const float *fp = f - (size_t)c.B * 2 * c.Z;
-      float s = 0.f;
-      for (int z = 0; z < c.Z; z++) { float m = f[z], lv = f[c.Z + z], e = PPO_ALPHA * fp[z] - m; s += expf(lv) / pv + e * e / pv - 1.f + logf(pv) - lv; }
+      for (int z = sub; z < c.Z; z += PPO_G) { float m = f[z], lv = f[c.Z + z], e = PPO_ALPHA * fp[z] - m; s += expf(lv) / pv + e * e / pv - 1.f + logf(pv) - lv; }
       acc[2] = s;
     }
   }
@@ -129,13 +132,13 @@ __global__ __launch_bounds__(1024) void k_ppo_b(PpoCfg c, const float *__restric
   }
 }
 
-// C: per (t, b): surrogate loss term and every gradient w.r.t. logits, baseline, fc2
+// C: per (t, b) (PPO_G lanes each): surrogate loss term and every gradient w.r.t. logits, baseline, fc2
 __global__ __launch_bounds__(PPO_BLOCK) void k_ppo_c(PpoCfg c, const float *__restrict__ logits, const float *__restrict__ raw_action,
                                                      const float *__restrict__ behaviour_logp, const float *__restrict__ noise,
                                                      const float *__restrict__ baseline, const float *__restrict__ fc2, float *dlogits,
                                                      float *dbaseline, float *dfc2, float *scratch, int nblk) {
   __shared__ float lds[32];
-  const int N = c.T * c.B, i = blockIdx.x * PPO_BLOCK + threadIdx.x;
+  const int N = c.T * c.B, gid = blockIdx.x * PPO_BLOCK + threadIdx.x, i = gid / PPO_G, sub = gid % PPO_G;
   const float *vs = scratch + N, *adv = scratch + 2 * (size_t)N, *scal = scratch + 4 * (size_t)N + (size_t)4 * nblk;
   float acc[1] = {0.f};
   if (i < N) {
@@ -144,27 +147,27 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_ppo_c(PpoCfg c, const float *__re
     if (c.normalize_advantage) ad = (ad - scal[0]) / (scal[1] + 1e-8f);
     float rho = expf(scratch[i] - behaviour_logp[i]), lo = 1.f - c.clip_eps, hi = 1.f + c.clip_eps;
     float rc = fminf(fmaxf(rho, lo), hi), s1 = rho * ad, s2 = rc * ad;
-    acc[0] = fminf(s1, s2);
+    if (sub == 0) acc[0] = fminf(s1, s2);
     // d(-mean min(s1, s2)) / d logp: s1 taken (ties included: both sides then have the same derivative) or unclipped s2
     float glp = (s1 <= s2 || (rho >= lo && rho <= hi)) ? -ad * rho / Nf : 0.f;
     const float ce = -c.entropy_cost / Nf;   // entropy_loss = -entropy_cost * mean(ent)
     const float *lg = logits + (size_t)i * 2 * c.A, *xa = raw_action + (size_t)i * c.A, *nz = noise + (size_t)i * c.A;
     float *dl = dlogits + (size_t)i * 2 * c.A;
-    for (int a = 0; a < c.A; a++) {
+    for (int a = sub; a < c.A; a += PPO_G) {
       float loc = lg[a], raw = lg[c.A + a], scale = ppo_softplus(raw) + 0.001f, sig = ppo_sigmoid(raw), x = xa[a], d = x - loc;
       float inv = 1.f / scale, dlp_loc = d * inv * inv, dlp_scale = d * d * inv * inv * inv - inv;
       float n = nz[a], th = tanhf(loc + scale * n), de_loc = -2.f * th, de_scale = inv - 2.f * th * n;
       dl[a] = glp * dlp_loc + ce * de_loc;
       dl[c.A + a] = (glp * dlp_scale + ce * de_scale) * sig;
     }
-    dbaseline[i] = -0.5f * (vs[i] - baseline[i]) / Nf;
+    if (sub == 0) dbaseline[i] = -0.5f * (vs[i] - baseline[i]) / Nf;
     // latent KL
     const int t = i / c.B;
     const float pv = 1.f - PPO_ALPHA * PPO_ALPHA, kw = c.kl_weight;
     const float c0 = kw / (float)c.T / (float)(c.B * c.Z), c1 = c.T > 1 ? kw * (float)(c.T - 1) / (float)c.T / (float)((c.T - 1) * c.B * c.Z) : 0.f;
     const float *f = fc2 + (size_t)i * 2 * c.Z, *fp = f - (size_t)c.B * 2 * c.Z, *fn = f + (size_t)c.B * 2 * c.Z;
     float *df = dfc2 + (size_t)i * 2 * c.Z;
-    for (int z = 0; z < c.Z; z++) {
+    for (int z = sub; z < c.Z; z += PPO_G) {
       float m = f[z], lv = f[c.Z + z], dm, dlv;
       if (t == 0) { dm = c0 * m; dlv = -0.5f * c0 * (1.f - expf(lv)); }
       else { float e = PPO_ALPHA * fp[z] - m; dm = -c1 * e / pv; dlv = 0.5f * c1 * (expf(lv) / pv - 1.f); }
@@ -196,7 +199,7 @@ __global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk) {
 // One wavefront per row, VPT = H / 64 consecutive columns per lane (H = 256: one float4), row statistics by wave
 // shuffles.  The backward kernel also produces the column sums d_gamma, d_beta, d_bias as per-block partials (rows are
 // dealt to blocks in contiguous slabs) that a second small kernel adds up: deterministic, no atomics.
-#define BLK_ROWS_PER_BLOCK 64
+#define BLK_ROWS_PER_BLOCK 128
 __device__ __forceinline__ float wave_sum(float x) { for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off); return x; }
 
 template <int VPT>
@@ -263,11 +266,18 @@ __global__ __launch_bounds__(256) void k_silu_ln_bwd(const float *__restrict__ d
     partial[(size_t)blockIdx.x * 3 * H + i] = lds[(which * 4 + 0) * H + c] + lds[(which * 4 + 1) * H + c] + lds[(which * 4 + 2) * H + c] + lds[(which * 4 + 3) * H + c];
   }
 }
-// column sums of the per-block partials -> [3][H] = d_gamma | d_beta | d_bias
-__global__ void k_colsum(const float *__restrict__ partial, float *__restrict__ out, int nblk, int width) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= width) return;
-  float s = 0.f;
-  for (int k = 0; k < nblk; k++) s += partial[(size_t)k * width + i];
-  out[i] = s;
+// column sums of the per-block partials -> [3][H] = d_gamma | d_beta | d_bias.  Block = 32 columns x 8 row slices (the first
+// version, one thread per column walking all partial rows, took 74 us for 320 x 768 floats: three workgroups, serial loads)
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partial, float *__restrict__ out, int nblk, int width) {
+  __shared__ float lds[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, col = blockIdx.x * 32 + cx;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < width) {
+    int k = ry;
+    for (; k + 8 < nblk; k += 16) { s0 += partial[(size_t)k * width + col]; s1 += partial[(size_t)(k + 8) * width + col]; }
+    if (k < nblk) s0 += partial[(size_t)k * width + col];
+  }
+  lds[ry][cx] = s0 + s1;
+  __syncthreads();
+  if (ry == 0 && col < width) { float s = 0.f; for (int j = 0; j < 8; j++) s += lds[j][cx]; out[col] = s; }
 }

@@ -365,7 +365,7 @@ int tmjx_gae(const float *truncation, const float *termination, const float *rew
   return check_launch("k_gae");
 }
 
-int tmjx_ppo_scratch_floats(int T, int B) { return 4 * T * B + 4 * ((T * B + PPO_BLOCK - 1) / PPO_BLOCK) + 16; }
+int tmjx_ppo_scratch_floats(int T, int B) { return 4 * T * B + 4 * ((T * B * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK) + 16; }
 
 int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *raw_action, const float *behaviour_logp,
                   const float *noise, const float *baseline, const float *bootstrap, const float *reward, const float *discount,
@@ -376,9 +376,9 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
   if (cfg->T < 1 || cfg->B < 1 || cfg->A < 1 || cfg->Z < 1) return fail(TMJX_EINVAL, "bad T / B / A / Z");
   PpoCfg c{cfg->T, cfg->B, cfg->A, cfg->Z, cfg->reward_scaling, cfg->discounting, cfg->gae_lambda, cfg->clip_eps, cfg->entropy_cost,
            cfg->kl_weight, cfg->normalize_advantage};
-  const int N = c.T * c.B, nblk = (N + PPO_BLOCK - 1) / PPO_BLOCK;
+  const int N = c.T * c.B, nblk = (N * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_ppo_a, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, noise, fc2, scratch);
+  hipLaunchKernelGGL(k_ppo_a, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, noise, fc2, scratch, nblk);
   hipLaunchKernelGGL(k_ppo_b, dim3(1), dim3(1024), 0, s, c, baseline, bootstrap, reward, discount, truncation, scratch, nblk);
   hipLaunchKernelGGL(k_ppo_c, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, behaviour_logp, noise, baseline, fc2, dlogits, dbaseline,
                      dfc2, scratch, nblk);
@@ -411,7 +411,7 @@ int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const f
   switch (H) { case 64: TMJX_BWD(1); break; case 128: TMJX_BWD(2); break; case 256: TMJX_BWD(4); break; case 512: TMJX_BWD(8); break;
                case 1024: TMJX_BWD(16); break; default: return fail(TMJX_EINVAL, "H must be 64, 128, 256, 512 or 1024"); }
 #undef TMJX_BWD
-  hipLaunchKernelGGL(k_colsum, dim3((3 * H + 255) / 256), dim3(256), 0, s, (const float *)partial, grads, nblk, 3 * H);
+  hipLaunchKernelGGL(k_colsum, dim3((3 * H + 31) / 32), dim3(256), 0, s, (const float *)partial, grads, nblk, 3 * H);
   return check_launch("k_silu_ln_bwd");
 }
 
