@@ -1233,7 +1233,7 @@ struct TmwLS { float alpha, cost, d0, d1; };
 // The constraint rows of a line search live in registers: per row e = lane + 64 s the three quadratic coefficients
 // t0 = D ja^2 / 2, t1 = D ja jv, t2 = D jv^2 / 2 and (ja, jv) for the activity test ja + alpha jv < 0.
 #define TMW_LS_SLOTS 4        // up to 256 constraint rows
-struct TmwLSRows { float ja[TMW_NL][TMW_LS_SLOTS], jv[TMW_NL][TMW_LS_SLOTS], t0[TMW_NL][TMW_LS_SLOTS], t1[TMW_NL][TMW_LS_SLOTS], t2[TMW_NL][TMW_LS_SLOTS]; };
+struct TmwLSRows { float ja[TMW_NL][TMW_LS_SLOTS], jv[TMW_NL][TMW_LS_SLOTS], D[TMW_NL][TMW_LS_SLOTS], t0[TMW_NL][TMW_LS_SLOTS], t1[TMW_NL][TMW_LS_SLOTS], t2[TMW_NL][TMW_LS_SLOTS]; };
 // NP line-search points evaluated together (alphas a[0..NP-1]): 3 NP partial sums over the rows, reduced together
 template <int NP>
 TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const float *a, float g0, float g1, float g2, TmwLS *out) {
@@ -1267,7 +1267,9 @@ TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const f
     out[p].d1 = 2.f * q2 + (q2 == 0.f ? TM_MINVAL : 0.f);
   }
 }
-TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
+// returns the cost of the new iterate and its Gauss term through `gauss` (what _update_constraint recomputes after the step:
+// the same sums as tmw_cost_from_state, taken in the same order, but from the rows and vectors already in registers)
+TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
   float smag = sqrtf(tmw_dot(c, K, K.l_search, K.l_search)) * scale;
@@ -1282,7 +1284,7 @@ TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
       int e = lane + 64 * sl;
       bool ok = e < K.nefc;
       float ja = ok ? L[K.l_Jaref + (ok ? e : 0)] : 1.f, jv = ok ? L[K.l_jv + (ok ? e : 0)] : 0.f, D = ok ? L[K.l_efc_D + (ok ? e : 0)] : 0.f;   // padding rows: never active
-      R.ja[TMW_LI][sl] = ja; R.jv[TMW_LI][sl] = jv;
+      R.ja[TMW_LI][sl] = ja; R.jv[TMW_LI][sl] = jv; R.D[TMW_LI][sl] = D;
       R.t0[TMW_LI][sl] = 0.5f * ja * ja * D; R.t1[TMW_LI][sl] = jv * ja * D; R.t2[TMW_LI][sl] = 0.5f * jv * jv * D;
     }
   }
@@ -1317,12 +1319,24 @@ TM_DEV void tmw_linesearch(WCtx &c, const WLayout &K, float gauss) {
   bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
   float ia = improved ? alpha : 0.f;
+  TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] += L[K.l_search + i] * ia; L[K.l_Ma + i] += L[K.l_mv + i] * ia; }
+    float sc = 0.f, sg = 0.f;
+    for (int i = lane; i < K.nv; i += 64) {
+      float qa = L[K.l_qacc + i] + L[K.l_search + i] * ia, ma = L[K.l_Ma + i] + L[K.l_mv + i] * ia;
+      L[K.l_qacc + i] = qa; L[K.l_Ma + i] = ma;
+      sg += (ma - L[K.l_qfrc_smooth + i]) * (qa - L[K.l_qacc_smooth + i]);
+    }
 #pragma unroll
-    for (int sl = 0; sl < TMW_LS_SLOTS; sl++) { int e = lane + 64 * sl; if (e < K.nefc) L[K.l_Jaref + e] = R.ja[TMW_LI][sl] + R.jv[TMW_LI][sl] * ia; }
+    for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
+      int e = lane + 64 * sl;
+      if (e < K.nefc) { float ja = R.ja[TMW_LI][sl] + R.jv[TMW_LI][sl] * ia; L[K.l_Jaref + e] = ja; if (ja < 0.f) sc += R.D[TMW_LI][sl] * ja * ja; }
+    }
+    pc[TMW_LI] = sc; pg[TMW_LI] = sg;
   }
   TMW_SYNC();
+  gauss = 0.5f * tmw_sum(pg);
+  return 0.5f * tmw_sum(pc) + gauss;
 }
 TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
@@ -1351,13 +1365,13 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
       float gradient = sqrtf(tmw_dot(c, K, K.l_grad, K.l_grad)) / scale;
       if (improvement < m.tolerance || gradient < m.tolerance) break;
     }
-    tmw_linesearch(c, K, gauss);
+    float cost_new = tmw_linesearch(c, K, gauss);
     TMW_TICK(7);
     float den = tmw_dot(c, K, K.l_grad, K.l_Mgrad);
     TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_Mgrad + i]; }
     TMW_SYNC();
     prev_cost = cost;
-    cost = tmw_cost_from_state(c, K, gauss);
+    cost = cost_new;
     tmw_update_gradient(c, K);
     TMW_REG(float, pn);
     TMW_FOR { float s = 0.f; for (int i = lane; i < K.nv; i += 64) s += L[K.l_grad + i] * (L[K.l_Mgrad + i] - L[K.l_tmp + i]); pn[TMW_LI] = s; }
