@@ -125,11 +125,49 @@ TM_DEV void tm_window_dim(const DModel &m, EnvRef r, int i, int bi, float a, flo
   }
   var_i = var / (float)W; jerk_i = jerk;
 }
+// The four long sums of tm_step_post as separately launchable parts (k_post_parts, one lane per (env, part)); results go to
+// rows 0..TM_NPOST-1 of `P` ([row][n]).  Same expressions and the same summation order as the inline code below.
+#define TM_NPOST 7   // joint distance | body-position sum | end-effector sum | energy sum | NaN flags of three state thirds
+TM_DEV void tm_post_part(const DModel &m, EnvRef r, const int *r_is, int part, float *P) {
+  int nj = m.nq - 7, nbp = m.nbody - 1;
+  if (part <= 2) {
+    int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame);
+    size_t row = tm_clip_row(m, clip, tm_cur_frame(m, ST(m.s_time, 0), start));
+    const float *rj = m.clip_joints + row * nj, *rb = m.clip_bodypos + row * (size_t)(nbp * 3);
+    float s = 0.f;
+    if (part == 0) {
+      for (int k = 0; k < nj; k++) { float df = ST(m.s_qpos, 7 + k) - rj[k]; s += df * df; }
+      OUTROW(P, 0) = s;
+    } else if (part == 1) {
+      for (int k = 0; k < m.n_body_idx; k++) {
+        int i = tm_clampi(m.body_idxs[k], 0, nbp - 1);
+        for (int c = 0; c < 3; c++) { float df = ST(m.s_xpos, (1 + i) * 3 + c) - rb[i * 3 + c]; s += df * df; }
+      }
+      OUTROW(P, 1) = s;
+    } else {
+      for (int k = 0; k < m.n_endeff_idx; k++) {
+        int i = tm_clampi(m.endeff_idxs[k], 0, nbp - 1);
+        for (int c = 0; c < 3; c++) { float df = ST(m.s_xpos, (1 + i) * 3 + c) - rb[i * 3 + c]; s += df * df; }
+      }
+      OUTROW(P, 2) = s;
+    }
+  } else if (part == 3) {
+    float s = 0.f;
+    for (int i = 6; i < m.nv; i++) s += fabsf(ST(m.s_qvel, i)) * fabsf(ST(m.s_qfrc_actuator, i));
+    OUTROW(P, 3) = s;
+  } else {
+    bool bad = false;
+    if (part == 4) for (int i = 0; i < m.nphys; i++) { float v = ST(m.s_qpos, i); bad |= (v != v); }
+    else if (part == 5) for (int i = 0; i < m.nbody * 3; i++) { float v = ST(m.s_xpos, i); bad |= (v != v); }
+    else for (int i = 0; i < m.nv; i++) { float v = ST(m.s_qfrc_actuator, i); bad |= (v != v); }
+    OUTROW(P, part) = bad ? 1.f : 0.f;
+  }
+}
 // `win`: per-(dim, env) partials [2*nu][n] produced by the (env x action-dim)-parallel window kernel, or nullptr to
 // compute the window terms inline (lane-per-env path).
 // `split`: the observation was written by k_obs and the auto-reset copies are left to k_autoreset (tmjx_hip.hip).
 TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *action, float *obs, float *reward, float *done_out,
-                         float *trunc_out, float *metrics, const float *win = nullptr, bool split = false) {
+                         float *trunc_out, float *metrics, const float *win = nullptr, bool split = false, const float *P = nullptr) {
   int nu = m.nu, W = m.window, nj = m.nq - 7, nbp = m.nbody - 1;
   int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame), bi = IS(m.i_buffer_index);
   int frame = tm_cur_frame(m, ST(m.s_time, 0), start);
@@ -159,26 +197,30 @@ TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *acti
   float dist = fminf(1.f, 2.f * dt * dt - 1.f), bq = 0.5f * acosf(dist), quat_distance = bq * bq;
   float quat_reward = w[RW_QUAT_W] * expf(-w[RW_QUAT_S] * quat_distance);
   float joint_distance = 0.f;
-  for (int k = 0; k < nj; k++) { float df = ST(m.s_qpos, 7 + k) - rj[k]; joint_distance += df * df; }
+  if (P) joint_distance = OUTROW(P, 0);
+  else for (int k = 0; k < nj; k++) { float df = ST(m.s_qpos, 7 + k) - rj[k]; joint_distance += df * df; }
   float joint_reward = w[RW_JOINT_W] * expf(-w[RW_JOINT_S] * joint_distance);
   s = 0.f;
   for (int k = 0; k < 3; k++) { float df = ST(m.s_qvel, 3 + k) - rwv[k]; s += df * df; }
   float angvel_reward = w[RW_ANGVEL_W] * expf(-w[RW_ANGVEL_S] * s);
   s = 0.f;
-  for (int k = 0; k < m.n_body_idx; k++) {
+  if (P) s = OUTROW(P, 1);
+  else for (int k = 0; k < m.n_body_idx; k++) {
     int i = tm_clampi(m.body_idxs[k], 0, nbp - 1);
     for (int c = 0; c < 3; c++) { float df = ST(m.s_xpos, (1 + i) * 3 + c) - rb[i * 3 + c]; s += df * df; }
   }
   float bodypos_reward = w[RW_BODYPOS_W] * expf(-w[RW_BODYPOS_S] * s);
   s = 0.f;
-  for (int k = 0; k < m.n_endeff_idx; k++) {
+  if (P) s = OUTROW(P, 2);
+  else for (int k = 0; k < m.n_endeff_idx; k++) {
     int i = tm_clampi(m.endeff_idxs[k], 0, nbp - 1);
     for (int c = 0; c < 3; c++) { float df = ST(m.s_xpos, (1 + i) * 3 + c) - rb[i * 3 + c]; s += df * df; }
   }
   float endeff_reward = w[RW_ENDEFF_W] * expf(-w[RW_ENDEFF_S] * s);
   float ctrl_cost = w[RW_CTRL_W] * ctrl_sq, ctrl_diff_cost = w[RW_CTRL_DIFF_W] * ctrl_diff;
   s = 0.f;
-  for (int i = 6; i < m.nv; i++) s += fabsf(ST(m.s_qvel, i)) * fabsf(ST(m.s_qfrc_actuator, i));
+  if (P) s = OUTROW(P, 3);
+  else for (int i = 6; i < m.nv; i++) s += fabsf(ST(m.s_qvel, i)) * fabsf(ST(m.s_qfrc_actuator, i));
   float energy_cost = w[RW_ENERGY_W] * fminf(s, 50.f);
   float torso_z = ST(m.s_xpos, m.torso_idx * 3 + 2);
   float healthy = torso_z < w[RW_ZLO] ? 0.f : 1.f;
@@ -201,7 +243,7 @@ TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *acti
               ctrl_diff_cost - energy_cost - var_cost - jerk_cost;
   float done = fmaxf(fmaxf(fall, too_far), fmaxf(bad_pose, bad_quat));
   rew = tm_nan_to_num(rew);
-  float nanf_ = tm_state_has_nan(m, r) ? 1.f : 0.f;
+  float nanf_ = P ? fmaxf(OUTROW(P, 4), fmaxf(OUTROW(P, 5), OUTROW(P, 6))) : (tm_state_has_nan(m, r) ? 1.f : 0.f);
   done = fmaxf(done, nanf_);
   OUTROW(metrics, 0) = pos_reward; OUTROW(metrics, 1) = quat_reward; OUTROW(metrics, 2) = joint_reward;
   OUTROW(metrics, 3) = angvel_reward; OUTROW(metrics, 4) = bodypos_reward; OUTROW(metrics, 5) = endeff_reward;

@@ -83,7 +83,15 @@ __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const 
   const DModel &m = *mp;
   EnvRef r{st, nullptr, n, e};
   tm_step_prologue(m, r);
-  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win, split != 0);
+  // split: the long sums were computed by k_post_parts into the workspace rows behind the 2 nu window partials
+  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win, split != 0, split ? win + (size_t)2 * m.nu * n : nullptr);
+}
+// the long reductions of the reward / termination step, one lane per (env, part) (env_core.h: tm_post_part)
+__global__ void k_post_parts(const DModel *__restrict__ mp, float *st, const int *is, float *P, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  EnvRef r{st, nullptr, n, e};
+  tm_post_part(*mp, r, is, blockIdx.y, P);
 }
 // observation, one lane per (env, part): parts 0 .. T-1 = the reference segments of one trajectory frame, part T = the
 // proprioceptive tail (6x the parallelism of lane-per-env; rows of obs stay coalesced over envs)
@@ -294,6 +302,7 @@ static void launch_post_split(tmjx_model *m, float *state, int32_t *istate, cons
                               float *truncation, float *metrics, float *workspace, int n_env, hipStream_t stream) {
   const DModel &h = m->h;
   hipLaunchKernelGGL(k_obs, dim3((n_env + 63) / 64, h.traj_length + 1), dim3(64), 0, stream, m->d, state, istate, obs, n_env);
+  hipLaunchKernelGGL(k_post_parts, dim3((n_env + 63) / 64, TM_NPOST), dim3(64), 0, stream, m->d, state, istate, workspace + (size_t)2 * h.nu * n_env, n_env);
   hipLaunchKernelGGL(k_post, dim3((n_env + 63) / 64), dim3(64), 0, stream, m->d, state, istate, action, obs, reward, done, truncation, metrics,
                      (const float *)workspace, 1, n_env);
   if (h.auto_reset) {
