@@ -119,6 +119,11 @@ int tmjx_silu_ln_fwd(const float *z, const float *bias, const float *gamma, cons
 int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, float *dz, float *grads,
                      float *partial, int rows, int H, void *stream);
 
+/* Minibatch gather fused with the observation normaliser (ppo.py:306-311 + running_statistics.normalize):
+ * out[t][b][:] = (src[t][idx[b]][:] - mean) / std; src [T][R][W], idx int64 [B], out [T][B][W], W % 4 == 0. */
+int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mean, const float *std, float *out, int T, int R, int B,
+                          int W, void *stream);
+
 /* Debug/test access: copy a named per-env workspace/intermediate array of the last tmjx_forward /
  * tmjx_physics call into `out` (device pointer, [count][n_env]); returns count or a negative code.
  * Names: "qM" (sparse rows), "qfrc_smooth", "qacc", "qacc_smooth", "efc_D", "efc_aref", "con_dist", ... */

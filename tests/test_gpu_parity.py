@@ -365,3 +365,20 @@ def test_fused_silu_layernorm_block_matches_torch(H):
     assert float((y - y_ref).abs().max()) < 2e-5
     for a, b in zip(g_fus, g_ref):
         assert float((a - b).abs().max()) <= 1e-4 * (float(b.abs().max()) + 1e-6), (a.shape, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.gpu
+def test_gather_normalize_matches_torch():
+    import torch
+    from track_mjx_amd.agent import losses
+    from track_mjx_amd.agent.networks import RunningStatistics
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(2)
+    src = torch.randn(5, 300, 696, generator=g, device=dev)
+    idx = torch.randint(0, 300, (77,), generator=g, device=dev)
+    norm = RunningStatistics(696, dev)
+    norm.update(src)
+    got = losses.gather_normalize(src, idx, norm)
+    ref = norm.normalize(src.index_select(1, idx))
+    assert torch.equal(got, ref)
+    assert torch.equal(losses.gather_normalize(src[0], idx, norm), norm.normalize(src[0].index_select(0, idx)))

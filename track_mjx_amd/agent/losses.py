@@ -31,6 +31,21 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambd
     return vs, adv
 
 
+def gather_normalize(src: torch.Tensor, idx: torch.Tensor, normalizer) -> torch.Tensor:
+    """(src[:, idx] - mean) / std in one kernel; src [T, R, W] (or [R, W]), idx int64 [B] on the GPU."""
+    squeeze = src.dim() == 2
+    if squeeze:
+        src = src.unsqueeze(0)
+    T, R, W = src.shape
+    out = torch.empty((T, idx.shape[0], W), dtype=torch.float32, device=src.device)
+    L = _hip.lib()
+    with torch.cuda.device(src.device):
+        stream = C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+        _hip.check(L.tmjx_gather_normalize(*[C.c_void_p(t.data_ptr()) for t in (src, idx, normalizer.mean, normalizer.std, out)], T, R,
+                                           idx.shape[0], W, stream), "tmjx_gather_normalize")
+    return out[0] if squeeze else out
+
+
 def create_ramp_schedule(max_value: float = 0.1, min_value: float = 0.0001, ramp_steps: int = 1000, warmup_steps: int = 0):
     """Linear ramp (losses.py:263-269): clip((step - warmup)/ramp_steps, min_value, 1) * max_value."""
     def schedule_fn(step: float) -> float:
@@ -76,11 +91,13 @@ def compute_ppo_loss_fused(policy, value, normalizer, data: dict, *, entropy_cos
                            clipping_epsilon: float = 0.3, normalize_advantage: bool = True):
     """compute_ppo_loss with the loss head (everything after the network outputs) in the HIP kernels of
     csrc/ppo_kernels.h.  Same inputs, same outputs; GPU only (the product path of PPOLearner.update)."""
-    obs = normalizer.normalize(data["observation"])
+    # `*_normalized` entries: already gathered + normalised by tmjx_gather_normalize (PPOLearner._minibatch_grads)
+    obs = data["observation_normalized"] if "observation_normalized" in data else normalizer.normalize(data["observation"])
     logits, fc2 = policy(obs, return_fc2=True)
     baseline = value(obs)
     with torch.no_grad():
-        bootstrap_value = value(normalizer.normalize(data["next_observation_last"]))
+        nxt = data["next_observation_last_normalized"] if "next_observation_last_normalized" in data else normalizer.normalize(data["next_observation_last"])
+        bootstrap_value = value(nxt)
         noise = torch.randn(data["raw_action"].shape, dtype=torch.float32, device=logits.device)   # entropy sample (randn_like(loc))
     cfg = dict(reward_scaling=reward_scaling, discounting=discounting, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
                entropy_cost=entropy_cost, kl_weight=kl_weight, normalize_advantage=normalize_advantage)

@@ -173,7 +173,12 @@ class PPOLearner:
     # ---- learning
     def _minibatch_grads(self, idx: torch.Tensor, kl_w: float) -> torch.Tensor:
         """Gather one minibatch, loss, gradients into the flat buffer; returns the 5 loss terms as one tensor."""
-        data = {k: (v.index_select(1, idx) if k != "next_observation_last" else v.index_select(0, idx)) for k, v in self.buf.items()}
+        fused_gather = self.dev.type == "cuda" and self.normalize_observations and self.buf["observation"].shape[-1] % 4 == 0
+        data = {k: (v.index_select(1, idx) if k != "next_observation_last" else v.index_select(0, idx)) for k, v in self.buf.items()
+                if not (fused_gather and k in ("observation", "next_observation_last"))}
+        if fused_gather:
+            data["observation_normalized"] = _losses.gather_normalize(self.buf["observation"], idx, self.normalizer)
+            data["next_observation_last_normalized"] = _losses.gather_normalize(self.buf["next_observation_last"], idx, self.normalizer)
         with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
             loss_fn = _losses.compute_ppo_loss_fused if self.dev.type == "cuda" else _losses.compute_ppo_loss
             loss, m = loss_fn(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)

@@ -281,3 +281,20 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partia
   __syncthreads();
   if (ry == 0 && col < width) { float s = 0.f; for (int j = 0; j < 8; j++) s += lds[j][cx]; out[col] = s; }
 }
+
+// minibatch gather + observation normalisation in one pass: out[t][b][:] = (src[t][idx[b]][:] - mean) / std
+// (index_select + two element-wise passes over 57 MB otherwise); float4 lanes, W = obs width (multiple of 4)
+__global__ __launch_bounds__(256) void k_gather_normalize(const float *__restrict__ src, const long long *__restrict__ idx, const float *__restrict__ mean,
+                                                          const float *__restrict__ stdv, float *__restrict__ out, int T, int R, int B, int W) {
+  const int w4 = W >> 2;
+  const size_t total = (size_t)T * B * w4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % w4);
+    size_t tb = i / w4;
+    int b = (int)(tb % B), t = (int)(tb / B);
+    const float4 v = reinterpret_cast<const float4 *>(src + ((size_t)t * R + (size_t)idx[b]) * W)[c];
+    const float4 m = reinterpret_cast<const float4 *>(mean)[c], s = reinterpret_cast<const float4 *>(stdv)[c];
+    float4 o = {(v.x - m.x) / s.x, (v.y - m.y) / s.y, (v.z - m.z) / s.z, (v.w - m.w) / s.w};
+    reinterpret_cast<float4 *>(out + tb * W)[c] = o;
+  }
+}

@@ -424,6 +424,16 @@ int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const f
   return check_launch("k_silu_ln_bwd");
 }
 
+int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mean, const float *std, float *out, int T, int R, int B,
+                          int W, void *stream) {
+  if (!src || !idx || !mean || !std || !out) return fail(TMJX_EINVAL, "null argument");
+  if (T < 1 || R < 1 || B < 1 || W < 4 || (W & 3)) return fail(TMJX_EINVAL, "bad T / R / B / W (W must be a multiple of 4)");
+  size_t total = (size_t)T * B * (W >> 2);
+  int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_gather_normalize, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (const long long *)idx, mean, std, out, T, R, B, W);
+  return check_launch("k_gather_normalize");
+}
+
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {
   if (!m || !name || !row0 || !count) return fail(TMJX_EINVAL, "null argument");
   for (const auto &e : tmjx_host::debug_rows(m->h))
