@@ -199,7 +199,7 @@ __global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk) {
 // One wavefront per row, VPT = H / 64 consecutive columns per lane (H = 256: one float4), row statistics by wave
 // shuffles.  The backward kernel also produces the column sums d_gamma, d_beta, d_bias as per-block partials (rows are
 // dealt to blocks in contiguous slabs) that a second small kernel adds up: deterministic, no atomics.
-#define BLK_ROWS_PER_BLOCK 128
+#define BLK_ROWS_PER_BLOCK 32
 __device__ __forceinline__ float wave_sum(float x) { for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off); return x; }
 
 template <int VPT>
