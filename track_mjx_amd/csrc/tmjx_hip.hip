@@ -122,14 +122,14 @@ __global__ void k_autoreset(const DModel *__restrict__ mp, float *st, float *obs
 // STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
 template <bool STATIC>
 __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
-                                                     int do_euler, float *ws_dump, int n) {
+                                                     int do_euler, float *ws_dump, int n, int e0) {
   extern __shared__ float tmw_lds[];
-  WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x, (int)threadIdx.x, nullptr, 0ull, nullptr};
+  WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x + e0, (int)threadIdx.x, nullptr, 0ull, nullptr};
 #ifndef TMW_PROFILE
   c.dump = ws_dump;
 #endif
 #ifdef TMW_PROFILE
-  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)blockIdx.x * 32; c.tlast = __builtin_amdgcn_s_memtime(); }
+  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)(blockIdx.x + e0) * 32; c.tlast = __builtin_amdgcn_s_memtime(); }
 #endif
   constexpr WLayout ks(TMW_RODENT_DIMS, 1);
   const WLayout kd = STATIC ? ks : WLayout(mp->nbody, mp->njnt, mp->nq, mp->nv, mp->nu, mp->ncon, mp->nlim, mp->nnz, mp->ngroup,
@@ -269,8 +269,13 @@ int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quatern
 static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream) {
   size_t lds = (size_t)m->h.lds_floats * sizeof(float);
   if (const char *pad = getenv("TMJX_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;  // occupancy experiments only
-  if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(n_env), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env);
-  else hipLaunchKernelGGL(k_physics_wave<false>, dim3(n_env), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env);
+  int parts = 1;
+  if (const char *sp = getenv("TMJX_SPLIT_LAUNCH")) { parts = atoi(sp); if (parts < 1 || n_env % parts) parts = 1; }   // scheduling experiments
+  for (int p = 0; p < parts; p++) {
+    int cnt = n_env / parts, e0 = p * cnt;
+    if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(cnt), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env, e0);
+    else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env, e0);
+  }
 }
 static int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
