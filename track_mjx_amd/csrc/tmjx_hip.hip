@@ -210,7 +210,7 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
     size_t lds_bytes = (size_t)m->h.lds_floats * sizeof(float);
     if (lds_bytes > 160 * 1024) { delete m; return fail(TMJX_EINVAL, "model does not fit the 160 KiB LDS of a CU"); }
     if (lds_bytes > 64 * 1024) { delete m; return fail(TMJX_EINVAL, "model needs more than 64 KiB of LDS per env"); }
-    if (m->h.nefc > 64 * TMW_LS_SLOTS) { delete m; return fail(TMJX_EINVAL, "more than 256 constraint rows (wave kernel keeps the line-search rows in 4 registers per lane)"); }
+    if (m->h.nefc > 254 || m->h.nlim > 128) { delete m; return fail(TMJX_EINVAL, "more than 254 constraint rows or 128 joint limits (wave kernel: byte row map, line-search rows in 4 registers per lane)"); }
     constexpr WLayout ks(TMW_RODENT_DIMS);
     const WLayout kd = tmjx_host::make_wave_layout(m->h);
     m->rodent = !getenv("TMJX_WAVE_DYNAMIC") && kd.nbody == ks.nbody && kd.njnt == ks.njnt && kd.nq == ks.nq && kd.nv == ks.nv &&

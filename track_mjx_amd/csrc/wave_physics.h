@@ -61,6 +61,7 @@ struct WCtx {
   unsigned long long *prof;   // TMW_PROFILE builds only: per-env phase cycle counters
   unsigned long long tlast;
   float *dump;                // tests only: lane-per-env workspace that receives intermediates (tmw_dump)
+  int nact;                   // number of ACTIVE constraint rows of the current substep (compact row space, tmw_make_constraint)
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
@@ -116,6 +117,19 @@ TM_DEV int tmw_table2(const float *a0, const float *a1, int idx) { return tm_f2i
 #else
 TM_DEV int tmw_table2(const float *a0, const float *a1, int idx) { return __builtin_amdgcn_readlane(tm_f2i(idx < 64 ? a0[0] : a1[0]), idx & 63); }
 #endif
+
+// exclusive count of set flags over the lanes of the wave (v_mbcnt of the ballot) and their total
+#ifdef TM_HOST_EMU
+TM_DEV int tmw_prefix(const int *flag, int *excl) { int s = 0; for (int l = 0; l < 64; l++) { excl[l] = s; s += flag[l] != 0; } return s; }
+#else
+TM_DEV int tmw_prefix(const int *flag, int *excl) {
+  unsigned long long b = __builtin_amdgcn_ballot_w64(flag[0] != 0);
+  excl[0] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+  return __builtin_popcountll(b);
+}
+#endif
+#define TMW_ROWMAP(K) ((unsigned char *)(L + (K).l_rowmap))
+#define TMW_CCROW(K) ((unsigned char *)(L + (K).l_ccrow))
 
 // ------------------------------------------------------------------------------------------ state in / out
 TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
@@ -1044,7 +1058,6 @@ TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
 TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int l = lane; l < K.nlim; l += 64) L[out + l] = L[K.l_lim_sign + l] * L[v + m.jnt_dofadr[m.lim_jnt[l]]];
     if (lane < K.ngroup * 6) {  // spatial velocity of each paw body, one lane per (group, component)
       int g = lane / 6, k = lane - g * 6, ld = tm_f2i(L[K.l_tgrp + 4 * g]);
       float s = 0.f;
@@ -1057,11 +1070,18 @@ TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
     }
   }
   TMW_SYNC();
+  // one lane per ACTIVE row (compact row space): a violated limit is one-hot, a pyramid edge of an active contact is
+  // n.vel +- mu t.vel of the paw body's point velocity
   TMW_FOR {
-    for (int cc = lane; cc < K.ncon; cc += 64) {
-      int r0 = K.nlim + 4 * cc;
-      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-      if (L[K.l_con_dist + cc] < 0.f) {
+    const unsigned char *rm = TMW_ROWMAP(K);
+    for (int kr = lane; kr < c.nact; kr += 64) {
+      int r = rm[kr];
+      float o;
+      if (r < K.nlim) {
+        float sv = L[K.l_lim_sign + r];
+        o = (sv > 0.f ? 1.f : -1.f) * L[v + m.jnt_dofadr[m.lim_jnt[r]]];
+      } else {
+        int cc = (r - K.nlim) >> 2, e = (r - K.nlim) & 3;
         const float *sv = L + K.l_sv + m.con_grp[cc] * 6, *off = L + K.l_con_off + cc * 3;
         float fr[9];
         for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
@@ -1069,10 +1089,10 @@ TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
         float cr[3], vel[3];
         tm_cross(cr, sv, off);
         for (int k = 0; k < 3; k++) vel[k] = sv[3 + k] + cr[k];
-        float mu = m.con_mu[cc], a0 = tm_dot3(fr, vel), a1 = tm_dot3(fr + 3, vel) * mu, a2 = tm_dot3(fr + 6, vel) * mu;
-        o0 = a0 + a1; o1 = a0 - a1; o2 = a0 + a2; o3 = a0 - a2;
+        float a0 = tm_dot3(fr, vel), at = tm_dot3(fr + 3 + 3 * (e >> 1), vel) * m.con_mu[cc];
+        o = (e & 1) ? a0 - at : a0 + at;
       }
-      L[out + r0] = o0; L[out + r0 + 1] = o1; L[out + r0 + 2] = o2; L[out + r0 + 3] = o3;
+      L[out + kr] = o;
     }
   }
   TMW_SYNC();
@@ -1084,7 +1104,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
     for (int cc = lane; cc < K.ncon; cc += 64) {
       float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (L[K.l_con_dist + cc] < 0.f) {
-        int r0 = K.nlim + 4 * cc;
+        int r0 = TMW_CCROW(K)[cc];      // first of the contact's four compact rows
         float f[4];
         for (int e = 0; e < 4; e++) { float ja = L[K.l_Jaref + r0 + e]; f[e] = ja < 0.f ? -L[K.l_efc_D + r0 + e] * ja : 0.f; }
         float mu = m.con_mu[cc], c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
@@ -1128,7 +1148,10 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
     for (int i = lane; i < K.nv; i += 64) {
       float s = 0.f;
       int lr = m.dof_limrow[i], su = m.dof_wsub[i];
-      if (lr >= 0) { float ja = L[K.l_Jaref + lr]; if (ja < 0.f) s = L[K.l_lim_sign + lr] * (-L[K.l_efc_D + lr] * ja); }
+      if (lr >= 0) {     // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise
+        float sv = L[K.l_lim_sign + lr];
+        if (sv != 0.f) { int kr = (int)fabsf(sv) - 1; float ja = L[K.l_Jaref + kr]; if (ja < 0.f) s = (sv > 0.f ? 1.f : -1.f) * (-L[K.l_efc_D + kr] * ja); }
+      }
       if (su >= 0) { const float *w = L + K.l_wr + su * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
       L[out + i] = s;
     }
@@ -1137,37 +1160,92 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
 }
 
 // ------------------------------------------------------------------------------------------ make_constraint
+// Only ACTIVE rows enter the solver: a limit row exists iff the limit is violated, the four pyramid rows of a contact iff it
+// penetrates (dist < 0).  MJX keeps all 187 rows, but an inactive row has a zero Jacobian row and aref <= 0, so Jaref >= 0
+// for every qacc and the row contributes exactly 0 to the cost, its gradient and every line-search sum.  The active rows are
+// numbered consecutively in the original order (limits, then contacts); l_rowmap maps back, lim_sign / l_ccrow map forward.
+// Typical counts (a few limits + 2..8 contacts) fit ONE 64-row slot instead of three.
 TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TMW_REG(int, f0); TMW_REG(int, f1); TMW_REG(int, fc); TMW_REG(int, x0); TMW_REG(int, x1); TMW_REG(int, xc);
+  TMW_REG(float, s0); TMW_REG(float, s1);
   TMW_FOR {
-    for (int l = lane; l < K.nlim; l += 64) {
-      int j = m.lim_jnt[l];
-      float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
-      float pos = fminf(dmin, dmax) - m.jnt_margin[j];
-      L[K.l_lim_sign + l] = pos < 0.f ? (dmin < dmax ? 1.f : -1.f) : 0.f;
+    for (int slot = 0; slot < 2; slot++) {
+      int l = lane + 64 * slot;
+      float sg = 0.f;
+      if (l < K.nlim) {
+        int j = m.lim_jnt[l];
+        float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
+        float pos = fminf(dmin, dmax) - m.jnt_margin[j];
+        sg = pos < 0.f ? (dmin < dmax ? 1.f : -1.f) : 0.f;
+      }
+      (slot ? s1 : s0)[TMW_LI] = sg; (slot ? f1 : f0)[TMW_LI] = sg != 0.f;
+    }
+    fc[TMW_LI] = lane < K.ncon && L[K.l_con_dist + (lane < K.ncon ? lane : 0)] < 0.f;
+  }
+  const int n0 = tmw_prefix(f0, x0), n1 = tmw_prefix(f1, x1), ncl = tmw_prefix(fc, xc), nla = n0 + n1;
+  c.nact = nla + 4 * ncl;
+  TMW_FOR {
+    unsigned char *rm = TMW_ROWMAP(K), *cr = TMW_CCROW(K);
+    if (lane < K.nlim) { L[K.l_lim_sign + lane] = s0[TMW_LI] * (float)(x0[TMW_LI] + 1); if (f0[TMW_LI]) rm[x0[TMW_LI]] = (unsigned char)lane; }
+    if (lane + 64 < K.nlim) { L[K.l_lim_sign + lane + 64] = s1[TMW_LI] * (float)(n0 + x1[TMW_LI] + 1); if (f1[TMW_LI]) rm[n0 + x1[TMW_LI]] = (unsigned char)(lane + 64); }
+    if (lane < K.ncon) {
+      int r0 = nla + 4 * xc[TMW_LI];
+      cr[lane] = fc[TMW_LI] ? (unsigned char)r0 : (unsigned char)255;
+      if (fc[TMW_LI]) for (int e = 0; e < 4; e++) rm[r0 + e] = (unsigned char)(K.nlim + 4 * lane + e);
     }
   }
   TMW_SYNC();
   tmw_jmul(c, K, K.l_qvel, K.l_jv);
   TMW_FOR {
-    for (int l = lane; l < K.nlim; l += 64) {
-      int j = m.lim_jnt[l];
-      float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
-      float pos = fminf(dmin, dmax) - m.jnt_margin[j], k, b, imp;
-      tm_kbi(m, m.jnt_solref[j], m.jnt_solimp[j], pos, k, b, imp);
-      float Rr = fmaxf(m.dof_invweight0[m.jnt_dofadr[j]] * (1.f - imp) / imp, TM_MINVAL);
-      L[K.l_efc_D + l] = 1.f / Rr;
-      L[K.l_efc_aref + l] = -b * L[K.l_jv + l] - k * imp * pos;
-    }
-    for (int cc = lane; cc < K.ncon; cc += 64) {
-      float k, b, imp, pos = L[K.l_con_dist + cc];
-      tm_kbi(m, m.con_solref[cc], m.con_solimp[cc], pos, k, b, imp);
-      float Rr = fmaxf(m.con_invweight[cc] * (1.f - imp) / imp, TM_MINVAL), D = 1.f / Rr;
-      int r0 = K.nlim + 4 * cc;
-      for (int e = 0; e < 4; e++) { L[K.l_efc_D + r0 + e] = D; L[K.l_efc_aref + r0 + e] = -b * L[K.l_jv + r0 + e] - k * imp * pos; }
+    const unsigned char *rm = TMW_ROWMAP(K);
+    for (int kr = lane; kr < c.nact; kr += 64) {
+      int r = rm[kr];
+      float k, b, imp, pos, iw;
+      if (r < K.nlim) {
+        int j = m.lim_jnt[r];
+        float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
+        pos = fminf(dmin, dmax) - m.jnt_margin[j];
+        tm_kbi(m, m.jnt_solref[j], m.jnt_solimp[j], pos, k, b, imp);
+        iw = m.dof_invweight0[m.jnt_dofadr[j]];
+      } else {
+        int cc = (r - K.nlim) >> 2;
+        pos = L[K.l_con_dist + cc];
+        tm_kbi(m, m.con_solref[cc], m.con_solimp[cc], pos, k, b, imp);
+        iw = m.con_invweight[cc];
+      }
+      float Rr = fmaxf(iw * (1.f - imp) / imp, TM_MINVAL);
+      L[K.l_efc_D + kr] = 1.f / Rr;
+      L[K.l_efc_aref + kr] = -b * L[K.l_jv + kr] - k * imp * pos;
     }
   }
   TMW_SYNC();
+  if (c.dump) {   // tests only: efc_D / efc_aref of ALL rows in the original order (inactive rows: J v = 0)
+    TMW_FOR {
+      for (int r = lane; r < K.nefc; r += 64) {
+        float k, b, imp, pos, iw; int kr = -1;
+        if (r < K.nlim) {
+          int j = m.lim_jnt[r];
+          float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
+          pos = fminf(dmin, dmax) - m.jnt_margin[j];
+          tm_kbi(m, m.jnt_solref[j], m.jnt_solimp[j], pos, k, b, imp);
+          iw = m.dof_invweight0[m.jnt_dofadr[j]];
+          float sv = L[K.l_lim_sign + r];
+          if (sv != 0.f) kr = (int)fabsf(sv) - 1;
+        } else {
+          int cc = (r - K.nlim) >> 2;
+          pos = L[K.l_con_dist + cc];
+          tm_kbi(m, m.con_solref[cc], m.con_solimp[cc], pos, k, b, imp);
+          iw = m.con_invweight[cc];
+          if (TMW_CCROW(K)[cc] != 255) kr = TMW_CCROW(K)[cc] + ((r - K.nlim) & 3);
+        }
+        float Rr = fmaxf(iw * (1.f - imp) / imp, TM_MINVAL);
+        c.dump[(size_t)(m.w_efc_D + r) * (size_t)c.n + (size_t)c.e] = 1.f / Rr;
+        // (l_jv aliases l_efc_aref: the active rows' J v has already been folded into aref above)
+        c.dump[(size_t)(m.w_efc_aref + r) * (size_t)c.n + (size_t)c.e] = kr >= 0 ? L[K.l_efc_aref + kr] : -k * imp * pos;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ CG solver
@@ -1188,7 +1266,7 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss) {
   TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
     float sc = 0.f, sg = 0.f;
-    for (int e = lane; e < K.nefc; e += 64) {
+    for (int e = lane; e < c.nact; e += 64) {
       float ja = L[K.l_Jaref + e] - L[K.l_efc_aref + e];
       L[K.l_Jaref + e] = ja;
       if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja;
@@ -1206,7 +1284,7 @@ TM_DEV float tmw_cost_from_state(WCtx &c, const WLayout &K, float &gauss) {
   TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
     float sc = 0.f, sg = 0.f;
-    for (int e = lane; e < K.nefc; e += 64) { float ja = L[K.l_Jaref + e]; if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja; }
+    for (int e = lane; e < c.nact; e += 64) { float ja = L[K.l_Jaref + e]; if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja; }
     for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - L[K.l_qfrc_smooth + i]) * (L[K.l_qacc + i] - L[K.l_qacc_smooth + i]);
     pc[TMW_LI] = sc; pg[TMW_LI] = sg;
   }
@@ -1239,7 +1317,7 @@ template <int NP>
 TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const float *a, float g0, float g1, float g2, TmwLS *out) {
   TMW_LANE_DECL
   float q[3 * NP][TMW_NL];
-  const int nslot = (K.nefc + 63) / 64;
+  const int nslot = (c.nact + 63) / 64;
   TMW_FOR {
     float s[3 * NP];
     for (int k = 0; k < 3 * NP; k++) s[k] = 0.f;
@@ -1282,7 +1360,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
 #pragma unroll
     for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
       int e = lane + 64 * sl;
-      bool ok = e < K.nefc;
+      bool ok = e < c.nact;
       float ja = ok ? L[K.l_Jaref + (ok ? e : 0)] : 1.f, jv = ok ? L[K.l_jv + (ok ? e : 0)] : 0.f, D = ok ? L[K.l_efc_D + (ok ? e : 0)] : 0.f;   // padding rows: never active
       R.ja[TMW_LI][sl] = ja; R.jv[TMW_LI][sl] = jv; R.D[TMW_LI][sl] = D;
       R.t0[TMW_LI][sl] = 0.5f * ja * ja * D; R.t1[TMW_LI][sl] = jv * ja * D; R.t2[TMW_LI][sl] = 0.5f * jv * jv * D;
@@ -1330,7 +1408,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
 #pragma unroll
     for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
       int e = lane + 64 * sl;
-      if (e < K.nefc) { float ja = R.ja[TMW_LI][sl] + R.jv[TMW_LI][sl] * ia; L[K.l_Jaref + e] = ja; if (ja < 0.f) sc += R.D[TMW_LI][sl] * ja * ja; }
+      if (e < c.nact) { float ja = R.ja[TMW_LI][sl] + R.jv[TMW_LI][sl] * ia; L[K.l_Jaref + e] = ja; if (ja < 0.f) sc += R.D[TMW_LI][sl] * ja * ja; }
     }
     pc[TMW_LI] = sc; pg[TMW_LI] = sg;
   }
@@ -1397,9 +1475,6 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   if (K.chains) tmw_invert_chains(c, K); else tmw_invert_l(c, K);
   TMW_TICK(3);
   tmw_make_constraint(c, K);
-  if (c.dump) {   // efc_aref shares its LDS words with jv / wr later on: copy it out now (tests only)
-    TMW_FOR { for (int i = lane; i < K.nefc; i += 64) c.dump[(size_t)(m.w_efc_aref + i) * (size_t)c.n + (size_t)c.e] = L[K.l_efc_aref + i]; }
-  }
   TMW_TICK(4);
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = L[K.l_qfrc_smooth + i]; }
   TMW_SYNC();
@@ -1464,10 +1539,12 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
       tm_cross(fr + 6, fr, fr + 3);
       for (int k = 0; k < 9; k++) WDUMP(m.w_con_frame, cc * 9 + k) = fr[k];
     }
-    for (int i = lane; i < K.nefc; i += 64) {
-      WDUMP(m.w_efc_D, i) = L[K.l_efc_D + i];
-      float ja = L[K.l_Jaref + i];
-      WDUMP(m.w_efc_force, i) = ja < 0.f ? -L[K.l_efc_D + i] * ja : 0.f;
+    for (int r = lane; r < K.nefc; r += 64) {   // efc_D / efc_aref were written by tmw_make_constraint; force per ORIGINAL row
+      int kr = -1;
+      if (r < K.nlim) { float sv = L[K.l_lim_sign + r]; if (sv != 0.f) kr = (int)fabsf(sv) - 1; }
+      else if (TMW_CCROW(K)[(r - K.nlim) >> 2] != 255) kr = TMW_CCROW(K)[(r - K.nlim) >> 2] + ((r - K.nlim) & 3);
+      float ja = kr >= 0 ? L[K.l_Jaref + kr] : 0.f;
+      WDUMP(m.w_efc_force, r) = ja < 0.f ? -L[K.l_efc_D + kr] * ja : 0.f;
     }
     if (lane < 3) WDUMP(m.w_com, lane) = L[K.l_com + lane];
   }
