@@ -62,6 +62,7 @@ struct WCtx {
   unsigned long long tlast;
   float *dump;                // tests only: lane-per-env workspace that receives intermediates (tmw_dump)
   int nact;                   // number of ACTIVE constraint rows of the current substep (compact row space, tmw_make_constraint)
+  int nla;                    // ... of which violated joint limits (the active contacts' rows follow, four each)
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
@@ -110,7 +111,6 @@ TM_DEV float tmw_sum_dpp(const float *vp) {
 }
 TM_DEV float tmw_readlane_dpp(const float *v, int src) { return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v[0]), src)); }
 #endif
-
 // element `idx` (uniform) of a 128-entry table kept as two lane vectors
 #ifdef TM_HOST_EMU
 TM_DEV int tmw_table2(const float *a0, const float *a1, int idx) { return tm_f2i(idx < 64 ? a0[idx] : a1[idx - 64]); }
@@ -1131,8 +1131,14 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
       if (idx < m.n_wsub * 6) {
         int su = idx / 6, k = idx - su * 6;
         unsigned m0 = m.wsub_cmask[su][0], m1 = m.wsub_cmask[su][1];
-#pragma unroll 8
-        for (int cc = 0; cc < K.ncon; cc++) { float w = L[K.l_wr + cc * 6 + k]; bool in = ((cc < 32 ? m0 >> cc : m1 >> (cc - 32)) & 1u) != 0u; sacc += in ? w : 0.f; }
+        // only the ACTIVE contacts carry a wrench: walk their compact rows (four per contact) back to the contact ids
+        const unsigned char *rm = TMW_ROWMAP(K);
+        for (int kr = c.nla; kr < c.nact; kr += 4) {
+          int cc = (rm[kr] - K.nlim) >> 2;
+          float w = L[K.l_wr + cc * 6 + k];
+          bool in = ((cc < 32 ? m0 >> cc : m1 >> (cc - 32)) & 1u) != 0u;
+          sacc += in ? w : 0.f;
+        }
       }
       (slot ? W1 : W0)[TMW_LI] = sacc;
       if (m.n_wsub * 6 <= 64) break;
@@ -1184,7 +1190,7 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
     fc[TMW_LI] = lane < K.ncon && L[K.l_con_dist + (lane < K.ncon ? lane : 0)] < 0.f;
   }
   const int n0 = tmw_prefix(f0, x0), n1 = tmw_prefix(f1, x1), ncl = tmw_prefix(fc, xc), nla = n0 + n1;
-  c.nact = nla + 4 * ncl;
+  c.nact = nla + 4 * ncl; c.nla = nla;
   TMW_FOR {
     unsigned char *rm = TMW_ROWMAP(K), *cr = TMW_CCROW(K);
     if (lane < K.nlim) { L[K.l_lim_sign + lane] = s0[TMW_LI] * (float)(x0[TMW_LI] + 1); if (f0[TMW_LI]) rm[x0[TMW_LI]] = (unsigned char)lane; }
