@@ -41,7 +41,7 @@ def make_oracle(blob, clip=None, precision="f32"):
     return O
 
 
-def make_env_and_oracle(num_envs=64, n_clips=4, device="cuda:0", wrappers=True, seed=0, precision="f32"):
+def make_env_and_oracle(num_envs=64, n_clips=4, device="cuda:0", wrappers=True, seed=0, precision="f32", episode_length=195):
     from track_mjx_amd.environment import MultiClipTracking, RewardConfig, wrap
     w, cfg = default_walker()
     cl = _clips.make_synthetic_clips(w.model, n_clips, seed=seed)
@@ -49,7 +49,7 @@ def make_env_and_oracle(num_envs=64, n_clips=4, device="cuda:0", wrappers=True, 
     env = MultiClipTracking(cl, w, RewardConfig(**cfg["env_config"]["reward_weights"]), **ea, **cfg["reference_config"],
                             num_envs=num_envs, device=device)
     if wrappers:
-        env = wrap(env, episode_length=195)
+        env = wrap(env, episode_length=episode_length)
     O = make_oracle(env._blob, cl, precision)
     return env, O, cl
 

@@ -382,3 +382,32 @@ def test_gather_normalize_matches_torch():
     ref = norm.normalize(src.index_select(1, idx))
     assert torch.equal(got, ref)
     assert torch.equal(losses.gather_normalize(src[0], idx, norm), norm.normalize(src[0].index_select(0, idx)))
+
+
+@pytest.mark.gpu
+def test_evaluator_first_episode_sums():
+    """agent/evaluator.py (brax acting.Evaluator + EvalWrapper semantics, ppo.py:83-124,629-668): episode_* are sums over the FIRST
+    episode of each env only, avg_episode_length counts its steps — checked against a numpy accumulation of the same roll-out."""
+    from track_mjx_amd.agent.evaluator import EvalWrapper, Evaluator
+    n = 32
+    env, _, _ = make_env_and_oracle(num_envs=n, n_clips=4, wrappers=True, episode_length=25)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    acts = [(torch.randn((38, n), generator=g, device="cuda") * 0.6).clamp(-1, 1) for _ in range(40)]
+    w = EvalWrapper(env)
+    st = w.reset(torch.Generator().manual_seed(0))
+    active = np.ones(n); ep_rew = np.zeros(n); ep_len = np.zeros(n); ep_pos = np.zeros(n)
+    for a in acts:
+        st = w.step(st, a)
+        rew, done = st.reward.cpu().numpy().astype(np.float64), st.done.cpu().numpy()
+        steps = st.info["steps"].cpu().numpy()
+        ep_len = np.where(active > 0, steps, ep_len)
+        ep_rew += rew * active; ep_pos += st.metrics["pos_reward"].cpu().numpy() * active
+        active = active * (1 - done)
+    assert (active == 0).all(), "every env must finish its first episode (episode_length 25 < 40 steps)"
+    assert np.allclose(w.episode_metrics["reward"].cpu().numpy(), ep_rew, rtol=1e-5, atol=1e-6)
+    assert np.allclose(w.episode_metrics["pos_reward"].cpu().numpy(), ep_pos, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(w.episode_steps.cpu().numpy(), ep_len) and ep_len.max() <= 25 and ep_len.min() >= 1
+    ev = Evaluator(env, lambda obs: (acts[0], None), episode_length=25, seed=1)
+    m = ev.run_evaluation({"training/sps": 1.0})
+    assert m["training/sps"] == 1.0 and "eval/episode_reward" in m and "eval/episode_reward_std" in m
+    assert 1 <= m["eval/avg_episode_length"] <= 25 and m["eval/sps"] > 0

@@ -248,7 +248,8 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
           clipping_epsilon: float = 0.3, gae_lambda: float = 0.95, kl_weight: float = 1e-3, use_kl_schedule: bool = True,
           encoder_hidden_layer_sizes=(1024, 1024), decoder_hidden_layer_sizes=(1024, 1024), value_hidden_layer_sizes=(1024, 1024),
           intention_latent_size: int = 60, progress_fn: Callable[[int, dict], None] = lambda *a: None,
-          max_training_steps: int | None = None, **unused):
+          max_training_steps: int | None = None, eval_env=None, num_eval_envs: int = 128, deterministic_eval: bool = False,
+          **unused):
     """ppo.train(environment, num_timesteps, episode_length, ...) -> (make_policy, params, metrics)  (ppo.py:128-172,809).
 
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
@@ -267,6 +268,12 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     kl_schedule = _losses.create_ramp_schedule(max_value=kl_weight, ramp_steps=max(int(num_evals * 0.25), 1)) if use_kl_schedule else None
     reset_gen = torch.Generator().manual_seed(seed + 1 + learner.rank)
     learner.state = env.reset(reset_gen)
+    # evaluator (ppo.py:629-668): an env of `num_eval_envs` wrapped like the training env; process 0 only (ppo.py:744)
+    evaluator = None
+    if eval_env is not None and learner.rank == 0:
+        from .evaluator import Evaluator
+        evaluator = Evaluator(wrap(eval_env, episode_length=int(episode_length), action_repeat=1),
+                              lambda obs: learner.act(obs, deterministic=deterministic_eval), episode_length=int(episode_length), seed=seed + 7)
     metrics: dict = {}
     total_steps, done_steps = 0, 0
     for it in range(1, num_evals_after_init + 1):
@@ -291,6 +298,8 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
             if max_training_steps is not None and done_steps >= max_training_steps:
                 break
         if learner.rank == 0:
+            if evaluator is not None:
+                metrics = evaluator.run_evaluation(metrics)
             progress_fn(total_steps, metrics)
         if max_training_steps is not None and done_steps >= max_training_steps:
             break

@@ -55,6 +55,10 @@ def main(argv=None) -> None:
     num_evals = int(tc["num_timesteps"] / ts["eval_every"])
     num_resets_per_eval = ts["eval_every"] // ts["reset_every"]
 
+    # evaluator env (ppo.py:629-647: the same environment class with num_eval_envs envs; rank 0 only)
+    num_eval_envs = int(tc.get("num_eval_envs", 128))
+    eval_env = build_env(cfg, num_eval_envs, device, n_clips=int(cfg.get("n_synthetic_clips", 64))) if int(os.environ.get("RANK", "0")) == 0 and num_eval_envs > 0 else None
+
     def progress(num_steps, metrics):
         print(f"[train] steps={num_steps} " + " ".join(f"{k}={v:.4g}" for k, v in sorted(metrics.items())), flush=True)
 
@@ -66,7 +70,8 @@ def main(argv=None) -> None:
               clipping_epsilon=tc["clipping_epsilon"], kl_weight=nc["kl_weight"], use_kl_schedule=nc["kl_schedule"],
               encoder_hidden_layer_sizes=nc["encoder_layer_sizes"], decoder_hidden_layer_sizes=nc["decoder_layer_sizes"],
               value_hidden_layer_sizes=nc["critic_layer_sizes"], intention_latent_size=nc["intention_size"], progress_fn=progress,
-              max_training_steps=cfg.get("max_training_steps"))
+              max_training_steps=cfg.get("max_training_steps"), eval_env=eval_env, num_eval_envs=num_eval_envs,
+              deterministic_eval=bool(tc.get("deterministic_eval", False)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
