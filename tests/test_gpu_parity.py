@@ -411,3 +411,32 @@ def test_evaluator_first_episode_sums():
     m = ev.run_evaluation({"training/sps": 1.0})
     assert m["training/sps"] == 1.0 and "eval/episode_reward" in m and "eval/episode_reward_std" in m
     assert 1 <= m["eval/avg_episode_length"] <= 25 and m["eval/sps"] > 0
+
+
+@pytest.mark.gpu
+def test_many_active_rows_multi_slot_gpu():
+    """All 67 joint limits violated and the body sunk into the floor: > 64 active constraint rows, i.e. the multi-slot path of the
+    compacted rows (ballot / mbcnt prefix counts on the device) against the float64 oracle."""
+    n = 8
+    env, _, cl = make_env_and_oracle(num_envs=n, wrappers=False)
+    O64 = make_oracle(env._blob, cl, "f64")
+    rng = np.random.default_rng(5)
+    qpos, qvel = _init_states(cl, n, rng)
+    rngs = np.asarray(env.walker.model["jnt_range"]).reshape(-1, 2)[1:]
+    for e in range(n):
+        over = rng.uniform(0.005, 0.03, size=67) * (rngs[:, 1] - rngs[:, 0])
+        qpos[e, 7:] = np.where(rng.random(67) < 0.5, rngs[:, 1] + over, rngs[:, 0] - over)
+        qpos[e, 2] -= 0.02 * (e + 1)
+    act = rng.uniform(-0.1, 0.1, size=(n, 38))
+    env.rows("qpos").copy_(torch.from_numpy(qpos.T.astype(np.float32)))
+    env.rows("qvel").copy_(torch.from_numpy(qvel.T.astype(np.float32)))
+    env.rows("act").copy_(torch.from_numpy(act.T.astype(np.float32)))
+    env.forward()
+    torch.cuda.synchronize()
+    ds = []
+    for e in range(n):
+        d = O64.new_data(qpos[e], qvel[e]); O64.set(d, "act", act[e]); O64.forward(d); ds.append(d)
+    for name, tol in (("efc_D", 5e-5), ("efc_aref", 5e-5), ("qacc_smooth", 5e-4), ("efc_force", 5e-3), ("qacc", 5e-3)):
+        got = env.rows(name).cpu().numpy().astype(np.float64)
+        ref = np.stack([O64.get(d, name) for d in ds], 1)
+        assert rel_err(got, ref) < tol, (name, rel_err(got, ref))

@@ -135,3 +135,28 @@ def test_env_step_and_golden_post(setup):
     keep = G["out_done"] == 0
     np.testing.assert_allclose(E2.obs.T[keep], G["out_obs"][keep], rtol=3e-5, atol=3e-6)
     assert np.array_equal(E2.obs.T[~keep], first_obs.T[~keep])   # auto-reset returns the snapshot bit-exactly
+
+
+def test_many_active_rows_multi_slot(setup):
+    """More than 64 active constraint rows (every joint pushed past a limit, the body sunk into the floor): exercises the multi-slot
+    path of the compacted constraint rows (wave_physics.h: tmw_make_constraint) against the float64 oracle, forward intermediates."""
+    w, blob, clip = setup
+    n = 4
+    E = Emu(blob, n); O64 = make_oracle(blob, clip, "f64")
+    rng = np.random.default_rng(5)
+    qpos, qvel = _states(clip, n, rng, 0.0)
+    rngs = np.asarray(w.model["jnt_range"]).reshape(-1, 2)[1:]          # hinge joints (joint 0 is the free joint)
+    for e in range(n):
+        over = rng.uniform(0.005, 0.03, size=67) * (rngs[:, 1] - rngs[:, 0])
+        qpos[e, 7:] = np.where(rng.random(67) < 0.5, rngs[:, 1] + over, rngs[:, 0] - over)
+        qpos[e, 2] -= 0.03 * (e + 1)
+    act = rng.uniform(-0.1, 0.1, size=(n, 38))
+    E.rows("qpos")[:] = qpos.T; E.rows("qvel")[:] = qvel.T; E.rows("act")[:] = act.T
+    E.physics_wave(None, 1, do_euler=False)
+    ds = []
+    for e in range(n):
+        d = O64.new_data(qpos[e], qvel[e]); O64.set(d, "act", act[e]); O64.forward(d); ds.append(d)
+    # by construction all 67 limits are violated (+ 4 rows per penetrating contact): more than one 64-row slot of active rows
+    for name, tol in (("efc_D", 5e-5), ("efc_aref", 5e-5), ("qacc_smooth", 5e-4), ("efc_force", 5e-3), ("qacc", 5e-3)):
+        ref = np.stack([O64.get(d, name) for d in ds], 1)
+        assert rel_err(E.rows(name), ref) < tol, (name, rel_err(E.rows(name), ref))
