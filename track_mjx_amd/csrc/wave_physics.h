@@ -1055,7 +1055,9 @@ TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
 }
 
 // ------------------------------------------------------------------------------------------ matrix-free J
-TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
+// J v in two stages (no barrier inside a stage, so a caller can put independent work next to it):
+//   stage 1: spatial velocity of each paw body -> l_sv;   stage 2 (after a barrier): one lane per active row
+TM_DEV void tmw_jmul_stage1(WCtx &c, const WLayout &K, int v) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     if (lane < K.ngroup * 6) {  // spatial velocity of each paw body, one lane per (group, component)
@@ -1069,7 +1071,9 @@ TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
       L[K.l_sv + lane] = s;
     }
   }
-  TMW_SYNC();
+}
+TM_DEV void tmw_jmul_stage2(WCtx &c, const WLayout &K, int v, int out) {
+  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   // one lane per ACTIVE row (compact row space): a violated limit is one-hot, a pyramid edge of an active contact is
   // n.vel +- mu t.vel of the paw body's point velocity
   TMW_FOR {
@@ -1095,6 +1099,11 @@ TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
       L[out + kr] = o;
     }
   }
+}
+TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
+  tmw_jmul_stage1(c, K, v);
+  TMW_SYNC();
+  tmw_jmul_stage2(c, K, v, out);
   TMW_SYNC();
 }
 // out = J^T f where f_r = active ? -D_r Jaref_r : 0 is formed on the fly (efc_force is never stored)
@@ -1163,6 +1172,23 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
     }
   }
   TMW_SYNC();
+}
+
+// y = M x and out = J x together: the two products are independent, so their LDS round trips share the two barriers of
+// M x instead of adding two more (chain layout only; the generic path runs them back to back)
+TM_DEV void tmw_mul_m_jmul(WCtx &c, const WLayout &K, int x, int y, int out) {
+  float *L = c.L; TMW_LANE_DECL
+  if (!K.chains) { tmw_mul_m(c, K, x, y); tmw_jmul(c, K, x, out); return; }
+  TMW_REG(float, z0); TMW_REG(float, z1);
+  TMW_TICK2(15);
+  tmw_jmul_stage1(c, K, x);
+  tmw_rowpart_chains(c, K, K.l_M, x, true, z0, z1);
+  TMW_SCHED_FENCE();
+  tmw_colpart_chains<false>(c, K, K.l_M, x, y);     // ends with a barrier: l_sv is complete as well
+  tmw_jmul_stage2(c, K, x, out);
+  TMW_FOR { L[y + lane] += z0[TMW_LI]; if (lane + 64 < K.nv) L[y + lane + 64] += z1[TMW_LI]; }
+  TMW_SYNC();
+  TMW_TICK2(24);
 }
 
 // ------------------------------------------------------------------------------------------ make_constraint
@@ -1265,9 +1291,7 @@ TM_DEV float tmw_dot(WCtx &c, const WLayout &K, int a, int b) {
 TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
-  tmw_mul_m(c, K, q, K.l_Ma);
-  TMW_TICK2(18);
-  tmw_jmul(c, K, q, K.l_Jaref);
+  tmw_mul_m_jmul(c, K, q, K.l_Ma, K.l_Jaref);
   TMW_TICK2(19);
   TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
@@ -1358,8 +1382,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   float scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
   float smag = sqrtf(tmw_dot(c, K, K.l_search, K.l_search)) * scale;
   float gtol = m.tolerance * m.ls_tolerance * smag;
-  tmw_mul_m(c, K, K.l_search, K.l_mv);
-  tmw_jmul(c, K, K.l_search, K.l_jv);
+  tmw_mul_m_jmul(c, K, K.l_search, K.l_mv, K.l_jv);
   float g0 = gauss, g1 = tmw_dot(c, K, K.l_search, K.l_Ma) - tmw_dot(c, K, K.l_search, K.l_qfrc_smooth), g2 = 0.5f * tmw_dot(c, K, K.l_search, K.l_mv);
   TmwLSRows R;
   TMW_FOR {
