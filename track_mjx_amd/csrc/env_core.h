@@ -41,8 +41,10 @@ TM_DEV float tm_nan_to_num(float x) {
   return x;
 }
 
-// _get_obs -> obs[obs_size][n]; applies nan_to_num when `sanitize`.  `part` < 0: everything; 0 .. T-1: the four reference
-// segments of trajectory frame `part`; T: the proprioceptive tail (the split kernel k_obs runs one part per blockIdx.y).
+// _get_obs -> obs[obs_size][n]; applies nan_to_num when `sanitize`.  `part` < 0: everything.  Otherwise one of the
+// TM_OBS_PARTS(T) = 3 T + 3 pieces the split kernel k_obs runs in parallel (one per blockIdx.y): 3 t + {0: root position +
+// quaternion, 1: joints, 2: bodies} of trajectory frame t, then 3 T + {0: qpos, 1: qvel, 2: actuator forces + torso + end effectors}.
+#define TM_OBS_PARTS(T) (3 * (T) + 3)
 TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *obs, bool sanitize, int part = -1) {
   int nj = m.nq - 7, nbp = m.nbody - 1, T = m.traj_length, o = 0;
   int start = tm_clampi(frame + 1, 0, m.n_frames_clip - T);
@@ -50,45 +52,56 @@ TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *ob
   TM_LD(root, ST, m.s_qpos, 0, 3);
   TM_LD(quat, ST, m.s_qpos, 3, 4);
 #define PUT(v) do { float v_ = (v); OUTROW(obs, o) = sanitize ? tm_nan_to_num(v_) : v_; o++; } while (0)
+#define WANT(p) (part < 0 || part == (p))
   for (int t = 0; t < T; t++) {
-    if (part >= 0 && part != t) continue;
-    o = 3 * t;
-    const float *rp = m.clip_pos + tm_clip_row(m, clip, start + t) * 3;
-    float v[3] = {rp[0] - root[0], rp[1] - root[1], rp[2] - root[2]}, w[3];
-    tm_rotate(w, v, quat);
-    PUT(w[0]); PUT(w[1]); PUT(w[2]);
-    o = 3 * T + 4 * t;
-    const float *rq = m.clip_quat + tm_clip_row(m, clip, start + t) * 4;
-    float inv[4] = {rq[0], -rq[1], -rq[2], -rq[3]}, wq[4];
-    tm_quat_mul(wq, quat, inv);
-    PUT(wq[0]); PUT(wq[1]); PUT(wq[2]); PUT(wq[3]);
-    o = 7 * T + m.n_joint_idx * t;
-    const float *rj = m.clip_joints + tm_clip_row(m, clip, start + t) * nj;
-    for (int k = 0; k < m.n_joint_idx; k++) { int i = tm_clampi(m.joint_idxs[k] - 1, 0, nj - 1); PUT(rj[i] - ST(m.s_qpos, 7 + i)); }
-    o = 7 * T + m.n_joint_idx * T + 3 * m.n_body_idx * t;
-    const float *rb = m.clip_bodypos + tm_clip_row(m, clip, start + t) * (size_t)(nbp * 3);
-    for (int k = 0; k < m.n_body_idx; k++) {
-      int i = tm_clampi(m.body_idxs[k], 0, nbp - 1);
-      float vb[3] = {rb[i * 3] - ST(m.s_xpos, (1 + i) * 3), rb[i * 3 + 1] - ST(m.s_xpos, (1 + i) * 3 + 1), rb[i * 3 + 2] - ST(m.s_xpos, (1 + i) * 3 + 2)}, wb[3];
-      tm_rotate(wb, vb, quat);
-      PUT(wb[0]); PUT(wb[1]); PUT(wb[2]);
+    if (part >= 0 && part / 3 != t) continue;
+    if (WANT(3 * t)) {
+      o = 3 * t;
+      const float *rp = m.clip_pos + tm_clip_row(m, clip, start + t) * 3;
+      float v[3] = {rp[0] - root[0], rp[1] - root[1], rp[2] - root[2]}, w[3];
+      tm_rotate(w, v, quat);
+      PUT(w[0]); PUT(w[1]); PUT(w[2]);
+      o = 3 * T + 4 * t;
+      const float *rq = m.clip_quat + tm_clip_row(m, clip, start + t) * 4;
+      float inv[4] = {rq[0], -rq[1], -rq[2], -rq[3]}, wq[4];
+      tm_quat_mul(wq, quat, inv);
+      PUT(wq[0]); PUT(wq[1]); PUT(wq[2]); PUT(wq[3]);
+    }
+    if (WANT(3 * t + 1)) {
+      o = 7 * T + m.n_joint_idx * t;
+      const float *rj = m.clip_joints + tm_clip_row(m, clip, start + t) * nj;
+      for (int k = 0; k < m.n_joint_idx; k++) { int i = tm_clampi(m.joint_idxs[k] - 1, 0, nj - 1); PUT(rj[i] - ST(m.s_qpos, 7 + i)); }
+    }
+    if (WANT(3 * t + 2)) {
+      o = 7 * T + m.n_joint_idx * T + 3 * m.n_body_idx * t;
+      const float *rb = m.clip_bodypos + tm_clip_row(m, clip, start + t) * (size_t)(nbp * 3);
+      for (int k = 0; k < m.n_body_idx; k++) {
+        int i = tm_clampi(m.body_idxs[k], 0, nbp - 1);
+        float vb[3] = {rb[i * 3] - ST(m.s_xpos, (1 + i) * 3), rb[i * 3 + 1] - ST(m.s_xpos, (1 + i) * 3 + 1), rb[i * 3 + 2] - ST(m.s_xpos, (1 + i) * 3 + 2)}, wb[3];
+        tm_rotate(wb, vb, quat);
+        PUT(wb[0]); PUT(wb[1]); PUT(wb[2]);
+      }
     }
   }
-  if (part >= 0 && part != T) return;
-  o = T * (7 + m.n_joint_idx + 3 * m.n_body_idx);
-  for (int i = 7; i < m.nq; i++) PUT(ST(m.s_qpos, i));
-  for (int i = 6; i < m.nv; i++) PUT(ST(m.s_qvel, i));
-  for (int i = 0; i < m.nv; i++) PUT(ST(m.s_qfrc_actuator, i));
-  int tb = m.torso_idx;
-  float tp[3], X[9];
-  TM_LD(tp, ST, m.s_xpos, tb * 3, 3);
-  TM_LD(X, ST, m.s_xmat_torso, 0, 9);
-  PUT(tp[2]); PUT(X[6]); PUT(X[7]); PUT(X[8]);
-  for (int k = 0; k < m.n_endeff_idx; k++) {
-    int b = m.endeff_idxs[k];
-    float v[3] = {ST(m.s_xpos, b * 3) - tp[0], ST(m.s_xpos, b * 3 + 1) - tp[1], ST(m.s_xpos, b * 3 + 2) - tp[2]};
-    for (int c = 0; c < 3; c++) PUT(v[0] * X[c] + v[1] * X[3 + c] + v[2] * X[6 + c]);
+  if (part >= 0 && part < 3 * T) return;
+  const int o0 = T * (7 + m.n_joint_idx + 3 * m.n_body_idx);
+  if (WANT(3 * T)) { o = o0; for (int i = 7; i < m.nq; i++) PUT(ST(m.s_qpos, i)); }
+  if (WANT(3 * T + 1)) { o = o0 + (m.nq - 7); for (int i = 6; i < m.nv; i++) PUT(ST(m.s_qvel, i)); }
+  if (WANT(3 * T + 2)) {
+    o = o0 + (m.nq - 7) + (m.nv - 6);
+    for (int i = 0; i < m.nv; i++) PUT(ST(m.s_qfrc_actuator, i));
+    int tb = m.torso_idx;
+    float tp[3], X[9];
+    TM_LD(tp, ST, m.s_xpos, tb * 3, 3);
+    TM_LD(X, ST, m.s_xmat_torso, 0, 9);
+    PUT(tp[2]); PUT(X[6]); PUT(X[7]); PUT(X[8]);
+    for (int k = 0; k < m.n_endeff_idx; k++) {
+      int b = m.endeff_idxs[k];
+      float v[3] = {ST(m.s_xpos, b * 3) - tp[0], ST(m.s_xpos, b * 3 + 1) - tp[1], ST(m.s_xpos, b * 3 + 2) - tp[2]};
+      for (int c = 0; c < 3; c++) PUT(v[0] * X[c] + v[1] * X[3 + c] + v[2] * X[6 + c]);
+    }
   }
+#undef WANT
 #undef PUT
 }
 
@@ -136,6 +149,7 @@ TM_DEV void tm_post_part(const DModel &m, EnvRef r, const int *r_is, int part, f
     const float *rj = m.clip_joints + row * nj, *rb = m.clip_bodypos + row * (size_t)(nbp * 3);
     float s = 0.f;
     if (part == 0) {
+#pragma unroll 8
       for (int k = 0; k < nj; k++) { float df = ST(m.s_qpos, 7 + k) - rj[k]; s += df * df; }
       OUTROW(P, 0) = s;
     } else if (part == 1) {
@@ -157,9 +171,16 @@ TM_DEV void tm_post_part(const DModel &m, EnvRef r, const int *r_is, int part, f
     OUTROW(P, 3) = s;
   } else {
     bool bad = false;
-    if (part == 4) for (int i = 0; i < m.nphys; i++) { float v = ST(m.s_qpos, i); bad |= (v != v); }
-    else if (part == 5) for (int i = 0; i < m.nbody * 3; i++) { float v = ST(m.s_xpos, i); bad |= (v != v); }
-    else for (int i = 0; i < m.nv; i++) { float v = ST(m.s_qfrc_actuator, i); bad |= (v != v); }
+    if (part == 4) {
+#pragma unroll 8
+      for (int i = 0; i < m.nphys; i++) { float v = ST(m.s_qpos, i); bad |= (v != v); }
+    } else if (part == 5) {
+#pragma unroll 8
+      for (int i = 0; i < m.nbody * 3; i++) { float v = ST(m.s_xpos, i); bad |= (v != v); }
+    } else {
+#pragma unroll 8
+      for (int i = 0; i < m.nv; i++) { float v = ST(m.s_qfrc_actuator, i); bad |= (v != v); }
+    }
     OUTROW(P, part) = bad ? 1.f : 0.f;
   }
 }

@@ -93,8 +93,7 @@ __global__ void k_post_parts(const DModel *__restrict__ mp, float *st, const int
   EnvRef r{st, nullptr, n, e};
   tm_post_part(*mp, r, is, blockIdx.y, P);
 }
-// observation, one lane per (env, part): parts 0 .. T-1 = the reference segments of one trajectory frame, part T = the
-// proprioceptive tail (6x the parallelism of lane-per-env; rows of obs stay coalesced over envs)
+// observation, one lane per (env, part): TM_OBS_PARTS(T) = 18 pieces (env_core.h: tm_get_obs); rows of obs stay coalesced over envs
 __global__ void k_obs(const DModel *__restrict__ mp, float *st, const int *is, float *obs, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x, part = blockIdx.y;
   if (e >= n) return;
@@ -306,7 +305,7 @@ int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip
 static void launch_post_split(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
                               float *truncation, float *metrics, float *workspace, int n_env, hipStream_t stream) {
   const DModel &h = m->h;
-  hipLaunchKernelGGL(k_obs, dim3((n_env + 63) / 64, h.traj_length + 1), dim3(64), 0, stream, m->d, state, istate, obs, n_env);
+  hipLaunchKernelGGL(k_obs, dim3((n_env + 63) / 64, TM_OBS_PARTS(h.traj_length)), dim3(64), 0, stream, m->d, state, istate, obs, n_env);
   hipLaunchKernelGGL(k_post_parts, dim3((n_env + 63) / 64, TM_NPOST), dim3(64), 0, stream, m->d, state, istate, workspace + (size_t)2 * h.nu * n_env, n_env);
   hipLaunchKernelGGL(k_post, dim3((n_env + 63) / 64), dim3(64), 0, stream, m->d, state, istate, action, obs, reward, done, truncation, metrics,
                      (const float *)workspace, 1, n_env);
