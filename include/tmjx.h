@@ -71,6 +71,10 @@ int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip
 int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward,
               float *done, float *truncation, float *metrics, float *workspace, int n_env, void *stream);
 
+/* The physics part of tmjx_step alone: n_frames substeps with the handle's configuration, through the same launches
+ * (state -> env-major record, wave-per-env kernel, record -> state; the record lives in `workspace`).  bench.py times this. */
+int tmjx_physics_step(tmjx_model *m, float *state, const float *action, float *workspace, int n_env, void *stream);
+
 /* K2 alone: `n_substeps` x (ctrl = action; mjx.step) on the physics rows of `state`
  * (brax PipelineEnv.pipeline_step, called at task/single_clip_tracking.py:219). */
 int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substeps, float *workspace, int n_env,

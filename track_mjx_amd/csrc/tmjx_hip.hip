@@ -22,7 +22,12 @@ struct tmjx_model {
   int wave = 1;       // 1: wave-per-env LDS physics kernel (default); 0: lane-per-env reference implementation
   bool rodent = false;  // dims match the compile-time specialisation of the wave kernel
 };
-static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream);
+// record stride: state rows qpos .. qfrc_actuator, then the action, rounded up to 16 words
+#define WAVE_REC_STRIDE(m) ((((m)->h.s_prev_ctrl + (m)->h.nu) + 15) & ~15)
+// workspace words in front of the record: window partials (2 nu rows) + post partials (16 rows), each n_env wide
+#define WAVE_REC_OFFSET(m, n) ((size_t)(2 * (m)->h.nu + 16) * (size_t)(n))
+static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream,
+                        float *rec = nullptr);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -117,13 +122,52 @@ __global__ void k_autoreset(const DModel *__restrict__ mp, float *st, float *obs
   }
 }
 
+// Env-major physics record of K2: rec[e][0 .. s_prev_ctrl) = the state rows qpos .. qfrc_actuator of env e (physics state + the
+// outputs K3 reads), rec[e][s_prev_ctrl .. + nu) = the action.  32 x 32 LDS-tiled transposes, coalesced on both sides: the
+// wave-per-env kernel then reads / writes contiguous words (without this each of its 4-byte accesses to the [row][n_env] buffers
+// occupied its own 32-byte sector: 131 MB of HBM traffic per launch for 14 MB of data, profiles/pmc_traffic.json).
+__global__ __launch_bounds__(256) void k_rec_in(const DModel *__restrict__ mp, const float *__restrict__ st, const float *__restrict__ action,
+                                                float *__restrict__ rec, int n, int rs) {
+  __shared__ float tile[32][33];
+  const DModel &m = *mp;
+  const int e0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // rows: nphys state rows, then nu action rows
+  const int nrow = m.nphys + m.nu;
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, e = e0 + tx;
+    float v = 0.f;
+    if (r < nrow && e < n) v = r < m.nphys ? st[(size_t)(m.s_qpos + r) * n + e] : action[(size_t)(r - m.nphys) * n + e];
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int e = e0 + j, r = r0 + tx;
+    if (r < nrow && e < n) rec[(size_t)e * rs + (r < m.nphys ? m.s_qpos + r : m.s_prev_ctrl + (r - m.nphys))] = tile[tx][j];
+  }
+}
+__global__ __launch_bounds__(256) void k_rec_out(const DModel *__restrict__ mp, float *__restrict__ st, const float *__restrict__ rec, int n, int rs) {
+  __shared__ float tile[32][33];
+  const DModel &m = *mp;
+  const int e0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int nrow = m.s_prev_ctrl - m.s_qpos;      // physics state + xpos / torso xmat / qfrc_actuator
+  for (int j = ty; j < 32; j += 8) {
+    int e = e0 + j, r = r0 + tx;
+    tile[j][tx] = (r < nrow && e < n) ? rec[(size_t)e * rs + m.s_qpos + r] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, e = e0 + tx;
+    if (r < nrow && e < n) st[(size_t)(m.s_qpos + r) * n + e] = tile[tx][j];
+  }
+}
+
 // K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
 // STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
 template <bool STATIC>
 __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
-                                                     int do_euler, float *ws_dump, int n, int e0) {
+                                                     int do_euler, float *ws_dump, int n, int e0, int rs) {
   extern __shared__ float tmw_lds[];
   WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x + e0, (int)threadIdx.x, nullptr, 0ull, nullptr};
+  c.rs = rs;
 #ifndef TMW_PROFILE
   c.dump = ws_dump;
 #endif
@@ -265,16 +309,28 @@ int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quatern
   return TMJX_OK;
 }
 
-static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream) {
+static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream,
+                        float *rec) {
   size_t lds = (size_t)m->h.lds_floats * sizeof(float);
   if (const char *pad = getenv("TMJX_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;  // occupancy experiments only
   int parts = 1;
   if (const char *sp = getenv("TMJX_SPLIT_LAUNCH")) { parts = atoi(sp); if (parts < 1 || n_env % parts) parts = 1; }   // scheduling experiments
+  const int rs = rec ? WAVE_REC_STRIDE(m) : 0;
+  if (rec) hipLaunchKernelGGL(k_rec_in, dim3((n_env + 31) / 32, (m->h.nphys + m->h.nu + 31) / 32), dim3(256), 0, stream, m->d, (const float *)state, action, rec, n_env, rs);
+  float *st = rec ? rec : state;
   for (int p = 0; p < parts; p++) {
     int cnt = n_env / parts, e0 = p * cnt;
-    if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(cnt), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env, e0);
-    else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, state, action, nsub, do_euler, ws, n_env, e0);
+    if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs);
+    else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs);
   }
+  if (rec) hipLaunchKernelGGL(k_rec_out, dim3((n_env + 31) / 32, (m->h.s_prev_ctrl - m->h.s_qpos + 31) / 32), dim3(256), 0, stream, m->d, state, (const float *)rec, n_env, rs);
+}
+// env-major physics record inside the caller's workspace (behind the K3 partial rows), or nullptr = direct [row][n_env] access
+// (TMJX_NO_RECORD=1, or a workspace too small for it)
+static float *wave_record(const tmjx_model *m, float *workspace, int n_env) {
+  if (!workspace || getenv("TMJX_NO_RECORD")) return nullptr;
+  if ((size_t)m->h.w_rows * (size_t)n_env < WAVE_REC_OFFSET(m, n_env) + (size_t)WAVE_REC_STRIDE(m) * (size_t)n_env) return nullptr;
+  return workspace + WAVE_REC_OFFSET(m, n_env);
 }
 static int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
@@ -321,7 +377,7 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
   if (m->wave) {
-    launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream);
+    launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env));
     hipLaunchKernelGGL(k_window, dim3((n_env + 255) / 256, m->h.nu), dim3(256), 0, (hipStream_t)stream, m->d, state, istate, action,
                        workspace, n_env);
     launch_post_split(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
@@ -330,6 +386,18 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
   hipLaunchKernelGGL(k_step, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
                      metrics, workspace, n_env);
   return check_launch("k_step");
+}
+
+// the physics part of tmjx_step alone (record transposes + K2 with the configured n_frames): what bench.py brackets with HIP events
+int tmjx_physics_step(tmjx_model *m, float *state, const float *action, float *workspace, int n_env, void *stream) {
+  if (!m || !state || !action || !workspace) return fail(TMJX_EINVAL, "null argument");
+  if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+  if (!m->wave) {
+    hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, action, m->h.n_frames, 1, workspace, n_env);
+    return check_launch("k_physics");
+  }
+  launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env));
+  return check_launch("k_physics_wave");
 }
 
 int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substeps, float *workspace, int n_env, void *stream) {

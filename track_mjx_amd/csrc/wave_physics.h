@@ -63,6 +63,7 @@ struct WCtx {
   float *dump;                // tests only: lane-per-env workspace that receives intermediates (tmw_dump)
   int nact;                   // number of ACTIVE constraint rows of the current substep (compact row space, tmw_make_constraint)
   int nla;                    // ... of which violated joint limits (the active contacts' rows follow, four each)
+  int rs;                     // 0: `st` is the [row][n_env] state; > 0: `st` is the env-major physics record with this stride
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
@@ -71,7 +72,10 @@ struct WCtx {
 #define TMW_TICK(idx) do { } while (0)
 #define TMW_TICK2(idx) do { } while (0)
 #endif
-#define WST(off, i) c.st[(size_t)((off) + (i)) * (size_t)c.n + (size_t)c.e]
+// state word (row off + i) of this env: the C-ABI layout [row][n_env], or — when the launch goes through the env-major physics
+// record (c.rs = record stride; tmjx_hip.hip: k_rec_in / k_rec_out) — word (off + i) of this env's contiguous record, so that the
+// one-wavefront-per-env kernel moves full sectors instead of one 4-byte word per 32-byte sector
+#define WST(off, i) c.st[c.rs ? (size_t)c.e * (size_t)c.rs + (size_t)((off) + (i)) : (size_t)((off) + (i)) * (size_t)c.n + (size_t)c.e]
 
 TM_DEV int tm_f2i(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
@@ -136,7 +140,8 @@ TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     for (int i = lane; i < K.nphys - 1; i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);
-    for (int a = lane; a < K.nu; a += 64) L[K.l_ctrl + a] = action ? action[(size_t)a * c.n + c.e] : 0.f;
+    // (record mode: the action rows were transposed in behind the state + output rows)
+    for (int a = lane; a < K.nu; a += 64) L[K.l_ctrl + a] = c.rs ? c.st[(size_t)c.e * (size_t)c.rs + (size_t)(m.s_prev_ctrl + a)] : (action ? action[(size_t)a * c.n + c.e] : 0.f);
     for (int i = lane; i < 2 * K.nv; i += 64) L[K.l_tdof + i] = tm_i2f(m.tdof[i]);  // index table of the sparse rows
     for (int g = lane; g < K.ngroup; g += 64) { L[K.l_tgrp + 4 * g] = tm_i2f(m.grp_lastdof[g]); L[K.l_tgrp + 4 * g + 1] = tm_i2f(m.grp_start[g]); L[K.l_tgrp + 4 * g + 2] = tm_i2f(m.grp_count[g]); }
   }

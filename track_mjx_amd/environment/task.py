@@ -233,7 +233,7 @@ class MultiClipTracking:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.device(self.device):
                 e0.record(torch.cuda.current_stream(self.device))
-                _hip.check(self._L.tmjx_physics(self._handle, _ptr(self.state_buf), _ptr(a), self._n_frames, None, n, self._stream()), "tmjx_physics")
+                _hip.check(self._L.tmjx_physics_step(self._handle, _ptr(self.state_buf), _ptr(a), _ptr(self.workspace), n, self._stream()), "tmjx_physics_step")
                 e1.record(torch.cuda.current_stream(self.device))
                 _hip.check(self._L.tmjx_reward_obs(self._handle, _ptr(self.state_buf), _ptr(self.istate_buf), _ptr(a), _ptr(self.obs_buf),
                                                    _ptr(self.reward_buf), _ptr(self.done_buf), _ptr(self.trunc_buf), _ptr(self.metrics_buf),

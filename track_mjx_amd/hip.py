@@ -29,7 +29,7 @@ class Layout(C.Structure):
 
 
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
-           "tmjx_physics", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
+           "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
@@ -75,6 +75,7 @@ def lib():
     L.tmjx_reset.argtypes = [vp, fp, vp, vp, vp, fp, fp, fp, fp, C.c_int, vp]
     L.tmjx_step.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
     L.tmjx_physics.argtypes = [vp, fp, fp, C.c_int, fp, C.c_int, vp]
+    L.tmjx_physics_step.argtypes = [vp, fp, fp, fp, C.c_int, vp]
     L.tmjx_forward.argtypes = [vp, fp, fp, C.c_int, vp]
     L.tmjx_reward_obs.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
     L.tmjx_gae.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, vp]
