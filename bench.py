@@ -151,7 +151,7 @@ def main():
                        "policy_params": learner.n_params(), "physics_kernel_ms": kernel_ms,
                        "physics_only_env_steps_per_s_per_gpu": n_local / (kernel_ms * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env)",
+                         "traffic": traffic, "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env; the HIP events also span its two record-transpose launches, < 1 % of the time)",
                          "algorithmic_bytes_per_launch": K2_ALGO_BYTES_PER_ENV_STEP * n_local, "avg_launch_ms": kernel_ms,
                          "whole_step_algorithmic_bytes_per_env": ALGO_BYTES_PER_ENV_STEP,
                          "whole_step_hbm_frac_at_rollout_rate": ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
