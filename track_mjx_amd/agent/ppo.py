@@ -140,7 +140,7 @@ class PPOLearner:
                 torch.cuda.current_stream(self.dev).wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 graph.register_generator_state(self.gen)
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     action, extra = self.act(obs)
                 self._act_graph, self._act_key, self._act_out = graph, key, (action, extra)
             except Exception as e:  # noqa: BLE001
@@ -199,7 +199,8 @@ class PPOLearner:
                 self._minibatch_grads(self._g_idx, kl_w)
         torch.cuda.current_stream(self.dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread polls events concurrently (world > 1) and must not invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._g_out = self._minibatch_grads(self._g_idx, kl_w)
         self._graph, self._graph_kl = graph, kl_w
 
