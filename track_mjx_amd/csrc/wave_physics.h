@@ -1,23 +1,26 @@
 // csrc/wave_physics.h — K2, wave-per-env: one 64-lane wavefront integrates one env; every per-env array of a
-// substep lives in LDS (DModel::l_* map, ~22 KB per env => 7 envs per CU), the 64 lanes split bodies / dofs /
-// constraint rows / matrix columns between them.
+// substep lives in LDS (wave_layout.h, 20.4 KB per env => 8 envs per CU = 2 waves per SIMD), the 64 lanes split bodies /
+// dofs / constraint rows / matrix columns between them.
 //
 // Same maths as physics_core.h (MJX `mjx.step`, reference call site
 // track_mjx/environment/task/single_clip_tracking.py:219) re-organised for the wavefront:
 //   * kinematics and velocity/acceleration prefixes by POINTER JUMPING over the tree (log2(depth) = 6 rounds
-//     instead of a 39-level walk),
-//   * composite inertias / body forces by a level-synchronous up-sweep,
-//   * tree-sparse M; L^T D L with one lane per row-k column and scalar-broadcast pivots; L is then inverted in
-//     place (the inverse has the same ancestor sparsity) so that every M^-1 apply in the CG loop is two parallel
-//     sparse mat-vecs instead of two 73-step dependent sweeps,
-//   * matrix-free constraint Jacobian (spatial velocity per paw body, wrench accumulation),
-//   * dot products / line-search sums by DPP wave reductions.
+//     instead of a 39-level walk); composite inertias / body forces by one branch-free reverse sweep,
+//   * tree-sparse M; for the rodent's chain-structured dof tree the factorisation L^T D L, the inverse L^-1 (same ancestor
+//     sparsity: every M^-1 apply of the CG loop is two sparse mat-vecs instead of two 73-step dependent sweeps), Euler's
+//     (M + hD)^-1 b and the column halves of M x / M^-1 x run REGISTER-RESIDENT: lane = ancestor depth, a matrix row is
+//     one register, updates are v_readlane + v_pk_fma_f32 (section "register-resident variants" below); any other tree
+//     takes the LDS-resident left-looking path,
+//   * matrix-free constraint Jacobian (spatial velocity per paw body, wrench accumulation per subset of paw bodies); only
+//     the ACTIVE rows (violated limits, penetrating contacts) are numbered and enter the solver,
+//   * dot products / line-search sums by DPP wave reductions; the rows of a line search live in registers.
 //
 // Single source for the GPU and for the TEST-ONLY host emulation: a block of lane code is written as
 //   TMW_FOR { ... uses `lane` ... }  TMW_SYNC();
-// On the GPU TMW_FOR is empty (the wave executes the block once, lane = threadIdx.x) and TMW_SYNC is a workgroup
-// barrier (one wave per workgroup, so it only orders LDS traffic); under TM_HOST_EMU TMW_FOR loops lane = 0..63.
-// Lane-private values that live across blocks are declared with TMW_REG (one slot on the GPU, 64 in emulation).
+// On the GPU TMW_FOR is empty (the wave executes the block once, lane = threadIdx.x) and TMW_SYNC is a wave-level
+// compiler barrier (one wave per workgroup: the LDS unit executes a wave's DS instructions in order); under TM_HOST_EMU
+// TMW_FOR loops lane = 0..63.  Lane-private values that live across blocks are declared with TMW_REG (one slot on the
+// GPU, 64 in emulation).
 #pragma once
 #include "physics_core.h"
 #include "wave_layout.h"
