@@ -440,3 +440,27 @@ def test_many_active_rows_multi_slot_gpu():
         got = env.rows(name).cpu().numpy().astype(np.float64)
         ref = np.stack([O64.get(d, name) for d in ds], 1)
         assert rel_err(got, ref) < tol, (name, rel_err(got, ref))
+
+
+@pytest.mark.gpu
+def test_fused_inference_tail_matches_torch_path():
+    """PPOLearner._act_fused (tmjx_latent_concat + tmjx_sample_action) against the plain torch inference path with the same
+    generator state: same action, raw action, log-prob."""
+    from track_mjx_amd.agent import ppo
+    env, _, _ = make_env_and_oracle(num_envs=64, n_clips=4, wrappers=True)
+    L = ppo.PPOLearner(env, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=5,
+                       batch_size=16, num_minibatches=4, num_updates_per_batch=1, seed=3, use_graph=False)
+    st = env.reset(torch.Generator().manual_seed(0))
+    state = L.gen.get_state()
+    a_f, e_f = L.act(st.obs)
+    L.gen.set_state(state)
+    x = L.normalizer.normalize(st.obs)
+    eps = torch.randn((64, 60), generator=L.gen, device=L.dev)
+    logits, mean, logvar = L.policy(x, eps=eps)
+    noise = torch.randn((64, 38), generator=L.gen, device=L.dev)
+    from track_mjx_amd.agent.networks import NormalTanh
+    raw = NormalTanh.sample_no_postprocessing(logits, noise)
+    assert torch.allclose(e_f["raw_action"], raw, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a_f, torch.tanh(raw), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(e_f["log_prob"], NormalTanh.log_prob(logits, raw), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(e_f["latent_mean"], mean, rtol=1e-5, atol=1e-6)

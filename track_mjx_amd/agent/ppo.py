@@ -113,6 +113,8 @@ class PPOLearner:
     @torch.no_grad()
     def act(self, obs: torch.Tensor, deterministic: bool = False):
         x = self.normalizer.normalize(obs) if self.normalize_observations else obs
+        if (not deterministic and self.dev.type == "cuda" and self.matmul_dtype is None and x.dim() == 2 and x.dtype == torch.float32):
+            return self._act_fused(x)
         with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
             eps = torch.randn((x.shape[0], self.policy.latents), generator=self.gen, device=self.dev)
             logits, mean, logvar = self.policy(x, eps=eps, deterministic=deterministic)
@@ -123,6 +125,32 @@ class PPOLearner:
         raw = NormalTanh.sample_no_postprocessing(logits, noise)
         return NormalTanh.postprocess(raw), {"raw_action": raw, "log_prob": NormalTanh.log_prob(logits, raw), "logits": logits,
                                              "latent_mean": mean, "latent_logvar": logvar}
+
+    def _act_fused(self, x: torch.Tensor):
+        """Stochastic inference with the latent sample + decoder-input concat and the action sample / tanh / log-prob as one
+        HIP kernel each (tmjx_latent_concat, tmjx_sample_action) instead of ~25 element-wise launches.  Same random draws, in
+        the same order, as the torch path of act()."""
+        import ctypes as C
+        from .. import hip as _hip
+        pol, n = self.policy, x.shape[0]
+        Z, A, ref = pol.latents, pol.action_size, pol.reference_obs_size
+        eps = torch.randn((n, Z), generator=self.gen, device=self.dev)
+        fc2 = pol.fc2(pol.encoder(x[..., :ref]))
+        xdec = torch.empty((n, Z + x.shape[1] - ref), dtype=torch.float32, device=self.dev)
+        L = _hip.lib()
+        with torch.cuda.device(self.dev):
+            stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            _hip.check(L.tmjx_latent_concat(*[C.c_void_p(t.data_ptr()) for t in (fc2, eps, x, xdec)], n, Z, x.shape[1], ref,
+                                            x.stride(0), x.stride(1), stream), "tmjx_latent_concat")
+            logits = pol.head(pol.decoder(xdec))
+            noise = torch.randn((n, A), generator=self.gen, device=self.dev)
+            raw = torch.empty((n, A), dtype=torch.float32, device=self.dev)
+            action_t = torch.empty((A, n), dtype=torch.float32, device=self.dev)
+            logp = torch.empty(n, dtype=torch.float32, device=self.dev)
+            _hip.check(L.tmjx_sample_action(*[C.c_void_p(t.data_ptr()) for t in (logits, noise, raw, action_t, logp)], n, A, stream),
+                       "tmjx_sample_action")
+        mean, logvar = torch.chunk(fc2, 2, dim=-1)
+        return action_t.t(), {"raw_action": raw, "log_prob": logp, "logits": logits, "latent_mean": mean, "latent_logvar": logvar}
 
     def _act_graphed(self, obs: torch.Tensor):
         """act() replayed as one hipGraph (~45 launches of the policy inference per control step).  Valid while `obs` is the

@@ -298,3 +298,34 @@ __global__ __launch_bounds__(256) void k_gather_normalize(const float *__restric
     reinterpret_cast<float4 *>(out + tb * W)[c] = o;
   }
 }
+
+// ---- policy inference tails (make_inference_fn, ppo_networks.py:46-96; reparameterize, intention_network.py:78-88)
+// latent sample + decoder input in one pass:  x[i] = [ mean + eps * exp(logvar / 2)  |  obs[i][ref:] ]
+__global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__ fc2, const float *__restrict__ eps, const float *__restrict__ obs,
+                                                       float *__restrict__ x, int n, int Z, int obs_w, int ref_w, long long obs_s0, long long obs_s1) {
+  const int W = Z + obs_w - ref_w;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * W; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % W); size_t e = i / W;
+    float v;
+    if (c < Z) v = fc2[e * 2 * Z + c] + eps[e * Z + c] * expf(0.5f * fc2[e * 2 * Z + Z + c]);
+    else v = obs[(long long)e * obs_s0 + (long long)(ref_w + c - Z) * obs_s1];
+    x[i] = v;
+  }
+}
+// action sample, tanh post-processing and log-prob of the sample: one lane group of PPO_G per env
+__global__ __launch_bounds__(PPO_BLOCK) void k_sample_action(const float *__restrict__ logits, const float *__restrict__ noise, float *__restrict__ raw,
+                                                             float *__restrict__ action_t, float *__restrict__ logp, int n, int A) {
+  const int gid = blockIdx.x * PPO_BLOCK + threadIdx.x, e = gid / PPO_G, sub = gid % PPO_G;
+  float lp = 0.f;
+  if (e < n) {
+    const float *lg = logits + (size_t)e * 2 * A;
+    for (int a = sub; a < A; a += PPO_G) {
+      float loc = lg[a], scale = ppo_softplus(lg[A + a]) + 0.001f, x = loc + scale * noise[(size_t)e * A + a], d = (x - loc) / scale;
+      raw[(size_t)e * A + a] = x;
+      action_t[(size_t)a * n + e] = tanhf(x);          // [A][n]: the env-minor layout tmjx_step takes
+      lp += -0.5f * d * d - logf(scale) - 0.91893853320467274f - ppo_fldj(x);
+    }
+  }
+  lp = ppo_group_sum(lp);
+  if (e < n && sub == 0) logp[e] = lp;
+}

@@ -506,6 +506,23 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
   return check_launch("k_gather_normalize");
 }
 
+int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
+                       int64_t obs_s0, int64_t obs_s1, void *stream) {
+  if (!fc2 || !eps || !obs || !x) return fail(TMJX_EINVAL, "null argument");
+  if (n < 1 || Z < 1 || ref_w < 0 || obs_w < ref_w) return fail(TMJX_EINVAL, "bad sizes");
+  size_t total = (size_t)n * (Z + obs_w - ref_w);
+  int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1);
+  return check_launch("k_latent_concat");
+}
+
+int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, void *stream) {
+  if (!logits || !noise || !raw || !action_t || !logp) return fail(TMJX_EINVAL, "null argument");
+  if (n < 1 || A < 1) return fail(TMJX_EINVAL, "bad sizes");
+  hipLaunchKernelGGL(k_sample_action, dim3((n * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK), dim3(PPO_BLOCK), 0, (hipStream_t)stream, logits, noise, raw, action_t, logp, n, A);
+  return check_launch("k_sample_action");
+}
+
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {
   if (!m || !name || !row0 || !count) return fail(TMJX_EINVAL, "null argument");
   for (const auto &e : tmjx_host::debug_rows(m->h))
