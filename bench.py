@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=2, help="env groups per GPU whose roll-outs are pipelined on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
     import torch
@@ -91,10 +92,13 @@ def main():
     cfg["network_config"].update(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256])
     tc = cfg["train_setup"]["train_config"]
     n_local = args.envs_per_gpu
-    env = build_env(cfg, n_local, device, n_clips=64)
-    env = wrap(env, episode_length=195)
+    # the rank's envs as `--pipeline` equal groups (same clips, same model): the learner pipelines their roll-outs on separate
+    # HIP streams so that one group's kernel tail + reward/obs kernels + policy inference run next to the other group's physics
+    ngrp = args.pipeline if args.pipeline >= 1 and n_local % max(args.pipeline, 1) == 0 else 1
+    envs = [wrap(build_env(cfg, n_local // ngrp, device, n_clips=64), episode_length=195) for _ in range(ngrp)]
+    env = envs[0]
     nc = cfg["network_config"]
-    learner = ppo.PPOLearner(env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"],
+    learner = ppo.PPOLearner(envs if ngrp > 1 else env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"],
                              critic_layers=nc["critic_layer_sizes"], latents=nc["intention_size"], learning_rate=tc["learning_rate"],
                              entropy_cost=tc["entropy_cost"], discounting=tc["discounting"], unroll_length=tc["unroll_length"],
                              batch_size=tc["batch_size"] * world * n_local // ENVS_PER_GPU, num_minibatches=tc["num_minibatches"],
@@ -103,13 +107,17 @@ def main():
     # deterministic synthetic reset inputs: clip = env % 64, start_frame = env % 44
     g = torch.Generator().manual_seed(1 + rank)
     idx = torch.arange(n_local, dtype=torch.int32) + rank * n_local
-    learner.state = env.reset(g, (idx % 64).to(torch.int32), start_frame=(idx % 44).to(torch.int32))
+    per = n_local // ngrp
+    for k, e in enumerate(envs):
+        sub = idx[k * per:(k + 1) * per]
+        learner.states[k] = e.reset(g, (sub % 64).to(torch.int32), start_frame=(sub % 44).to(torch.int32))
 
     # HIP-event timing of the dominant kernel (k_physics_wave: the 10 physics substeps of one control step for all envs) on
     # the launch stream: env.step issues K2 and K3 as two ABI calls and records events around K2 (environment/task.py)
     for _ in range(args.warmup):
         learner.training_step(1)
-    env._physics_events = []
+    for e in envs:
+        e._physics_events = []
 
     def sync():
         torch.cuda.synchronize(device)
@@ -128,16 +136,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     env_steps = learner.env_steps_per_training_step * args.steps
-    ev = env._physics_events
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    ev = [p for e in envs for p in e._physics_events]
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)      # per launch (n_local / ngrp envs each)
+    per_launch = n_local // ngrp
 
     if rank == 0:
-        achieved = K2_ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
+        achieved = K2_ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch") * per_launch / ENVS_PER_GPU   # measured at 4096 envs per launch
             except Exception:
                 traffic = None
         out = {
@@ -148,13 +157,13 @@ def main():
             "config": {"workload": "rodent tracking PPO training step: 4096 envs/GPU, 4x20-step unrolls (10 physics substeps each) + 64 minibatch updates, 2x256 intention policy + critic, fp32",
                        "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
                        "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}",
-                       "policy_params": learner.n_params(), "physics_kernel_ms": kernel_ms,
-                       "physics_only_env_steps_per_s_per_gpu": n_local / (kernel_ms * 1e-3)},
+                       "policy_params": learner.n_params(), "physics_kernel_ms": kernel_ms, "envs_per_physics_launch": per_launch,
+                       "concurrent_physics_launches": ngrp},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env; the HIP events also span its two record-transpose launches, < 1 % of the time)",
-                         "algorithmic_bytes_per_launch": K2_ALGO_BYTES_PER_ENV_STEP * n_local, "avg_launch_ms": kernel_ms,
+                         "traffic": traffic, "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env; the HIP events also span its two record-transpose launches, < 1 % of the time; with --pipeline 2 two such launches of 2048 envs run concurrently, each sharing the GPU)",
+                         "algorithmic_bytes_per_launch": K2_ALGO_BYTES_PER_ENV_STEP * per_launch, "avg_launch_ms": kernel_ms,
                          "whole_step_algorithmic_bytes_per_env": ALGO_BYTES_PER_ENV_STEP,
-                         "whole_step_hbm_frac_at_rollout_rate": ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "whole_step_hbm_frac_at_training_rate": ALGO_BYTES_PER_ENV_STEP * (env_steps / elapsed) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -464,3 +464,17 @@ def test_fused_inference_tail_matches_torch_path():
     assert torch.allclose(a_f, torch.tanh(raw), rtol=1e-5, atol=1e-6)
     assert torch.allclose(e_f["log_prob"], NormalTanh.log_prob(logits, raw), rtol=1e-4, atol=1e-3)
     assert torch.allclose(e_f["latent_mean"], mean, rtol=1e-5, atol=1e-6)
+    # the LDS-free variant (tmjx_linear_nolds for every dense layer, normaliser folded into the first layer / the concat)
+    L.normalizer.update(st.obs.reshape(1, 64, -1) * 1.0)
+    x = L.normalizer.normalize(st.obs)
+    L.gen.set_state(state)
+    eps = torch.randn((64, 60), generator=L.gen, device=L.dev)
+    logits, mean, logvar = L.policy(x, eps=eps)
+    noise = torch.randn((64, 38), generator=L.gen, device=L.dev)
+    raw = NormalTanh.sample_no_postprocessing(logits, noise)
+    L.lds_free = True
+    L.gen.set_state(state)
+    a_l, e_l = L.act(st.obs)
+    assert torch.allclose(e_l["logits"], logits, rtol=1e-3, atol=2e-4), float((e_l["logits"] - logits).abs().max())
+    assert torch.allclose(e_l["raw_action"], raw, rtol=1e-3, atol=3e-4)
+    assert torch.allclose(a_l, torch.tanh(raw), rtol=1e-3, atol=3e-4)

@@ -21,6 +21,10 @@ from . import losses as _losses
 from .networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet
 
 
+import contextlib
+_nullctx = contextlib.nullcontext
+
+
 class FlatGrads:
     """All parameter gradients live in ONE contiguous fp32 buffer, so the data-parallel mean is a single
     all-reduce of 2.5-17 MB (sized for the 7 x 153 GB/s xGMI links: one large message instead of per-tensor
@@ -68,12 +72,18 @@ class PPOLearner:
                  clipping_epsilon: float = 0.2, unroll_length: int = 20, batch_size: int = 1024, num_minibatches: int = 16,
                  num_updates_per_batch: int = 4, normalize_observations: bool = True, kl_weight: float = 0.1,
                  seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None, use_graph: bool = True):
+        # `env` may be a LIST of envs (equal halves of this rank's envs): their roll-outs are then pipelined on one HIP stream
+        # each (collect()), so that the tail of one half's physics kernel, its reward / observation kernels and its policy
+        # inference run next to the other half's physics kernel
+        self.envs = list(env) if isinstance(env, (list, tuple)) else [env]
+        env = self.envs[0]
         self.env, self.group = env, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         dev = env.device
         self.dev = dev
-        n_local = env.num_envs
+        n_local = sum(e.num_envs for e in self.envs)
+        self.n_local = n_local
         self.num_envs_global = n_local * self.world
         if (batch_size * num_minibatches) % self.num_envs_global:
             raise AssertionError(f"batch_size*num_minibatches % num_envs = {(batch_size * num_minibatches) % self.num_envs_global}")
@@ -94,6 +104,7 @@ class PPOLearner:
         self.opt = torch.optim.Adam(self.params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, fused=bool(dev.type == "cuda"))
         self.normalizer = RunningStatistics(obs, dev)
         self.gen = torch.Generator(device=dev).manual_seed(seed * 1000 + 17 + self.rank)
+        self.gens = [self.gen] + [torch.Generator(device=dev).manual_seed(seed * 1000 + 17 + self.rank + 7919 * g) for g in range(1, len(self.envs))]
         rows = self.unrolls * n_local
         T = self.T
         f32 = dict(dtype=torch.float32, device=dev)
@@ -102,101 +113,172 @@ class PPOLearner:
                     "discount": torch.empty((T, rows), **f32), "truncation": torch.empty((T, rows), **f32),
                     "next_observation_last": torch.empty((rows, obs), **f32)}
         self.matmul_dtype = matmul_dtype
-        self.state = None
         self.use_graph, self._graph, self._graph_kl = use_graph, None, None
-        self._act_graph, self._act_key, self._act_out = None, None, None
+        self._act_graphs: dict = {}
+        self.lds_free = len(self.envs) > 1 and dev.type == "cuda"   # pipelined roll-outs: LDS-free inference kernels (see _act_fused)
+        self.states = [None] * len(self.envs)
+        self._streams = [torch.cuda.Stream(device=dev) for _ in self.envs] if (len(self.envs) > 1 and dev.type == "cuda") else None
+
+    @property
+    def state(self):
+        return self.states[0]
+
+    @state.setter
+    def state(self, st):
+        self.states[0] = st
 
     def n_params(self) -> int:
         return int(self.grads.flat.numel())
 
     # ---- acting (brax acting.generate_unroll / actor_step through make_inference_fn, ppo_networks.py:46-96)
     @torch.no_grad()
-    def act(self, obs: torch.Tensor, deterministic: bool = False):
+    def act(self, obs: torch.Tensor, deterministic: bool = False, gen: torch.Generator | None = None):
+        gen = self.gen if gen is None else gen
+        if (not deterministic and self.dev.type == "cuda" and self.matmul_dtype is None and obs.dim() == 2 and obs.dtype == torch.float32):
+            if self.lds_free:
+                return self._act_fused(None, obs_raw=obs, gen=gen)
+            return self._act_fused(self.normalizer.normalize(obs) if self.normalize_observations else obs, gen=gen)
         x = self.normalizer.normalize(obs) if self.normalize_observations else obs
-        if (not deterministic and self.dev.type == "cuda" and self.matmul_dtype is None and x.dim() == 2 and x.dtype == torch.float32):
-            return self._act_fused(x)
         with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
-            eps = torch.randn((x.shape[0], self.policy.latents), generator=self.gen, device=self.dev)
+            eps = torch.randn((x.shape[0], self.policy.latents), generator=gen, device=self.dev)
             logits, mean, logvar = self.policy(x, eps=eps, deterministic=deterministic)
         logits = logits.float()
         if deterministic:
             return NormalTanh.mode(logits), {"latent_mean": mean, "latent_logvar": logvar}
-        noise = torch.randn((x.shape[0], self.policy.action_size), generator=self.gen, device=self.dev)
+        noise = torch.randn((x.shape[0], self.policy.action_size), generator=gen, device=self.dev)
         raw = NormalTanh.sample_no_postprocessing(logits, noise)
         return NormalTanh.postprocess(raw), {"raw_action": raw, "log_prob": NormalTanh.log_prob(logits, raw), "logits": logits,
                                              "latent_mean": mean, "latent_logvar": logvar}
 
-    def _act_fused(self, x: torch.Tensor):
+    def _act_fused(self, x: torch.Tensor, obs_raw: torch.Tensor | None = None, gen: torch.Generator | None = None):
         """Stochastic inference with the latent sample + decoder-input concat and the action sample / tanh / log-prob as one
         HIP kernel each (tmjx_latent_concat, tmjx_sample_action) instead of ~25 element-wise launches.  Same random draws, in
-        the same order, as the torch path of act()."""
+        the same order, as the torch path of act().
+
+        With `self.lds_free` (pipelined roll-outs) every dense layer goes through tmjx_linear_nolds (`obs_raw` = the env's
+        observation buffer, normalised here element-wise): no kernel of the inference touches LDS, so it runs on its stream NEXT TO the other half's physics kernel, which owns every CU's LDS."""
         import ctypes as C
         from .. import hip as _hip
-        pol, n = self.policy, x.shape[0]
+        gen = self.gen if gen is None else gen
+        pol, L = self.policy, _hip.lib()
         Z, A, ref = pol.latents, pol.action_size, pol.reference_obs_size
-        eps = torch.randn((n, Z), generator=self.gen, device=self.dev)
-        fc2 = pol.fc2(pol.encoder(x[..., :ref]))
-        xdec = torch.empty((n, Z + x.shape[1] - ref), dtype=torch.float32, device=self.dev)
-        L = _hip.lib()
+        lds_free = self.lds_free and obs_raw is not None
+        if lds_free:     # element-wise normalisation keeps the [obs][n_env] memory layout of the env's buffer (and uses no LDS)
+            x = self.normalizer.normalize(obs_raw) if self.normalize_observations else obs_raw
+        src = x
+        n, W = src.shape
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(self.dev):
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-            _hip.check(L.tmjx_latent_concat(*[C.c_void_p(t.data_ptr()) for t in (fc2, eps, x, xdec)], n, Z, x.shape[1], ref,
-                                            x.stride(0), x.stride(1), stream), "tmjx_latent_concat")
-            logits = pol.head(pol.decoder(xdec))
-            noise = torch.randn((n, A), generator=self.gen, device=self.dev)
-            raw = torch.empty((n, A), dtype=torch.float32, device=self.dev)
-            action_t = torch.empty((A, n), dtype=torch.float32, device=self.dev)
-            logp = torch.empty(n, dtype=torch.float32, device=self.dev)
-            _hip.check(L.tmjx_sample_action(*[C.c_void_p(t.data_ptr()) for t in (logits, noise, raw, action_t, logp)], n, A, stream),
-                       "tmjx_sample_action")
+
+            def linear(a, sa_row, sa_k, K, lin, bias=True):
+                out = torch.empty((n, lin.out_features), **f32)
+                _hip.check(L.tmjx_linear_nolds(p(a), sa_row, sa_k, p(lin.weight), p(lin.bias) if bias else None, p(out),
+                                               n, lin.out_features, K, stream), "tmjx_linear_nolds")
+                return out
+
+            def block(a, sa_row, sa_k, K, blk):
+                z = linear(a, sa_row, sa_k, K, blk.dense, bias=False)
+                y = torch.empty_like(z)
+                stats = torch.empty((n, 2), **f32)
+                _hip.check(L.tmjx_silu_ln_fwd(p(z), p(blk.dense.bias), p(blk.norm.weight), p(blk.norm.bias), p(y), p(stats), n,
+                                              blk.dense.out_features, float(blk.norm.eps), stream), "tmjx_silu_ln_fwd")
+                return y
+
+            eps = torch.randn((n, Z), generator=gen, device=self.dev)
+            if lds_free:
+                h, first = None, True
+                for blk in pol.encoder:
+                    h = block(src, src.stride(0), src.stride(1), ref, blk) if first else block(h, h.shape[1], 1, h.shape[1], blk)
+                    first = False
+                fc2 = linear(h, h.shape[1], 1, h.shape[1], pol.fc2)
+            else:
+                fc2 = pol.fc2(pol.encoder(x[..., :ref]))
+            xdec = torch.empty((n, Z + W - ref), **f32)
+            fold = False
+            _hip.check(L.tmjx_latent_concat(p(fc2), p(eps), p(src), p(xdec), n, Z, W, ref, src.stride(0), src.stride(1),
+                                            p(self.normalizer.mean) if fold else None, p(self.normalizer.std) if fold else None, stream),
+                       "tmjx_latent_concat")
+            if lds_free:
+                h = xdec
+                for blk in pol.decoder:
+                    h = block(h, h.shape[1], 1, h.shape[1], blk)
+                logits = linear(h, h.shape[1], 1, h.shape[1], pol.head)
+            else:
+                logits = pol.head(pol.decoder(xdec))
+            noise = torch.randn((n, A), generator=gen, device=self.dev)
+            raw = torch.empty((n, A), **f32)
+            action_t = torch.empty((A, n), **f32)
+            logp = torch.empty(n, **f32)
+            _hip.check(L.tmjx_sample_action(p(logits), p(noise), p(raw), p(action_t), p(logp), n, A, stream), "tmjx_sample_action")
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
         return action_t.t(), {"raw_action": raw, "log_prob": logp, "logits": logits, "latent_mean": mean, "latent_logvar": logvar}
 
-    def _act_graphed(self, obs: torch.Tensor):
-        """act() replayed as one hipGraph (~45 launches of the policy inference per control step).  Valid while `obs` is the
-        env's persistent observation buffer (same pointer every step); falls back to eager launches otherwise."""
+    def _act_graphed(self, obs: torch.Tensor, g: int = 0):
+        """act() replayed as one hipGraph per env group.  Valid while `obs` is the group's persistent observation buffer (same
+        pointer every step); falls back to eager launches otherwise."""
+        gen = self.gens[g]
         if not (self.use_graph and self.dev.type == "cuda"):
-            return self.act(obs)
+            return self.act(obs, gen=gen)
         key = (obs.data_ptr(), tuple(obs.shape), tuple(obs.stride()))
-        if self._act_graph is None or self._act_key != key:
+        ent = self._act_graphs.get(g)
+        if ent is None or ent[1] != key:
             try:
+                cur = torch.cuda.current_stream(self.dev)
                 side = torch.cuda.Stream(device=self.dev)
-                side.wait_stream(torch.cuda.current_stream(self.dev))
+                side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     for _ in range(2):
-                        self.act(obs)
-                torch.cuda.current_stream(self.dev).wait_stream(side)
+                        self.act(obs, gen=gen)
+                cur.wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                graph.register_generator_state(self.gen)
+                graph.register_generator_state(gen)
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    action, extra = self.act(obs)
-                self._act_graph, self._act_key, self._act_out = graph, key, (action, extra)
+                    out = self.act(obs, gen=gen)
+                ent = (graph, key, out)
             except Exception as e:  # noqa: BLE001
                 print(f"[track_mjx_amd] hipGraph capture of the policy inference failed ({type(e).__name__}: {e}); running eagerly", flush=True)
-                self._act_graph, self._act_key = False, key
+                ent = (False, key, None)
                 torch.cuda.synchronize(self.dev)
-        if self._act_graph is False:
-            return self.act(obs)
-        self._act_graph.replay()
-        return self._act_out
+            self._act_graphs[g] = ent
+        if ent[0] is False:
+            return self.act(obs, gen=gen)
+        ent[0].replay()
+        return ent[2]
 
     @torch.no_grad()
     def collect(self) -> None:
-        env, n, T = self.env, self.env.num_envs, self.T
-        st = self.state
+        T, n_local = self.T, self.n_local
+        offs = [0]
+        for e in self.envs:
+            offs.append(offs[-1] + e.num_envs)
+        cur = torch.cuda.current_stream(self.dev) if self._streams else None
+        if self._streams:
+            for sg in self._streams:
+                sg.wait_stream(cur)        # parameters / normaliser written by the previous update()
         for u in range(self.unrolls):
-            sl = slice(u * n, (u + 1) * n)
             for t in range(T):
-                self.buf["observation"][t, sl] = st.obs
-                action, extra = self._act_graphed(st.obs)
-                self.buf["raw_action"][t, sl] = extra["raw_action"]     # before env.step: the graph's outputs are re-used next step
-                self.buf["log_prob"][t, sl] = extra["log_prob"]
-                st = env.step(st, action)
-                self.buf["reward"][t, sl] = st.reward
-                self.buf["discount"][t, sl] = 1.0 - st.done
-                self.buf["truncation"][t, sl] = st.info["truncation"]
-            self.buf["next_observation_last"][sl] = st.obs
-        self.state = st
+                for g, env in enumerate(self.envs):
+                    sl = slice(u * n_local + offs[g], u * n_local + offs[g + 1])
+                    with torch.cuda.stream(self._streams[g]) if self._streams else _nullctx():
+                        st = self.states[g]
+                        self.buf["observation"][t, sl] = st.obs
+                        action, extra = self._act_graphed(st.obs, g)
+                        self.buf["raw_action"][t, sl] = extra["raw_action"]     # before env.step: the graph's outputs are re-used next step
+                        self.buf["log_prob"][t, sl] = extra["log_prob"]
+                        st = env.step(st, action)
+                        self.buf["reward"][t, sl] = st.reward
+                        self.buf["discount"][t, sl] = 1.0 - st.done
+                        self.buf["truncation"][t, sl] = st.info["truncation"]
+                        self.states[g] = st
+            for g in range(len(self.envs)):
+                sl = slice(u * n_local + offs[g], u * n_local + offs[g + 1])
+                with torch.cuda.stream(self._streams[g]) if self._streams else _nullctx():
+                    self.buf["next_observation_last"][sl] = self.states[g].obs
+        if self._streams:
+            for sg in self._streams:
+                cur.wait_stream(sg)
 
     # ---- learning
     def _minibatch_grads(self, idx: torch.Tensor, kl_w: float) -> torch.Tensor:

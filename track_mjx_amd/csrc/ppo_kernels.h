@@ -302,13 +302,14 @@ __global__ __launch_bounds__(256) void k_gather_normalize(const float *__restric
 // ---- policy inference tails (make_inference_fn, ppo_networks.py:46-96; reparameterize, intention_network.py:78-88)
 // latent sample + decoder input in one pass:  x[i] = [ mean + eps * exp(logvar / 2)  |  obs[i][ref:] ]
 __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__ fc2, const float *__restrict__ eps, const float *__restrict__ obs,
-                                                       float *__restrict__ x, int n, int Z, int obs_w, int ref_w, long long obs_s0, long long obs_s1) {
+                                                       float *__restrict__ x, int n, int Z, int obs_w, int ref_w, long long obs_s0, long long obs_s1,
+                                                       const float *__restrict__ mean, const float *__restrict__ stdv) {
   const int W = Z + obs_w - ref_w;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * W; i += (size_t)gridDim.x * 256) {
     int c = (int)(i % W); size_t e = i / W;
     float v;
     if (c < Z) v = fc2[e * 2 * Z + c] + eps[e * Z + c] * expf(0.5f * fc2[e * 2 * Z + Z + c]);
-    else v = obs[(long long)e * obs_s0 + (long long)(ref_w + c - Z) * obs_s1];
+    else { int k = ref_w + c - Z; v = obs[(long long)e * obs_s0 + (long long)k * obs_s1]; if (mean) v = (v - mean[k]) / stdv[k]; }
     x[i] = v;
   }
 }
@@ -328,4 +329,67 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_sample_action(const float *__rest
   }
   lp = ppo_group_sum(lp);
   if (e < n && sub == 0) logp[e] = lp;
+}
+
+// ---- LDS-free dense layer for the policy inference that runs NEXT TO the physics kernel --------------------------------------
+// C[M][N] = A' W^T + bias, A'[i][k] = (A[i * sa_row + k * sa_k] - mean[k]) / std[k] (mean == nullptr: A as is), W [N][K] row-major.
+// The wave-per-env physics kernel owns all 160 KB of LDS of every CU for ~2 ms at a time; a library GEMM (LDS tiles) launched
+// on another stream cannot start until physics workgroups retire.  This kernel keeps its 4 x 4 register tile per thread in
+// VGPRs and reads operands through L1/L2 only, so it co-runs with the physics kernel and its time disappears behind it.
+// Throughput is modest (plain v_fma, ~10 TFLOP/s) and irrelevant: the whole inference is 1.7 GFLOP per 2048 envs.
+#define NL_TM 4
+#define NL_TN 4
+// V = vector width of the loads along K (largest of 4 / 2 / 1 dividing K, with 4 V-byte aligned rows); A_KMAJOR: A[i][k] at
+// A[k * sa_k + i] (the env-minor observation buffer): one float4 then fetches the thread's four consecutive rows.
+template <int V> struct NlVec;
+template <> struct NlVec<4> { typedef float4 T; };
+template <> struct NlVec<2> { typedef float2 T; };
+template <> struct NlVec<1> { typedef float T; };
+template <int V> __device__ __forceinline__ void nl_unpack(const typename NlVec<V>::T &v, float *o);
+template <> __device__ __forceinline__ void nl_unpack<4>(const float4 &v, float *o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void nl_unpack<2>(const float2 &v, float *o) { o[0] = v.x; o[1] = v.y; }
+template <> __device__ __forceinline__ void nl_unpack<1>(const float &v, float *o) { o[0] = v; }
+
+template <int V, bool A_KMAJOR>
+__global__ __launch_bounds__(128) void k_linear_nolds(const float *__restrict__ A, long long sa_row, long long sa_k, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K) {
+  typedef typename NlVec<V>::T VT;
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;                   // 16 x 8 threads: a 64-row x 32-column tile per workgroup
+  const int row0 = blockIdx.x * 64 + ty * NL_TM, col0 = blockIdx.y * 32 + tx * NL_TN;
+  float acc[NL_TM][NL_TN];
+#pragma unroll
+  for (int i = 0; i < NL_TM; i++)
+#pragma unroll
+    for (int j = 0; j < NL_TN; j++) acc[i][j] = 0.f;
+  int cc[NL_TN];
+#pragma unroll
+  for (int j = 0; j < NL_TN; j++) cc[j] = col0 + j < N ? col0 + j : N - 1;      // clamp: out-of-range tiles compute duplicates, never store
+  const int rbase = row0 + NL_TM <= M ? row0 : (M >= NL_TM ? M - NL_TM : 0);     // K-major loads need 4 valid consecutive rows
+  for (int k = 0; k < K; k += V) {
+    float a[NL_TM][V], w[NL_TN][V];
+    if (A_KMAJOR) {
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        float4 t = *reinterpret_cast<const float4 *>(A + (long long)(k + v) * sa_k + rbase);
+        a[0][v] = t.x; a[1][v] = t.y; a[2][v] = t.z; a[3][v] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL_TM; i++) { int r = row0 + i < M ? row0 + i : M - 1; nl_unpack<V>(*reinterpret_cast<const VT *>(A + (long long)r * sa_row + k), a[i]); }
+    }
+#pragma unroll
+    for (int j = 0; j < NL_TN; j++) nl_unpack<V>(*reinterpret_cast<const VT *>(W + (size_t)cc[j] * K + k), w[j]);
+#pragma unroll
+    for (int v = 0; v < V; v++)
+#pragma unroll
+      for (int i = 0; i < NL_TM; i++)
+#pragma unroll
+        for (int j = 0; j < NL_TN; j++) acc[i][j] = fmaf(a[i][v], w[j][v], acc[i][j]);
+  }
+  const int rout = A_KMAJOR ? rbase : row0;
+#pragma unroll
+  for (int i = 0; i < NL_TM; i++)
+#pragma unroll
+    for (int j = 0; j < NL_TN; j++)
+      if (rout + i < M && col0 + j < N && (!A_KMAJOR || rout == row0 || rout + i >= row0)) C[(size_t)(rout + i) * N + col0 + j] = acc[i][j] + (bias ? bias[col0 + j] : 0.f);
 }

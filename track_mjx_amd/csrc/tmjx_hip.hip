@@ -507,12 +507,12 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
 }
 
 int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
-                       int64_t obs_s0, int64_t obs_s1, void *stream) {
+                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, void *stream) {
   if (!fc2 || !eps || !obs || !x) return fail(TMJX_EINVAL, "null argument");
   if (n < 1 || Z < 1 || ref_w < 0 || obs_w < ref_w) return fail(TMJX_EINVAL, "bad sizes");
   size_t total = (size_t)n * (Z + obs_w - ref_w);
   int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1);
+  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1, mean, std);
   return check_launch("k_latent_concat");
 }
 
@@ -521,6 +521,26 @@ int tmjx_sample_action(const float *logits, const float *noise, float *raw, floa
   if (n < 1 || A < 1) return fail(TMJX_EINVAL, "bad sizes");
   hipLaunchKernelGGL(k_sample_action, dim3((n * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK), dim3(PPO_BLOCK), 0, (hipStream_t)stream, logits, noise, raw, action_t, logp, n, A);
   return check_launch("k_sample_action");
+}
+
+int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
+                      void *stream) {
+  if (!A || !W || !C) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1) return fail(TMJX_EINVAL, "bad sizes");
+  const bool kmajor = sa_row == 1 && sa_k != 1;
+  if (!kmajor && sa_k != 1) return fail(TMJX_EINVAL, "A must be row-major (sa_k == 1) or K-major (sa_row == 1)");
+  if (kmajor && ((M & 3) || (sa_k & 3) || ((uintptr_t)A & 15))) return fail(TMJX_EINVAL, "K-major A needs M % 4 == 0 and 16-byte aligned columns");
+  // widest vector along K that keeps every row of W (and of a row-major A) aligned
+  int V = 1;
+  if (!(K & 3) && !((uintptr_t)W & 15) && (kmajor || (!(sa_row & 3) && !((uintptr_t)A & 15)))) V = 4;
+  else if (!(K & 1) && !((uintptr_t)W & 7) && (kmajor || (!(sa_row & 1) && !((uintptr_t)A & 7)))) V = 2;
+  dim3 grid((M + 63) / 64, (N + 31) / 32), block(128);
+  hipStream_t s = (hipStream_t)stream;
+#define TMJX_NL(VV, KM) hipLaunchKernelGGL((k_linear_nolds<VV, KM>), grid, block, 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K)
+  if (kmajor) { if (V == 4) TMJX_NL(4, true); else if (V == 2) TMJX_NL(2, true); else TMJX_NL(1, true); }
+  else { if (V == 4) TMJX_NL(4, false); else if (V == 2) TMJX_NL(2, false); else TMJX_NL(1, false); }
+#undef TMJX_NL
+  return check_launch("k_linear_nolds");
 }
 
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {
