@@ -131,11 +131,11 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
 /* Policy inference tails (ppo_networks.py:46-96, intention_network.py:78-88).
  * tmjx_latent_concat: x[i] = [ mean_i + eps_i * exp(logvar_i / 2) | obs_i[ref_w:] ], fc2 [n][2Z] = mean | logvar, eps [n][Z], obs
  *   addressed as obs[i * obs_s0 + c * obs_s1] (so the [obs][n_env] buffer of tmjx_step can be passed as is) and normalised with
- *   (. - mean[c]) / std[c] when mean != NULL, x [n][Z + obs_w - ref_w].
+ *   (. - mean[c]) / std[c] when mean != NULL, x [n][x_stride >= Z + obs_w - ref_w] (columns beyond are left alone).
  * tmjx_sample_action: raw = loc + (softplus(raw_scale) + 0.001) * noise; action = tanh(raw) written as [A][n] (the layout
  *   tmjx_step takes); logp = NormalTanh log-prob of the sample; logits [n][2A], noise / raw [n][A], logp [n]. */
 int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
-                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, void *stream);
+                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, int x_stride, void *stream);
 int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, void *stream);
 
 /* LDS-free dense layer (policy inference next to the physics kernel, which owns every CU's LDS):

@@ -115,6 +115,7 @@ class PPOLearner:
         self.matmul_dtype = matmul_dtype
         self.use_graph, self._graph, self._graph_kl = use_graph, None, None
         self._act_graphs: dict = {}
+        self._wpad: dict = {}
         self.lds_free = len(self.envs) > 1 and dev.type == "cuda"   # pipelined roll-outs: LDS-free inference kernels (see _act_fused)
         self.states = [None] * len(self.envs)
         self._streams = [torch.cuda.Stream(device=dev) for _ in self.envs] if (len(self.envs) > 1 and dev.type == "cuda") else None
@@ -173,9 +174,12 @@ class PPOLearner:
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
             def linear(a, sa_row, sa_k, K, lin, bias=True):
+                # weights whose row length is not a multiple of 4 are used through a zero-padded copy (refreshed at the start of
+                # every collect()): the kernel then takes its float4 path; the extra k read finite activations x 0
+                w = self._padded_weight(lin)
                 out = torch.empty((n, lin.out_features), **f32)
-                _hip.check(L.tmjx_linear_nolds(p(a), sa_row, sa_k, p(lin.weight), p(lin.bias) if bias else None, p(out),
-                                               n, lin.out_features, K, stream), "tmjx_linear_nolds")
+                _hip.check(L.tmjx_linear_nolds(p(a), sa_row, sa_k, p(w), p(lin.bias) if bias else None, p(out),
+                                               n, lin.out_features, w.shape[1], stream), "tmjx_linear_nolds")
                 return out
 
             def block(a, sa_row, sa_k, K, blk):
@@ -195,11 +199,10 @@ class PPOLearner:
                 fc2 = linear(h, h.shape[1], 1, h.shape[1], pol.fc2)
             else:
                 fc2 = pol.fc2(pol.encoder(x[..., :ref]))
-            xdec = torch.empty((n, Z + W - ref), **f32)
-            fold = False
-            _hip.check(L.tmjx_latent_concat(p(fc2), p(eps), p(src), p(xdec), n, Z, W, ref, src.stride(0), src.stride(1),
-                                            p(self.normalizer.mean) if fold else None, p(self.normalizer.std) if fold else None, stream),
-                       "tmjx_latent_concat")
+            wdec = Z + W - ref
+            xdec = torch.zeros((n, (wdec + 3) // 4 * 4), **f32) if lds_free else torch.empty((n, wdec), **f32)
+            _hip.check(L.tmjx_latent_concat(p(fc2), p(eps), p(src), p(xdec), n, Z, W, ref, src.stride(0), src.stride(1), None, None,
+                                            xdec.shape[1], stream), "tmjx_latent_concat")
             if lds_free:
                 h = xdec
                 for blk in pol.decoder:
@@ -214,6 +217,21 @@ class PPOLearner:
             _hip.check(L.tmjx_sample_action(p(logits), p(noise), p(raw), p(action_t), p(logp), n, A, stream), "tmjx_sample_action")
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
         return action_t.t(), {"raw_action": raw, "log_prob": logp, "logits": logits, "latent_mean": mean, "latent_logvar": logvar}
+
+    def _padded_weight(self, lin) -> torch.Tensor:
+        K = lin.in_features
+        if K % 4 == 0:
+            return lin.weight
+        buf = self._wpad.get(lin)
+        if buf is None:
+            buf = torch.zeros((lin.out_features, (K + 3) // 4 * 4), dtype=torch.float32, device=self.dev)
+            buf[:, :K].copy_(lin.weight.detach())
+            self._wpad[lin] = buf
+        return buf
+
+    def _refresh_padded_weights(self) -> None:
+        for lin, buf in self._wpad.items():
+            buf[:, :lin.in_features].copy_(lin.weight.detach())
 
     def _act_graphed(self, obs: torch.Tensor, g: int = 0):
         """act() replayed as one hipGraph per env group.  Valid while `obs` is the group's persistent observation buffer (same
@@ -253,6 +271,7 @@ class PPOLearner:
         offs = [0]
         for e in self.envs:
             offs.append(offs[-1] + e.num_envs)
+        self._refresh_padded_weights()
         cur = torch.cuda.current_stream(self.dev) if self._streams else None
         if self._streams:
             for sg in self._streams:

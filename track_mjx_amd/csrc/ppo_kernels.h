@@ -303,14 +303,14 @@ __global__ __launch_bounds__(256) void k_gather_normalize(const float *__restric
 // latent sample + decoder input in one pass:  x[i] = [ mean + eps * exp(logvar / 2)  |  obs[i][ref:] ]
 __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__ fc2, const float *__restrict__ eps, const float *__restrict__ obs,
                                                        float *__restrict__ x, int n, int Z, int obs_w, int ref_w, long long obs_s0, long long obs_s1,
-                                                       const float *__restrict__ mean, const float *__restrict__ stdv) {
+                                                       const float *__restrict__ mean, const float *__restrict__ stdv, int x_stride) {
   const int W = Z + obs_w - ref_w;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * W; i += (size_t)gridDim.x * 256) {
     int c = (int)(i % W); size_t e = i / W;
     float v;
     if (c < Z) v = fc2[e * 2 * Z + c] + eps[e * Z + c] * expf(0.5f * fc2[e * 2 * Z + Z + c]);
     else { int k = ref_w + c - Z; v = obs[(long long)e * obs_s0 + (long long)k * obs_s1]; if (mean) v = (v - mean[k]) / stdv[k]; }
-    x[i] = v;
+    x[e * (size_t)x_stride + c] = v;
   }
 }
 // action sample, tanh post-processing and log-prob of the sample: one lane group of PPO_G per env
@@ -365,20 +365,37 @@ __global__ __launch_bounds__(128) void k_linear_nolds(const float *__restrict__ 
 #pragma unroll
   for (int j = 0; j < NL_TN; j++) cc[j] = col0 + j < N ? col0 + j : N - 1;      // clamp: out-of-range tiles compute duplicates, never store
   const int rbase = row0 + NL_TM <= M ? row0 : (M >= NL_TM ? M - NL_TM : 0);     // K-major loads need 4 valid consecutive rows
+  int rr[NL_TM];
+#pragma unroll
+  for (int i = 0; i < NL_TM; i++) rr[i] = row0 + i < M ? row0 + i : M - 1;
+  // register double buffering: the operands of step k + V are in flight while step k is multiplied (one or two waves per SIMD
+  // is all this kernel gets next to the physics kernel, so nothing else hides the L1/L2 latency)
+  VT an[NL_TM], wn[NL_TN];
+  float4 akn[V];
+  auto load = [&](int k) {
+    if (A_KMAJOR) {
+#pragma unroll
+      for (int v = 0; v < V; v++) akn[v] = *reinterpret_cast<const float4 *>(A + (long long)(k + v) * sa_k + rbase);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL_TM; i++) an[i] = *reinterpret_cast<const VT *>(A + (long long)rr[i] * sa_row + k);
+    }
+#pragma unroll
+    for (int j = 0; j < NL_TN; j++) wn[j] = *reinterpret_cast<const VT *>(W + (size_t)cc[j] * K + k);
+  };
+  load(0);
   for (int k = 0; k < K; k += V) {
     float a[NL_TM][V], w[NL_TN][V];
     if (A_KMAJOR) {
 #pragma unroll
-      for (int v = 0; v < V; v++) {
-        float4 t = *reinterpret_cast<const float4 *>(A + (long long)(k + v) * sa_k + rbase);
-        a[0][v] = t.x; a[1][v] = t.y; a[2][v] = t.z; a[3][v] = t.w;
-      }
+      for (int v = 0; v < V; v++) { a[0][v] = akn[v].x; a[1][v] = akn[v].y; a[2][v] = akn[v].z; a[3][v] = akn[v].w; }
     } else {
 #pragma unroll
-      for (int i = 0; i < NL_TM; i++) { int r = row0 + i < M ? row0 + i : M - 1; nl_unpack<V>(*reinterpret_cast<const VT *>(A + (long long)r * sa_row + k), a[i]); }
+      for (int i = 0; i < NL_TM; i++) nl_unpack<V>(an[i], a[i]);
     }
 #pragma unroll
-    for (int j = 0; j < NL_TN; j++) nl_unpack<V>(*reinterpret_cast<const VT *>(W + (size_t)cc[j] * K + k), w[j]);
+    for (int j = 0; j < NL_TN; j++) nl_unpack<V>(wn[j], w[j]);
+    if (k + V < K) load(k + V);
 #pragma unroll
     for (int v = 0; v < V; v++)
 #pragma unroll

@@ -507,12 +507,12 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
 }
 
 int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
-                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, void *stream) {
+                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, int x_stride, void *stream) {
   if (!fc2 || !eps || !obs || !x) return fail(TMJX_EINVAL, "null argument");
-  if (n < 1 || Z < 1 || ref_w < 0 || obs_w < ref_w) return fail(TMJX_EINVAL, "bad sizes");
+  if (n < 1 || Z < 1 || ref_w < 0 || obs_w < ref_w || x_stride < Z + obs_w - ref_w) return fail(TMJX_EINVAL, "bad sizes");
   size_t total = (size_t)n * (Z + obs_w - ref_w);
   int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1, mean, std);
+  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1, mean, std, x_stride);
   return check_launch("k_latent_concat");
 }
 

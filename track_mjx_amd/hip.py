@@ -85,7 +85,7 @@ def lib():
     L.tmjx_silu_ln_fwd.argtypes = [fp] * 6 + [C.c_int, C.c_int, C.c_float, vp]
     L.tmjx_silu_ln_bwd.argtypes = [fp] * 8 + [C.c_int, C.c_int, vp]
     L.tmjx_gather_normalize.argtypes = [fp] * 5 + [C.c_int] * 4 + [vp]
-    L.tmjx_latent_concat.argtypes = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, vp]
+    L.tmjx_latent_concat.argtypes = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, C.c_int, vp]
     L.tmjx_sample_action.argtypes = [fp] * 5 + [C.c_int, C.c_int, vp]
     L.tmjx_linear_nolds.argtypes = [fp, C.c_int64, C.c_int64, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
     L.tmjx_debug_rows.argtypes = [vp, C.c_char_p, ip, ip]
