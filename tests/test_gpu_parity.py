@@ -478,3 +478,30 @@ def test_fused_inference_tail_matches_torch_path():
     assert torch.allclose(e_l["logits"], logits, rtol=1e-3, atol=2e-4), float((e_l["logits"] - logits).abs().max())
     assert torch.allclose(e_l["raw_action"], raw, rtol=1e-3, atol=3e-4)
     assert torch.allclose(a_l, torch.tanh(raw), rtol=1e-3, atol=3e-4)
+
+
+@pytest.mark.gpu
+def test_pipelined_rollout_two_env_groups():
+    """PPOLearner with a LIST of envs (bench.py --pipeline 2): the groups' roll-outs run on separate HIP streams with the LDS-free
+    inference.  The roll-out buffer must hold each group's rows in its own slice, and a full training step must stay finite."""
+    from track_mjx_amd.agent import ppo
+    envs = [make_env_and_oracle(num_envs=64, n_clips=4, wrappers=True, seed=k)[0] for k in range(2)]
+    L = ppo.PPOLearner(envs, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=5,
+                       batch_size=32, num_minibatches=4, num_updates_per_batch=2, seed=3)
+    assert L.lds_free and L.n_local == 128 and L.unrolls == 1
+    first = []
+    for k, e in enumerate(envs):
+        L.states[k] = e.reset(torch.Generator().manual_seed(10 + k))
+        first.append(L.states[k].obs.clone())
+    before = L.grads.params[0].detach().clone()
+    L.collect()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(L.buf["observation"][0, 64 * k:64 * (k + 1)], first[k])
+        assert torch.equal(L.buf["next_observation_last"][64 * k:64 * (k + 1)], L.states[k].obs)
+    for name, v in L.buf.items():
+        assert torch.isfinite(v).all(), name
+    m = L.update(1)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in m.values())
+    assert not torch.equal(before, L.grads.params[0].detach())

@@ -385,8 +385,10 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
     ppo.py:469-475 (wrappers.wrap with the default use_lstm=True wrapper semantics)."""
     from ..environment import wrap
-    env = wrap(environment, episode_length=int(episode_length), action_repeat=1)
-    learner = PPOLearner(env, encoder_layers=encoder_hidden_layer_sizes, decoder_layers=decoder_hidden_layer_sizes,
+    # a list of environments = equal groups of this rank's envs whose roll-outs are pipelined on separate HIP streams (collect())
+    env_list = [wrap(e, episode_length=int(episode_length), action_repeat=1) for e in (environment if isinstance(environment, (list, tuple)) else [environment])]
+    env = env_list[0]
+    learner = PPOLearner(env_list if len(env_list) > 1 else env, encoder_layers=encoder_hidden_layer_sizes, decoder_layers=decoder_hidden_layer_sizes,
                          critic_layers=value_hidden_layer_sizes, latents=intention_latent_size, learning_rate=learning_rate,
                          entropy_cost=entropy_cost, discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
                          clipping_epsilon=clipping_epsilon, unroll_length=unroll_length, batch_size=batch_size,
@@ -397,7 +399,11 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     steps_per_epoch = int(math.ceil(num_timesteps / (num_evals_after_init * env_step_per_training_step * max(num_resets_per_eval, 1))))
     kl_schedule = _losses.create_ramp_schedule(max_value=kl_weight, ramp_steps=max(int(num_evals * 0.25), 1)) if use_kl_schedule else None
     reset_gen = torch.Generator().manual_seed(seed + 1 + learner.rank)
-    learner.state = env.reset(reset_gen)
+
+    def reset_all():
+        for k, e in enumerate(env_list):
+            learner.states[k] = e.reset(reset_gen)
+    reset_all()
     # evaluator (ppo.py:629-668): an env of `num_eval_envs` wrapped like the training env; process 0 only (ppo.py:744)
     evaluator = None
     if eval_env is not None and learner.rank == 0:
@@ -424,7 +430,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
             metrics = {"training/sps": n_done * env_step_per_training_step / dt, "training/walltime": dt,
                        **{f"training/{k}": float(v / n_done) for k, v in acc.items()}}
             if num_resets_per_eval > 0:
-                learner.state = env.reset(reset_gen)
+                reset_all()
             if max_training_steps is not None and done_steps >= max_training_steps:
                 break
         if learner.rank == 0:

@@ -47,7 +47,12 @@ def main(argv=None) -> None:
         dist.init_process_group("nccl", device_id=device)
     tc = cfg["train_setup"]["train_config"]
     lo, hi = ppo.shard_range(int(tc["num_envs"]), int(os.environ.get("RANK", "0")), world)
-    env = build_env(cfg, hi - lo, device, n_clips=int(cfg.get("n_synthetic_clips", 64)))
+    # `rollout_groups` equal env groups per rank (default 2): their roll-outs are pipelined on separate HIP streams (agent/ppo.py)
+    ngrp = int(cfg.get("rollout_groups", 2))
+    if ngrp < 1 or (hi - lo) % ngrp:
+        ngrp = 1
+    envs = [build_env(cfg, (hi - lo) // ngrp, device, n_clips=int(cfg.get("n_synthetic_clips", 64))) for _ in range(ngrp)]
+    env = envs[0]
     rc, ts = cfg["reference_config"], cfg["train_setup"]
     # train.py:221-225
     episode_length = (rc["clip_length"] - rc["random_init_range"] - rc["traj_length"]) * env._steps_for_cur_frame
@@ -62,7 +67,7 @@ def main(argv=None) -> None:
     def progress(num_steps, metrics):
         print(f"[train] steps={num_steps} " + " ".join(f"{k}={v:.4g}" for k, v in sorted(metrics.items())), flush=True)
 
-    ppo.train(env, num_timesteps=tc["num_timesteps"], episode_length=int(episode_length), num_evals=num_evals,
+    ppo.train(envs if ngrp > 1 else env, num_timesteps=tc["num_timesteps"], episode_length=int(episode_length), num_evals=num_evals,
               num_resets_per_eval=num_resets_per_eval, learning_rate=tc["learning_rate"], entropy_cost=tc["entropy_cost"],
               discounting=tc["discounting"], seed=tc["seed"], unroll_length=tc["unroll_length"], batch_size=tc["batch_size"],
               num_minibatches=tc["num_minibatches"], num_updates_per_batch=tc["num_updates_per_batch"],
