@@ -136,7 +136,7 @@ class PPOLearner:
     def act(self, obs: torch.Tensor, deterministic: bool = False, gen: torch.Generator | None = None):
         gen = self.gen if gen is None else gen
         if (not deterministic and self.dev.type == "cuda" and self.matmul_dtype is None and obs.dim() == 2 and obs.dtype == torch.float32):
-            if self.lds_free:
+            if self.lds_free and obs.shape[0] % 4 == 0 and obs.stride(0) == 1:     # K-major float4 loads need 4 | n_env
                 return self._act_fused(None, obs_raw=obs, gen=gen)
             return self._act_fused(self.normalizer.normalize(obs) if self.normalize_observations else obs, gen=gen)
         x = self.normalizer.normalize(obs) if self.normalize_observations else obs
