@@ -123,41 +123,41 @@ __global__ void k_autoreset(const DModel *__restrict__ mp, float *st, float *obs
 }
 
 // Env-major physics record of K2: rec[e][0 .. s_prev_ctrl) = the state rows qpos .. qfrc_actuator of env e (physics state + the
-// outputs K3 reads), rec[e][s_prev_ctrl .. + nu) = the action.  32 x 32 LDS-tiled transposes, coalesced on both sides: the
-// wave-per-env kernel then reads / writes contiguous words (without this each of its 4-byte accesses to the [row][n_env] buffers
-// occupied its own 32-byte sector: 131 MB of HBM traffic per launch for 14 MB of data, profiles/pmc_traffic.json).
-__global__ __launch_bounds__(256) void k_rec_in(const DModel *__restrict__ mp, const float *__restrict__ st, const float *__restrict__ action,
-                                                float *__restrict__ rec, int n, int rs) {
-  __shared__ float tile[32][33];
+// outputs K3 reads), rec[e][s_prev_ctrl .. + nu) = the action.  The wave-per-env kernel then reads / writes contiguous words
+// (without this each of its 4-byte accesses to the [row][n_env] buffers occupied its own 32-byte sector: 131 MB of HBM traffic
+// per launch for 14 MB of data, profiles/pmc_traffic.json).  The two transposes use NO LDS: with pipelined env groups they are
+// launched while the other group's physics kernel owns every CU's LDS, and an LDS-tiled version sat in the queue for up to
+// 1.2 ms waiting for it.  One lane = one env and 16 consecutive rows: the [row][n_env] side is coalesced across lanes, the
+// record side is four float4 accesses per lane whose 64-byte lines are completed by the lane itself (L1 / L2 absorb them).
+#define REC_ROWS_PER_THREAD 16
+__global__ __launch_bounds__(64) void k_rec_in(const DModel *__restrict__ mp, const float *__restrict__ st, const float *__restrict__ action,
+                                               float *__restrict__ rec, int n, int rs) {
   const DModel &m = *mp;
-  const int e0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // rows: nphys state rows, then nu action rows
+  const int e = blockIdx.x * 64 + threadIdx.x, r0 = blockIdx.y * REC_ROWS_PER_THREAD;     // rows: nphys state rows, then nu action rows
   const int nrow = m.nphys + m.nu;
-  for (int j = ty; j < 32; j += 8) {
-    int r = r0 + j, e = e0 + tx;
-    float v = 0.f;
-    if (r < nrow && e < n) v = r < m.nphys ? st[(size_t)(m.s_qpos + r) * n + e] : action[(size_t)(r - m.nphys) * n + e];
-    tile[j][tx] = v;
+  if (e >= n) return;
+  float v[REC_ROWS_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < REC_ROWS_PER_THREAD; j++) {
+    int r = r0 + j;
+    v[j] = r < m.nphys ? st[(size_t)(m.s_qpos + r) * n + e] : (r < nrow ? action[(size_t)(r - m.nphys) * n + e] : 0.f);
   }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    int e = e0 + j, r = r0 + tx;
-    if (r < nrow && e < n) rec[(size_t)e * rs + (r < m.nphys ? m.s_qpos + r : m.s_prev_ctrl + (r - m.nphys))] = tile[tx][j];
+#pragma unroll
+  for (int j = 0; j < REC_ROWS_PER_THREAD; j++) {
+    int r = r0 + j;
+    if (r < nrow) rec[(size_t)e * rs + (r < m.nphys ? m.s_qpos + r : m.s_prev_ctrl + (r - m.nphys))] = v[j];
   }
 }
-__global__ __launch_bounds__(256) void k_rec_out(const DModel *__restrict__ mp, float *__restrict__ st, const float *__restrict__ rec, int n, int rs) {
-  __shared__ float tile[32][33];
+__global__ __launch_bounds__(64) void k_rec_out(const DModel *__restrict__ mp, float *__restrict__ st, const float *__restrict__ rec, int n, int rs) {
   const DModel &m = *mp;
-  const int e0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int e = blockIdx.x * 64 + threadIdx.x, r0 = blockIdx.y * REC_ROWS_PER_THREAD;
   const int nrow = m.s_prev_ctrl - m.s_qpos;      // physics state + xpos / torso xmat / qfrc_actuator
-  for (int j = ty; j < 32; j += 8) {
-    int e = e0 + j, r = r0 + tx;
-    tile[j][tx] = (r < nrow && e < n) ? rec[(size_t)e * rs + m.s_qpos + r] : 0.f;
-  }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    int r = r0 + j, e = e0 + tx;
-    if (r < nrow && e < n) st[(size_t)(m.s_qpos + r) * n + e] = tile[tx][j];
-  }
+  if (e >= n) return;
+  float v[REC_ROWS_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < REC_ROWS_PER_THREAD; j++) { int r = r0 + j; v[j] = r < nrow ? rec[(size_t)e * rs + m.s_qpos + r] : 0.f; }
+#pragma unroll
+  for (int j = 0; j < REC_ROWS_PER_THREAD; j++) { int r = r0 + j; if (r < nrow) st[(size_t)(m.s_qpos + r) * n + e] = v[j]; }
 }
 
 // K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
@@ -316,14 +316,14 @@ static void launch_wave(const tmjx_model *m, float *state, const float *action, 
   int parts = 1;
   if (const char *sp = getenv("TMJX_SPLIT_LAUNCH")) { parts = atoi(sp); if (parts < 1 || n_env % parts) parts = 1; }   // scheduling experiments
   const int rs = rec ? WAVE_REC_STRIDE(m) : 0;
-  if (rec) hipLaunchKernelGGL(k_rec_in, dim3((n_env + 31) / 32, (m->h.nphys + m->h.nu + 31) / 32), dim3(256), 0, stream, m->d, (const float *)state, action, rec, n_env, rs);
+  if (rec) hipLaunchKernelGGL(k_rec_in, dim3((n_env + 63) / 64, (m->h.nphys + m->h.nu + REC_ROWS_PER_THREAD - 1) / REC_ROWS_PER_THREAD), dim3(64), 0, stream, m->d, (const float *)state, action, rec, n_env, rs);
   float *st = rec ? rec : state;
   for (int p = 0; p < parts; p++) {
     int cnt = n_env / parts, e0 = p * cnt;
     if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs);
     else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs);
   }
-  if (rec) hipLaunchKernelGGL(k_rec_out, dim3((n_env + 31) / 32, (m->h.s_prev_ctrl - m->h.s_qpos + 31) / 32), dim3(256), 0, stream, m->d, state, (const float *)rec, n_env, rs);
+  if (rec) hipLaunchKernelGGL(k_rec_out, dim3((n_env + 63) / 64, (m->h.s_prev_ctrl - m->h.s_qpos + REC_ROWS_PER_THREAD - 1) / REC_ROWS_PER_THREAD), dim3(64), 0, stream, m->d, state, (const float *)rec, n_env, rs);
 }
 // env-major physics record inside the caller's workspace (behind the K3 partial rows), or nullptr = direct [row][n_env] access
 // (TMJX_NO_RECORD=1, or a workspace too small for it)
