@@ -88,3 +88,12 @@ constexpr int tmw_chain_first(int i) {
 }
 // longest run of in-chain ancestors (i - chain start) among dofs i0 .. i1-1
 constexpr int tmw_chain_maxrun(int i0, int i1) { int r = 0; for (int i = i0; i < i1; i++) if (i - tmw_chain_first(i) > r) r = i - tmw_chain_first(i); return r; }
+// number of leaf-chain rows eliminated BEFORE the chain starting at dof `first` (chains in list order): position of the chain's
+// rows in the 4-deep operand queue of the MFMA Schur accumulation (wave_physics.h)
+constexpr int tmw_chain_rows_before(int first) {
+  int n = 0;
+#define TMW_X(f, len, d0) if (f == first) return n; n += len;
+  TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+  return n;
+}

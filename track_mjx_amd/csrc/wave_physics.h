@@ -758,10 +758,83 @@ TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float 
 // Dinv) and the eliminated rhs; the Schur complement lands in the remaining chain rows and in the trunk rows `tr`
 // (registers, shared by all chains).  Software-pipelined by hand: as soon as the first update of step k has finished row
 // k-1, the pivot chain of step k-1 (readlane -> rcp -> scale) is issued and the remaining updates of step k cover it.
+// ---- Schur complement of the leaf chains on the trunk rows as MFMA.  Eliminating chain row k subtracts L(k, i) * M'(k, j) from
+// trunk entry (i, j) for all 12 x 12 trunk pairs: over the 61 chain rows that is S -= A^T B with A[k][i] = L(k, trunk_i) and
+// B[k][j] = M'(k, trunk_j) — 55 % of all rank-1 updates of the factorisation and a genuine [12 x 61] . [61 x 12] product.
+// Four finished rows are packed into one operand register (lanes 16 kk + i = row kk, trunk column i; two v_permlane16_swap + one
+// v_permlane32_swap) and go through v_mfma_f32_16x16x4_f32: 7 instructions per four rows instead of 4 x 18 (readlane + pk_fma).
+// The accumulator holds C[i][j] at (register i % 4, lane 16 (i / 4) + j) and is subtracted from the trunk rows once, at the end.
+struct TmwSchur {
+#ifdef TM_HOST_EMU
+  float C[16][16];
+#else
+  float __attribute__((ext_vector_type(4))) c;
+#endif
+  float qa[4][TMW_NL], qb[4][TMW_NL];      // operand queue: scaled rows (L) and unscaled rows (M') of the last <= 4 pivots
+  float yt[TMW_NL];                        // Euler: lane i = sum_k L(k, trunk_i) y_k   (forward elimination of the rhs on the trunk)
+};
+#ifndef TM_HOST_EMU
+TM_DEV float tmw_pack4(float x0, float x1, float x2, float x3) {     // [x0.row0 | x1.row0 | x2.row0 | x3.row0], row = 16 lanes
+  auto s01 = __builtin_amdgcn_permlane16_swap(tm_f2i(x0), tm_f2i(x1), false, false);
+  auto s23 = __builtin_amdgcn_permlane16_swap(tm_f2i(x2), tm_f2i(x3), false, false);
+  auto p = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+  return tm_i2f(p[0]);
+}
+#endif
+// The accumulator STARTS from minus the trunk rows, so that the contributions are taken off the trunk block one group at a
+// time, in elimination order, exactly like the register version did (summing all 61 contributions first and subtracting them
+// from the large trunk entries at the end costs a factor ~1.4 in accuracy: the trunk diagonal is a small difference of large terms)
+TM_DEV void tmw_schur_init(WCtx &c, TmwSchur &S, tmw_f2 (*tr)[TMW_NL]) {
+#ifdef TM_HOST_EMU
+  for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) S.C[i][j] = (i < TMW_RODENT_TRUNK) ? -((i & 1) ? tr[i >> 1][j].y : tr[i >> 1][j].x) : 0.f;
+  for (int q = 0; q < 4; q++) for (int l = 0; l < 64; l++) S.qa[q][l] = S.qb[q][l] = 0.f;
+  for (int l = 0; l < 64; l++) S.yt[l] = 0.f;
+#else
+#define TMW_TRROW(i) ((i) < TMW_RODENT_TRUNK ? -(((i) & 1) ? tr[(i) >> 1][0].y : tr[(i) >> 1][0].x) : 0.f)
+  S.c[0] = tmw_pack4(TMW_TRROW(0), TMW_TRROW(4), TMW_TRROW(8), TMW_TRROW(12));
+  S.c[1] = tmw_pack4(TMW_TRROW(1), TMW_TRROW(5), TMW_TRROW(9), TMW_TRROW(13));
+  S.c[2] = tmw_pack4(TMW_TRROW(2), TMW_TRROW(6), TMW_TRROW(10), TMW_TRROW(14));
+  S.c[3] = tmw_pack4(TMW_TRROW(3), TMW_TRROW(7), TMW_TRROW(11), TMW_TRROW(15));
+#undef TMW_TRROW
+  for (int q = 0; q < 4; q++) S.qa[q][0] = S.qb[q][0] = 0.f;
+  S.yt[0] = 0.f;
+#endif
+}
+// C += sum over the queued rows of  qa (x) qb  (the queue slots not filled since the last flush must hold zeros)
+TM_DEV void tmw_schur_flush(TmwSchur &S) {
+#ifdef TM_HOST_EMU
+  for (int q = 0; q < 4; q++) for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) S.C[i][j] += S.qa[q][i] * S.qb[q][j];
+  for (int q = 0; q < 4; q++) for (int l = 0; l < 64; l++) S.qa[q][l] = S.qb[q][l] = 0.f;
+#else
+  float A = tmw_pack4(S.qa[0][0], S.qa[1][0], S.qa[2][0], S.qa[3][0]), B = tmw_pack4(S.qb[0][0], S.qb[1][0], S.qb[2][0], S.qb[3][0]);
+  S.c = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, S.c, 0, 0, 0);
+  for (int q = 0; q < 4; q++) S.qa[q][0] = S.qb[q][0] = 0.f;
+#endif
+}
+// trunk rows <- -C (and, Euler, their rhs lane -= yt): row i of C sits in register i % 4, lanes 16 (i / 4) ..
+template <bool EULER>
+TM_DEV void tmw_schur_apply(WCtx &c, TmwSchur &S, tmw_f2 (*tr)[TMW_NL]) {
+  TMW_LANE_DECL
+#pragma unroll
+  for (int i = 0; i < TMW_RODENT_TRUNK; i++) {
+#ifdef TM_HOST_EMU
+    TMW_FOR { float v = TMW_ROW(tr, i); if (lane < 16) v = -S.C[i][lane]; if (EULER && lane == TMW_RL) v -= S.yt[i]; TMW_SET_ROW(tr, i, v); }
+#else
+    float x = S.c[i & 3];
+    if (i / 4 == 1) x = tm_i2f(__builtin_amdgcn_permlane16_swap(tm_f2i(x), 0, false, false)[1]);        // row 1 of x -> row 0
+    else if (i / 4 == 2) x = tm_i2f(__builtin_amdgcn_permlane32_swap(tm_f2i(x), 0, false, false)[1]);   // rows 2, 3 -> rows 0, 1
+    float v = TMW_MASK(TMW_M_LT(16)) ? -x : TMW_ROW(tr, i);
+    if (EULER) { float y = tmw_readlane(S.yt, i); v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? v - y : v; }
+    TMW_SET_ROW(tr, i, v);
+#endif
+  }
+}
+
 template <int FIRST, int N, int D0, bool EULER>
-TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], tmw_f2 (*tr)[TMW_NL], int rhs) {
+TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], TmwSchur *S, int rhs) {
   float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
+  constexpr int Q0 = D0 > 0 ? tmw_chain_rows_before(FIRST) : 0;      // rows queued before this chain (mod 4 = first queue slot)
   float rs[2][TMW_NL], rk[2][TMW_NL], inv[2];
   TMW_REG(float, dv);
   TMW_FOR { rk[(N - 1) & 1][TMW_LI] = TMW_ROW(r, N - 1); }
@@ -777,7 +850,16 @@ TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], tmw_
         TMW_FOR { rs[b ^ 1][TMW_LI] = rk[b ^ 1][TMW_LI] * inv[b ^ 1]; TMW_PIN(rs[b ^ 1][TMW_LI]); }
       });
     }
-    if (D0 > 0) tmw_rank1_rows(tr, D0, 0, rs[b], rk[b], []() {});
+    if (D0 > 0) {     // trunk part of the finished row -> operand queue of the Schur MFMA (lanes >= D0 are not trunk columns: zero them)
+      const int slot = (Q0 + (N - 1 - k)) & 3;
+      TMW_FOR {
+        float a = D0 < 16 ? (TMW_MASK(TMW_M_LT(D0)) ? rs[b][TMW_LI] : 0.f) : rs[b][TMW_LI];
+        S->qa[slot][TMW_LI] = a;
+        S->qb[slot][TMW_LI] = D0 < 16 ? (TMW_MASK(TMW_M_LT(D0)) ? rk[b][TMW_LI] : 0.f) : rk[b][TMW_LI];
+      }
+      if (EULER) { float yk = tmw_readlane(rk[b], TMW_RL); TMW_FOR { S->yt[TMW_LI] += S->qa[slot][TMW_LI] * yk; } }
+      if (slot == 3) tmw_schur_flush(*S);
+    }
     TMW_FOR {
       if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = rs[b][TMW_LI];
       dv[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? inv[b] : dv[TMW_LI];
@@ -787,21 +869,25 @@ TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], tmw_
   TMW_FOR { if (TMW_MASK(TMW_M_RANGE(D0, D0 + N))) L[K.l_Dinv + FIRST - D0 + lane] = dv[TMW_LI]; }
 }
 template <int FIRST, int N, int D0, bool EULER>
-TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, tmw_f2 (*tr)[TMW_NL], float hdamp, int rhs) {
+TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, TmwSchur *S, float hdamp, int rhs) {
   tmw_f2 r[(N + 1) / 2][TMW_NL];
   tmw_rows_load<FIRST, N, D0, EULER>(c, K, r, hdamp, rhs);
-  tmw_rows_factor<FIRST, N, D0, EULER>(c, K, r, tr, rhs);
+  tmw_rows_factor<FIRST, N, D0, EULER>(c, K, r, S, rhs);
 }
 // LD <- L^T D L of M (EULER = false) or of M + hdamp diag(damping) with the rhs eliminated alongside (EULER = true),
 // read straight from l_M; same outputs as tmw_factor except that the diagonal words of LD are left alone
 template <bool EULER>
 TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs) {
   tmw_f2 tr[(TMW_RODENT_TRUNK + 1) / 2][TMW_NL];
+  TmwSchur S;
   tmw_rows_load<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, hdamp, rhs);
-#define TMW_X(first, n, d0) tmw_chain_factor<first, n, d0, EULER>(c, K, tr, hdamp, rhs);
+  tmw_schur_init(c, S, tr);
+#define TMW_X(first, n, d0) tmw_chain_factor<first, n, d0, EULER>(c, K, &S, hdamp, rhs);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
 #undef TMW_X
-  tmw_rows_factor<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, tr, rhs);
+  tmw_schur_flush(S);                       // the last, partly filled group (unused slots hold zeros)
+  tmw_schur_apply<EULER>(c, S, tr);
+  tmw_rows_factor<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, nullptr, rhs);
   TMW_SYNC();
 }
 // rows of N = L^-1, root -> leaf:  N(k,:) = e_k - sum_{j < depth_k} L(k, anc_j) N(anc_j, :).  `tn`: the finished trunk rows
