@@ -900,11 +900,57 @@ TM_DEV void tmw_rows_accum(tmw_f2 &acc, const tmw_f2 (*S)[TMW_NL], const int CNT
     acc = tmw_fnma2(alo, ahi, S[p][li].x, S[p][li].y, acc);
   }
 }
+// Trunk-ancestor part of the rows of L^-1 of a whole leaf chain as MFMA:  P[k][q] = sum_{j < D0} L(k, trunk_j) N(trunk_j, q).
+// A[i][kk] = L(k0 + i, trunk 4 m + kk) is read from LDS directly in operand layout (lane 16 kk + i), B = four trunk rows of
+// L^-1 packed into one register (tmw_pack4), 16 chain rows per accumulator; the rows of P are then pulled out of the accumulator
+// (register i % 4, lanes 16 (i / 4) ..) with at most two v_permlane swaps each — instead of 12 readlane + 6 pk_fma per row.
 template <int FIRST, int N, int D0>
-TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, tmw_f2 (*n)[TMW_NL], tmw_f2 (*tn)[TMW_NL]) {
+TM_DEV void tmw_chain_trunk_products(WCtx &c, const WLayout &K, const float (*Bp)[TMW_NL], const tmw_f2 (*tn)[TMW_NL], float (*P)[TMW_NL]) {
   float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
-  float l[N][TMW_NL];
+#ifdef TM_HOST_EMU
+  (void)Bp;
+  for (int k = 0; k < N; k++)
+    TMW_FOR {
+      float s = 0.f;
+      if (lane < D0) for (int j = 0; j < D0; j++) s += L[adr0 + k * D0 + k * (k - 1) / 2 + k + (D0 + k) - j] * ((j & 1) ? tn[j >> 1][lane].y : tn[j >> 1][lane].x);
+      P[k][TMW_LI] = s;
+    }
+#else
+  (void)tn;
+  typedef float __attribute__((ext_vector_type(4))) f4;
+#pragma unroll
+  for (int k0 = 0; k0 < N; k0 += 16) {
+    const int kq = k0 + (lane & 15), kk = lane >> 4;
+    const bool rowok = kq < N;
+    const int kc = rowok ? kq : N - 1;
+    const int base = adr0 + kc * D0 + kc * (kc - 1) / 2 + kc + (D0 + kc) - kk;      // entry of trunk column kk; column 4 m + kk is 4 m words below
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; 4 * m < D0; m++) {
+      float a = L[base - 4 * m];
+      a = (rowok && 4 * m + kk < D0) ? a : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bp[m][0], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if (k0 + i >= N) break;
+      float x = acc[i & 3];
+      if ((i >> 2) == 1) x = tm_i2f(__builtin_amdgcn_permlane16_swap(tm_f2i(x), 0, false, false)[1]);
+      else if ((i >> 2) >= 2) {
+        x = tm_i2f(__builtin_amdgcn_permlane32_swap(tm_f2i(x), 0, false, false)[1]);
+        if ((i >> 2) == 3) x = tm_i2f(__builtin_amdgcn_permlane16_swap(tm_f2i(x), 0, false, false)[1]);
+      }
+      P[k0 + i][0] = TMW_MASK(TMW_M_LT(D0)) ? x : 0.f;
+    }
+  }
+#endif
+}
+template <int FIRST, int N, int D0>
+TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, tmw_f2 (*n)[TMW_NL], tmw_f2 (*tn)[TMW_NL], const float (*Bp)[TMW_NL]) {
+  float *L = c.L; TMW_LANE_DECL
+  const int adr0 = K.l_LD + tmw_chain_madr(FIRST);
+  float l[N][TMW_NL], P[D0 > 0 ? N : 1][TMW_NL];
   tmw_f2 acc[TMW_NL];
   // all rows of L first: the loads of later rows must not queue behind the stores of the finished rows of N
   TMW_FOR {
@@ -918,11 +964,11 @@ TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, tmw_f2 (*n)[TMW_NL], tmw_
 #pragma unroll
     for (int p = 0; p < (N + 1) / 2; p++) { n[p][TMW_LI].x = 0.f; n[p][TMW_LI].y = 0.f; }
   }
+  if (D0 > 0) tmw_chain_trunk_products<FIRST, N, D0>(c, K, Bp, tn, P);
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;
-    TMW_FOR { acc[TMW_LI].x = TMW_MASK(TMW_M_EQ(dk)) ? 1.f : 0.f; acc[TMW_LI].y = 0.f; }
-    if (D0 > 0) { TMW_FOR { tmw_rows_accum(acc[TMW_LI], tn, D0, 0, l[k], TMW_LI); } }
+    TMW_FOR { acc[TMW_LI].x = (TMW_MASK(TMW_M_EQ(dk)) ? 1.f : 0.f) - (D0 > 0 ? P[D0 > 0 ? k : 0][TMW_LI] : 0.f); acc[TMW_LI].y = 0.f; }
     if (k > 0) { TMW_FOR { tmw_rows_accum(acc[TMW_LI], n, k, D0, l[k], TMW_LI); } }
     TMW_FOR {
       float v = acc[TMW_LI].x + acc[TMW_LI].y;
@@ -932,14 +978,22 @@ TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, tmw_f2 (*n)[TMW_NL], tmw_
   }
 }
 template <int FIRST, int N, int D0>
-TM_DEV void tmw_chain_invert(WCtx &c, const WLayout &K, tmw_f2 (*tn)[TMW_NL]) {
+TM_DEV void tmw_chain_invert(WCtx &c, const WLayout &K, tmw_f2 (*tn)[TMW_NL], const float (*Bp)[TMW_NL]) {
   tmw_f2 n[(N + 1) / 2][TMW_NL];
-  tmw_rows_invert<FIRST, N, D0>(c, K, n, tn);
+  tmw_rows_invert<FIRST, N, D0>(c, K, n, tn, Bp);
 }
 TM_DEV void tmw_invert_chains(WCtx &c, const WLayout &K) {
   tmw_f2 tn[(TMW_RODENT_TRUNK + 1) / 2][TMW_NL];
-  tmw_rows_invert<0, TMW_RODENT_TRUNK, 0>(c, K, tn, tn);
-#define TMW_X(first, n, d0) tmw_chain_invert<first, n, d0>(c, K, tn);
+  float Bp[(TMW_RODENT_TRUNK + 3) / 4][TMW_NL];
+  tmw_rows_invert<0, TMW_RODENT_TRUNK, 0>(c, K, tn, tn, Bp);
+#ifndef TM_HOST_EMU
+  // B operands of the trunk products: four finished trunk rows of L^-1 per register (exact zeros beyond each row's depth)
+#define TMW_TN(i) ((i) < TMW_RODENT_TRUNK ? (((i) & 1) ? tn[(i) >> 1][0].y : tn[(i) >> 1][0].x) : 0.f)
+#pragma unroll
+  for (int m = 0; m < (TMW_RODENT_TRUNK + 3) / 4; m++) Bp[m][0] = tmw_pack4(TMW_TN(4 * m), TMW_TN(4 * m + 1), TMW_TN(4 * m + 2), TMW_TN(4 * m + 3));
+#undef TMW_TN
+#endif
+#define TMW_X(first, n, d0) tmw_chain_invert<first, n, d0>(c, K, tn, Bp);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
 #undef TMW_X
   TMW_SYNC();
