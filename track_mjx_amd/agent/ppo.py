@@ -408,8 +408,9 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     evaluator = None
     if eval_env is not None and learner.rank == 0:
         from .evaluator import Evaluator
+        eval_gen = torch.Generator(device=learner.dev).manual_seed(seed * 1000 + 991)   # not the roll-out generators (registered with hipGraphs)
         evaluator = Evaluator(wrap(eval_env, episode_length=int(episode_length), action_repeat=1),
-                              lambda obs: learner.act(obs, deterministic=deterministic_eval), episode_length=int(episode_length), seed=seed + 7)
+                              lambda obs: learner.act(obs, deterministic=deterministic_eval, gen=eval_gen), episode_length=int(episode_length), seed=seed + 7)
     metrics: dict = {}
     total_steps, done_steps = 0, 0
     for it in range(1, num_evals_after_init + 1):
