@@ -118,6 +118,24 @@ TM_DEV float tmw_sum_dpp(const float *vp) {
 }
 TM_DEV float tmw_readlane_dpp(const float *v, int src) { return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v[0]), src)); }
 #endif
+// sum over the first WIDTH (16 / 32 / 64, compile time) lanes when the others are known to hold zeros: the two row_bcast steps
+// (the expensive ones: v_mov_dpp + add + hazard nops) disappear for WIDTH = 16, one of them for WIDTH = 32
+#ifdef TM_HOST_EMU
+template <int WIDTH> TM_DEV float tmw_sum_w(const float *v) { return tmw_sum(v); }
+#else
+template <int WIDTH> TM_DEV float tmw_sum_w(const float *vp) {
+  float v = vp[0];
+  v = tmw_dpp_add<0x111, 0xf, 0xf>(v);
+  v = tmw_dpp_add<0x112, 0xf, 0xf>(v);
+  v = tmw_dpp_add<0x114, 0xf, 0xe>(v);
+  v = tmw_dpp_add<0x118, 0xf, 0xc>(v);
+  if (WIDTH <= 16) return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 15));
+  v = tmw_dpp_add<0x142, 0xa, 0xf>(v);
+  if (WIDTH <= 32) return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 31));
+  v = tmw_dpp_add<0x143, 0xc, 0xf>(v);
+  return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 63));
+}
+#endif
 // element `idx` (uniform) of a 128-entry table kept as two lane vectors
 #ifdef TM_HOST_EMU
 TM_DEV int tmw_table2(const float *a0, const float *a1, int idx) { return tm_f2i(idx < 64 ? a0[idx] : a1[idx - 64]); }
@@ -1491,7 +1509,7 @@ struct TmwLS { float alpha, cost, d0, d1; };
 #define TMW_LS_SLOTS 4        // up to 256 constraint rows
 struct TmwLSRows { float ja[TMW_NL][TMW_LS_SLOTS], jv[TMW_NL][TMW_LS_SLOTS], D[TMW_NL][TMW_LS_SLOTS], t0[TMW_NL][TMW_LS_SLOTS], t1[TMW_NL][TMW_LS_SLOTS], t2[TMW_NL][TMW_LS_SLOTS]; };
 // NP line-search points evaluated together (alphas a[0..NP-1]): 3 NP partial sums over the rows, reduced together
-template <int NP>
+template <int NP, int WIDTH>
 TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const float *a, float g0, float g1, float g2, TmwLS *out) {
   TMW_LANE_DECL
   float q[3 * NP][TMW_NL];
@@ -1513,7 +1531,7 @@ TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const f
   }
   float qq[3 * NP];
 #pragma unroll
-  for (int k = 0; k < 3 * NP; k++) qq[k] = tmw_sum(q[k]);
+  for (int k = 0; k < 3 * NP; k++) qq[k] = tmw_sum_w<WIDTH>(q[k]);
 #pragma unroll
   for (int p = 0; p < NP; p++) {
     float q0 = g0 + qq[3 * p], q1 = g1 + qq[3 * p + 1], q2 = g2 + qq[3 * p + 2], al = a[p];
@@ -1522,6 +1540,41 @@ TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const f
     out[p].d0 = 2.f * al * q2 + q1;
     out[p].d1 = 2.f * q2 + (q2 == 0.f ? TM_MINVAL : 0.f);
   }
+}
+// the iteration proper (MJX _linesearch: Newton steps from both ends of the bracket + the midpoint), for a compile-time width of
+// the wave reductions: WIDTH = 16 / 32 when all active rows sit in the first 16 / 32 lanes (the usual case), else 64
+template <int WIDTH>
+TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0, float g1, float g2, float gtol) {
+  const DModel &m = *c.mp;
+  TmwLS pt[3];
+  float al[3] = {0.f, 0.f, 0.f};
+  tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
+  TmwLS p0 = pt[0];
+  al[0] = p0.alpha - p0.d0 / p0.d1;
+  tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
+  TmwLS lo0 = pt[0];
+  bool lesser = lo0.d0 < p0.d0;
+  TmwLS hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
+  bool swap = true;
+  for (int it = 0; it < m.ls_iterations; it++) {
+    bool done = !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
+    if (done) break;
+    al[0] = lo.alpha - lo.d0 / lo.d1; al[1] = hi.alpha - hi.d0 / hi.d1; al[2] = 0.5f * (lo.alpha + hi.alpha);
+    tmw_ls_points<3, WIDTH>(c, K, R, al, g0, g1, g2, pt);
+    TmwLS lo_next = pt[0], hi_next = pt[1], mid = pt[2];
+    bool s1 = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
+    if (s1) lo = lo_next;
+    bool s2 = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
+    if (s2) lo = mid;
+    bool s3 = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
+    if (s3) hi = hi_next;
+    bool s4 = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
+    if (s4) hi = mid;
+    swap = s1 || s2 || s3 || s4;
+  }
+  bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+  float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  return improved ? alpha : 0.f;
 }
 // returns the cost of the new iterate and its Gauss term through `gauss` (what _update_constraint recomputes after the step:
 // the same sums as tmw_cost_from_state, taken in the same order, but from the rows and vectors already in registers)
@@ -1544,36 +1597,12 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
     }
   }
   TMW_TICK2(13);
-  TmwLS pt[3];
-  float al[3] = {0.f, 0.f, 0.f};
-  tmw_ls_points<1>(c, K, R, al, g0, g1, g2, pt);
-  TmwLS p0 = pt[0];
-  al[0] = p0.alpha - p0.d0 / p0.d1;
-  tmw_ls_points<1>(c, K, R, al, g0, g1, g2, pt);
-  TmwLS lo0 = pt[0];
-  bool lesser = lo0.d0 < p0.d0;
-  TmwLS hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
-  bool swap = true;
-  for (int it = 0; it < m.ls_iterations; it++) {
-    bool done = !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
-    if (done) break;
-    al[0] = lo.alpha - lo.d0 / lo.d1; al[1] = hi.alpha - hi.d0 / hi.d1; al[2] = 0.5f * (lo.alpha + hi.alpha);
-    tmw_ls_points<3>(c, K, R, al, g0, g1, g2, pt);
-    TmwLS lo_next = pt[0], hi_next = pt[1], mid = pt[2];
-    bool s1 = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
-    if (s1) lo = lo_next;
-    bool s2 = (mid.d0 < 0.f) && (lo.d0 < mid.d0);
-    if (s2) lo = mid;
-    bool s3 = (hi.d0 < 0.f) || (hi.d0 > hi_next.d0);
-    if (s3) hi = hi_next;
-    bool s4 = (mid.d0 > 0.f) && (hi.d0 > mid.d0);
-    if (s4) hi = mid;
-    swap = s1 || s2 || s3 || s4;
-  }
+  // one uniform branch picks the reduction width for the whole search: the active rows fill lanes 0 .. nact-1 of slot 0
+  float ia;
+  if (c.nact <= 16) ia = tmw_ls_core<16>(c, K, R, g0, g1, g2, gtol);
+  else if (c.nact <= 32) ia = tmw_ls_core<32>(c, K, R, g0, g1, g2, gtol);
+  else ia = tmw_ls_core<64>(c, K, R, g0, g1, g2, gtol);
   TMW_TICK2(14);
-  bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-  float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
-  float ia = improved ? alpha : 0.f;
   TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
     float sc = 0.f, sg = 0.f;
