@@ -396,8 +396,16 @@ TM_DEV void tm_kbi(const DModel &m, const float *solref, const float *solimp, fl
   if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
   if (solref[1] <= 0.f) b = -solref[1] / dmax;
   float x = fabsf(pos) / width;
-  float ia = (1.f / powf(mid, power - 1.f)) * powf(x, power);
-  float ib = 1.f - (1.f / powf(1.f - mid, power - 1.f)) * powf(1.f - x, power);
+  // power == 2 (MuJoCo's default solimp, every joint and geom of the rodent): squares instead of four powf calls (~150 VALU
+  // instructions each on the GPU; powf(x, 2) is x * x up to the last bit anyway)
+  float ia, ib;
+  if (power == 2.f) {
+    ia = (1.f / mid) * (x * x);
+    ib = 1.f - (1.f / (1.f - mid)) * ((1.f - x) * (1.f - x));
+  } else {
+    ia = (1.f / powf(mid, power - 1.f)) * powf(x, power);
+    ib = 1.f - (1.f / powf(1.f - mid, power - 1.f)) * powf(1.f - x, power);
+  }
   float y = x < mid ? ia : ib;
   float im = dmin + y * (dmax - dmin);
   im = fminf(fmaxf(im, dmin), dmax);

@@ -211,7 +211,8 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
           tm_rotate(r, m.jnt_pos[j], q);
           for (int k = 0; k < 3; k++) an[k] = t[k] + r[k];
           tm_rotate(ax, m.jnt_axis[j], q);
-          float ang = (L[K.l_qpos + qa] - m.qpos0[qa]) * 0.5f, sn = sinf(ang), cs = cosf(ang);
+          float ang = (L[K.l_qpos + qa] - m.qpos0[qa]) * 0.5f, sn, cs;
+          sincosf(ang, &sn, &cs);      // one shared range reduction
           ql[0] = cs; ql[1] = m.jnt_axis[j][0] * sn; ql[2] = m.jnt_axis[j][1] * sn; ql[3] = m.jnt_axis[j][2] * sn;
           tm_quat_mul(q2, q, ql);
           for (int k = 0; k < 4; k++) q[k] = q2[k];
@@ -1400,18 +1401,20 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
     for (int kr = lane; kr < c.nact; kr += 64) {
       int r = rm[kr];
       float k, b, imp, pos, iw;
+      const float *solref, *solimp;      // ONE impedance evaluation for limit and contact rows (both kinds share a wave)
       if (r < K.nlim) {
         int j = m.lim_jnt[r];
         float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
         pos = fminf(dmin, dmax) - m.jnt_margin[j];
-        tm_kbi(m, m.jnt_solref[j], m.jnt_solimp[j], pos, k, b, imp);
+        solref = m.jnt_solref[j]; solimp = m.jnt_solimp[j];
         iw = m.dof_invweight0[m.jnt_dofadr[j]];
       } else {
         int cc = (r - K.nlim) >> 2;
         pos = L[K.l_con_dist + cc];
-        tm_kbi(m, m.con_solref[cc], m.con_solimp[cc], pos, k, b, imp);
+        solref = m.con_solref[cc]; solimp = m.con_solimp[cc];
         iw = m.con_invweight[cc];
       }
+      tm_kbi(m, solref, solimp, pos, k, b, imp);
       float Rr = fmaxf(iw * (1.f - imp) / imp, TM_MINVAL);
       L[K.l_efc_D + kr] = 1.f / Rr;
       L[K.l_efc_aref + kr] = -b * L[K.l_jv + kr] - k * imp * pos;
@@ -1711,7 +1714,8 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
         for (int k = 0; k < 3; k++) L[K.l_qpos + qa + k] += h * L[K.l_qvel + da + k];
         float v[3] = {L[K.l_qvel + da + 3], L[K.l_qvel + da + 4], L[K.l_qvel + da + 5]}, q[4], qr[4], q2[4];
         for (int k = 0; k < 4; k++) q[k] = L[K.l_qpos + qa + 3 + k];
-        float nn = tm_normalize3(v), ang = h * nn * 0.5f, sn = sinf(ang), cs = cosf(ang);
+        float nn = tm_normalize3(v), ang = h * nn * 0.5f, sn, cs;
+        sincosf(ang, &sn, &cs);
         qr[0] = cs; qr[1] = v[0] * sn; qr[2] = v[1] * sn; qr[3] = v[2] * sn;
         tm_quat_mul(q2, q, qr);
         tm_normalize4(q2);
