@@ -44,7 +44,7 @@ struct WLayout {
     l_jv = l_efc_aref; l_wr = l_efc_aref;
     l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
     l_Mgrad = l; l += nv; l_search = l; l += nv; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
-    l_dummy = l_mv;   // per-lane sink of masked LDS reads (needs 64 <= nv words; mv is only live inside the line search)
+    l_dummy = l_mv;   // per-lane source of masked LDS READS (never written through; needs 64 <= nv words)
     int endA = l;
     l = l_alias0;
     l_scanA = l; l += nbody * 8; l_scanB = l; l += nbody * 8; l_jl_anchor = l; l += njnt * 3; l_jl_axis = l; l += njnt * 3;

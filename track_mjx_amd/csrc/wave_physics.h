@@ -1457,10 +1457,13 @@ TM_DEV float tmw_dot(WCtx &c, const WLayout &K, int a, int b) {
   return tmw_sum(p);
 }
 // Jaref <- J q - aref ; Ma <- M q ; returns cost and gauss for qacc vector `q`
-TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss) {
+// `jonly`: q IS qacc_smooth = M^-1 qfrc_smooth: the Gauss term is exactly zero (q - qacc_smooth = 0 in MJX's own arithmetic as
+// well) and M q is not needed by the caller (tmw_solve_cg) — no product with M
+TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool jonly = false) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
-  tmw_mul_m_jmul(c, K, q, K.l_Ma, K.l_Jaref);
+  if (jonly) tmw_jmul(c, K, q, K.l_Jaref);
+  else tmw_mul_m_jmul(c, K, q, K.l_Ma, K.l_Jaref);
   TMW_TICK2(19);
   TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
@@ -1470,41 +1473,75 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss) {
       L[K.l_Jaref + e] = ja;
       if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja;
     }
-    for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - L[K.l_qfrc_smooth + i]) * (L[q + i] - L[K.l_qacc_smooth + i]);
+    if (!jonly) for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - L[K.l_qfrc_smooth + i]) * (L[q + i] - L[K.l_qacc_smooth + i]);
     pc[TMW_LI] = sc; pg[TMW_LI] = sg;
   }
   TMW_SYNC();
-  gauss = 0.5f * tmw_sum(pg);
+  gauss = jonly ? 0.f : 0.5f * tmw_sum(pg);
   return 0.5f * tmw_sum(pc) + gauss;
 }
-// cost/gauss from the current Jaref, Ma, qacc (no mat-vecs)
-TM_DEV float tmw_cost_from_state(WCtx &c, const WLayout &K, float &gauss) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
-  TMW_REG(float, pc); TMW_REG(float, pg);
+// ---- The CG iteration runs in the coordinates y = L qacc of the factorisation M = L^T D L (N = L^-1 sits in l_LD):
+//   Gauss term      1/2 (y - y_s)^T D (y - y_s)            (diagonal: no product with M inside the iteration)
+//   preconditioner  M^-1 = N D^-1 N^T  ->  D^-1            (diagonal)
+//   search_q = N s  (root -> leaf half of the M^-1 product),  w = D^-1 N^T grad_q  (leaf -> root half)
+// so one iteration costs ONE M^-1 product split into its two halves instead of M x + M^-1 x.  In exact arithmetic the
+// iterates are those of MJX's solver (same Polak-Ribiere directions: g.M^-1 g = ghat.D^-1 ghat, search.M search = s.D s, ...);
+// the state is self-consistent in fp32 (ut = y - y_s is advanced by the step actually taken).  LDS vectors of the y-space
+// quantities (names of the q-space vectors they replace): l_Ma = ut = y - y_s, l_Mgrad = w = D^-1 ghat, l_tmp = previous w,
+// l_mv = s, l_grad = D;  l_search = search_q, l_qacc, l_qfrc_constraint stay in q-space.
+// x -> out = D^-1 N^T x   (leaf -> root; out may alias x)
+TM_DEV void tmw_solve_up(WCtx &c, const WLayout &K, int x, int out) {
+  float *L = c.L; TMW_LANE_DECL
+  if (K.chains) { tmw_colpart_chains<true>(c, K, K.l_LD, x, out); return; }
+  TMW_REG(float, z0); TMW_REG(float, z1);
   TMW_FOR {
-    float sc = 0.f, sg = 0.f;
-    for (int e = lane; e < c.nact; e += 64) { float ja = L[K.l_Jaref + e]; if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja; }
-    for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - L[K.l_qfrc_smooth + i]) * (L[K.l_qacc + i] - L[K.l_qacc_smooth + i]);
-    pc[TMW_LI] = sc; pg[TMW_LI] = sg;
+    for (int slot = 0; slot < 2; slot++) {
+      int i = lane + 64 * slot;
+      if (i >= K.nv) continue;
+      (slot ? z1 : z0)[TMW_LI] = (L[x + i] + tmw_col_dot(L, K, K.l_LD, x, i)) * L[K.l_Dinv + i];
+    }
   }
-  gauss = 0.5f * tmw_sum(pg);
-  return 0.5f * tmw_sum(pc) + gauss;
+  TMW_SYNC();
+  TMW_FOR { for (int slot = 0; slot < 2; slot++) { int i = lane + 64 * slot; if (i < K.nv) L[out + i] = (slot ? z1 : z0)[TMW_LI]; } }
+  TMW_SYNC();
 }
-TM_DEV void tmw_update_gradient(WCtx &c, const WLayout &K) {
+// out = N x   (root -> leaf; out may NOT alias x)
+TM_DEV void tmw_solve_down(WCtx &c, const WLayout &K, int x, int out) {
+  float *L = c.L; TMW_LANE_DECL
+  if (K.chains) {
+    TMW_REG(float, z0); TMW_REG(float, z1);
+    tmw_rowpart_chains(c, K, K.l_LD, x, false, z0, z1);
+    TMW_FOR { L[out + lane] = z0[TMW_LI] + L[x + lane]; if (lane + 64 < K.nv) L[out + lane + 64] = z1[TMW_LI] + L[x + lane + 64]; }
+    TMW_SYNC();
+    return;
+  }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[out + i] = L[x + i] + tmw_row_dot(L, K, K.l_LD, x, i, false); }
+  TMW_SYNC();
+}
+// qfrc_constraint = J^T f at the current Jaref;  w = ut - D^-1 N^T qfrc_constraint;  returns gn = w.D w (= grad.M^-1 grad) and,
+// through `num`, w.D (w - w_prev) with w_prev = l_tmp (Polak-Ribiere numerator)
+TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
   tmw_jt_force(c, K, K.l_qfrc_constraint);
   TMW_TICK2(16);
+  tmw_solve_up(c, K, K.l_qfrc_constraint, K.l_Mgrad);
+  TMW_TICK2(26);
+  TMW_REG(float, pa); TMW_REG(float, pb);
   TMW_FOR {
+    float sa = 0.f, sb = 0.f;
     for (int i = lane; i < K.nv; i += 64) {
-      float g = L[K.l_Ma + i] - L[K.l_qfrc_smooth + i] - L[K.l_qfrc_constraint + i];
-      L[K.l_grad + i] = g; L[K.l_Mgrad + i] = g;
+      float w = L[K.l_Ma + i] - L[K.l_Mgrad + i], dw = L[K.l_grad + i] * w;
+      L[K.l_Mgrad + i] = w;
+      sa += dw * w; sb += dw * (w - L[K.l_tmp + i]);
     }
+    pa[TMW_LI] = sa; pb[TMW_LI] = sb;
   }
   TMW_SYNC();
-  TMW_TICK2(15);
-  tmw_solve(c, K, K.l_Mgrad);
+  num = tmw_sum(pb);
+  float gn = tmw_sum(pa);
   TMW_TICK2(17);
+  return gn;
 }
 struct TmwLS { float alpha, cost, d0, d1; };
 // The constraint rows of a line search live in registers: per row e = lane + 64 s the three quadratic coefficients
@@ -1580,14 +1617,25 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
   return improved ? alpha : 0.f;
 }
 // returns the cost of the new iterate and its Gauss term through `gauss` (what _update_constraint recomputes after the step:
-// the same sums as tmw_cost_from_state, taken in the same order, but from the rows and vectors already in registers)
+// 1/2 sum D ja^2 over the active rows + 1/2 ut.D ut, from the rows and vectors already in registers)
 TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
-  float smag = sqrtf(tmw_dot(c, K, K.l_search, K.l_search)) * scale;
+  tmw_solve_down(c, K, K.l_mv, K.l_search);            // search_q = N s
+  tmw_jmul(c, K, K.l_search, K.l_jv);
+  // |search_q|^2, s.D ut (= search.Ma - search.qfrc_smooth) and s.D s (= search.M search) in one pass, three reductions side by side
+  TMW_REG(float, p0); TMW_REG(float, p1); TMW_REG(float, p2);
+  TMW_FOR {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = lane; i < K.nv; i += 64) {
+      float sq = L[K.l_search + i], ds = L[K.l_grad + i] * L[K.l_mv + i];
+      a0 += sq * sq; a1 += ds * L[K.l_Ma + i]; a2 += ds * L[K.l_mv + i];
+    }
+    p0[TMW_LI] = a0; p1[TMW_LI] = a1; p2[TMW_LI] = a2;
+  }
+  float smag = sqrtf(tmw_sum(p0)) * scale;
   float gtol = m.tolerance * m.ls_tolerance * smag;
-  tmw_mul_m_jmul(c, K, K.l_search, K.l_mv, K.l_jv);
-  float g0 = gauss, g1 = tmw_dot(c, K, K.l_search, K.l_Ma) - tmw_dot(c, K, K.l_search, K.l_qfrc_smooth), g2 = 0.5f * tmw_dot(c, K, K.l_search, K.l_mv);
+  float g0 = gauss, g1 = tmw_sum(p1), g2 = 0.5f * tmw_sum(p2);
   TmwLSRows R;
   TMW_FOR {
 #pragma unroll
@@ -1610,9 +1658,9 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   TMW_FOR {
     float sc = 0.f, sg = 0.f;
     for (int i = lane; i < K.nv; i += 64) {
-      float qa = L[K.l_qacc + i] + L[K.l_search + i] * ia, ma = L[K.l_Ma + i] + L[K.l_mv + i] * ia;
-      L[K.l_qacc + i] = qa; L[K.l_Ma + i] = ma;
-      sg += (ma - L[K.l_qfrc_smooth + i]) * (qa - L[K.l_qacc_smooth + i]);
+      float qa = L[K.l_qacc + i] + L[K.l_search + i] * ia, ut = L[K.l_Ma + i] + L[K.l_mv + i] * ia;
+      L[K.l_qacc + i] = qa; L[K.l_Ma + i] = ut;
+      sg += L[K.l_grad + i] * ut * ut;
     }
 #pragma unroll
     for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
@@ -1628,42 +1676,45 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
 TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float gauss, scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc + i] = L[K.l_warm + i]; }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] = L[K.l_warm + i]; L[K.l_grad + i] = 1.f / L[K.l_Dinv + i]; L[K.l_tmp + i] = 0.f; } }
   TMW_SYNC();
   // start from the warm start unless the unconstrained acceleration has the lower cost (MJX evaluates warm, smooth and
-  // then the winner again; evaluating smooth FIRST leaves Ma / Jaref of the warm start — the usual winner — in place, the
-  // same numbers with one evaluation less)
-  float gs, cs = tmw_eval_cost(c, K, K.l_qacc_smooth, gs);
+  // then the winner again; evaluating smooth FIRST leaves M qacc / Jaref of the warm start — the usual winner — in place)
+  float gs, cs = tmw_eval_cost(c, K, K.l_qacc_smooth, gs, true);
   float cw = tmw_eval_cost(c, K, K.l_qacc, gauss);
   float cost = cw;
-  if (!(cw < cs)) {
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc + i] = L[K.l_qacc_smooth + i]; }
+  if (cw < cs) {     // ut = y - y_s = D^-1 N^T (M qacc - qfrc_smooth)
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Ma + i] -= L[K.l_qfrc_smooth + i]; }
     TMW_SYNC();
-    cost = tmw_eval_cost(c, K, K.l_qacc, gauss);
+    tmw_solve_up(c, K, K.l_Ma, K.l_Ma);
+  } else {
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] = L[K.l_qacc_smooth + i]; L[K.l_Ma + i] = 0.f; } }
+    TMW_SYNC();
+    cost = tmw_eval_cost(c, K, K.l_qacc, gauss, true);
   }
-  float prev_cost = INFINITY;
-  tmw_update_gradient(c, K);
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_search + i] = -L[K.l_Mgrad + i]; }
+  float prev_cost = INFINITY, num;
+  float gn = tmw_update_gradient(c, K, num);
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_mv + i] = -L[K.l_Mgrad + i]; }
   TMW_SYNC();
   TMW_TICK(6);
   for (int it = 0; it < m.iterations; it++) {
     if (m.iterations != 1) {
+      // MJX tests |grad_q| / scale; grad_q = L^T ghat is not formed here: its M^-1-norm (gn, at hand) scaled by the mean inertia
+      // stands in for it — both only detect an already converged iterate (tolerance 1e-8)
       float improvement = (prev_cost - cost) / scale;
-      float gradient = sqrtf(tmw_dot(c, K, K.l_grad, K.l_grad)) / scale;
+      float gradient = sqrtf(m.meaninertia * fmaxf(gn, 0.f)) / scale;
       if (improvement < m.tolerance || gradient < m.tolerance) break;
     }
     float cost_new = tmw_linesearch(c, K, gauss);
     TMW_TICK(7);
-    float den = tmw_dot(c, K, K.l_grad, K.l_Mgrad);
     TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_Mgrad + i]; }
     TMW_SYNC();
     prev_cost = cost;
     cost = cost_new;
-    tmw_update_gradient(c, K);
-    TMW_REG(float, pn);
-    TMW_FOR { float s = 0.f; for (int i = lane; i < K.nv; i += 64) s += L[K.l_grad + i] * (L[K.l_Mgrad + i] - L[K.l_tmp + i]); pn[TMW_LI] = s; }
-    float beta = fmaxf(0.f, tmw_sum(pn) / fmaxf(TM_MINVAL, den));
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_search + i] = -L[K.l_Mgrad + i] + beta * L[K.l_search + i]; }
+    float den = gn;
+    gn = tmw_update_gradient(c, K, num);
+    float beta = fmaxf(0.f, num / fmaxf(TM_MINVAL, den));
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_mv + i] = -L[K.l_Mgrad + i] + beta * L[K.l_mv + i]; }
     TMW_SYNC();
     TMW_TICK(8);
   }
