@@ -29,6 +29,17 @@ ALGO_BYTES_PER_ENV_STEP = 15644        # SURVEY.md §8 d4 / BASELINE.md §2: 391
 K2_ALGO_BYTES_PER_ENV_STEP = 842 * 4
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md)
 ENVS_PER_GPU = 4096
+FULL_NETS = dict(encoder_layer_sizes=[1024, 512, 512, 512, 512], decoder_layer_sizes=[512, 512, 512, 256, 256],
+                 critic_layer_sizes=[512, 512, 512, 512, 512, 256])            # rodent-full-clips.yaml:50-57
+# BASELINE.json configs: cfg2 = configs[1] is the line the metric is quoted on
+CONFIGS = {
+    "cfg2": dict(envs_per_gpu=4096, n_clips=64, nets=dict(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256]),
+                 matmul_dtype=None, random_clips=False, label="2x256 intention policy + critic, fp32"),
+    "cfg4": dict(envs_per_gpu=4096, n_clips=64, nets=FULL_NETS, matmul_dtype=None, random_clips=False,
+                 label="rodent-mc-intention nets (enc 1024-512x4, dec 512x3-256x2, critic 512x5-256), fp32"),
+    "cfg5": dict(envs_per_gpu=8192, n_clips=1024, nets=FULL_NETS, matmul_dtype="bf16", random_clips=True,
+                 label="1024-clip table (per-env clip gather), rodent-mc-intention nets with bf16 GEMM inputs / fp32 accumulate"),
+}
 
 
 def cpu_baseline(blob, clip, seconds_budget: float = 15.0):
@@ -65,10 +76,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=2, help="env groups per GPU whose roll-outs are pipelined on separate HIP streams (1 = off)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
+                    help="BASELINE.json configs[1] (default, the headline line) / configs[3] / configs[4]; the others are extra measurements")
     args = ap.parse_args()
+    bc = CONFIGS[args.config]
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = bc["envs_per_gpu"]
 
     import torch
     import torch.distributed as dist
@@ -89,13 +105,17 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     cfg = _config.default_config()
-    cfg["network_config"].update(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256])
+    cfg["network_config"].update(**bc["nets"])
     tc = cfg["train_setup"]["train_config"]
     n_local = args.envs_per_gpu
     # the rank's envs as `--pipeline` equal groups (same clips, same model): the learner pipelines their roll-outs on separate
     # HIP streams so that one group's kernel tail + reward/obs kernels + policy inference run next to the other group's physics
     ngrp = args.pipeline if args.pipeline >= 1 and n_local % max(args.pipeline, 1) == 0 else 1
-    envs = [wrap(build_env(cfg, n_local // ngrp, device, n_clips=64), episode_length=195) for _ in range(ngrp)]
+    from track_mjx_amd import clips as _clips
+    from track_mjx_amd.walker import Rodent
+    table = _clips.make_synthetic_clips(Rodent(**cfg["walker_config"]).model, bc["n_clips"], n_frames=cfg["reference_config"]["clip_length"],
+                                        mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"])
+    envs = [wrap(build_env(cfg, n_local // ngrp, device, reference_clip=table), episode_length=195) for _ in range(ngrp)]
     env = envs[0]
     nc = cfg["network_config"]
     learner = ppo.PPOLearner(envs if ngrp > 1 else env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"],
@@ -103,14 +123,15 @@ def main():
                              entropy_cost=tc["entropy_cost"], discounting=tc["discounting"], unroll_length=tc["unroll_length"],
                              batch_size=tc["batch_size"] * world * n_local // ENVS_PER_GPU, num_minibatches=tc["num_minibatches"],
                              num_updates_per_batch=tc["num_updates_per_batch"], normalize_observations=True, kl_weight=nc["kl_weight"],
-                             seed=0)
-    # deterministic synthetic reset inputs: clip = env % 64, start_frame = env % 44
+                             seed=0, matmul_dtype=torch.bfloat16 if bc["matmul_dtype"] == "bf16" else None)
+    # deterministic synthetic reset inputs: clip = env % 64, start_frame = env % 44; cfg5: clip ~ U{0..1023}
     g = torch.Generator().manual_seed(1 + rank)
     idx = torch.arange(n_local, dtype=torch.int32) + rank * n_local
     per = n_local // ngrp
     for k, e in enumerate(envs):
         sub = idx[k * per:(k + 1) * per]
-        learner.states[k] = e.reset(g, (sub % 64).to(torch.int32), start_frame=(sub % 44).to(torch.int32))
+        clip_idx = torch.randint(0, bc["n_clips"], (per,), generator=g, dtype=torch.int32) if bc["random_clips"] else (sub % bc["n_clips"]).to(torch.int32)
+        learner.states[k] = e.reset(g, clip_idx, start_frame=(sub % 44).to(torch.int32))
 
     # HIP-event timing of the dominant kernel (k_physics_wave: the 10 physics substeps of one control step for all envs) on
     # the launch stream: env.step issues K2 and K3 as two ABI calls and records events around K2 (environment/task.py)
@@ -154,7 +175,8 @@ def main():
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "rodent tracking PPO training step: 4096 envs/GPU, 4x20-step unrolls (10 physics substeps each) + 64 minibatch updates, 2x256 intention policy + critic, fp32",
+            "config": {"workload": f"rodent tracking PPO training step ({args.config}): {n_local} envs/GPU, {learner.env_steps_per_training_step // (n_local * learner.T)}x{learner.T}-step unrolls (10 physics substeps each) + 64 minibatch updates, {bc['label']}",
+                       "n_clips": bc["n_clips"], "mlp_gemm_inputs": bc["matmul_dtype"] or "f32",
                        "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
                        "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}",
                        "policy_params": learner.n_params(), "physics_kernel_ms": kernel_ms, "envs_per_physics_launch": per_launch,

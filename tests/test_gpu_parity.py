@@ -506,3 +506,62 @@ def test_pipelined_rollout_two_env_groups():
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(v).all()) for v in m.values())
     assert not torch.equal(before, L.grads.params[0].detach())
+
+
+@pytest.mark.gpu
+def test_bf16_gemm_inputs_match_fp32_gradients():
+    """BASELINE config 5: MLP GEMMs with bf16 inputs / fp32 accumulation (autocast around the networks, parameters, loss head,
+    optimizer in fp32).  On the same roll-out buffer and parameters the loss and the flat gradient must agree with the fp32
+    learner to bf16 resolution (loss 2 %, gradient cosine > 0.98), through the eager path and through the captured hipGraph."""
+    from track_mjx_amd.agent import ppo
+    env = make_env_and_oracle(num_envs=256, n_clips=4, wrappers=True)[0]
+    kw = dict(encoder_layers=(256, 256), decoder_layers=(256, 256), critic_layers=(256, 256), latents=60, unroll_length=20,
+              batch_size=256, num_minibatches=4, num_updates_per_batch=1, seed=5)
+    L32 = ppo.PPOLearner(env, use_graph=False, **kw)
+    L16 = ppo.PPOLearner(env, use_graph=False, matmul_dtype=torch.bfloat16, **kw)
+    L32.states[0] = env.reset(torch.Generator().manual_seed(1))
+    L32.collect()
+    for k in L32.buf:
+        L16.buf[k].copy_(L32.buf[k])
+    for n in (L32, L16):
+        n.normalizer.update(n.buf["observation"])
+    idx = torch.arange(L32.local_batch, device=env.device)
+    torch.manual_seed(0)
+    m32 = L32._minibatch_grads(idx, 0.1)
+    g32 = L32.grads.flat.clone()
+    torch.manual_seed(0)
+    m16 = L16._minibatch_grads(idx, 0.1)
+    g16 = L16.grads.flat.clone()
+    assert torch.isfinite(g16).all() and g16.dtype == torch.float32
+    cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    assert cos > 0.98, cos
+    assert abs(float(m16[0]) - float(m32[0])) <= 0.02 * abs(float(m32[0])) + 1e-3, (m16, m32)
+    # the captured-graph path of a full update (what bench.py --config cfg5 runs)
+    L16.use_graph = True
+    out = L16.update(0)
+    torch.cuda.synchronize()
+    assert L16._graph is not None, "hipGraph capture of the bf16 SGD step failed"
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())
+
+
+@pytest.mark.gpu
+def test_full_size_networks_training_step():
+    """BASELINE config 4 (rodent-mc-intention nets of rodent-full-clips.yaml:50-57): parameter count, one training step finite,
+    fused block path (widths 1024 / 512 / 256) equal to the torch composition."""
+    from track_mjx_amd.agent import ppo
+    env = make_env_and_oracle(num_envs=128, n_clips=4, wrappers=True)[0]
+    L = ppo.PPOLearner(env, encoder_layers=(1024, 512, 512, 512, 512), decoder_layers=(512, 512, 512, 256, 256),
+                       critic_layers=(512, 512, 512, 512, 512, 256), latents=60, unroll_length=20, batch_size=128, num_minibatches=2,
+                       num_updates_per_batch=1, seed=2)
+    assert L.n_params() == 4_294_853, L.n_params()     # SURVEY.md §8 a20: 4.29 M parameters
+    L.states[0] = env.reset(torch.Generator().manual_seed(3))
+    out = L.training_step(0)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())
+    x = torch.randn(512, 470, device=env.device)
+    with torch.no_grad():
+        h_fused = L.policy.encoder(x)
+        h_ref = x
+        for blk in L.policy.encoder:
+            h_ref = blk.norm(torch.nn.functional.silu(torch.nn.functional.linear(h_ref, blk.dense.weight, blk.dense.bias)))
+    assert float((h_fused - h_ref).abs().max()) < 5e-4

@@ -44,18 +44,20 @@ class _SplitKLinearFn(torch.autograd.Function):
     SPLIT = 8
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         return torch.addmm(b, x, w.t())
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")      # backward under the forward's autocast state: bf16 GEMM inputs when requested
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         m, s = x.shape[0], _SplitKLinearFn.SPLIT
-        dx = dy @ w if ctx.needs_input_grad[0] else None
-        dw = torch.bmm(dy.view(s, m // s, dy.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).sum(0)
-        return dx, dw, dy.sum(0)
+        dx = (dy @ w).to(x.dtype) if ctx.needs_input_grad[0] else None
+        dw = torch.bmm(dy.view(s, m // s, dy.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).to(w.dtype).sum(0)
+        return dx, dw, dy.to(w.dtype).sum(0)
 
 
 class _Dense(nn.Linear):
@@ -78,20 +80,22 @@ class _SplitKMatmulFn(torch.autograd.Function):
     """z = x W^T (no bias) with the split-K weight gradient of _SplitKLinearFn."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
         return x @ w.t()
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
         m, s = x.shape[0], _SplitKLinearFn.SPLIT
-        dx = dz @ w if ctx.needs_input_grad[0] else None
+        dx = (dz @ w).to(x.dtype) if ctx.needs_input_grad[0] else None
         if m % s == 0 and m >= 4096:
-            dw = torch.bmm(dz.view(s, m // s, dz.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).sum(0)
+            dw = torch.bmm(dz.view(s, m // s, dz.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).to(w.dtype).sum(0)
         else:
             dw = dz.t() @ x
-        return dx, dw
+        return dx, dw.to(w.dtype)
 
 
 class _SiluLayerNormFn(torch.autograd.Function):

@@ -21,13 +21,15 @@ from .environment import MultiClipTracking, RewardConfig
 from .walker import Rodent
 
 
-def build_env(cfg: dict, num_envs_local: int, device, n_clips: int = 64, clip_seed: int = 0):
+def build_env(cfg: dict, num_envs_local: int, device, n_clips: int = 64, clip_seed: int = 0, reference_clip=None):
+    """`reference_clip`: a clip table built earlier (env groups of one rank share it); None = generate the synthetic table."""
     walker = Rodent(**cfg["walker_config"])
     reward_config = RewardConfig(**cfg["env_config"]["reward_weights"])
     if cfg.get("data_path", "synthetic") != "synthetic":
         raise NotImplementedError("HDF5 clip loading is a 'next' item (SURVEY.md §8 f2); use data_path=synthetic")
-    reference_clip = _clips.make_synthetic_clips(walker.model, n_clips, n_frames=cfg["reference_config"]["clip_length"], seed=clip_seed,
-                                                 mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"])
+    if reference_clip is None:
+        reference_clip = _clips.make_synthetic_clips(walker.model, n_clips, n_frames=cfg["reference_config"]["clip_length"], seed=clip_seed,
+                                                     mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"])
     env = MultiClipTracking(reference_clip, walker, reward_config, **cfg["env_config"]["env_args"], **cfg["reference_config"],
                             num_envs=num_envs_local, device=device)
     return env
