@@ -565,3 +565,28 @@ def test_full_size_networks_training_step():
         for blk in L.policy.encoder:
             h_ref = blk.norm(torch.nn.functional.silu(torch.nn.functional.linear(h_ref, blk.dense.weight, blk.dense.bias)))
     assert float((h_fused - h_ref).abs().max()) < 5e-4
+
+
+@pytest.mark.gpu
+def test_reset_from_jax_key_draws():
+    """reset(key) with a jax PRNG key: clip index, start frame and noise are the threefry draws of the reference's reset
+    (bit-exact integers; the state equals the reference frame + that noise)."""
+    from track_mjx_amd import jax_random as jr
+    env, O, cl = make_env_and_oracle(num_envs=64, n_clips=4, wrappers=True)
+    key = jr.PRNGKey(42)
+    st = env.reset(key)
+    torch.cuda.synchronize()
+    keys = jr.split(key, 64)
+    ci, sf, qn, vn = jr.reset_draws_batch(keys, 4, 74, 73, env._reset_noise_scale)
+    assert np.array_equal(st.info["clip_idx"].cpu().numpy(), ci) and np.array_equal(st.info["start_frame"].cpu().numpy(), sf)
+    L = env.layout
+    qpos = env.state_buf[L.qpos:L.qpos + L.nq].cpu().numpy()
+    ref = np.concatenate([cl.position[ci, sf], cl.quaternion[ci, sf], cl.joints[ci, sf]], axis=-1).T
+    want = ref + qn
+    want[3:7] /= np.linalg.norm(want[3:7], axis=0, keepdims=True)      # the forward pass stores the normalised root quaternion (MJX kinematics)
+    assert np.abs(qpos - want).max() < 1e-6
+    qvel = env.state_buf[L.qvel:L.qvel + L.nv].cpu().numpy()
+    assert np.array_equal(qvel, vn) and np.array_equal(vn, qn[:73])      # the reference draws both from rng1
+    st2 = env.reset(keys)           # per-env keys give the same state
+    torch.cuda.synchronize()
+    assert np.array_equal(env.state_buf[L.qvel:L.qvel + L.nv].cpu().numpy(), vn)

@@ -1,0 +1,51 @@
+"""Same-seed RNG (track_mjx_amd/jax_random.py) against the known answers that exist for jax's generator:
+the Random123 Threefry-2x32 vectors jax's own test-suite checks (tests/random_test.py::testThreefry2x32) and the values jax's
+documentation prints for key 0 / seed 1701 (legacy counter layout: split, bits, normal; partitionable layout: split)."""
+import numpy as np
+
+from track_mjx_amd import jax_random as jr
+
+
+def test_threefry2x32_random123_known_answers():
+    for key, cnt, exp in (((0x0, 0x0), (0x0, 0x0), (0x6b200159, 0x99ba4efe)),
+                          ((0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0x1cb996fc, 0xbb002be7)),
+                          ((0x13198a2e, 0x03707344), (0x243f6a88, 0x85a308d3), (0xc4923a9c, 0x483df7a0))):
+        y0, y1 = jr.threefry2x32(np.array(key, dtype=np.uint32), np.array([cnt[0]], np.uint32), np.array([cnt[1]], np.uint32))
+        assert (int(y0[0]), int(y1[0])) == exp
+
+
+def test_legacy_layout_known_answers():
+    assert jr.bits(jr.PRNGKey(1701), (3,), partitionable=False).tolist() == [56197195, 4200222568, 961309823]
+    assert jr.split(jr.PRNGKey(0), 2, partitionable=False).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    np.testing.assert_allclose(jr.normal(jr.PRNGKey(0), (3,), partitionable=False), [1.8160863, -0.48262316, 0.33988908], rtol=2e-6)
+
+
+def test_partitionable_layout_known_answer_and_prefix_property():
+    assert jr.split(jr.PRNGKey(0), 2).tolist() == [[1797259609, 2579123966], [928981903, 3453687069]]
+    k = jr.PRNGKey(7)
+    # one counter per element: a shorter draw is a prefix of a longer one — the reference's qvel noise (same key as qpos noise,
+    # single_clip_tracking.py:153-161) therefore repeats the first nv values of the qpos noise
+    assert np.array_equal(jr.uniform(k, (74,), -1e-3, 1e-3)[:73], jr.uniform(k, (73,), -1e-3, 1e-3))
+    assert np.array_equal(jr.fold_in(jr.PRNGKey(0), 1), jr.split(jr.PRNGKey(0), 2)[1])     # both are threefry(key, (0, 1))
+
+
+def test_ranges_and_permutation():
+    k = jr.PRNGKey(3)
+    u = jr.uniform(k, (10000,), -0.5, 0.25)
+    assert u.dtype == np.float32 and u.min() >= -0.5 and u.max() < 0.25 and abs(float(u.mean()) + 0.125) < 0.01
+    r = jr.randint(k, (10000,), 0, 44)
+    assert r.dtype == np.int32 and r.min() == 0 and r.max() == 43 and len(np.unique(r)) == 44
+    p = jr.permutation(k, 16384)
+    assert sorted(p.tolist()) == list(range(16384)) and not np.array_equal(p, np.arange(16384))
+    z = jr.normal(k, (20000,))
+    assert abs(float(z.mean())) < 0.03 and abs(float(z.std()) - 1.0) < 0.03
+
+
+def test_reset_draws_batch_matches_scalar_path():
+    keys = jr.split(jr.PRNGKey(11), 37)
+    ci, sf, qn, vn = jr.reset_draws_batch(keys, 64, 74, 73, 1e-3)
+    assert qn.shape == (74, 37) and vn.shape == (73, 37)
+    for e in (0, 5, 36):
+        c1, s1, q1, v1 = jr.reset_draws(keys[e], 64, 74, 73, 1e-3)
+        assert (int(ci[e]), int(sf[e])) == (c1, s1)
+        assert np.array_equal(qn[:, e], q1) and np.array_equal(vn[:, e], v1)

@@ -185,15 +185,31 @@ class MultiClipTracking:
         return State(ps, self.obs_buf.t(), self.reward_buf, self.done_buf, metrics, info)
 
     # ---- reset / step
-    def reset(self, rng: torch.Generator | int | None = None, clip_idx: torch.Tensor | None = None, *,
+    def reset(self, rng=None, clip_idx: torch.Tensor | None = None, *,
               start_frame: torch.Tensor | None = None, qpos_noise: torch.Tensor | None = None,
               qvel_noise: torch.Tensor | None = None) -> State:
         """reset(rng, clip_idx=None) (reference: task/multi_clip_tracking.py:74-96).
 
         start_frame ~ randint[0,44) and clip_idx ~ randint[0,n_clips) as in the reference; the noise is
         U(-reset_noise_scale, +reset_noise_scale) for qpos[nq] and qvel[nv].  Explicit tensors override the draws
-        (layout: clip_idx/start_frame [n] int32, qpos_noise [nq][n], qvel_noise [nv][n])."""
+        (layout: clip_idx/start_frame [n] int32, qpos_noise [nq][n], qvel_noise [nv][n]).  `rng`: a torch.Generator / int seed
+        (torch's generator), or a jax PRNG key as a uint32 numpy array ([2] or [n, 2]): then clip, start frame and noise are the
+        reference's own draws from that key (threefry, jax_random.py)."""
         n, L, dev = self.num_envs, self.layout, self.device
+        import numpy as _np
+        if isinstance(rng, _np.ndarray) and rng.dtype == _np.uint32 and rng.shape[-1] == 2:
+            # a jax PRNG key ([2] uint32: split into one key per env as brax's vmapped reset receives them, or [n, 2] per-env
+            # keys): the draws of the reference from the same key(s) (jax_random.py; SURVEY.md §8 f3)
+            from .. import jax_random as _jr
+            keys = _jr.split(rng, n) if rng.ndim == 1 else rng
+            if keys.shape != (n, 2):
+                raise ValueError(f"per-env keys must be [{n}, 2] uint32")
+            ci_, sf_, qn_, vn_ = _jr.reset_draws_batch(keys, max(self._n_clips, 1), int(L.nq), int(L.nv), self._reset_noise_scale)
+            clip_idx = torch.from_numpy(ci_) if clip_idx is None else clip_idx
+            start_frame = torch.from_numpy(sf_) if start_frame is None else start_frame
+            qpos_noise = torch.from_numpy(qn_) if qpos_noise is None else qpos_noise
+            qvel_noise = torch.from_numpy(vn_) if qvel_noise is None else qvel_noise
+            rng = None
         g = rng if isinstance(rng, torch.Generator) else torch.Generator(device="cpu").manual_seed(int(rng or 0))
         if start_frame is None:
             start_frame = torch.randint(0, 44, (n,), generator=g, dtype=torch.int32)
