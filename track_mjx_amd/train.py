@@ -21,15 +21,35 @@ from .environment import MultiClipTracking, RewardConfig
 from .walker import Rodent
 
 
+def load_clip_sets(cfg: dict, n_synthetic_clips: int = 64, clip_seed: int = 0):
+    """(train_clips, test_clips or None) as track_mjx/train.py:163-209 selects them: `data_path` = an HDF5 clip file in the
+    stac-mjx or ReferenceClip layout (io/load.py) or "synthetic"; a JSON split file (`train_setup.train_test_split_info`), a
+    random split (`train_subset_ratio` with a file) or the whole set."""
+    import json
+    from .io import load
+    ts = cfg["train_setup"]
+    path = cfg.get("data_path", "synthetic")
+    if path == "synthetic":
+        walker = Rodent(**cfg["walker_config"])
+        return _clips.make_synthetic_clips(walker.model, n_synthetic_clips, n_frames=cfg["reference_config"]["clip_length"], seed=clip_seed,
+                                           mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"]), None
+    all_clips = load.load_data(path)
+    if ts.get("train_test_split_info") is not None:
+        with open(ts["train_test_split_info"], "r") as f:
+            split = json.load(f)
+        train_idx = split["train"] if ts.get("train_subset_ratio") is None else split["train_subset"][f"{ts['train_subset_ratio']:.2f}"]
+        return load.select_clips(all_clips, train_idx), load.select_clips(all_clips, split["test"])
+    if ts.get("train_subset_ratio") is not None:
+        return load.generate_train_test_split(all_clips, test_ratio=1 - ts["train_subset_ratio"])
+    return all_clips, None
+
+
 def build_env(cfg: dict, num_envs_local: int, device, n_clips: int = 64, clip_seed: int = 0, reference_clip=None):
     """`reference_clip`: a clip table built earlier (env groups of one rank share it); None = generate the synthetic table."""
     walker = Rodent(**cfg["walker_config"])
     reward_config = RewardConfig(**cfg["env_config"]["reward_weights"])
-    if cfg.get("data_path", "synthetic") != "synthetic":
-        raise NotImplementedError("HDF5 clip loading is a 'next' item (SURVEY.md §8 f2); use data_path=synthetic")
     if reference_clip is None:
-        reference_clip = _clips.make_synthetic_clips(walker.model, n_clips, n_frames=cfg["reference_config"]["clip_length"], seed=clip_seed,
-                                                     mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"])
+        reference_clip = load_clip_sets(cfg, n_clips, clip_seed)[0]
     env = MultiClipTracking(reference_clip, walker, reward_config, **cfg["env_config"]["env_args"], **cfg["reference_config"],
                             num_envs=num_envs_local, device=device)
     return env
@@ -53,7 +73,8 @@ def main(argv=None) -> None:
     ngrp = int(cfg.get("rollout_groups", 2))
     if ngrp < 1 or (hi - lo) % ngrp:
         ngrp = 1
-    envs = [build_env(cfg, (hi - lo) // ngrp, device, n_clips=int(cfg.get("n_synthetic_clips", 64))) for _ in range(ngrp)]
+    train_clips, test_clips = load_clip_sets(cfg, int(cfg.get("n_synthetic_clips", 64)))
+    envs = [build_env(cfg, (hi - lo) // ngrp, device, reference_clip=train_clips) for _ in range(ngrp)]
     env = envs[0]
     rc, ts = cfg["reference_config"], cfg["train_setup"]
     # train.py:221-225
@@ -64,7 +85,9 @@ def main(argv=None) -> None:
 
     # evaluator env (ppo.py:629-647: the same environment class with num_eval_envs envs; rank 0 only)
     num_eval_envs = int(tc.get("num_eval_envs", 128))
-    eval_env = build_env(cfg, num_eval_envs, device, n_clips=int(cfg.get("n_synthetic_clips", 64))) if int(os.environ.get("RANK", "0")) == 0 and num_eval_envs > 0 else None
+    # evaluated on the held-out clips when there is a split, else on the training set (train.py:176-209)
+    eval_env = build_env(cfg, num_eval_envs, device, reference_clip=test_clips if test_clips is not None and test_clips.position.shape[0] > 0 else train_clips) \
+        if int(os.environ.get("RANK", "0")) == 0 and num_eval_envs > 0 else None
 
     def progress(num_steps, metrics):
         print(f"[train] steps={num_steps} " + " ".join(f"{k}={v:.4g}" for k, v in sorted(metrics.items())), flush=True)
