@@ -16,6 +16,7 @@
 #include "../../track_mjx_amd/csrc/env_core.h"
 #include "../../track_mjx_amd/csrc/model_host.h"
 #include "../../track_mjx_amd/csrc/wave_physics.h"
+#include <algorithm>
 #include <vector>
 
 struct EmuModel { DModel h; float *clips[5]; };
@@ -68,10 +69,12 @@ void emu_physics(EmuModel *mm, float *st, const float *action, int nsub, int do_
 }
 // wave-per-env kernel body (csrc/wave_physics.h): one emulated 64-lane wavefront + an LDS image per env
 void emu_physics_wave(EmuModel *mm, float *st, const float *action, int nsub, int do_euler, float *ws_dump, int n) {
-  std::vector<float> lds(mm->h.lds_floats + 64);
+  std::vector<float> lds(std::max(tmjx_host::make_wave_layout(mm->h, true).lds_floats, tmjx_host::make_wave_layout(mm->h, false).lds_floats) + 64);
   for (int e = 0; e < n; e++) {
     for (auto &v : lds) v = 0.f;
     WCtx c{&mm->h, lds.data(), st, n, e, 0, nullptr, 0ull, ws_dump};
+    std::vector<float> spill(mm->h.nnz + 64, 0.f);
+    c.mspill = spill.data() + 64;
     const WLayout K = tmjx_host::make_wave_layout(mm->h, !getenv("TMJX_EMU_GENERIC"));
     float time = tmw_load_state(c, K, action);
     for (int f = 0; f < nsub; f++) { tmw_forward(c, K, f == nsub - 1); if (do_euler) time = tmw_euler(c, K, time); }

@@ -21,7 +21,13 @@ struct tmjx_model {
   int block = 64;     // lanes per workgroup for the lane-per-env kernels (K1/K3 and the v1 physics)
   int wave = 1;       // 1: wave-per-env LDS physics kernel (default); 0: lane-per-env reference implementation
   bool rodent = false;  // dims match the compile-time specialisation of the wave kernel
+  // chain layout of the wave kernel (wave_layout.h): per-env global copy of the inertia matrix M (written after "M rows", read by
+  // Euler's factorisation of M + h D).  Owned by the handle, (re)allocated when a launch needs more envs than it holds — the one
+  // piece of mutable per-handle scratch: a handle serves one stream at a time (include/tmjx.h)
+  mutable float *mspill = nullptr;
+  mutable int mspill_envs = 0;
 };
+#define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
 // record stride: state rows qpos .. qfrc_actuator, then the action, rounded up to 16 words
 #define WAVE_REC_STRIDE(m) ((((m)->h.s_prev_ctrl + (m)->h.nu) + 15) & ~15)
 // workspace words in front of the record: window partials (2 nu rows) + post partials (16 rows), each n_env wide
@@ -164,10 +170,11 @@ __global__ __launch_bounds__(64) void k_rec_out(const DModel *__restrict__ mp, f
 // STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
 template <bool STATIC>
 __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
-                                                     int do_euler, float *ws_dump, int n, int e0, int rs) {
+                                                     int do_euler, float *ws_dump, int n, int e0, int rs, float *spill, int spill_stride) {
   extern __shared__ float tmw_lds[];
   WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x + e0, (int)threadIdx.x, nullptr, 0ull, nullptr};
   c.rs = rs;
+  c.mspill = spill ? spill + 64 + (size_t)(blockIdx.x + e0) * (size_t)spill_stride : nullptr;
 #ifndef TMW_PROFILE
   c.dump = ws_dump;
 #endif
@@ -250,11 +257,11 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
   const char *impl = getenv("TMJX_IMPL");
   if (impl && !strcmp(impl, "lane")) m->wave = 0;
   if (m->wave) {
-    size_t lds_bytes = (size_t)m->h.lds_floats * sizeof(float);
+    size_t lds_bytes = (size_t)tmjx_host::make_wave_layout(m->h, false).lds_floats * sizeof(float);   // the larger (generic) layout
     if (lds_bytes > 160 * 1024) { delete m; return fail(TMJX_EINVAL, "model does not fit the 160 KiB LDS of a CU"); }
     if (lds_bytes > 64 * 1024) { delete m; return fail(TMJX_EINVAL, "model needs more than 64 KiB of LDS per env"); }
     if (m->h.nefc > 254 || m->h.nlim > 128) { delete m; return fail(TMJX_EINVAL, "more than 254 constraint rows or 128 joint limits (wave kernel: byte row map, line-search rows in 4 registers per lane)"); }
-    constexpr WLayout ks(TMW_RODENT_DIMS);
+    constexpr WLayout ks(TMW_RODENT_DIMS, 1);
     const WLayout kd = tmjx_host::make_wave_layout(m->h);
     m->rodent = !getenv("TMJX_WAVE_DYNAMIC") && kd.nbody == ks.nbody && kd.njnt == ks.njnt && kd.nq == ks.nq && kd.nv == ks.nv &&
                 kd.nu == ks.nu && kd.ncon == ks.ncon && kd.nlim == ks.nlim && kd.nnz == ks.nnz && kd.ngroup == ks.ngroup &&
@@ -272,6 +279,7 @@ void tmjx_model_destroy(tmjx_model *m) {
   if (!m) return;
   for (int i = 0; i < 5; i++) if (m->clips[i]) hipFree(m->clips[i]);
   if (m->d) hipFree(m->d);
+  if (m->mspill) hipFree(m->mspill);
   delete m;
 }
 
@@ -311,8 +319,17 @@ int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quatern
 
 static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream,
                         float *rec) {
-  size_t lds = (size_t)m->h.lds_floats * sizeof(float);
+  // the compile-time (rodent) kernel uses the chain layout, the run-time one the generic layout of the same dims
+  size_t lds = (size_t)(m->rodent ? m->h.lds_floats : tmjx_host::make_wave_layout(m->h, false).lds_floats) * sizeof(float);
   if (const char *pad = getenv("TMJX_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;  // occupancy experiments only
+  const int sstride = WAVE_SPILL_STRIDE(m);
+  if (m->rodent && m->mspill_envs < n_env) {
+    if (m->mspill) hipFree(m->mspill);            // (hipFree waits for the launches that may still read the old block)
+    m->mspill = nullptr; m->mspill_envs = 0;
+    if (hipMalloc((void **)&m->mspill, ((size_t)n_env * sstride + 64) * sizeof(float)) == hipSuccess) m->mspill_envs = n_env;
+    else { m->mspill = nullptr; return; }         // reported by the caller's check_launch via hipGetLastError
+  }
+  float *spill = m->rodent ? m->mspill : nullptr;
   int parts = 1;
   if (const char *sp = getenv("TMJX_SPLIT_LAUNCH")) { parts = atoi(sp); if (parts < 1 || n_env % parts) parts = 1; }   // scheduling experiments
   const int rs = rec ? WAVE_REC_STRIDE(m) : 0;
@@ -320,8 +337,8 @@ static void launch_wave(const tmjx_model *m, float *state, const float *action, 
   float *st = rec ? rec : state;
   for (int p = 0; p < parts; p++) {
     int cnt = n_env / parts, e0 = p * cnt;
-    if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs);
-    else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs);
+    if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs, spill, sstride);
+    else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs, spill, sstride);
   }
   if (rec) hipLaunchKernelGGL(k_rec_out, dim3((n_env + 63) / 64, (m->h.s_prev_ctrl - m->h.s_qpos + REC_ROWS_PER_THREAD - 1) / REC_ROWS_PER_THREAD), dim3(64), 0, stream, m->d, state, (const float *)rec, n_env, rs);
 }

@@ -57,7 +57,35 @@ struct WLayout {
     int endB2 = l;
     lds_floats = endA > endB1 ? endA : endB1;
     if (endB2 > lds_floats) lds_floats = endB2;
+    if (ch && 2 * nbody * 8 <= nnz && nv * 7 <= nbody * 8) {
+      // Chain layout (register-resident factorisation, wave_physics.h): ONE matrix region.  M is factorised IN PLACE (a chain's
+      // rows are in registers before its first row of L is stored), so l_LD == l_M; M itself goes to a per-env global scratch right
+      // after it is built (Euler's second factorisation reads it back from there, M * warm start is taken before the first one).
+      // Between Euler and the next "M rows" step the region is dead and hosts the transform / dof scan buffers.  With that the
+      // solver-stage region A loses LD and the kinematics region B its scan buffers: 15.9 KB per env instead of 20.4 KB, i.e. 10
+      // instead of 8 envs per CU.
+      l_LD = l_M;
+      l_scanA = l_M; l_scanB = l_M + nbody * 8; l_dscanA = l_scanA; l_dscanB = l_scanB;
+      l = l_alias0;
+      l_Dinv = l; l += nv; l_efc_D = l; l += nefc; l_efc_aref = l; l += nefc; l_Jaref = l; l += nefc;
+      l_jv = l_efc_aref; l_wr = l_efc_aref;
+      l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
+      l_Mgrad = l; l += nv; l_search = l; l += nv; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
+      l_dummy = l_mv;
+      int eA = l;
+      // region B: xipos | joint anchors | joint axes; cinert overlays the joint frames (dead once cdof is built) but not xipos,
+      // which the cinert step still reads; cfrc behind cinert
+      l = l_alias0;
+      l_xipos = l; l += nbody * 3; l_jl_anchor = l; l += njnt * 3; l_jl_axis = l; l += njnt * 3;
+      int eB1 = l;
+      l_cinert = l_alias0 + nbody * 3; l_cfrc = l_cinert + nbody * 10;
+      int eB2 = l_cfrc + nbody * 6;
+      lds_floats = eA > eB1 ? eA : eB1;
+      if (eB2 > lds_floats) lds_floats = eB2;
+    }
   }
+  // true when M lives in the per-env global scratch outside the "M rows" -> first factorisation window (see above)
+  constexpr bool m_spilled() const { return chains && l_LD == l_M; }
 };
 
 // the rodent walker of the reference (track_mjx/environment/walker/assets/rodent/rodent.xml): 68 bodies, 68 joints,

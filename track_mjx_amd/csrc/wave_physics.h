@@ -67,6 +67,7 @@ struct WCtx {
   int nact;                   // number of ACTIVE constraint rows of the current substep (compact row space, tmw_make_constraint)
   int nla;                    // ... of which violated joint limits (the active contacts' rows follow, four each)
   int rs;                     // 0: `st` is the [row][n_env] state; > 0: `st` is the env-major physics record with this stride
+  float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
@@ -758,13 +759,16 @@ template <int FIRST, int N, int D0, bool EULER>
 TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float hdamp, int rhs) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_M + tmw_chain_madr(FIRST);
+  // Euler with the shared matrix region: l_M holds L^-1 by now, M comes back from the env's global copy (same word order; the
+  // loads of a chain's rows are independent and issued together, lanes beyond a row read the words in front of it)
+  const float *G = (EULER && K.m_spilled()) ? c.mspill + tmw_chain_madr(FIRST) : nullptr;
   TMW_REG(float, hd);   // hdamp * damping of the chain dof whose DIAGONAL sits in this lane (depth = lane)
   if (EULER) { TMW_FOR { bool mine = TMW_MASK(TMW_M_RANGE(D0, D0 + N)); hd[TMW_LI] = mine ? hdamp * m.dof_damping[mine ? FIRST + lane - D0 : 0] : 0.f; } }
   TMW_FOR {
 #pragma unroll
     for (int k = 0; k < N; k++) {
       const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;   // Madr(FIRST + k) - Madr(FIRST): rows are stored back to back
-      float v = L[adr0 - lane + (off + dk)];   // lanes beyond the row read (and discard) whatever precedes it in LDS
+      float v = (EULER && K.m_spilled()) ? G[(off + dk) - lane] : L[adr0 - lane + (off + dk)];   // lanes beyond the row read (and discard) whatever precedes it
       if (EULER) v += TMW_MASK(TMW_M_EQ(dk)) ? hd[TMW_LI] : 0.f;
       v = TMW_MASK(TMW_M_LT(dk + 1)) ? v : 0.f;
       if (EULER) v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? L[rhs + FIRST + k] : v;
@@ -1459,10 +1463,11 @@ TM_DEV float tmw_dot(WCtx &c, const WLayout &K, int a, int b) {
 // Jaref <- J q - aref ; Ma <- M q ; returns cost and gauss for qacc vector `q`
 // `jonly`: q IS qacc_smooth = M^-1 qfrc_smooth: the Gauss term is exactly zero (q - qacc_smooth = 0 in MJX's own arithmetic as
 // well) and M q is not needed by the caller (tmw_solve_cg) — no product with M
-TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool jonly = false) {
+// `have_ma`: l_Ma already holds M q (chain layout: taken before M was factorised in place) — J q only, Gauss term from l_Ma
+TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool jonly = false, bool have_ma = false) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
-  if (jonly) tmw_jmul(c, K, q, K.l_Jaref);
+  if (jonly || have_ma) tmw_jmul(c, K, q, K.l_Jaref);
   else tmw_mul_m_jmul(c, K, q, K.l_Ma, K.l_Jaref);
   TMW_TICK2(19);
   TMW_REG(float, pc); TMW_REG(float, pg);
@@ -1681,7 +1686,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   // start from the warm start unless the unconstrained acceleration has the lower cost (MJX evaluates warm, smooth and
   // then the winner again; evaluating smooth FIRST leaves M qacc / Jaref of the warm start — the usual winner — in place)
   float gs, cs = tmw_eval_cost(c, K, K.l_qacc_smooth, gs, true);
-  float cw = tmw_eval_cost(c, K, K.l_qacc, gauss);
+  float cw = tmw_eval_cost(c, K, K.l_qacc, gauss, false, K.m_spilled());
   float cost = cw;
   if (cw < cs) {     // ut = y - y_s = D^-1 N^T (M qacc - qfrc_smooth)
     TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Ma + i] -= L[K.l_qfrc_smooth + i]; }
@@ -1730,6 +1735,12 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   TMW_TICK(0);
   tmw_velocity_inertia(c, K);
   TMW_TICK(1);
+  if (K.m_spilled()) {
+    // M is about to be factorised in place: keep a copy in global memory for Euler's factorisation of M + h D, and take the one
+    // product with M the solver needs (M * warm start, tmw_solve_cg) now
+    TMW_FOR { for (int i = lane; i < K.nnz; i += 64) c.mspill[i] = L[K.l_M + i]; }
+    tmw_mul_m(c, K, K.l_warm, K.l_Ma);
+  }
   if (K.chains) tmw_factor_chains<false>(c, K, 0.f, -1); else tmw_factor(c, K, 0.f);
   TMW_TICK(2);
   if (K.chains) tmw_invert_chains(c, K); else tmw_invert_l(c, K);
@@ -1787,7 +1798,7 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
 #define WDUMP(row, i) ws[(size_t)((row) + (i)) * (size_t)c.n + (size_t)c.e]
   TMW_FOR {
-    for (int i = lane; i < K.nnz; i += 64) WDUMP(m.w_M, i) = L[K.l_M + i];
+    for (int i = lane; i < K.nnz; i += 64) WDUMP(m.w_M, i) = K.m_spilled() ? c.mspill[i] : L[K.l_M + i];
     for (int i = lane; i < K.nv * 6; i += 64) WDUMP(m.w_cdof, i) = L[K.l_cdof + i];
     for (int i = lane; i < K.nv; i += 64) {
       WDUMP(m.w_qfrc_smooth, i) = L[K.l_qfrc_smooth + i]; WDUMP(m.w_qacc_smooth, i) = L[K.l_qacc_smooth + i];
