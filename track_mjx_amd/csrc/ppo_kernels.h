@@ -368,40 +368,51 @@ __global__ __launch_bounds__(128) void k_linear_nolds(const float *__restrict__ 
   int rr[NL_TM];
 #pragma unroll
   for (int i = 0; i < NL_TM; i++) rr[i] = row0 + i < M ? row0 + i : M - 1;
-  // register double buffering: the operands of step k + V are in flight while step k is multiplied (one or two waves per SIMD
-  // is all this kernel gets next to the physics kernel, so nothing else hides the L1/L2 latency)
-  VT an[NL_TM], wn[NL_TN];
-  float4 akn[V];
-  auto load = [&](int k) {
+  // register prefetch ring, two steps deep: the operands of steps k + V and k + 2V are in flight while step k is multiplied (one
+  // or two waves per SIMD is all this kernel gets next to the physics kernel, so nothing else hides the L2 latency: the K loop is
+  // a chain of load -> use round trips, and a ring one step deep left one full latency per step exposed)
+  struct Stage { VT an[NL_TM], wn[NL_TN]; float4 akn[V]; };
+  auto load = [&](Stage &st, int k) {
     if (A_KMAJOR) {
 #pragma unroll
-      for (int v = 0; v < V; v++) akn[v] = *reinterpret_cast<const float4 *>(A + (long long)(k + v) * sa_k + rbase);
+      for (int v = 0; v < V; v++) st.akn[v] = *reinterpret_cast<const float4 *>(A + (long long)(k + v) * sa_k + rbase);
     } else {
 #pragma unroll
-      for (int i = 0; i < NL_TM; i++) an[i] = *reinterpret_cast<const VT *>(A + (long long)rr[i] * sa_row + k);
+      for (int i = 0; i < NL_TM; i++) st.an[i] = *reinterpret_cast<const VT *>(A + (long long)rr[i] * sa_row + k);
     }
 #pragma unroll
-    for (int j = 0; j < NL_TN; j++) wn[j] = *reinterpret_cast<const VT *>(W + (size_t)cc[j] * K + k);
+    for (int j = 0; j < NL_TN; j++) st.wn[j] = *reinterpret_cast<const VT *>(W + (size_t)cc[j] * K + k);
   };
-  load(0);
-  for (int k = 0; k < K; k += V) {
+  auto fma_stage = [&](const Stage &st) {
     float a[NL_TM][V], w[NL_TN][V];
     if (A_KMAJOR) {
 #pragma unroll
-      for (int v = 0; v < V; v++) { a[0][v] = akn[v].x; a[1][v] = akn[v].y; a[2][v] = akn[v].z; a[3][v] = akn[v].w; }
+      for (int v = 0; v < V; v++) { a[0][v] = st.akn[v].x; a[1][v] = st.akn[v].y; a[2][v] = st.akn[v].z; a[3][v] = st.akn[v].w; }
     } else {
 #pragma unroll
-      for (int i = 0; i < NL_TM; i++) nl_unpack<V>(an[i], a[i]);
+      for (int i = 0; i < NL_TM; i++) nl_unpack<V>(st.an[i], a[i]);
     }
 #pragma unroll
-    for (int j = 0; j < NL_TN; j++) nl_unpack<V>(wn[j], w[j]);
-    if (k + V < K) load(k + V);
+    for (int j = 0; j < NL_TN; j++) nl_unpack<V>(st.wn[j], w[j]);
 #pragma unroll
     for (int v = 0; v < V; v++)
 #pragma unroll
       for (int i = 0; i < NL_TM; i++)
 #pragma unroll
         for (int j = 0; j < NL_TN; j++) acc[i][j] = fmaf(a[i][v], w[j][v], acc[i][j]);
+  };
+  Stage s0, s1, s2;
+  load(s0, 0);
+  if (V < K) load(s1, V);
+  for (int k = 0; k < K; k += 3 * V) {          // the ring as three named stages (register arrays cannot be indexed dynamically)
+    if (k + 2 * V < K) load(s2, k + 2 * V);
+    fma_stage(s0);
+    if (k + V >= K) break;
+    if (k + 3 * V < K) load(s0, k + 3 * V);
+    fma_stage(s1);
+    if (k + 2 * V >= K) break;
+    if (k + 4 * V < K) load(s1, k + 4 * V);
+    fma_stage(s2);
   }
   const int rout = A_KMAJOR ? rbase : row0;
 #pragma unroll
