@@ -1553,9 +1553,47 @@ struct TmwLS { float alpha, cost, d0, d1; };
 // t0 = D ja^2 / 2, t1 = D ja jv, t2 = D jv^2 / 2 and (ja, jv) for the activity test ja + alpha jv < 0.
 #define TMW_LS_SLOTS 4        // up to 256 constraint rows
 struct TmwLSRows { float ja[TMW_NL][TMW_LS_SLOTS], jv[TMW_NL][TMW_LS_SLOTS], D[TMW_NL][TMW_LS_SLOTS], t0[TMW_NL][TMW_LS_SLOTS], t1[TMW_NL][TMW_LS_SLOTS], t2[TMW_NL][TMW_LS_SLOTS]; };
+// sums over the three 16-lane rows 0 / 1 / 2 of the wave (lanes 0-15, 16-31, 32-47): four row-local DPP steps, then one readlane per row
+#ifdef TM_HOST_EMU
+template <int NROW> TM_DEV void tmw_rowsum16(const float *v, float *out) { for (int r = 0; r < NROW; r++) { float s = 0.f; for (int l = 0; l < 16; l++) s += v[16 * r + l]; out[r] = s; } }
+#else
+template <int NROW> TM_DEV void tmw_rowsum16(const float *vp, float *out) {
+  float v = vp[0];
+  v = tmw_dpp_add<0x111, 0xf, 0xf>(v);
+  v = tmw_dpp_add<0x112, 0xf, 0xf>(v);
+  v = tmw_dpp_add<0x114, 0xf, 0xe>(v);
+  v = tmw_dpp_add<0x118, 0xf, 0xc>(v);
+#pragma unroll
+  for (int r = 0; r < NROW; r++) out[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 16 * r + 15));
+}
+#endif
+// At most 16 active rows (the usual case): the rows are replicated in lanes 0-15, 16-31 and 32-47 (tmw_linesearch) and the three
+// candidates of an iteration are evaluated side by side, one per 16-lane row — 3 masked sums and 3 row reductions instead of 9 + 9
+template <int NP>
+TM_DEV void tmw_ls_points16(WCtx &c, const TmwLSRows &R, const float *a, float g0, float g1, float g2, TmwLS *out) {
+  TMW_LANE_DECL
+  TMW_REG(float, q0); TMW_REG(float, q1); TMW_REG(float, q2);
+  TMW_FOR {
+    float al = a[0];
+    if (NP > 1) al = TMW_MASK(TMW_M_LT(16)) ? a[0] : (TMW_MASK(TMW_M_LT(32)) ? a[1] : a[2]);
+    bool act = R.ja[TMW_LI][0] + al * R.jv[TMW_LI][0] < 0.f;
+    q0[TMW_LI] = act ? R.t0[TMW_LI][0] : 0.f; q1[TMW_LI] = act ? R.t1[TMW_LI][0] : 0.f; q2[TMW_LI] = act ? R.t2[TMW_LI][0] : 0.f;
+  }
+  float s0[NP], s1[NP], s2[NP];
+  tmw_rowsum16<NP>(q0, s0); tmw_rowsum16<NP>(q1, s1); tmw_rowsum16<NP>(q2, s2);
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    float r0 = g0 + s0[p], r1 = g1 + s1[p], r2 = g2 + s2[p], al = a[p];
+    out[p].alpha = al;
+    out[p].cost = al * al * r2 + al * r1 + r0;
+    out[p].d0 = 2.f * al * r2 + r1;
+    out[p].d1 = 2.f * r2 + (r2 == 0.f ? TM_MINVAL : 0.f);
+  }
+}
 // NP line-search points evaluated together (alphas a[0..NP-1]): 3 NP partial sums over the rows, reduced together
 template <int NP, int WIDTH>
 TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const float *a, float g0, float g1, float g2, TmwLS *out) {
+  if (WIDTH == 16) { tmw_ls_points16<NP>(c, R, a, g0, g1, g2, out); return; }
   TMW_LANE_DECL
   float q[3 * NP][TMW_NL];
   const int nslot = (c.nact + 63) / 64;
@@ -1595,7 +1633,7 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
   float al[3] = {0.f, 0.f, 0.f};
   tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
   TmwLS p0 = pt[0];
-  al[0] = p0.alpha - p0.d0 / p0.d1;
+  al[0] = p0.alpha - p0.d0 * tmw_rcp(p0.d1);     // d1 = 2 q2 > 0: hardware reciprocal + one Newton step instead of the IEEE division sequence
   tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
   TmwLS lo0 = pt[0];
   bool lesser = lo0.d0 < p0.d0;
@@ -1604,7 +1642,7 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
   for (int it = 0; it < m.ls_iterations; it++) {
     bool done = !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
     if (done) break;
-    al[0] = lo.alpha - lo.d0 / lo.d1; al[1] = hi.alpha - hi.d0 / hi.d1; al[2] = 0.5f * (lo.alpha + hi.alpha);
+    al[0] = lo.alpha - lo.d0 * tmw_rcp(lo.d1); al[1] = hi.alpha - hi.d0 * tmw_rcp(hi.d1); al[2] = 0.5f * (lo.alpha + hi.alpha);
     tmw_ls_points<3, WIDTH>(c, K, R, al, g0, g1, g2, pt);
     TmwLS lo_next = pt[0], hi_next = pt[1], mid = pt[2];
     bool s1 = (lo.d0 > 0.f) || (lo.d0 < lo_next.d0);
@@ -1642,11 +1680,13 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   float gtol = m.tolerance * m.ls_tolerance * smag;
   float g0 = gauss, g1 = tmw_sum(p1), g2 = 0.5f * tmw_sum(p2);
   TmwLSRows R;
+  const bool w16 = c.nact <= 16;
   TMW_FOR {
 #pragma unroll
     for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
-      int e = lane + 64 * sl;
-      bool ok = e < c.nact;
+      // nact <= 16: the rows sit in lanes 0-15 and are replicated in lanes 16-31 and 32-47 (tmw_ls_points16)
+      int e = w16 ? (lane & 15) : lane + 64 * sl;
+      bool ok = w16 ? (sl == 0 && lane < 48 && e < c.nact) : e < c.nact;
       float ja = ok ? L[K.l_Jaref + (ok ? e : 0)] : 1.f, jv = ok ? L[K.l_jv + (ok ? e : 0)] : 0.f, D = ok ? L[K.l_efc_D + (ok ? e : 0)] : 0.f;   // padding rows: never active
       R.ja[TMW_LI][sl] = ja; R.jv[TMW_LI][sl] = jv; R.D[TMW_LI][sl] = D;
       R.t0[TMW_LI][sl] = 0.5f * ja * ja * D; R.t1[TMW_LI][sl] = jv * ja * D; R.t2[TMW_LI][sl] = 0.5f * jv * jv * D;
@@ -1681,6 +1721,9 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
 TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float gauss, scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
+#if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
+  if (c.prof && c.lane == 0) { c.prof[10] += (c.nact <= 16) ? 1000 : 0; c.prof[18] += (c.nact > 16 && c.nact <= 32) ? 1000 : 0; }   // histogram of active rows (x1000) in two unused slots
+#endif
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] = L[K.l_warm + i]; L[K.l_grad + i] = 1.f / L[K.l_Dinv + i]; L[K.l_tmp + i] = 0.f; } }
   TMW_SYNC();
   // start from the warm start unless the unconstrained acceleration has the lower cost (MJX evaluates warm, smooth and
