@@ -166,6 +166,7 @@ TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
     for (int a = lane; a < K.nu; a += 64) L[K.l_ctrl + a] = c.rs ? c.st[(size_t)c.e * (size_t)c.rs + (size_t)(m.s_prev_ctrl + a)] : (action ? action[(size_t)a * c.n + c.e] : 0.f);
     for (int i = lane; i < 2 * K.nv; i += 64) L[K.l_tdof + i] = tm_i2f(m.tdof[i]);  // index table of the sparse rows
     for (int g = lane; g < K.ngroup; g += 64) { L[K.l_tgrp + 4 * g] = tm_i2f(m.grp_lastdof[g]); L[K.l_tgrp + 4 * g + 1] = tm_i2f(m.grp_start[g]); L[K.l_tgrp + 4 * g + 2] = tm_i2f(m.grp_count[g]); }
+    for (int i = lane; i < K.nv; i += 64) L[K.l_hdamp + i] = m.timestep * m.dof_damping[i];
   }
   TMW_SYNC();
   return WST(m.s_time, 0);
@@ -759,16 +760,14 @@ template <int FIRST, int N, int D0, bool EULER>
 TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float hdamp, int rhs) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_M + tmw_chain_madr(FIRST);
-  // Euler with the shared matrix region: l_M holds L^-1 by now, M comes back from the env's global copy (same word order; the
-  // loads of a chain's rows are independent and issued together, lanes beyond a row read the words in front of it)
-  const float *G = (EULER && K.m_spilled()) ? c.mspill + tmw_chain_madr(FIRST) : nullptr;
-  TMW_REG(float, hd);   // hdamp * damping of the chain dof whose DIAGONAL sits in this lane (depth = lane)
-  if (EULER) { TMW_FOR { bool mine = TMW_MASK(TMW_M_RANGE(D0, D0 + N)); hd[TMW_LI] = mine ? hdamp * m.dof_damping[mine ? FIRST + lane - D0 : 0] : 0.f; } }
+  TMW_REG(float, hd);   // hdamp * damping of the chain dof whose DIAGONAL sits in this lane (depth = lane): from LDS (l_hdamp = timestep *
+                        // damping; a global load of the model constant here cost one exposed memory latency per chain)
+  if (EULER) { TMW_FOR { bool mine = TMW_MASK(TMW_M_RANGE(D0, D0 + N)); hd[TMW_LI] = mine ? L[K.l_hdamp + (mine ? FIRST + lane - D0 : 0)] : 0.f; } }
   TMW_FOR {
 #pragma unroll
     for (int k = 0; k < N; k++) {
       const int dk = D0 + k, off = k * D0 + k * (k - 1) / 2 + k;   // Madr(FIRST + k) - Madr(FIRST): rows are stored back to back
-      float v = (EULER && K.m_spilled()) ? G[(off + dk) - lane] : L[adr0 - lane + (off + dk)];   // lanes beyond the row read (and discard) whatever precedes it
+      float v = L[adr0 - lane + (off + dk)];   // lanes beyond the row read (and discard) whatever precedes it in LDS
       if (EULER) v += TMW_MASK(TMW_M_EQ(dk)) ? hd[TMW_LI] : 0.f;
       v = TMW_MASK(TMW_M_LT(dk + 1)) ? v : 0.f;
       if (EULER) v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? L[rhs + FIRST + k] : v;
@@ -1803,6 +1802,19 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_qfrc_smooth + i] + L[K.l_qfrc_constraint + i]; }
   TMW_SYNC();
   TMW_TICK(8);
+  if (K.m_spilled()) {
+    // the matrix region holds L^-1 of the solver stage, which is dead now: M comes back from the env's global copy in one sweep
+    // (all loads of a lane in flight together: one memory latency for the whole matrix), then Euler factorises it in place again
+    constexpr int MAXU = 20;                       // nnz <= 1280 (model_host.h)
+    float mr[TMW_NL][MAXU];
+    TMW_FOR {
+#pragma unroll
+      for (int u = 0; u < MAXU; u++) { int i = lane + 64 * u; if (64 * u < K.nnz) mr[TMW_LI][u] = c.mspill[i < K.nnz ? i : K.nnz - 1]; }
+#pragma unroll
+      for (int u = 0; u < MAXU; u++) { int i = lane + 64 * u; if (64 * u < K.nnz && i < K.nnz) L[K.l_M + i] = mr[TMW_LI][u]; }
+    }
+    TMW_SYNC();
+  }
   if (K.chains) tmw_factor_chains<true>(c, K, h, K.l_tmp); else tmw_factor(c, K, h, K.l_tmp);
   TMW_TICK(9);
   if (K.chains) tmw_subst_chains(c, K, K.l_tmp); else tmw_subst_down(c, K, K.l_tmp);
