@@ -9,9 +9,13 @@
  *     last failure on the calling thread is available from tmjx_last_error().
  *   - every per-env buffer is CALLER-OWNED DEVICE memory (e.g. a torch tensor's data_ptr) laid
  *     out structure-of-arrays with the ENV INDEX CONTIGUOUS:  buf[field_index * n_env + env].
- *   - the library owns only the immutable model constants and the clip table of a handle.
- *   - all work is enqueued on the caller's HIP stream; no hidden synchronisation.
- *   - one handle per host thread / GPU (thread-compatible, not thread-safe).
+ *   - the library owns only the immutable model constants and the clip table of a handle, plus ONE
+ *     piece of per-handle device scratch: the physics kernel's per-env copy of the inertia matrix
+ *     (4.5 KB per env for the rodent), allocated at the first launch and re-allocated only when a
+ *     later launch has more envs (that one call synchronises the device; every other call enqueues only).
+ *   - all work is enqueued on the caller's HIP stream; no hidden synchronisation (see above).
+ *   - one handle per host thread / GPU AND per stream: launches of one handle must not overlap
+ *     (thread-compatible, not thread-safe; pipelined env groups use one handle each).
  *   - `stream` is a hipStream_t passed as void* so that this header needs no HIP include.
  */
 #ifndef TMJX_H

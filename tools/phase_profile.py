@@ -8,8 +8,8 @@ import torch
 from tests.common import make_env_and_oracle
 
 NAMES = ["position", "velocity+M", "factor", "invert_L", "make_constraint", "solve(qacc_smooth)", "cg init (3 cost evals + grad)",
-         "cg linesearch", "cg update (+euler rhs)", "euler factor", "euler invert_L", "euler solve", "load/store/other", "  (ls: M*search, J*search, dots)", "  (ls: point evaluations)", "  (misc between sub-phases)",
-         "  (J^T force)", "  (M^-1 grad)", "  (eval_cost: M*q)", "  (eval_cost: J*q)", "  (vel: dof velocity scan)", "  (vel: cdof_dot + acc scan)", "  (vel: body forces)", "  (vel: subtree sums)", "  (M*x: column part)", "  (M*x: row part)", "  (M^-1: column part)", "  (pos: local transforms)", "  (pos: pointer jumping)", "  (pos: com)", "  (pos: collision)", "  (pos: cdof)"]
+         "cg linesearch", "cg update (+euler rhs)", "euler factor", "[count] solves with <= 16 active rows, per 1000", "euler solve", "load/store/other", "  (ls: M*search, J*search, dots)", "  (ls: point evaluations)", "  (misc between sub-phases)",
+         "  (J^T force)", "  (M^-1 grad)", "[count] solves with 17..32 active rows, per 1000", "  (eval_cost: J*q)", "  (vel: dof velocity scan)", "  (vel: cdof_dot + acc scan)", "  (vel: body forces)", "  (vel: subtree sums)", "  (M*x: column part)", "  (M*x: row part)", "  (M^-1: column part)", "  (pos: local transforms)", "  (pos: pointer jumping)", "  (pos: com)", "  (pos: collision)", "  (pos: cdof)"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env, _, _ = make_env_and_oracle(num_envs=n, n_clips=64, wrappers=True)
 g = torch.Generator().manual_seed(0)
