@@ -40,3 +40,22 @@ def test_no_product_import_of_oracle_or_emulation():
         src = p.read_text()
         assert not pat.search(src), p
         assert "liboracle" not in src and "libhostemu" not in src, p
+
+
+def test_chain_layout_fits_ten_envs_per_cu():
+    """The rodent (chain) LDS map of the wave kernel must stay within 16 KiB per env: gfx950 allocates LDS in 2 KiB granules, so
+    that is what lets 10 envs share a CU's 160 KiB (csrc/wave_layout.h); the generic layout is the 8-per-CU one."""
+    import subprocess, tempfile, textwrap
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    src = textwrap.dedent(f'''
+        #include <cstdio>
+        #include "{root}/track_mjx_amd/csrc/wave_layout.h"
+        int main() {{ constexpr WLayout k(TMW_RODENT_DIMS, 1); constexpr WLayout g(TMW_RODENT_DIMS, 0);
+          static_assert(k.m_spilled(), "chain layout shares the matrix region");
+          printf("%d %d\\n", k.lds_floats, g.lds_floats); return 0; }}''')
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "l.cpp").write_text(src)
+        subprocess.run(["g++", "-std=c++17", "-o", f"{d}/l", f"{d}/l.cpp"], check=True)
+        chain, generic = (int(v) for v in subprocess.run([f"{d}/l"], check=True, capture_output=True, text=True).stdout.split())
+    assert chain * 4 <= 16 * 1024 and generic * 4 <= 20 * 1024 + 2048

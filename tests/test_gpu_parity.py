@@ -590,3 +590,32 @@ def test_reset_from_jax_key_draws():
     st2 = env.reset(keys)           # per-env keys give the same state
     torch.cuda.synchronize()
     assert np.array_equal(env.state_buf[L.qvel:L.qvel + L.nv].cpu().numpy(), vn)
+
+
+@pytest.mark.gpu
+def test_config5_clip_table_gather_bit_exact():
+    """BASELINE config 5: 8192 envs on a 1024-clip table (206 MB of body positions alone: a real HBM gather).  With zero reset
+    noise the reset state must be the gathered clip frame bit for bit (positions, joints; the root quaternion normalised), the
+    reference half of the observation must be finite, and one control step must leave the integer frame bookkeeping exact."""
+    n, C = 8192, 1024
+    env, O, cl = make_env_and_oracle(num_envs=n, n_clips=C, wrappers=True)
+    rng = np.random.default_rng(2)
+    ci = rng.integers(0, C, n).astype(np.int32)
+    sf = rng.integers(0, 44, n).astype(np.int32)
+    z74, z73 = torch.zeros((74, n)), torch.zeros((73, n))
+    st = env.reset(None, torch.from_numpy(ci), start_frame=torch.from_numpy(sf), qpos_noise=z74, qvel_noise=z73)
+    torch.cuda.synchronize()
+    L = env.layout
+    qpos = env.state_buf[L.qpos:L.qpos + L.nq].cpu().numpy()
+    assert np.array_equal(qpos[:3], cl.position[ci, sf].T) and np.array_equal(qpos[7:], cl.joints[ci, sf].T)
+    q = cl.quaternion[ci, sf].T
+    assert np.abs(qpos[3:7] - q / np.linalg.norm(q, axis=0, keepdims=True)).max() < 1e-6
+    assert np.array_equal(st.info["clip_idx"].cpu().numpy(), ci) and np.array_equal(st.info["start_frame"].cpu().numpy(), sf)
+    assert torch.isfinite(st.obs).all()
+    # at reset the tracked root position offset of the first trajectory frame is the clip's own displacement between two frames,
+    # rotated by the root quaternion: zero noise => |obs[:3]| is bounded by that displacement (0.1 m over 250 frames + z jitter)
+    assert float(st.obs[:, :15].abs().max()) < 0.05
+    st = env.step(st, torch.zeros((38, n), device=DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(st.obs).all() and torch.isfinite(st.reward).all()
+    assert np.array_equal(st.info["clip_idx"].cpu().numpy(), ci)
