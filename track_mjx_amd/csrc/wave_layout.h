@@ -10,7 +10,7 @@ struct WLayout {
   int nbody, njnt, nq, nv, nu, ncon, nlim, nefc, ngroup, nnz, nphys, nround_body, nround_dof;
   // persistent part
   int l_qpos, l_qvel, l_act, l_warm, l_ctrl, l_cdof, l_M, l_con_dist, l_con_off, l_con_frame, l_lim_sign, l_qfrc_smooth,
-      l_qfrc_actuator, l_act_dot, l_com, l_sv, l_wr, l_tdof, l_tgrp, l_hdamp, l_rowmap, l_ccrow, l_dummy, l_alias0;
+      l_qfrc_actuator, l_act_dot, l_com, l_sv, l_wr, l_tdof, l_tgrp, l_hdamp, l_con_mu, l_con_grpb, l_rowmap, l_ccrow, l_dummy, l_alias0;
   // aliased region A (solver stage)
   int l_LD, l_Dinv, l_efc_D, l_efc_aref, l_Jaref, l_jv, l_qacc_smooth, l_qacc, l_Ma, l_grad, l_Mgrad, l_search, l_mv,
       l_qfrc_constraint, l_tmp;
@@ -23,7 +23,7 @@ struct WLayout {
       : nbody(nb), njnt(nj), nq(nq_), nv(nv_), nu(nu_), ncon(nc), nlim(nl), nefc(nl + 4 * nc), ngroup(ng), nnz(nnz_),
         nphys(nq_ + nv_ + nu_ + nv_ + 1), nround_body(rb), nround_dof(rd),
         l_qpos(0), l_qvel(0), l_act(0), l_warm(0), l_ctrl(0), l_cdof(0), l_M(0), l_con_dist(0), l_con_off(0), l_con_frame(0),
-        l_lim_sign(0), l_qfrc_smooth(0), l_qfrc_actuator(0), l_act_dot(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_hdamp(0), l_rowmap(0), l_ccrow(0), l_dummy(0),
+        l_lim_sign(0), l_qfrc_smooth(0), l_qfrc_actuator(0), l_act_dot(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_hdamp(0), l_con_mu(0), l_con_grpb(0), l_rowmap(0), l_ccrow(0), l_dummy(0),
         l_alias0(0), l_LD(0), l_Dinv(0), l_efc_D(0), l_efc_aref(0), l_Jaref(0), l_jv(0), l_qacc_smooth(0), l_qacc(0), l_Ma(0),
         l_grad(0), l_Mgrad(0), l_search(0), l_mv(0), l_qfrc_constraint(0), l_tmp(0), l_scanA(0), l_scanB(0), l_jl_anchor(0),
         l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0), chains(ch) {
@@ -34,6 +34,8 @@ struct WLayout {
     l_act_dot = l; l += nu; l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_tdof = l; l += nv * 2;
     l_tgrp = l; l += ngroup * 4;
     l_hdamp = l; l += nv;     // timestep * joint damping (diagonal of Euler's M + h D), filled once per launch
+    l_con_mu = l; l += ncon;  // friction coefficient and (bytes) paw group of every contact slot: model constants the products with
+    l_con_grpb = l; l += (ncon + 3) / 4;   // J / J^T need on every call — kept here instead of being fetched from global memory each time
     // byte tables of the ACTIVE constraint rows (wave_physics.h: tmw_make_constraint): compact row -> original row, contact -> its
     // first compact row (255 = none)
     l_rowmap = l; l += (nefc + 3) / 4; l_ccrow = l; l += (nc + 3) / 4;

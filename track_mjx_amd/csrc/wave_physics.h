@@ -67,6 +67,9 @@ struct WCtx {
   int nact;                   // number of ACTIVE constraint rows of the current substep (compact row space, tmw_make_constraint)
   int nla;                    // ... of which violated joint limits (the active contacts' rows follow, four each)
   int rs;                     // 0: `st` is the [row][n_env] state; > 0: `st` is the env-major physics record with this stride
+  // per-lane model constants of the J / J^T products, fetched once per launch (a global load in every call left its latency exposed):
+  int kdof[TMW_NL];           // dof slots lane / lane + 64: (limit row + 1) | (wrench subset + 1) << 8, second slot << 16
+  unsigned kmask[2][TMW_NL];  // lane = (subset, component) of tmw_jt_force: contact mask of the subset (valid if n_wsub * 6 <= 64)
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
@@ -167,6 +170,16 @@ TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
     for (int i = lane; i < 2 * K.nv; i += 64) L[K.l_tdof + i] = tm_i2f(m.tdof[i]);  // index table of the sparse rows
     for (int g = lane; g < K.ngroup; g += 64) { L[K.l_tgrp + 4 * g] = tm_i2f(m.grp_lastdof[g]); L[K.l_tgrp + 4 * g + 1] = tm_i2f(m.grp_start[g]); L[K.l_tgrp + 4 * g + 2] = tm_i2f(m.grp_count[g]); }
     for (int i = lane; i < K.nv; i += 64) L[K.l_hdamp + i] = m.timestep * m.dof_damping[i];
+    for (int cc = lane; cc < K.ncon; cc += 64) { L[K.l_con_mu + cc] = m.con_mu[cc]; ((unsigned char *)(L + K.l_con_grpb))[cc] = (unsigned char)m.con_grp[cc]; }
+    {
+      int i0 = lane, i1 = lane + 64;
+      int a = (m.dof_limrow[i0] + 1) | ((m.dof_wsub[i0] + 1) << 8);
+      int b = i1 < K.nv ? ((m.dof_limrow[i1] + 1) | ((m.dof_wsub[i1] + 1) << 8)) : 0;
+      c.kdof[TMW_LI] = a | (b << 16);
+      int su = lane / 6;
+      bool ok = lane < m.n_wsub * 6;
+      c.kmask[0][TMW_LI] = ok ? m.wsub_cmask[su][0] : 0u; c.kmask[1][TMW_LI] = ok ? m.wsub_cmask[su][1] : 0u;
+    }
   }
   TMW_SYNC();
   return WST(m.s_time, 0);
@@ -1251,19 +1264,18 @@ TM_DEV void tmw_jmul_stage2(WCtx &c, const WLayout &K, int v, int out) {
     for (int kr = lane; kr < c.nact; kr += 64) {
       int r = rm[kr];
       float o;
-      if (r < K.nlim) {
-        float sv = L[K.l_lim_sign + r];
-        o = (sv > 0.f ? 1.f : -1.f) * L[v + m.jnt_dofadr[m.lim_jnt[r]]];
+      if (kr < c.nla) {       // limit rows come first; their map byte is dof | (negative side) << 7 (tmw_make_constraint)
+        o = ((r & 0x80) ? -1.f : 1.f) * L[v + (r & 0x7f)];
       } else {
         int cc = (r - K.nlim) >> 2, e = (r - K.nlim) & 3;
-        const float *sv = L + K.l_sv + m.con_grp[cc] * 6, *off = L + K.l_con_off + cc * 3;
+        const float *sv = L + K.l_sv + ((const unsigned char *)(L + K.l_con_grpb))[cc] * 6, *off = L + K.l_con_off + cc * 3;
         float fr[9];
         for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
         tm_cross(fr + 6, fr, fr + 3);
         float cr[3], vel[3];
         tm_cross(cr, sv, off);
         for (int k = 0; k < 3; k++) vel[k] = sv[3 + k] + cr[k];
-        float a0 = tm_dot3(fr, vel), at = tm_dot3(fr + 3 + 3 * (e >> 1), vel) * m.con_mu[cc];
+        float a0 = tm_dot3(fr, vel), at = tm_dot3(fr + 3 + 3 * (e >> 1), vel) * L[K.l_con_mu + cc];
         o = (e & 1) ? a0 - at : a0 + at;
       }
       L[out + kr] = o;
@@ -1286,7 +1298,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
         int r0 = TMW_CCROW(K)[cc];      // first of the contact's four compact rows
         float f[4];
         for (int e = 0; e < 4; e++) { float ja = L[K.l_Jaref + r0 + e]; f[e] = ja < 0.f ? -L[K.l_efc_D + r0 + e] * ja : 0.f; }
-        float mu = m.con_mu[cc], c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
+        float mu = L[K.l_con_mu + cc], c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
         const float *off = L + K.l_con_off + cc * 3;
         float fr[9];
         for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
@@ -1309,7 +1321,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
       float sacc = 0.f;
       if (idx < m.n_wsub * 6) {
         int su = idx / 6, k = idx - su * 6;
-        unsigned m0 = m.wsub_cmask[su][0], m1 = m.wsub_cmask[su][1];
+        unsigned m0 = slot == 0 && m.n_wsub * 6 <= 64 ? c.kmask[0][TMW_LI] : m.wsub_cmask[su][0], m1 = slot == 0 && m.n_wsub * 6 <= 64 ? c.kmask[1][TMW_LI] : m.wsub_cmask[su][1];
         // only the ACTIVE contacts carry a wrench: walk their compact rows (four per contact) back to the contact ids
         const unsigned char *rm = TMW_ROWMAP(K);
         for (int kr = c.nla; kr < c.nact; kr += 4) {
@@ -1332,7 +1344,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       float s = 0.f;
-      int lr = m.dof_limrow[i], su = m.dof_wsub[i];
+      int kd = i < 64 ? c.kdof[TMW_LI] : (c.kdof[TMW_LI] >> 16), lr = (kd & 0xff) - 1, su = ((kd >> 8) & 0xff) - 1;
       if (lr >= 0) {     // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise
         float sv = L[K.l_lim_sign + lr];
         if (sv != 0.f) { int kr = (int)fabsf(sv) - 1; float ja = L[K.l_Jaref + kr]; if (ja < 0.f) s = (sv > 0.f ? 1.f : -1.f) * (-L[K.l_efc_D + kr] * ja); }
@@ -1370,13 +1382,15 @@ TM_DEV void tmw_mul_m_jmul(WCtx &c, const WLayout &K, int x, int y, int out) {
 TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_REG(int, f0); TMW_REG(int, f1); TMW_REG(int, fc); TMW_REG(int, x0); TMW_REG(int, x1); TMW_REG(int, xc);
-  TMW_REG(float, s0); TMW_REG(float, s1);
+  TMW_REG(float, s0); TMW_REG(float, s1); TMW_REG(int, d0); TMW_REG(int, d1);
   TMW_FOR {
     for (int slot = 0; slot < 2; slot++) {
       int l = lane + 64 * slot;
       float sg = 0.f;
+      (slot ? d1 : d0)[TMW_LI] = 0;
       if (l < K.nlim) {
         int j = m.lim_jnt[l];
+        (slot ? d1 : d0)[TMW_LI] = m.jnt_dofadr[j];
         float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
         float pos = fminf(dmin, dmax) - m.jnt_margin[j];
         sg = pos < 0.f ? (dmin < dmax ? 1.f : -1.f) : 0.f;
@@ -1389,8 +1403,9 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
   c.nact = nla + 4 * ncl; c.nla = nla;
   TMW_FOR {
     unsigned char *rm = TMW_ROWMAP(K), *cr = TMW_CCROW(K);
-    if (lane < K.nlim) { L[K.l_lim_sign + lane] = s0[TMW_LI] * (float)(x0[TMW_LI] + 1); if (f0[TMW_LI]) rm[x0[TMW_LI]] = (unsigned char)lane; }
-    if (lane + 64 < K.nlim) { L[K.l_lim_sign + lane + 64] = s1[TMW_LI] * (float)(n0 + x1[TMW_LI] + 1); if (f1[TMW_LI]) rm[n0 + x1[TMW_LI]] = (unsigned char)(lane + 64); }
+    // map byte of a limit row: its dof | (violated on the upper side) << 7 — all that J and J^T need; of a contact row: nlim + 4 cc + e
+    if (lane < K.nlim) { L[K.l_lim_sign + lane] = s0[TMW_LI] * (float)(x0[TMW_LI] + 1); if (f0[TMW_LI]) rm[x0[TMW_LI]] = (unsigned char)(d0[TMW_LI] | (s0[TMW_LI] < 0.f ? 0x80 : 0)); }
+    if (lane + 64 < K.nlim) { L[K.l_lim_sign + lane + 64] = s1[TMW_LI] * (float)(n0 + x1[TMW_LI] + 1); if (f1[TMW_LI]) rm[n0 + x1[TMW_LI]] = (unsigned char)(d1[TMW_LI] | (s1[TMW_LI] < 0.f ? 0x80 : 0)); }
     if (lane < K.ncon) {
       int r0 = nla + 4 * xc[TMW_LI];
       cr[lane] = fc[TMW_LI] ? (unsigned char)r0 : (unsigned char)255;
@@ -1405,8 +1420,8 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
       int r = rm[kr];
       float k, b, imp, pos, iw;
       const float *solref, *solimp;      // ONE impedance evaluation for limit and contact rows (both kinds share a wave)
-      if (r < K.nlim) {
-        int j = m.lim_jnt[r];
+      if (kr < c.nla) {
+        int j = m.dof_jntid[r & 0x7f];
         float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
         pos = fminf(dmin, dmax) - m.jnt_margin[j];
         solref = m.jnt_solref[j]; solimp = m.jnt_solimp[j];
