@@ -9,7 +9,8 @@ Mirrors (paths relative to /root/reference/track_mjx/agent/mlp_ppo):
   brax.training.distribution.NormalTanhDistribution (third-party, restated from its published definition):
                                 loc, raw = split(logits); scale = softplus(raw) + 0.001; tanh bijector
 The dense contractions go to the matrix cores through rocBLAS/hipBLASLt (plain library GEMMs); everything is fp32
-as in the reference unless `matmul_dtype=torch.bfloat16` is requested (BASELINE config 5).
+as in the reference unless `matmul_dtype=torch.bfloat16` is requested (BASELINE config 5): then the GEMM INPUTS are bf16
+(`gemm_inputs`), accumulation, outputs and everything around the GEMMs stay fp32.
 """
 from __future__ import annotations
 
@@ -35,6 +36,42 @@ def _lecun_normal_(w: torch.Tensor) -> None:
         nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std)
 
 
+class gemm_inputs:
+    """`with gemm_inputs(torch.bfloat16):` — the dense contractions of the networks take bf16 INPUTS with fp32 accumulation and
+    fp32 OUTPUTS (`torch.mm(..., out_dtype=float32)`: v_mfma_f32_*_bf16 through hipBLASLt); parameters, activations between the
+    layers, the fused epilogues, the loss head and the optimiser stay fp32 (BASELINE config 5).  No autocast: the cast of each
+    GEMM operand is explicit (one elementwise pass), everything around the GEMMs keeps its fused fp32 kernels.  None = fp32."""
+    dtype = None
+
+    def __init__(self, dtype):
+        self.new = dtype
+
+    def __enter__(self):
+        self.old, gemm_inputs.dtype = gemm_inputs.dtype, self.new
+
+    def __exit__(self, *a):
+        gemm_inputs.dtype = self.old
+        return False
+
+
+def _mm_nt(x, w):
+    """x [m, k] @ w[n, k]^T -> fp32 [m, n] in the current GEMM-input dtype; also returns the operands as they went into the GEMM."""
+    dt = gemm_inputs.dtype
+    if dt is None or not x.is_cuda:
+        return x @ w.t(), x, w
+    xb, wb = x.to(dt), w.to(dt)
+    return torch.mm(xb, wb.t(), out_dtype=torch.float32), xb, wb
+
+
+def _splitk_dw(dy, x, s):
+    """dy^T x as SPLIT row slabs (one batched GEMM) + a sum; operands in their stored dtype, fp32 result."""
+    m = x.shape[0]
+    a, b = dy.view(s, m // s, dy.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])
+    if x.dtype != torch.float32 and x.dtype != torch.float64:
+        return torch.bmm(a, b, out_dtype=torch.float32).sum(0)
+    return torch.bmm(a, b).sum(0)
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     """y = x W^T + b with a weight gradient computed as a split-K batched GEMM.
 
@@ -44,20 +81,25 @@ class _SplitKLinearFn(torch.autograd.Function):
     SPLIT = 8
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        return torch.addmm(b, x, w.t())
+        if gemm_inputs.dtype is None or not x.is_cuda:
+            ctx.save_for_backward(x, w)
+            return torch.addmm(b, x, w.t())
+        y, xs, ws = _mm_nt(x, w)
+        ctx.save_for_backward(xs, ws)          # the operands as they went into the GEMM (bf16 copies)
+        return y + b
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")      # backward under the forward's autocast state: bf16 GEMM inputs when requested
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        m, s = x.shape[0], _SplitKLinearFn.SPLIT
-        dx = (dy @ w).to(x.dtype) if ctx.needs_input_grad[0] else None
-        dw = torch.bmm(dy.view(s, m // s, dy.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).to(w.dtype).sum(0)
-        return dx, dw, dy.to(w.dtype).sum(0)
+        s = _SplitKLinearFn.SPLIT
+        dys = dy if x.dtype == dy.dtype else dy.to(x.dtype)
+        if x.dtype == dy.dtype:
+            dx = dys @ w if ctx.needs_input_grad[0] else None
+        else:
+            dx = torch.mm(dys, w, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        return dx, _splitk_dw(dys, x, s).to(dy.dtype), dy.sum(0)
 
 
 class _Dense(nn.Linear):
@@ -65,6 +107,9 @@ class _Dense(nn.Linear):
         rows = x.numel() // x.shape[-1]
         if torch.is_grad_enabled() and self.weight.requires_grad and rows >= 4096 and rows % _SplitKLinearFn.SPLIT == 0 and x.is_cuda:
             y = _SplitKLinearFn.apply(x.reshape(rows, x.shape[-1]), self.weight, self.bias)
+            return y.view(*x.shape[:-1], self.out_features)
+        if gemm_inputs.dtype is not None and x.is_cuda:
+            y = _mm_nt(x.reshape(rows, x.shape[-1]), self.weight)[0] + self.bias
             return y.view(*x.shape[:-1], self.out_features)
         return F.linear(x, self.weight, self.bias)
 
@@ -80,22 +125,26 @@ class _SplitKMatmulFn(torch.autograd.Function):
     """z = x W^T (no bias) with the split-K weight gradient of _SplitKLinearFn."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return x @ w.t()
+        z, xs, ws = _mm_nt(x, w)
+        ctx.save_for_backward(xs, ws)
+        return z
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dz):
         x, w = ctx.saved_tensors
         m, s = x.shape[0], _SplitKLinearFn.SPLIT
-        dx = (dz @ w).to(x.dtype) if ctx.needs_input_grad[0] else None
+        dz = dz.contiguous()
+        low = x.dtype != dz.dtype
+        dzs = dz.to(x.dtype) if low else dz
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dzs, w, out_dtype=torch.float32) if low else dzs @ w
         if m % s == 0 and m >= 4096:
-            dw = torch.bmm(dz.view(s, m // s, dz.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])).to(w.dtype).sum(0)
+            dw = _splitk_dw(dzs, x, s)
         else:
-            dw = dz.t() @ x
-        return dx, dw.to(w.dtype)
+            dw = torch.mm(dzs.t(), x, out_dtype=torch.float32) if low else dzs.t() @ x
+        return dx, dw.to(dz.dtype)
 
 
 class _SiluLayerNormFn(torch.autograd.Function):
@@ -150,7 +199,7 @@ class _Block(nn.Module):
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and self.dense.out_features in self.FUSED_WIDTHS and not torch.is_autocast_enabled():
             x2 = x.reshape(-1, x.shape[-1])
-            z = _SplitKMatmulFn.apply(x2, self.dense.weight) if torch.is_grad_enabled() else x2 @ self.dense.weight.t()
+            z = _SplitKMatmulFn.apply(x2, self.dense.weight) if torch.is_grad_enabled() else _mm_nt(x2, self.dense.weight)[0]
             y = _SiluLayerNormFn.apply(z, self.dense.bias, self.norm.weight, self.norm.bias, self.norm.eps)
             return y.view(*x.shape[:-1], self.dense.out_features)
         return self.norm(F.silu(self.dense(x)))

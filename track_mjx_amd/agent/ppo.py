@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import losses as _losses
-from .networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet
+from .networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet, gemm_inputs
 
 
 import contextlib
@@ -140,7 +140,7 @@ class PPOLearner:
                 return self._act_fused(None, obs_raw=obs, gen=gen)
             return self._act_fused(self.normalizer.normalize(obs) if self.normalize_observations else obs, gen=gen)
         x = self.normalizer.normalize(obs) if self.normalize_observations else obs
-        with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
+        with gemm_inputs(self.matmul_dtype):
             eps = torch.randn((x.shape[0], self.policy.latents), generator=gen, device=self.dev)
             logits, mean, logvar = self.policy(x, eps=eps, deterministic=deterministic)
         logits = logits.float()
@@ -308,7 +308,7 @@ class PPOLearner:
         if fused_gather:
             data["observation_normalized"] = _losses.gather_normalize(self.buf["observation"], idx, self.normalizer)
             data["next_observation_last_normalized"] = _losses.gather_normalize(self.buf["next_observation_last"], idx, self.normalizer)
-        with torch.autocast("cuda", dtype=self.matmul_dtype, enabled=self.matmul_dtype is not None):
+        with gemm_inputs(self.matmul_dtype):
             loss_fn = _losses.compute_ppo_loss_fused if self.dev.type == "cuda" else _losses.compute_ppo_loss
             loss, m = loss_fn(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
         self.grads.assign(torch.autograd.grad(loss, self.grads.params))
