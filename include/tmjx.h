@@ -148,6 +148,12 @@ int tmjx_sample_action(const float *logits, const float *noise, float *raw, floa
 int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
                       void *stream);
 
+/* optax.chain(optax.clip_by_global_norm(max_norm), optax.adam(lr)) (track_mjx/agent/mlp_ppo/ppo.py:517-520) on FLAT fp32 device
+ * buffers of n elements: param -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps) with the gradient scaled by max_norm / max(max_norm,
+ * *grad_norm); `grad_norm` is a device scalar (the caller's ||grad||_2 of the averaged gradient), bias_correction{1,2} = 1 - beta^t. */
+int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *grad_norm, long long n, float lr,
+                   float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream);
+
 /* Debug/test access: copy a named per-env workspace/intermediate array of the last tmjx_forward /
  * tmjx_physics call into `out` (device pointer, [count][n_env]); returns count or a negative code.
  * Names: "qM" (sparse rows), "qfrc_smooth", "qacc", "qacc_smooth", "efc_D", "efc_aref", "con_dist", ... */

@@ -619,3 +619,10 @@ def test_config5_clip_table_gather_bit_exact():
     torch.cuda.synchronize()
     assert torch.isfinite(st.obs).all() and torch.isfinite(st.reward).all()
     assert np.array_equal(st.info["clip_idx"].cpu().numpy(), ci)
+
+
+@pytest.mark.gpu
+def test_fused_clip_adam_kernel_matches_torch():
+    """tmjx_adam_clip (optax clip_by_global_norm -> adam on the flat buffers) against torch.optim.Adam + clip_grad_norm_."""
+    from tests.test_learner_math import _flat_adam_vs_torch
+    _flat_adam_vs_torch("cuda:0")

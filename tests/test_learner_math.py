@@ -106,3 +106,31 @@ def test_splitk_linear_matches_autograd_linear():
     ref = torch.autograd.grad((F.linear(x, w, b) * up).sum(), (x, w, b))
     for a, r in zip(got, ref):
         assert torch.allclose(a, r, rtol=1e-12, atol=1e-12)
+
+
+def _flat_adam_vs_torch(device, steps=5, tol=1e-6):
+    from track_mjx_amd.agent.ppo import FlatAdam, FlatGrads
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(device)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(device)
+    ref.load_state_dict(net.state_dict())
+    fg = FlatGrads(list(net.parameters()))
+    opt = FlatAdam(fg, 1e-2, max_norm=0.5)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    g = torch.Generator().manual_seed(1)
+    for s in range(steps):
+        x = torch.randn(16, 7, generator=g).to(device) * (10.0 if s % 2 else 0.01)     # norms on both sides of the clip threshold
+        fg.assign(torch.autograd.grad(net(x).square().sum(), fg.params))
+        opt.step()
+        ropt.zero_grad()
+        ref(x).square().sum().backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)       # same scale: max_norm / max(norm, max_norm) up to its 1e-6 epsilon
+        ropt.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=tol), float((a - b).abs().max())
+    # parameters are views of one flat buffer and stay so after the steps
+    assert all(p.data_ptr() >= opt.flat.data_ptr() and p.data_ptr() < opt.flat.data_ptr() + opt.flat.numel() * 4 for p in net.parameters())
+
+
+def test_flat_adam_matches_torch_adam_with_global_norm_clip():
+    _flat_adam_vs_torch("cpu")

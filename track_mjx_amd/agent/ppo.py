@@ -58,6 +58,51 @@ class FlatGrads:
         return norm
 
 
+class FlatAdam:
+    """optax.chain(clip_by_global_norm(max_norm), adam(lr)) (reference: ppo.py:517-520) on the flat buffers: the parameters are
+    re-seated as views of ONE contiguous fp32 buffer (like the gradients of FlatGrads), so the optimiser step is a norm reduction
+    plus one launch of tmjx_adam_clip instead of the clip kernels, a multi-tensor scale and a multi-tensor Adam over ~30 tensors.
+    Must be built before any hipGraph captures the parameters' addresses.  CPU tensors (tests) take the same maths in torch."""
+
+    def __init__(self, grads: FlatGrads, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 10.0):
+        self.grads, self.lr, self.betas, self.eps, self.max_norm = grads, lr, betas, eps, max_norm
+        flat = torch.empty_like(grads.flat)
+        off = 0
+        with torch.no_grad():
+            for p in grads.params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view_as(p)
+                off += n
+        self.flat = flat
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self):
+        g = self.grads.flat
+        self.t += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+        norm = torch.linalg.vector_norm(g)
+        if g.is_cuda:
+            import ctypes as C
+            from .. import hip as _hip
+            with torch.cuda.device(g.device):
+                _hip.check(_hip.lib().tmjx_adam_clip(*[C.c_void_p(t.data_ptr()) for t in (self.flat, g, self.exp_avg, self.exp_avg_sq, norm)],
+                                                     g.numel(), self.lr, b1, b2, self.eps, bc1, bc2, self.max_norm,
+                                                     C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "tmjx_adam_clip")
+        else:
+            gs = g * (self.max_norm / torch.clamp(norm, min=self.max_norm))
+            self.exp_avg.mul_(b1).add_(gs, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(gs, gs, value=1 - b2)
+            self.flat.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
+        return norm
+
+    def state_dict(self):
+        return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+
+
 def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous env range [lo, hi) owned by `rank` (reference: reshape (local_devices, num_envs/devices), ppo.py:477-480)."""
     if total % world:
@@ -101,7 +146,7 @@ class PPOLearner:
         self.value = ValueNet(obs, critic_layers).to(dev)
         self.params = list(self.policy.parameters()) + list(self.value.parameters())
         self.grads = FlatGrads(self.params)
-        self.opt = torch.optim.Adam(self.params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, fused=bool(dev.type == "cuda"))
+        self.opt = FlatAdam(self.grads, learning_rate, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0)   # optax.clip_by_global_norm(10.0) -> adam
         self.normalizer = RunningStatistics(obs, dev)
         self.gen = torch.Generator(device=dev).manual_seed(seed * 1000 + 17 + self.rank)
         self.gens = [self.gen] + [torch.Generator(device=dev).manual_seed(seed * 1000 + 17 + self.rank + 7919 * g) for g in range(1, len(self.envs))]
@@ -358,8 +403,7 @@ class PPOLearner:
                 else:
                     out = self._minibatch_grads(idx, kl_w)
                 self.grads.all_reduce_mean(self.group)       # C1: one RCCL all-reduce per minibatch step
-                self.grads.clip_by_global_norm(10.0)          # optax.clip_by_global_norm(10.0) -> adam (ppo.py:517-520)
-                self.opt.step()
+                self.opt.step()                               # clip_by_global_norm(10.0) -> adam (ppo.py:517-520), one fused launch
                 acc += out
         acc /= self.num_updates * self.num_minibatches
         res = {k: acc[i] for i, k in enumerate(self.METRIC_KEYS)}

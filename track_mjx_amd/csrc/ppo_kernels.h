@@ -421,3 +421,21 @@ __global__ __launch_bounds__(128) void k_linear_nolds(const float *__restrict__ 
     for (int j = 0; j < NL_TN; j++)
       if (rout + i < M && col0 + j < N && (!A_KMAJOR || rout == row0 || rout + i >= row0)) C[(size_t)(rout + i) * N + col0 + j] = acc[i][j] + (bias ? bias[col0 + j] : 0.f);
 }
+
+// ---- optimiser: optax.chain(clip_by_global_norm(max_norm), adam(lr)) (reference: agent/mlp_ppo/ppo.py:517-520) over FLAT fp32 buffers
+// (parameters, gradients and the two moments as one contiguous array each): one launch instead of the norm-dependent scale kernels,
+// the multi-tensor scale and the multi-tensor Adam.  `grad_norm` is the device scalar ||g||_2 of the (already averaged) gradient.
+__global__ __launch_bounds__(256) void k_adam_clip(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                                   const float *__restrict__ grad_norm, long long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2, float max_norm) {
+  const float nrm = grad_norm[0];
+  const float scale = max_norm / fmaxf(max_norm, nrm);               // g if ||g|| < max_norm else g / ||g|| * max_norm
+  const float step = lr / bc1, rs = 1.f / sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float gi = g[i] * scale;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step * mi / (sqrtf(vi) * rs + eps);
+  }
+}

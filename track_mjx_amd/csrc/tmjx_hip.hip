@@ -523,6 +523,16 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
   return check_launch("k_gather_normalize");
 }
 
+int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *grad_norm, long long n, float lr,
+                   float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm) return fail(TMJX_EINVAL, "null argument");
+  if (n < 1 || !(bias_correction1 > 0.f) || !(bias_correction2 > 0.f) || !(max_norm > 0.f)) return fail(TMJX_EINVAL, "bad n / bias corrections / max_norm");
+  int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_adam_clip, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, grad_norm, n, lr, beta1, beta2, eps,
+                     bias_correction1, bias_correction2, max_norm);
+  return check_launch("k_adam_clip");
+}
+
 int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
                        int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, int x_stride, void *stream) {
   if (!fc2 || !eps || !obs || !x) return fail(TMJX_EINVAL, "null argument");
