@@ -783,10 +783,21 @@ TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float 
       float v = L[adr0 - lane + (off + dk)];   // lanes beyond the row read (and discard) whatever precedes it in LDS
       if (EULER) v += TMW_MASK(TMW_M_EQ(dk)) ? hd[TMW_LI] : 0.f;
       v = TMW_MASK(TMW_M_LT(dk + 1)) ? v : 0.f;
-      if (EULER) v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? L[rhs + FIRST + k] : v;
       TMW_SET_ROW(r, k, v);
     }
     if (N & 1) r[N >> 1][TMW_LI].y = 0.f;
+  }
+  if (EULER) {
+    // the right-hand side rides in lane TMW_RL of every row: one vector load of the chain's N values, then per row a v_readlane +
+    // a masked move — no per-row LDS access (a uniform-address ds_read per row and, in the factorisation, an exec-masked ds_write
+    // per row cost 9 k cycles per substep)
+    TMW_REG(float, rhsv);
+    TMW_FOR { rhsv[TMW_LI] = L[rhs + FIRST + (lane < N ? lane : N - 1)]; }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      float sk = tmw_readlane(rhsv, k);
+      TMW_FOR { if (TMW_MASK(TMW_M_EQ(TMW_RL))) TMW_SET_ROW(r, k, sk); }
+    }
   }
 }
 // eliminate the chain leaf -> root: finished rows go to LD (strict part = L; the diagonal word is not written, D^-1 goes to
@@ -872,7 +883,8 @@ TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], TmwS
   constexpr int Q0 = D0 > 0 ? tmw_chain_rows_before(FIRST) : 0;      // rows queued before this chain (mod 4 = first queue slot)
   float rs[2][TMW_NL], rk[2][TMW_NL], inv[2];
   TMW_REG(float, dv);
-  TMW_FOR { rk[(N - 1) & 1][TMW_LI] = TMW_ROW(r, N - 1); }
+  TMW_REG(float, yv);       // Euler: lane k = eliminated right-hand side of chain row k, stored once behind the loop
+  TMW_FOR { yv[TMW_LI] = 0.f; rk[(N - 1) & 1][TMW_LI] = TMW_ROW(r, N - 1); }
   inv[(N - 1) & 1] = tmw_rcp(tmw_readlane(rk[(N - 1) & 1], D0 + N - 1));
   TMW_FOR { rs[(N - 1) & 1][TMW_LI] = rk[(N - 1) & 1][TMW_LI] * inv[(N - 1) & 1]; }
 #pragma unroll
@@ -885,6 +897,8 @@ TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], TmwS
         TMW_FOR { rs[b ^ 1][TMW_LI] = rk[b ^ 1][TMW_LI] * inv[b ^ 1]; TMW_PIN(rs[b ^ 1][TMW_LI]); }
       });
     }
+    float yk = 0.f;
+    if (EULER) { yk = tmw_readlane(rk[b], TMW_RL); TMW_FOR { yv[TMW_LI] = TMW_MASK(TMW_M_EQ(k)) ? yk : yv[TMW_LI]; } }
     if (D0 > 0) {     // trunk part of the finished row -> operand queue of the Schur MFMA (lanes >= D0 are not trunk columns: zero them)
       const int slot = (Q0 + (N - 1 - k)) & 3;
       TMW_FOR {
@@ -892,16 +906,18 @@ TM_DEV void tmw_rows_factor(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], TmwS
         S->qa[slot][TMW_LI] = a;
         S->qb[slot][TMW_LI] = D0 < 16 ? (TMW_MASK(TMW_M_LT(D0)) ? rk[b][TMW_LI] : 0.f) : rk[b][TMW_LI];
       }
-      if (EULER) { float yk = tmw_readlane(rk[b], TMW_RL); TMW_FOR { S->yt[TMW_LI] += S->qa[slot][TMW_LI] * yk; } }
+      if (EULER) { TMW_FOR { S->yt[TMW_LI] += S->qa[slot][TMW_LI] * yk; } }
       if (slot == 3) tmw_schur_flush(*S);
     }
     TMW_FOR {
       if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = rs[b][TMW_LI];
       dv[TMW_LI] = TMW_MASK(TMW_M_EQ(dk)) ? inv[b] : dv[TMW_LI];
-      if (EULER && TMW_MASK(TMW_M_EQ(TMW_RL))) L[rhs + FIRST + k] = rk[b][TMW_LI];
     }
   }
-  TMW_FOR { if (TMW_MASK(TMW_M_RANGE(D0, D0 + N))) L[K.l_Dinv + FIRST - D0 + lane] = dv[TMW_LI]; }
+  TMW_FOR {
+    if (TMW_MASK(TMW_M_RANGE(D0, D0 + N))) L[K.l_Dinv + FIRST - D0 + lane] = dv[TMW_LI];
+    if (EULER && TMW_MASK(TMW_M_LT(N))) L[rhs + FIRST + lane] = yv[TMW_LI];
+  }
 }
 template <int FIRST, int N, int D0, bool EULER>
 TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, TmwSchur *S, float hdamp, int rhs) {
