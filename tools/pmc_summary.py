@@ -15,7 +15,7 @@ K2_ALGO = 842 * 4 * ENVS
 step_kernels = ("void k_physics_wave", "k_rec_in", "k_rec_out", "k_window", "k_obs", "k_post_parts", "k_post", "k_autoreset")
 out = {}
 for kind in ("fetch", "write"):
-    f = glob.glob(str(src / f"pmc_{kind}" / "*" / "*_counter_collection.csv"))[0]
+    f = max(glob.glob(str(src / f"pmc_{kind}" / "*" / "*_counter_collection.csv")), key=lambda p: Path(p).stat().st_mtime)   # newest run
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
