@@ -1,5 +1,6 @@
 // csrc/wave_physics.h — K2, wave-per-env: one 64-lane wavefront integrates one env; every per-env array of a
-// substep lives in LDS (wave_layout.h, 20.4 KB per env => 8 envs per CU = 2 waves per SIMD), the 64 lanes split bodies /
+// substep lives in LDS (wave_layout.h: 16 KB per env for the rodent's chain layout => 10 envs per CU = 2-3 waves per SIMD; the
+// inertia matrix is additionally kept in a per-env global copy between its two factorisations), the 64 lanes split bodies /
 // dofs / constraint rows / matrix columns between them.
 //
 // Same maths as physics_core.h (MJX `mjx.step`, reference call site
@@ -13,7 +14,10 @@
 //     takes the LDS-resident left-looking path,
 //   * matrix-free constraint Jacobian (spatial velocity per paw body, wrench accumulation per subset of paw bodies); only
 //     the ACTIVE rows (violated limits, penetrating contacts) are numbered and enter the solver,
-//   * dot products / line-search sums by DPP wave reductions; the rows of a line search live in registers.
+//   * the CG iteration runs in the coordinates y = L qacc of the factorisation (diagonal Gauss term and preconditioner: one split
+//     M^-1 product per iteration, no product with M inside the loop),
+//   * dot products / line-search sums by DPP wave reductions; the rows of a line search live in registers (<= 16 active rows:
+//     the three candidates of an iteration side by side in three 16-lane rows).
 //
 // Single source for the GPU and for the TEST-ONLY host emulation: a block of lane code is written as
 //   TMW_FOR { ... uses `lane` ... }  TMW_SYNC();
