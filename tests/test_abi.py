@@ -59,3 +59,24 @@ def test_chain_layout_fits_ten_envs_per_cu():
         subprocess.run(["g++", "-std=c++17", "-o", f"{d}/l", f"{d}/l.cpp"], check=True)
         chain, generic = (int(v) for v in subprocess.run([f"{d}/l"], check=True, capture_output=True, text=True).stdout.split())
     assert chain * 4 <= 16 * 1024 and generic * 4 <= 20 * 1024 + 2048
+
+
+def test_physics_kernel_resources_allow_ten_envs_per_cu(tmp_path):
+    """The rodent physics kernel in the built library must keep <= 168 VGPRs (three waves per SIMD: 3 x 168 <= 512) and no scratch:
+    172 registers once silently cut the pipelined roll-out back to 8 envs per CU.  Read from the code object's metadata."""
+    import shutil, subprocess
+    from track_mjx_amd import hip
+    bundler, readelf = "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (hip.SO_PATH.exists() and shutil.which("objcopy") and Path(bundler).exists() and Path(readelf).exists()):
+        import pytest
+        pytest.skip("library or LLVM tools missing")
+    fat, co = tmp_path / "fat.bin", tmp_path / "k.co"
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(hip.SO_PATH), str(fat)], check=True)
+    subprocess.run([bundler, "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    notes = subprocess.run([readelf, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+    i = notes.index(".name:           _Z14k_physics_waveILb1EE")
+    after = notes[i:i + 1500]          # the fields of a kernel's metadata map follow its .name line in alphabetical order
+    vg = int(re.search(r"\.vgpr_count:\s+(\d+)", after).group(1))
+    sp = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", after).group(1))
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", after).group(1))
+    assert vg <= 168 and sp == 0 and scratch == 0, (vg, sp, scratch)

@@ -72,8 +72,7 @@ struct WCtx {
   int nla;                    // ... of which violated joint limits (the active contacts' rows follow, four each)
   int rs;                     // 0: `st` is the [row][n_env] state; > 0: `st` is the env-major physics record with this stride
   // per-lane model constants of the J / J^T products, fetched once per launch (a global load in every call left its latency exposed):
-  int kdof[TMW_NL];           // dof slots lane / lane + 64: (limit row + 1) | (wrench subset + 1) << 8, second slot << 16
-  unsigned kmask[2][TMW_NL];  // lane = (subset, component) of tmw_jt_force: contact mask of the subset (valid if n_wsub * 6 <= 64)
+  unsigned kmask[TMW_NL];     // lane = (subset, component) of tmw_jt_force: contact mask (slots 0..31) of the subset (valid if n_wsub * 6 <= 64)
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
@@ -171,26 +170,30 @@ TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
     for (int i = lane; i < K.nphys - 1; i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);
     // (record mode: the action rows were transposed in behind the state + output rows)
     for (int a = lane; a < K.nu; a += 64) L[K.l_ctrl + a] = c.rs ? c.st[(size_t)c.e * (size_t)c.rs + (size_t)(m.s_prev_ctrl + a)] : (action ? action[(size_t)a * c.n + c.e] : 0.f);
-    for (int i = lane; i < 2 * K.nv; i += 64) L[K.l_tdof + i] = tm_i2f(m.tdof[i]);  // index table of the sparse rows
+    for (int i = lane; i < 2 * K.nv; i += 64) {   // index table of the sparse rows (+ the dof's limit row / wrench subset in the top bytes)
+      int dof = i >> 1, extra = (i & 1) ? m.dof_wsub[dof] + 1 : m.dof_limrow[dof] + 1;
+      L[K.l_tdof + i] = tm_i2f(m.tdof[i] | (extra << 24));
+    }
     for (int g = lane; g < K.ngroup; g += 64) { L[K.l_tgrp + 4 * g] = tm_i2f(m.grp_lastdof[g]); L[K.l_tgrp + 4 * g + 1] = tm_i2f(m.grp_start[g]); L[K.l_tgrp + 4 * g + 2] = tm_i2f(m.grp_count[g]); }
     for (int i = lane; i < K.nv; i += 64) L[K.l_hdamp + i] = m.timestep * m.dof_damping[i];
     for (int cc = lane; cc < K.ncon; cc += 64) { L[K.l_con_mu + cc] = m.con_mu[cc]; ((unsigned char *)(L + K.l_con_grpb))[cc] = (unsigned char)m.con_grp[cc]; }
     {
-      int i0 = lane, i1 = lane + 64;
-      int a = (m.dof_limrow[i0] + 1) | ((m.dof_wsub[i0] + 1) << 8);
-      int b = i1 < K.nv ? ((m.dof_limrow[i1] + 1) | ((m.dof_wsub[i1] + 1) << 8)) : 0;
-      c.kdof[TMW_LI] = a | (b << 16);
       int su = lane / 6;
       bool ok = lane < m.n_wsub * 6;
-      c.kmask[0][TMW_LI] = ok ? m.wsub_cmask[su][0] : 0u; c.kmask[1][TMW_LI] = ok ? m.wsub_cmask[su][1] : 0u;
+      c.kmask[TMW_LI] = ok ? m.wsub_cmask[su][0] : 0u;
     }
   }
   TMW_SYNC();
   return WST(m.s_time, 0);
 }
-// packed per-dof words in LDS: w0 = (Madr + depth) | depth << 16, w1 = chain_start | (jump + 1) << 8 | ndesc << 16
+// packed per-dof words in LDS: w0 = (Madr + depth) | depth << 16 | (limit row + 1) << 24, w1 = chain_start | (jump + 1) << 8 | ndesc << 16 | (wrench subset + 1) << 24
 #define TMW_MEND(w0) ((w0) & 0xffff)              /* address of the LAST entry of the row = Madr + depth */
-#define TMW_ADR(w0) (((w0) & 0xffff) - ((w0) >> 16)) /* Madr: address of the diagonal entry */
+#define TMW_DEPTH(w0) (((w0) >> 16) & 0xff)
+#define TMW_ADR(w0) (((w0) & 0xffff) - TMW_DEPTH(w0)) /* Madr: address of the diagonal entry */
+// the top bytes of the two words carry two more per-dof model constants for tmw_jt_force (filled in tmw_load_state): w0 bits 24..31 =
+// limit row + 1, w1 bits 24..31 = wrench subset + 1 (0 = none)
+#define TMW_LIMROW1(w0) (((w0) >> 24) & 0xff)
+#define TMW_WSUB1(w1) (((w1) >> 24) & 0xff)
 #define TMW_W0(i) tm_f2i(L[K.l_tdof + 2 * (i)])
 #define TMW_W1(i) tm_f2i(L[K.l_tdof + 2 * (i) + 1])
 // q-th ancestor of dof i (q = 0: i itself): the chain i, i-1, .., chain_start, then jump, jump-1, .., 0
@@ -398,6 +401,41 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
   TMW_SYNC();
 }
 
+// Inclusive prefix sums along the dof tree for the CHAIN layout, in place on scan entries of TMW_DS floats at `base` (6-vector per
+// dof): one lane per (chain, component) walks its chain serially — the trunk first, then every leaf chain starting from the trunk's
+// finished value at its attachment point.  36 dependent-free load / add / store steps instead of 6 pointer-jumping rounds over all
+// dofs x two dof slots with a barrier each (the loads do not depend on the running sum, the stores are fire-and-forget).
+TM_DEV void tmw_chain_scan(WCtx &c, const WLayout &K, int base) {
+  float *L = c.L; TMW_LANE_DECL
+  TMW_FOR {
+    if (lane < 6) {
+      float acc = 0.f;
+#pragma unroll 1
+      for (int t = 0; t < TMW_RODENT_TRUNK; t++) { float *p = L + base + t * TMW_DS + lane; acc += *p; *p = acc; }
+    }
+  }
+  TMW_SYNC();
+  TMW_FOR {
+    if (lane < TMW_RODENT_NCHAIN * 6) {
+      const int ci = lane / 6, k = lane - ci * 6;
+      int first = 0, n = 0, d0 = 1, idx = 0;
+#define TMW_X(f, nn, dd) if (ci == idx) { first = f; n = nn; d0 = dd; } idx++;
+      TMW_RODENT_LEAF_CHAINS(TMW_X)
+#undef TMW_X
+      float acc = L[base + (d0 - 1) * TMW_DS + k];
+      float *p = L + base + first * TMW_DS + k;
+      constexpr int MAXN = tmw_chain_maxrun(TMW_RODENT_TRUNK, 73) + 1;        // longest leaf chain (TMW_RODENT_DIMS: nv = 73)
+#pragma unroll 1
+      for (int t = 0; t < MAXN; t++) {       // t >= n: re-reads the chain's first entry, no store
+        float v = p[(t < n ? t : 0) * TMW_DS];
+        acc += v;
+        if (t < n) p[t * TMW_DS] = acc;
+      }
+    }
+  }
+  TMW_SYNC();
+}
+
 // ------------------------------------------------------------------------------------------ fwd_velocity + smooth forces
 // com_vel / rne prefixes by pointer jumping over dofs, body forces, up-sweep (crb, cfrc), M, qfrc_smooth, act_dot
 TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
@@ -409,10 +447,12 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       float qv = L[K.l_qvel + i];
       float *o = L + K.l_dscanA + i * TMW_DS;
       for (int k = 0; k < 6; k++) o[k] = L[K.l_cdof + i * 6 + k] * qv;
-      o[6] = tm_i2f(m.dof_parentid[i]);
+      if (!K.chains) o[6] = tm_i2f(m.dof_parentid[i]);
     }
   }
   TMW_SYNC();
+  if (K.chains) tmw_chain_scan(c, K, K.l_dscanA);
+  else
   for (int r = 0; r < R; r++) {
     const float *cur = L + ((r & 1) ? K.l_dscanB : K.l_dscanA);
     float *nxt = L + ((r & 1) ? K.l_dscanA : K.l_dscanB);
@@ -460,10 +500,12 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       float qv = L[K.l_qvel + i];
       float *o = L + K.l_dscanA + i * TMW_DS;
       for (int k = 0; k < 6; k++) o[k] = dd[k] * qv;
-      o[6] = tm_i2f(m.dof_parentid[i]);
+      if (!K.chains) o[6] = tm_i2f(m.dof_parentid[i]);
     }
   }
   TMW_SYNC();
+  if (K.chains) tmw_chain_scan(c, K, K.l_dscanA);
+  else
   for (int r = 0; r < R; r++) {
     const float *cur = L + ((r & 1) ? K.l_dscanB : K.l_dscanA);
     float *nxt = L + ((r & 1) ? K.l_dscanA : K.l_dscanB);
@@ -547,7 +589,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       for (int k = 0; k < 6; k++) fb[k] = L[K.l_cfrc + b * 6 + k];
       for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
       tm_inert_mul(buf, I, cd);
-      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = w0 >> 16;
+      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = TMW_DEPTH(w0);
 #pragma unroll 4
       for (int k = 0; k <= d; k++) {
         const float *cj = L + K.l_cdof + tmw_anc(i, k, w1) * 6;
@@ -592,7 +634,7 @@ TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
   }
   TMW_REG(float, a0); TMW_REG(float, a1); TMW_REG(float, b0); TMW_REG(float, b1); TMW_REG(float, acc); TMW_REG(float, pr);
   for (int i = K.nv - 1; i >= 0; i--) {
-    int w0 = TMW_W0(i), adr = TMW_ADR(w0), d = w0 >> 16, nd = (TMW_W1(i) >> 16) & 0xff;
+    int w0 = TMW_W0(i), adr = TMW_ADR(w0), d = TMW_DEPTH(w0), nd = (TMW_W1(i) >> 16) & 0xff;
     TMW_FOR {
       float rsum = 0.f;
 #pragma unroll
@@ -648,7 +690,7 @@ TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
   // rows still hold M' = D L: scale the strict part to the unit-lower L
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
-      int w0 = TMW_W0(i), adr = TMW_ADR(w0), d = w0 >> 16;
+      int w0 = TMW_W0(i), adr = TMW_ADR(w0), d = TMW_DEPTH(w0);
       float inv = L[K.l_Dinv + i];
       for (int q = 1; q <= d; q++) L[K.l_LD + adr + q] *= inv;
     }
@@ -660,7 +702,7 @@ TM_DEV void tmw_subst_down(WCtx &c, const WLayout &K, int x) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, t);
   for (int i = 0; i < K.nv; i++) {
-    int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = w0 >> 16;
+    int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = TMW_DEPTH(w0);
     TMW_FOR { t[TMW_LI] = (lane >= 1 && lane <= d) ? L[K.l_LD + adr + lane] * L[x + tmw_anc(i, lane, w1)] : 0.f; }
     float s = d > 0 ? tmw_sum(t) : 0.f;
     TMW_FOR { if (lane == 0) L[x + i] = L[x + i] * L[K.l_Dinv + i] - s; }
@@ -674,7 +716,7 @@ TM_DEV void tmw_invert_l(WCtx &c, const WLayout &K) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, x); TMW_REG(float, arow); TMW_REG(float, acc);
   for (int k = 1; k < K.nv; k++) {
-    int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = TMW_ADR(w0k), d = w0k >> 16;
+    int w0k = TMW_W0(k), w1k = TMW_W1(k), ak = TMW_ADR(w0k), d = TMW_DEPTH(w0k);
     if (d == 0) continue;
     TMW_FOR {
       float xv = (lane >= 1 && lane <= d) ? L[K.l_LD + ak + lane] : 0.f;
@@ -1137,7 +1179,7 @@ TM_DEV void tmw_colpart_chains(WCtx &c, const WLayout &K, int A, int x, int out)
 // word per descendant for the column.  `diag`: include q = 0.
 TM_DEV float tmw_row_dot(const float *L, const WLayout &K, int A, int x, int i, bool diag) {
   int w0 = tm_f2i(L[K.l_tdof + 2 * i]), w1 = tm_f2i(L[K.l_tdof + 2 * i + 1]);
-  int d = w0 >> 16, adr = TMW_ADR(w0), r = i - (w1 & 0xff), jp1 = (w1 >> 8) & 0xff;
+  int d = TMW_DEPTH(w0), adr = TMW_ADR(w0), r = i - (w1 & 0xff), jp1 = (w1 >> 8) & 0xff;
   const float *Ap = L + A + adr, *xp = L + x;
   float acc = diag ? Ap[0] * xp[i] : 0.f;
 #pragma unroll 4
@@ -1148,7 +1190,7 @@ TM_DEV float tmw_row_dot(const float *L, const WLayout &K, int A, int x, int i, 
   return acc;
 }
 TM_DEV float tmw_col_dot(const float *L, const WLayout &K, int A, int x, int i) {
-  int w0 = tm_f2i(L[K.l_tdof + 2 * i]), nd = (tm_f2i(L[K.l_tdof + 2 * i + 1]) >> 16) & 0xff, d = w0 >> 16;
+  int w0 = tm_f2i(L[K.l_tdof + 2 * i]), nd = (tm_f2i(L[K.l_tdof + 2 * i + 1]) >> 16) & 0xff, d = TMW_DEPTH(w0);
   const float *Ap = L + A - d, *xp = L + x + i + 1;
   const float *tw = L + K.l_tdof + 2 * (i + 1);
   float acc = 0.f;
@@ -1171,8 +1213,8 @@ TM_DEV void tmw_row_runs2(const float *L, const WLayout &K, int A, int x, int la
   const int i0 = lane, i1 = lane + 64 < K.nv ? lane + 64 : 64;
   int w00 = tm_f2i(L[K.l_tdof + 2 * i0]), w01 = tm_f2i(L[K.l_tdof + 2 * i0 + 1]);
   int w10 = tm_f2i(L[K.l_tdof + 2 * i1]), w11 = tm_f2i(L[K.l_tdof + 2 * i1 + 1]);
-  int d0 = w00 >> 16, r0 = i0 - (w01 & 0xff), j0 = (w01 >> 8) & 0xff;
-  int d1 = w10 >> 16, r1 = i1 - (w11 & 0xff), j1 = (w11 >> 8) & 0xff;
+  int d0 = TMW_DEPTH(w00), r0 = i0 - (w01 & 0xff), j0 = (w01 >> 8) & 0xff;
+  int d1 = TMW_DEPTH(w10), r1 = i1 - (w11 & 0xff), j1 = (w11 >> 8) & 0xff;
   const float *A0 = L + A + TMW_ADR(w00), *x0 = L + x + i0, *A1 = L + A + TMW_ADR(w10), *x1 = L + x + i1;
   float a0 = diag ? A0[0] * x0[0] : 0.f, a1 = diag ? A1[0] * x1[0] : 0.f;
   const int maxr0 = tmw_opaque_s(MAXR0), maxr1 = tmw_opaque_s(MAXR1), maxt = tmw_opaque_s(MAXT);
@@ -1267,7 +1309,7 @@ TM_DEV void tmw_jmul_stage1(WCtx &c, const WLayout &K, int v) {
       int g = lane / 6, k = lane - g * 6, ld = tm_f2i(L[K.l_tgrp + 4 * g]);
       float s = 0.f;
       if (ld >= 0) {
-        int w1 = TMW_W1(ld), d = TMW_W0(ld) >> 16;
+        int w1 = TMW_W1(ld), d = TMW_DEPTH(TMW_W0(ld));
 #pragma unroll 4
         for (int q = 0; q <= d; q++) { int i = tmw_anc(ld, q, w1); s += L[K.l_cdof + i * 6 + k] * L[v + i]; }
       }
@@ -1341,7 +1383,8 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
       float sacc = 0.f;
       if (idx < m.n_wsub * 6) {
         int su = idx / 6, k = idx - su * 6;
-        unsigned m0 = slot == 0 && m.n_wsub * 6 <= 64 ? c.kmask[0][TMW_LI] : m.wsub_cmask[su][0], m1 = slot == 0 && m.n_wsub * 6 <= 64 ? c.kmask[1][TMW_LI] : m.wsub_cmask[su][1];
+        // (contact slots 32.. exist only for ncon > 32: their mask word is fetched on demand instead of occupying a register for the whole kernel)
+        unsigned m0 = slot == 0 && m.n_wsub * 6 <= 64 ? c.kmask[TMW_LI] : m.wsub_cmask[su][0], m1 = K.ncon > 32 ? m.wsub_cmask[su][1] : 0u;
         // only the ACTIVE contacts carry a wrench: walk their compact rows (four per contact) back to the contact ids
         const unsigned char *rm = TMW_ROWMAP(K);
         for (int kr = c.nla; kr < c.nact; kr += 4) {
@@ -1364,7 +1407,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       float s = 0.f;
-      int kd = i < 64 ? c.kdof[TMW_LI] : (c.kdof[TMW_LI] >> 16), lr = (kd & 0xff) - 1, su = ((kd >> 8) & 0xff) - 1;
+      int lr = TMW_LIMROW1(TMW_W0(i)) - 1, su = TMW_WSUB1(TMW_W1(i)) - 1;
       if (lr >= 0) {     // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise
         float sv = L[K.l_lim_sign + lr];
         if (sv != 0.f) { int kr = (int)fabsf(sv) - 1; float ja = L[K.l_Jaref + kr]; if (ja < 0.f) s = (sv > 0.f ? 1.f : -1.f) * (-L[K.l_efc_D + kr] * ja); }
