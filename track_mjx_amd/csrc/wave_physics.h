@@ -1851,10 +1851,15 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
 TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK(12);
+#ifndef TMW_STOP
+#define TMW_STOP 99      // instruction-count experiments (tools/scratch/valu_phases.sh): leave the substep after phase TMW_STOP
+#endif
   tmw_position(c, K, emit);
   TMW_TICK(0);
+  if (TMW_STOP <= 0) return;
   tmw_velocity_inertia(c, K);
   TMW_TICK(1);
+  if (TMW_STOP <= 1) return;
   if (K.m_spilled()) {
     // M is about to be factorised in place: keep a copy in global memory for Euler's factorisation of M + h D, and take the one
     // product with M the solver needs (M * warm start, tmw_solve_cg) now
@@ -1863,10 +1868,13 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   }
   if (K.chains) tmw_factor_chains<false>(c, K, 0.f, -1); else tmw_factor(c, K, 0.f);
   TMW_TICK(2);
+  if (TMW_STOP <= 2) return;
   if (K.chains) tmw_invert_chains(c, K); else tmw_invert_l(c, K);
   TMW_TICK(3);
+  if (TMW_STOP <= 3) return;
   tmw_make_constraint(c, K);
   TMW_TICK(4);
+  if (TMW_STOP <= 4) return;
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = L[K.l_qfrc_smooth + i]; }
   TMW_SYNC();
   tmw_solve(c, K, K.l_qacc_smooth);
