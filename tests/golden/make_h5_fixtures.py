@@ -67,4 +67,18 @@ with h5py.File(HERE / "refclip_small.h5", "w") as f:
 
 np.savez_compressed(HERE / "h5_expected.npz", qpos=qpos, qvel=qvel, xpos=xpos, xquat=xquat,
                     config=np.frombuffer(config.encode("utf-8"), dtype=np.uint8), **{"leaf_" + k: v for k, v in leaves.items()})
+# cross-check of the WRITER in track_mjx_amd/h5lite.py: a file it writes must read back identically through the real h5py
+import sys, tempfile
+sys.path.insert(0, str(HERE.parents[1]))
+from track_mjx_amd import h5lite  # noqa: E402
+with tempfile.TemporaryDirectory() as d:
+    out = Path(d) / "written_by_h5lite.h5"
+    payload = {"qpos": qpos, "qvel": qvel, "xpos": xpos, "xquat": xquat, "config": config.encode("utf-8"), "offsets": np.arange(12, dtype=np.int64).reshape(3, 4)}
+    h5lite.write_file(out, payload)
+    with h5py.File(out, "r") as f:
+        assert sorted(f.keys()) == sorted(payload)
+        for k, v in payload.items():
+            got = f[k][()]
+            assert (got == v) if isinstance(v, bytes) else (got.dtype == v.dtype and np.array_equal(got, v)), k
+print("h5lite.write_file -> h5py round trip ok")
 print("wrote", [p.name for p in HERE.glob("*.h5")])

@@ -7,6 +7,8 @@ Tolerances (fp32 path, BASELINE.json asks for 1e-5 rel on qpos/qvel):
     (DESIGN.md "Parity method").
   * integer paths (frame index, contact slot -> geom pair, active sets, done flags): bit exact.
 """
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -626,3 +628,43 @@ def test_fused_clip_adam_kernel_matches_torch():
     """tmjx_adam_clip (optax clip_by_global_norm -> adam on the flat buffers) against torch.optim.Adam + clip_grad_norm_."""
     from tests.test_learner_math import _flat_adam_vs_torch
     _flat_adam_vs_torch("cuda:0")
+
+
+@pytest.mark.gpu
+def test_train_from_hdf5_clip_file(tmp_path):
+    """SURVEY §8 f2 end to end: synthetic clips exported in the stac-mjx HDF5 layout, loaded through io/load.py by the train
+    entrypoint's clip selection (random train/test split), envs built on the training clips, one PPO training step finite; the
+    env on the file's clips steps exactly like the env on the in-memory clips."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import make_clips_h5
+    from track_mjx_amd import clips as _clips, config as _config
+    from track_mjx_amd.agent import ppo
+    from track_mjx_amd.environment import wrap
+    from track_mjx_amd.train import build_env, load_clip_sets
+    from track_mjx_amd.walker import Rodent
+    cfg = _config.default_config()
+    cl = _clips.make_synthetic_clips(Rodent(**cfg["walker_config"]).model, 10)
+    make_clips_h5.export(cl, tmp_path / "clips.h5")
+    cfg["data_path"] = str(tmp_path / "clips.h5")
+    cfg["train_setup"]["train_subset_ratio"] = None
+    allc, none = load_clip_sets(cfg)
+    assert none is None and np.array_equal(allc.joints, cl.joints)
+    e_file, e_mem = build_env(cfg, 32, DEV, reference_clip=allc), build_env(cfg, 32, DEV, reference_clip=cl)
+    g1, g2 = torch.Generator().manual_seed(4), torch.Generator().manual_seed(4)
+    s1, s2 = e_file.reset(g1), e_mem.reset(g2)
+    a = (torch.randn((38, 32), generator=g1) * 0.1).clamp(-1, 1).to(DEV)
+    s1, s2 = e_file.step(s1, a), e_mem.step(s2, a)
+    torch.cuda.synchronize()
+    assert torch.equal(s1.obs, s2.obs) and torch.equal(s1.reward, s2.reward)
+    cfg["train_setup"]["train_subset_ratio"] = 0.8
+    np.random.seed(0)
+    train, test = load_clip_sets(cfg)
+    assert train.position.shape[0] == 9 and test.position.shape[0] == 1      # int(10 * (1 - 0.8)) = 1 in floating point, as in the reference
+    env = wrap(build_env(cfg, 128, DEV, reference_clip=train), episode_length=195)
+    L = ppo.PPOLearner(env, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=5, batch_size=128,
+                       num_minibatches=2, num_updates_per_batch=1, seed=1)
+    L.states[0] = env.reset(torch.Generator().manual_seed(2))
+    out = L.training_step(0)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())

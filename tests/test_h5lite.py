@@ -98,3 +98,27 @@ def test_train_entrypoint_clip_selection(tmp_path):
     cfg["train_setup"]["train_subset_ratio"] = 0.5
     train, test = load_clip_sets(cfg)
     assert train.original_clip_idx.ravel().tolist() == [2] and np.array_equal(train.joints[0], E["leaf_joints"][2])
+
+
+def test_writer_round_trip_and_clip_export(tmp_path):
+    """h5lite.write_file (also read back by the real h5py in tests/golden/make_h5_fixtures.py) and tools/make_clips_h5.export:
+    synthetic clips -> stac-mjx file -> io.load.load_data gives the clips back bit for bit."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import make_clips_h5
+    from tests.common import default_walker
+    from track_mjx_amd import clips as _clips
+    payload = {"a": np.arange(6, dtype=np.int32).reshape(2, 3), "b": np.linspace(0, 1, 5), "c": b"hello: world\n"}
+    h5lite.write_file(tmp_path / "w.h5", payload)
+    with h5lite.File(tmp_path / "w.h5") as f:
+        assert sorted(f.keys()) == ["a", "b", "c"] and f["c"][()] == payload["c"]
+        assert np.array_equal(f["a"][()], payload["a"]) and f["a"].dtype == np.int32 and np.array_equal(f["b"][()], payload["b"])
+    with pytest.raises(h5lite.H5Error):
+        h5lite.write_file(tmp_path / "x.h5", {f"d{i}": np.zeros(1) for i in range(9)})
+    w, _ = default_walker()
+    cl = _clips.make_synthetic_clips(w.model, 3, n_frames=40)
+    make_clips_h5.export(cl, tmp_path / "clips.h5")
+    back = load.load_data(str(tmp_path / "clips.h5"))
+    for k in ("position", "quaternion", "joints", "body_positions", "velocity", "angular_velocity", "joints_velocity", "body_quaternions"):
+        assert np.array_equal(getattr(back, k), getattr(cl, k)), k
+    assert load.load_clips_metadata(str(tmp_path / "clips.h5")) == [("Synth", 0), ("Synth", 1), ("Synth", 2)]
