@@ -668,3 +668,31 @@ def test_train_from_hdf5_clip_file(tmp_path):
     out = L.training_step(0)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(v).all()) for v in out.values())
+
+
+@pytest.mark.gpu
+def test_loss_head_outside_autograd_gives_the_same_gradients():
+    """PPOLearner's path (losses.ppo_loss_and_output_grads: tmjx_ppo_loss outside autograd + one autograd.grad from the network
+    outputs with grad_outputs) against the autograd.Function path (compute_ppo_loss_fused + autograd.grad(loss))."""
+    from track_mjx_amd.agent import losses as LS, ppo
+    env = make_env_and_oracle(num_envs=128, n_clips=4, wrappers=True)[0]
+    L = ppo.PPOLearner(env, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=20, batch_size=128,
+                       num_minibatches=2, num_updates_per_batch=1, seed=7, use_graph=False)
+    L.states[0] = env.reset(torch.Generator().manual_seed(3))
+    L.collect()
+    L.normalizer.update(L.buf["observation"])
+    idx = torch.arange(L.local_batch, device=env.device)
+    data = {k: (v.index_select(1, idx) if k != "next_observation_last" else v.index_select(0, idx)) for k, v in L.buf.items()}
+    torch.manual_seed(0)
+    loss, m_ref = LS.compute_ppo_loss_fused(L.policy, L.value, L.normalizer, data, kl_weight=0.1, **L.hp)
+    g_ref = torch.autograd.grad(loss, L.grads.params)
+    torch.manual_seed(0)
+    m, outs, gouts, out8 = LS.ppo_loss_and_output_grads(L.policy, L.value, L.normalizer, data, kl_weight=0.1, **L.hp)
+    g = torch.autograd.grad(outs, L.grads.params, grad_outputs=gouts)
+    for a, b in zip(g, g_ref):
+        assert torch.equal(a, b)
+    for k in m:
+        assert float(m[k]) == float(m_ref[k])
+    torch.manual_seed(0)
+    vec = L._minibatch_grads(idx, 0.1)
+    assert [float(x) for x in vec] == [float(m_ref[k]) for k in L.METRIC_KEYS]

@@ -86,6 +86,37 @@ class _FusedLossHead(torch.autograd.Function):
         return (dlogits * g_total, dbaseline * g_total, dfc2 * g_total) + (None,) * 8
 
 
+def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
+                              discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
+                              clipping_epsilon: float = 0.3, normalize_advantage: bool = True):
+    """The learner's form of compute_ppo_loss_fused: network outputs with autograd, then tmjx_ppo_loss OUTSIDE autograd; returns
+    (metrics, outputs, output_grads) so that the caller runs ONE torch.autograd.grad(outputs, params, grad_outputs=output_grads) —
+    no autograd node for the loss head, no `grad * 1.0` passes over the three gradient arrays, no clone of the scalar."""
+    obs = data["observation_normalized"] if "observation_normalized" in data else normalizer.normalize(data["observation"])
+    logits, fc2 = policy(obs, return_fc2=True)
+    baseline = value(obs)
+    with torch.no_grad():
+        nxt = data["next_observation_last_normalized"] if "next_observation_last_normalized" in data else normalizer.normalize(data["next_observation_last"])
+        bootstrap = value(nxt)
+        noise = torch.randn(data["raw_action"].shape, dtype=torch.float32, device=logits.device)   # entropy sample (randn_like(loc))
+        T, B = data["reward"].shape
+        dev = logits.device
+        args = [a.detach().contiguous().float() for a in (logits, data["raw_action"], data["log_prob"], noise, baseline, bootstrap, data["reward"],
+                                                          data["discount"], data["truncation"], fc2)]
+        dlogits, dbaseline, dfc2 = torch.empty_like(args[0]), torch.empty_like(args[4]), torch.empty_like(args[9])
+        L = _hip.lib()
+        scratch = torch.empty(L.tmjx_ppo_scratch_floats(T, B), dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        c = _hip.PpoCfg(T, B, data["raw_action"].shape[-1], fc2.shape[-1] // 2, reward_scaling, discounting, gae_lambda, clipping_epsilon,
+                        entropy_cost, kl_weight, int(normalize_advantage))
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            ptr = [C.c_void_p(a.data_ptr()) for a in args + [dlogits, dbaseline, dfc2, scratch, out]]
+            _hip.check(L.tmjx_ppo_loss(C.byref(c), *ptr, stream), "tmjx_ppo_loss")
+    metrics = {"total_loss": out[0], "policy_loss": out[1], "v_loss": out[2], "kl_latent_loss": out[4], "entropy_loss": out[3]}
+    return metrics, (logits, baseline, fc2), (dlogits.view_as(logits), dbaseline.view_as(baseline), dfc2.view_as(fc2)), out
+
+
 def compute_ppo_loss_fused(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
                            discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
                            clipping_epsilon: float = 0.3, normalize_advantage: bool = True):

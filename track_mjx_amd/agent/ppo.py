@@ -158,6 +158,7 @@ class PPOLearner:
                     "discount": torch.empty((T, rows), **f32), "truncation": torch.empty((T, rows), **f32),
                     "next_observation_last": torch.empty((rows, obs), **f32)}
         self.matmul_dtype = matmul_dtype
+        self._metric_index = torch.tensor([0, 1, 2, 4, 3], dtype=torch.long, device=dev)    # METRIC_KEYS -> slots of tmjx_ppo_loss's output
         self.use_graph, self._graph, self._graph_kl = use_graph, None, None
         self._act_graphs: dict = {}
         self._wpad: dict = {}
@@ -354,8 +355,12 @@ class PPOLearner:
             data["observation_normalized"] = _losses.gather_normalize(self.buf["observation"], idx, self.normalizer)
             data["next_observation_last_normalized"] = _losses.gather_normalize(self.buf["next_observation_last"], idx, self.normalizer)
         with gemm_inputs(self.matmul_dtype):
-            loss_fn = _losses.compute_ppo_loss_fused if self.dev.type == "cuda" else _losses.compute_ppo_loss
-            loss, m = loss_fn(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
+            if self.dev.type == "cuda":
+                # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
+                m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
+                self.grads.assign(torch.autograd.grad(outs, self.grads.params, grad_outputs=gouts))
+                return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
+            loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
         self.grads.assign(torch.autograd.grad(loss, self.grads.params))
         return torch.stack([m[k].float() for k in self.METRIC_KEYS])
 
