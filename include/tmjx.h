@@ -148,6 +148,11 @@ int tmjx_sample_action(const float *logits, const float *noise, float *raw, floa
 int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
                       void *stream);
 
+/* out[width] = column sums of the row-major src[rows][width] (the bias gradient dy.sum(0) of a dense layer: flax nn.Dense's bias in
+ * track_mjx/agent/mlp_ppo/intention_network.py:32-44 and brax's value MLP); `scratch`: tmjx_colsum_scratch_floats(width) floats. */
+int tmjx_colsum_scratch_floats(int width);
+int tmjx_colsum(const float *src, float *out, float *scratch, int rows, int width, void *stream);
+
 /* optax.chain(optax.clip_by_global_norm(max_norm), optax.adam(lr)) (track_mjx/agent/mlp_ppo/ppo.py:517-520) on FLAT fp32 device
  * buffers of n elements: param -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps) with the gradient scaled by max_norm / max(max_norm,
  * *grad_norm); `grad_norm` is a device scalar (the caller's ||grad||_2 of the averaged gradient), bias_correction{1,2} = 1 - beta^t. */

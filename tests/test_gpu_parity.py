@@ -696,3 +696,14 @@ def test_loss_head_outside_autograd_gives_the_same_gradients():
     torch.manual_seed(0)
     vec = L._minibatch_grads(idx, 0.1)
     assert [float(x) for x in vec] == [float(m_ref[k]) for k in L.METRIC_KEYS]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(20480, 76), (20480, 256), (40960, 120), (1025, 1), (4099, 33)])
+def test_colsum_kernel_matches_torch(shape):
+    """tmjx_colsum (bias gradients of the dense layers) against a float64 column sum."""
+    from track_mjx_amd.agent.networks import _colsum
+    x = torch.randn(shape, device=DEV)
+    got = _colsum(x)
+    ref = x.double().sum(0)
+    assert got.shape == (shape[1],) and float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max() + shape[0] ** 0.5)

@@ -63,6 +63,23 @@ def _mm_nt(x, w):
     return torch.mm(xb, wb.t(), out_dtype=torch.float32), xb, wb
 
 
+def _colsum(dy: torch.Tensor) -> torch.Tensor:
+    """dy.sum(0) of a contiguous fp32 [rows, width] CUDA tensor through tmjx_colsum (two launches of ~4 us; torch's generic reduction
+    needs 10-25 us for the tall, narrow bias-gradient inputs); anything else goes to torch."""
+    if not (dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 2 and dy.is_contiguous() and dy.shape[0] >= 1024):
+        return dy.sum(0)
+    import ctypes as C
+    from .. import hip as _hip
+    L = _hip.lib()
+    rows, width = dy.shape
+    out = torch.empty(width, dtype=torch.float32, device=dy.device)
+    scratch = torch.empty(L.tmjx_colsum_scratch_floats(width), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _hip.check(L.tmjx_colsum(C.c_void_p(dy.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()), rows, width,
+                                 C.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream)), "tmjx_colsum")
+    return out
+
+
 def _splitk_dw(dy, x, s):
     """dy^T x as SPLIT row slabs (one batched GEMM) + a sum; operands in their stored dtype, fp32 result."""
     m = x.shape[0]
@@ -99,7 +116,7 @@ class _SplitKLinearFn(torch.autograd.Function):
             dx = dys @ w if ctx.needs_input_grad[0] else None
         else:
             dx = torch.mm(dys, w, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        return dx, _splitk_dw(dys, x, s).to(dy.dtype), dy.sum(0)
+        return dx, _splitk_dw(dys, x, s).to(dy.dtype), _colsum(dy)
 
 
 class _Dense(nn.Linear):

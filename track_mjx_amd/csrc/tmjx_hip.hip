@@ -525,6 +525,17 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
   return check_launch("k_gather_normalize");
 }
 
+int tmjx_colsum_scratch_floats(int width) { return COLSUM_CHUNKS * width; }
+
+int tmjx_colsum(const float *src, float *out, float *scratch, int rows, int width, void *stream) {
+  if (!src || !out || !scratch) return fail(TMJX_EINVAL, "null argument");
+  if (rows < 1 || width < 1) return fail(TMJX_EINVAL, "rows and width must be >= 1");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_colsum_rows, dim3((width + 31) / 32, COLSUM_CHUNKS), dim3(256), 0, s, src, scratch, rows, width);
+  hipLaunchKernelGGL(k_colsum, dim3((width + 31) / 32), dim3(256), 0, s, (const float *)scratch, out, COLSUM_CHUNKS, width);
+  return check_launch("k_colsum_rows");
+}
+
 int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *grad_norm, long long n, float lr,
                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm) return fail(TMJX_EINVAL, "null argument");
