@@ -132,6 +132,10 @@ int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const f
 int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mean, const float *std, float *out, int T, int R, int B,
                           int W, void *stream);
 
+/* Backward of the latent sample inside tmjx_latent_concat (reparameterize, intention_network.py:78-88): from d x [n][dx_stride]
+ * to d fc2 [n][2 Z] = [d mean | d logvar]. */
+int tmjx_latent_concat_bwd(const float *dx, const float *eps, const float *fc2, float *dfc2, int n, int Z, int dx_stride, void *stream);
+
 /* Policy inference tails (ppo_networks.py:46-96, intention_network.py:78-88).
  * tmjx_latent_concat: x[i] = [ mean_i + eps_i * exp(logvar_i / 2) | obs_i[ref_w:] ], fc2 [n][2Z] = mean | logvar, eps [n][Z], obs
  *   addressed as obs[i * obs_s0 + c * obs_s1] (so the [obs][n_env] buffer of tmjx_step can be passed as is) and normalised with

@@ -222,6 +222,41 @@ class _Block(nn.Module):
         return self.norm(F.silu(self.dense(x)))
 
 
+class _LatentConcatFn(torch.autograd.Function):
+    """x = [mean + eps * exp(logvar / 2) | obs[:, ref:]] from fc2 = [mean | logvar] (reparameterize + the decoder-input concat,
+    intention_network.py:78-88,128-139) as one launch forward (tmjx_latent_concat) and one backward (tmjx_latent_concat_bwd) instead
+    of chunk / exp / mul / add / cat and their five backward kernels.  obs is not differentiated (network input)."""
+
+    @staticmethod
+    def forward(ctx, fc2, eps, obs, ref):
+        import ctypes as C
+        from .. import hip as _hip
+        n, Z = eps.shape
+        W = obs.shape[1]
+        fc2, eps, obs = fc2.contiguous(), eps.contiguous(), obs.contiguous()
+        x = torch.empty((n, Z + W - ref), dtype=torch.float32, device=fc2.device)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(fc2.device):
+            _hip.check(_hip.lib().tmjx_latent_concat(p(fc2), p(eps), p(obs), p(x), n, Z, W, ref, obs.stride(0), obs.stride(1), None, None, x.shape[1],
+                                                     C.c_void_p(torch.cuda.current_stream(fc2.device).cuda_stream)), "tmjx_latent_concat")
+        ctx.save_for_backward(fc2, eps)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        import ctypes as C
+        from .. import hip as _hip
+        fc2, eps = ctx.saved_tensors
+        n, Z = eps.shape
+        dx = dx.contiguous()
+        dfc2 = torch.empty_like(fc2)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(fc2.device):
+            _hip.check(_hip.lib().tmjx_latent_concat_bwd(p(dx), p(eps), p(fc2), p(dfc2), n, Z, dx.shape[1],
+                                                         C.c_void_p(torch.cuda.current_stream(fc2.device).cuda_stream)), "tmjx_latent_concat_bwd")
+        return dfc2, None, None, None
+
+
 class IntentionPolicy(nn.Module):
     """Encoder-decoder "intention" policy (intention_network.py:90-142)."""
 
@@ -248,6 +283,18 @@ class IntentionPolicy(nn.Module):
         h = self.encoder(traj)
         fc2 = self.fc2(h)
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
+        if (not deterministic and fc2.is_cuda and fc2.dtype == torch.float32 and obs.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and fc2.numel() >= 2 * self.latents * 1024):
+            # training-sized batches: latent sample + concat (and their backward) as one launch each
+            lead = fc2.shape[:-1]
+            if eps is None:
+                eps = torch.randn_like(mean)
+            x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size)
+            x = x.view(*lead, x.shape[-1])
+            logits = self.head(self.decoder(x))
+            if return_fc2:
+                return logits, fc2
+            return logits, mean, logvar
         if deterministic:
             z = mean
         else:

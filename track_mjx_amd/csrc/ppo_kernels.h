@@ -313,6 +313,17 @@ __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__
     x[e * (size_t)x_stride + c] = v;
   }
 }
+// gradient of the latent sample w.r.t. the two halves of fc2 = [mean | logvar] from d x (the decoder-input gradient, row stride
+// dx_stride): d mean = dx[:, :Z];  d logvar = dx[:, :Z] * eps * exp(logvar / 2) / 2   (reparameterize, intention_network.py:78-88)
+__global__ __launch_bounds__(256) void k_latent_concat_bwd(const float *__restrict__ dx, const float *__restrict__ eps, const float *__restrict__ fc2,
+                                                           float *__restrict__ dfc2, int n, int Z, int dx_stride) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * Z; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % Z); size_t e = i / Z;
+    float g = dx[e * (size_t)dx_stride + c];
+    dfc2[e * 2 * Z + c] = g;
+    dfc2[e * 2 * Z + Z + c] = g * eps[e * Z + c] * (0.5f * expf(0.5f * fc2[e * 2 * Z + Z + c]));
+  }
+}
 // action sample, tanh post-processing and log-prob of the sample: one lane group of PPO_G per env
 __global__ __launch_bounds__(PPO_BLOCK) void k_sample_action(const float *__restrict__ logits, const float *__restrict__ noise, float *__restrict__ raw,
                                                              float *__restrict__ action_t, float *__restrict__ logp, int n, int A) {

@@ -30,7 +30,7 @@ class Layout(C.Structure):
 
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
-           "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
+           "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
 
@@ -88,6 +88,7 @@ def lib():
     L.tmjx_silu_ln_bwd.argtypes = [fp] * 8 + [C.c_int, C.c_int, vp]
     L.tmjx_gather_normalize.argtypes = [fp] * 5 + [C.c_int] * 4 + [vp]
     L.tmjx_latent_concat.argtypes = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, C.c_int, vp]
+    L.tmjx_latent_concat_bwd.argtypes = [fp] * 4 + [C.c_int] * 3 + [vp]
     L.tmjx_sample_action.argtypes = [fp] * 5 + [C.c_int, C.c_int, vp]
     L.tmjx_linear_nolds.argtypes = [fp, C.c_int64, C.c_int64, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
     L.tmjx_colsum_scratch_floats.argtypes = [C.c_int]
