@@ -156,6 +156,31 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # d1 of the measurement contract also asks for the ROLL-OUT-ONLY rate (random actions, no policy, no learner): the same env
+    # groups stepped on their own streams, outside the timed region of the training metric
+    rollout_only = None
+    try:
+        gen = torch.Generator(device=device).manual_seed(5)
+        acts = [torch.randn((38, e.num_envs), generator=gen, device=device).clamp(-1, 1) * 0.3 for e in envs]
+        streams = [torch.cuda.Stream(device=device) for _ in envs]
+        sts = list(learner.states)
+        saved_events = [e._physics_events for e in envs]
+        for e in envs:
+            e._physics_events = None          # the per-launch HIP events of the timed region stay as they are
+        nroll = 40
+        for _rep in range(2):                 # first repetition = warm-up
+            torch.cuda.synchronize(device)
+            tr0 = time.perf_counter()
+            for _ in range(nroll):
+                for k, e in enumerate(envs):
+                    with torch.cuda.stream(streams[k]):
+                        sts[k] = e.step(sts[k], acts[k])
+            torch.cuda.synchronize(device)
+            rollout_only = n_local * nroll / (time.perf_counter() - tr0)
+        for e, ev_ in zip(envs, saved_events):
+            e._physics_events = ev_
+    except Exception:
+        rollout_only = None
     env_steps = learner.env_steps_per_training_step * args.steps
     ev = [p for e in envs for p in e._physics_events]
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)      # per launch (n_local / ngrp envs each)
@@ -180,7 +205,8 @@ def main():
                        "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
                        "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}",
                        "policy_params": learner.n_params(), "physics_kernel_ms": kernel_ms, "envs_per_physics_launch": per_launch,
-                       "concurrent_physics_launches": ngrp},
+                       "concurrent_physics_launches": ngrp,
+                       "rollout_only_env_steps_per_s_per_gpu": rollout_only},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env; the HIP events also span its two record-transpose launches, < 1 % of the time; with --pipeline 2 two such launches of 2048 envs run concurrently, each sharing the GPU)",
                          "algorithmic_bytes_per_launch": K2_ALGO_BYTES_PER_ENV_STEP * per_launch, "avg_launch_ms": kernel_ms,
