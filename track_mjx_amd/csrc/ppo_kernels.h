@@ -271,13 +271,17 @@ __global__ __launch_bounds__(256) void k_silu_ln_bwd(const float *__restrict__ d
 __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partial, float *__restrict__ out, int nblk, int width) {
   __shared__ float lds[8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, col = blockIdx.x * 32 + cx;
-  float s0 = 0.f, s1 = 0.f;
+  // eight independent loads in flight per thread: with two the 80 loads of a thread (640 partial rows) were a chain of memory latencies
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < width) {
     int k = ry;
-    for (; k + 8 < nblk; k += 16) { s0 += partial[(size_t)k * width + col]; s1 += partial[(size_t)(k + 8) * width + col]; }
-    if (k < nblk) s0 += partial[(size_t)k * width + col];
+    for (; k + 56 < nblk; k += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += partial[(size_t)(k + 8 * u) * width + col];
+    }
+    for (; k < nblk; k += 8) acc[0] += partial[(size_t)k * width + col];
   }
-  lds[ry][cx] = s0 + s1;
+  lds[ry][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (ry == 0 && col < width) { float s = 0.f; for (int j = 0; j < 8; j++) s += lds[j][cx]; out[col] = s; }
 }
@@ -459,13 +463,16 @@ __global__ __launch_bounds__(256) void k_colsum_rows(const float *__restrict__ s
   __shared__ float lds[8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, col = blockIdx.x * 32 + cx;
   const int per = (rows + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS, r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
-  float s0 = 0.f, s1 = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < width) {
     int r = r0 + ry;
-    for (; r + 8 < r1; r += 16) { s0 += src[(size_t)r * width + col]; s1 += src[(size_t)(r + 8) * width + col]; }
-    if (r < r1) s0 += src[(size_t)r * width + col];
+    for (; r + 56 < r1; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += src[(size_t)(r + 8 * u) * width + col];
+    }
+    for (; r < r1; r += 8) acc[0] += src[(size_t)r * width + col];
   }
-  lds[ry][cx] = s0 + s1;
+  lds[ry][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (ry == 0 && col < width) { float s = 0.f; for (int j = 0; j < 8; j++) s += lds[j][cx]; partial[(size_t)blockIdx.y * width + col] = s; }
 }
