@@ -88,8 +88,44 @@ __global__ __launch_bounds__(1024) void k_ppo_b(PpoCfg c, const float *__restric
   const int N = c.T * c.B;
   float *vs = scratch + N, *adv = scratch + 2 * (size_t)N, *part = scratch + 4 * (size_t)N, *scal = part + (size_t)4 * nblk;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // sum adv, sum adv^2 (shifted later), sum v_err^2, ent, kl0, klt
+  constexpr int TMAX = 24;     // unroll_length <= TMAX: the whole column lives in registers (all loads of a column in flight together;
+                               // the two scans below were chains of 2 T memory latencies before)
   for (int b = threadIdx.x; b < c.B; b += blockDim.x) {
-    float a = 0.f, bv = bootstrap[b], vnext = bv;
+    float bv = bootstrap[b];
+    if (c.T <= TMAX) {
+      float rw[TMAX], te[TMAX], tm[TMAX], vv[TMAX], vsr[TMAX];
+#pragma unroll
+      for (int t = 0; t < TMAX; t++) {
+        size_t i = (size_t)(t < c.T ? t : 0) * c.B + b;
+        float tr = truncation[i];
+        rw[t] = reward[i] * c.reward_scaling; te[t] = (1.f - discount[i]) * (1.f - tr); tm[t] = 1.f - tr; vv[t] = baseline[i];
+      }
+      float a = 0.f, vnext = bv;
+#pragma unroll
+      for (int t = TMAX - 1; t >= 0; t--) {
+        if (t < c.T) {
+          float delta = (rw[t] + c.discounting * (1.f - te[t]) * vnext - vv[t]) * tm[t];
+          a = delta + c.discounting * (1.f - te[t]) * tm[t] * c.gae_lambda * a;
+          vsr[t] = a + vv[t];
+          vs[(size_t)t * c.B + b] = vsr[t];
+          vnext = vv[t];
+        }
+      }
+      float vsn = bv;
+#pragma unroll
+      for (int t = TMAX - 1; t >= 0; t--) {
+        if (t < c.T) {
+          float ad = (rw[t] + c.discounting * (1.f - te[t]) * vsn - vv[t]) * tm[t];
+          adv[(size_t)t * c.B + b] = ad;
+          acc[0] += ad;
+          float ve = vsr[t] - vv[t];
+          acc[2] += ve * ve;
+          vsn = vsr[t];
+        }
+      }
+      continue;
+    }
+    float a = 0.f, vnext = bv;
     for (int t = c.T - 1; t >= 0; t--) {
       size_t i = (size_t)t * c.B + b;
       float tr = truncation[i], te = (1.f - discount[i]) * (1.f - tr), tm = 1.f - tr, v = baseline[i];
