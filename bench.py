@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=2, help="env groups per GPU whose roll-outs are pipelined on separate HIP streams (1 = off)")
+    ap.add_argument("--no-rollout-only", action="store_true", help="skip the extra roll-out-only measurement (tools/profile_gpu.sh: keeps the "
+                    "rocprofv3 kernel averages those of the timed training steps)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
                     help="BASELINE.json configs[1] (default, the headline line) / configs[3] / configs[4]; the others are extra measurements")
     args = ap.parse_args()
@@ -160,6 +162,8 @@ def main():
     # groups stepped on their own streams, outside the timed region of the training metric
     rollout_only = None
     try:
+        if args.no_rollout_only:
+            raise RuntimeError("skipped")
         gen = torch.Generator(device=device).manual_seed(5)
         acts = [torch.randn((38, e.num_envs), generator=gen, device=device).clamp(-1, 1) * 0.3 for e in envs]
         streams = [torch.cuda.Stream(device=device) for _ in envs]
