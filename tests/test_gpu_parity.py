@@ -733,3 +733,28 @@ def test_fused_latent_concat_forward_backward_matches_torch():
     gr = torch.autograd.grad((rl * up).sum() + rf.square().sum(), list(pol.parameters()))
     for a, b in zip(g, gr):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max() + 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,kmajor", [(2048, 256, 256, False), (2048, 256, 472, True), (2048, 76, 256, False), (132, 64, 36, False),
+                                          (100, 40, 20, True), (64, 33, 7, False), (2048, 512, 1024, False)])
+def test_lds_free_linear_matches_torch(M, N, K, kmajor, monkeypatch):
+    """tmjx_linear_nolds (the acting policy's dense layers next to the other env group's physics kernel): the matrix-core variant
+    (K % 4 == 0: v_mfma_f32_16x16x4_f32 fed from global memory) and the vector variant against a float64 product; ragged M / N /
+    K tails, row-major and K-major A."""
+    import ctypes as C
+    from track_mjx_amd import hip as _hip
+    L = _hip.lib()
+    A = torch.randn((K, M), device=DEV).t() if kmajor else torch.randn((M, K), device=DEV)
+    if kmajor and (M % 4 or A.stride(1) % 4):
+        pytest.skip("K-major A needs M % 4 == 0")
+    W, b = torch.randn((N, K), device=DEV), torch.randn(N, device=DEV)
+    ref = A.double() @ W.double().t() + b.double()
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for valu in (False, True):
+        if valu:
+            monkeypatch.setenv("TMJX_NOLDS_VALU", "1")
+        out = torch.full((M, N), float("nan"), device=DEV)
+        _hip.check(L.tmjx_linear_nolds(p(A), A.stride(0), A.stride(1), p(W), p(b), p(out), M, N, K, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nolds")
+        torch.cuda.synchronize()
+        assert float((out.double() - ref).abs().max()) <= 5e-6 * float(ref.abs().max()), (valu, M, N, K)

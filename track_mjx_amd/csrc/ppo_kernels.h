@@ -322,6 +322,80 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partia
   if (ry == 0 && col < width) { float s = 0.f; for (int j = 0; j < 8; j++) s += lds[j][cx]; out[col] = s; }
 }
 
+// The same contraction on the MATRIX cores, still without LDS: v_mfma_f32_16x16x4_f32 takes A[i][k] in lane 16 k + i and B[k][j] in
+// lane 16 k + j, so a lane's float4 along K (k = 4 (lane / 16) + s, s = 0..3) feeds four MFMAs straight from global memory — any
+// assignment of the 16 k of a step to the four MFMAs works as long as A and B use the same one.  One wave per 32 x 32 output tile
+// (2 x 2 MFMA tiles, 16 accumulator registers), operands of the next K step in flight while the 16 MFMAs of this one issue.  Next
+// to the other env group's physics kernel this matters twice: the fp32 MFMA rate equals the vector FMA rate, but the matrix pipe
+// is idle there while the vector ALU is what the physics kernel is bound by; and a one-wave workgroup fits any free wave slot.
+template <bool A_KMAJOR>
+__global__ __launch_bounds__(64) void k_linear_nolds_mfma(const float *__restrict__ A, long long sa_row, long long sa_k, const float *__restrict__ W,
+                                                          const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K) {
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
+  int ar[2], wc[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) { int r = row0 + 16 * t + li; ar[t] = r < M ? r : M - 1; int c = col0 + 16 * t + li; wc[t] = c < N ? c : N - 1; }
+  f4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+  struct Frag { float4 a[2], w[2]; };
+  auto load = [&](Frag &f, int k0) {
+    const int k = k0 + 4 * kq;
+    const bool ok = k < K;                       // K is a multiple of 4 (host check): a float4 is inside or outside as a whole
+    const int kc = ok ? k : 0;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      float4 v;
+      if (A_KMAJOR) {
+        v.x = A[(long long)kc * sa_k + ar[t]]; v.y = A[(long long)(kc + 1) * sa_k + ar[t]];
+        v.z = A[(long long)(kc + 2) * sa_k + ar[t]]; v.w = A[(long long)(kc + 3) * sa_k + ar[t]];
+      } else {
+        v = *reinterpret_cast<const float4 *>(A + (long long)ar[t] * sa_row + kc);
+      }
+      f.a[t] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+      float4 w = *reinterpret_cast<const float4 *>(W + (size_t)wc[t] * K + kc);
+      f.w[t] = ok ? w : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto mma = [&](const Frag &f) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[a].x, f.w[b].x, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[a].y, f.w[b].y, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[a].z, f.w[b].z, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[a].w, f.w[b].w, acc[a][b], 0, 0, 0);
+      }
+  };
+  Frag f0, f1;
+  load(f0, 0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    if (k0 + 16 < K) load(f1, k0 + 16);
+    mma(f0);
+    if (k0 + 16 >= K) break;
+    if (k0 + 32 < K) load(f0, k0 + 32);
+    mma(f1);
+  }
+  // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const int c = col0 + 16 * b + li;
+      const float bv = (bias && c < N) ? bias[c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + 16 * a + 4 * kq + r;
+        if (row < M && c < N) C[(size_t)row * N + c] = acc[a][b][r] + bv;
+      }
+    }
+}
+
 // minibatch gather + observation normalisation in one pass: out[t][b][:] = (src[t][idx[b]][:] - mean) / std
 // (index_select + two element-wise passes over 57 MB otherwise); float4 lanes, W = obs width (multiple of 4)
 __global__ __launch_bounds__(256) void k_gather_normalize(const float *__restrict__ src, const long long *__restrict__ idx, const float *__restrict__ mean,

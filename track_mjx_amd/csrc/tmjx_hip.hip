@@ -583,8 +583,14 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
   int V = 1;
   if (!(K & 3) && !((uintptr_t)W & 15) && (kmajor || (!(sa_row & 3) && !((uintptr_t)A & 15)))) V = 4;
   else if (!(K & 1) && !((uintptr_t)W & 7) && (kmajor || (!(sa_row & 1) && !((uintptr_t)A & 7)))) V = 2;
-  dim3 grid((M + 63) / 64, (N + 31) / 32), block(128);
   hipStream_t s = (hipStream_t)stream;
+  if (V == 4 && !getenv("TMJX_NOLDS_VALU")) {      // matrix-core variant: float4 operands along K
+    dim3 g2((M + 31) / 32, (N + 31) / 32);
+    if (kmajor) hipLaunchKernelGGL((k_linear_nolds_mfma<true>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K);
+    else hipLaunchKernelGGL((k_linear_nolds_mfma<false>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K);
+    return check_launch("k_linear_nolds_mfma");
+  }
+  dim3 grid((M + 63) / 64, (N + 31) / 32), block(128);
 #define TMJX_NL(VV, KM) hipLaunchKernelGGL((k_linear_nolds<VV, KM>), grid, block, 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K)
   if (kmajor) { if (V == 4) TMJX_NL(4, true); else if (V == 2) TMJX_NL(2, true); else TMJX_NL(1, true); }
   else { if (V == 4) TMJX_NL(4, false); else if (V == 2) TMJX_NL(2, false); else TMJX_NL(1, false); }
