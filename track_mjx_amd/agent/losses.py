@@ -88,16 +88,31 @@ class _FusedLossHead(torch.autograd.Function):
 
 def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
                               discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
-                              clipping_epsilon: float = 0.3, normalize_advantage: bool = True):
+                              clipping_epsilon: float = 0.3, normalize_advantage: bool = True, side_stream=None):
     """The learner's form of compute_ppo_loss_fused: network outputs with autograd, then tmjx_ppo_loss OUTSIDE autograd; returns
     (metrics, outputs, output_grads) so that the caller runs ONE torch.autograd.grad(outputs, params, grad_outputs=output_grads) —
     no autograd node for the loss head, no `grad * 1.0` passes over the three gradient arrays, no clone of the scalar."""
     obs = data["observation_normalized"] if "observation_normalized" in data else normalizer.normalize(data["observation"])
-    logits, fc2 = policy(obs, return_fc2=True)
-    baseline = value(obs)
+    nxt = data["next_observation_last_normalized"] if "next_observation_last_normalized" in data else normalizer.normalize(data["next_observation_last"])
+    if side_stream is not None:
+        # the value network is independent of the policy until the loss head: its forward — and, because autograd runs a node's
+        # backward on the stream of its forward, its backward too — goes to a second stream (a parallel branch of the captured
+        # graph): its GEMMs run next to the policy's epilogue / reduction kernels and vice versa
+        cur = torch.cuda.current_stream(obs.device)
+        side_stream.wait_stream(cur)
+        with torch.cuda.stream(side_stream):
+            baseline = value(obs)
+            with torch.no_grad():
+                bootstrap = value(nxt)
+        logits, fc2 = policy(obs, return_fc2=True)
+        cur.wait_stream(side_stream)
+        baseline.record_stream(cur); bootstrap.record_stream(cur)
+    else:
+        logits, fc2 = policy(obs, return_fc2=True)
+        baseline = value(obs)
+        with torch.no_grad():
+            bootstrap = value(nxt)
     with torch.no_grad():
-        nxt = data["next_observation_last_normalized"] if "next_observation_last_normalized" in data else normalizer.normalize(data["next_observation_last"])
-        bootstrap = value(nxt)
         noise = torch.randn(data["raw_action"].shape, dtype=torch.float32, device=logits.device)   # entropy sample (randn_like(loc))
         T, B = data["reward"].shape
         dev = logits.device

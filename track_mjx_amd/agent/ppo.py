@@ -22,6 +22,7 @@ from .networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet, 
 
 
 import contextlib
+import os
 _nullctx = contextlib.nullcontext
 
 
@@ -158,6 +159,9 @@ class PPOLearner:
                     "discount": torch.empty((T, rows), **f32), "truncation": torch.empty((T, rows), **f32),
                     "next_observation_last": torch.empty((rows, obs), **f32)}
         self.matmul_dtype = matmul_dtype
+        self._sgd_side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and os.environ.get("TMJX_SGD_TWO_STREAMS", "1") != "0") else None
+        if self._sgd_side is not None and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)    # intentional: the value net's gradients arrive from the side stream
         self._metric_index = torch.tensor([0, 1, 2, 4, 3], dtype=torch.long, device=dev)    # METRIC_KEYS -> slots of tmjx_ppo_loss's output
         self.use_graph, self._graph, self._graph_kl = use_graph, None, None
         self._act_graphs: dict = {}
@@ -357,8 +361,12 @@ class PPOLearner:
         with gemm_inputs(self.matmul_dtype):
             if self.dev.type == "cuda":
                 # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
-                m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
-                self.grads.assign(torch.autograd.grad(outs, self.grads.params, grad_outputs=gouts))
+                m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,
+                                                                         side_stream=self._sgd_side, **self.hp)
+                grads = torch.autograd.grad(outs, self.grads.params, grad_outputs=gouts)
+                if self._sgd_side is not None:
+                    torch.cuda.current_stream(self.dev).wait_stream(self._sgd_side)     # the value net's backward ran there
+                self.grads.assign(grads)
                 return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
             loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
         self.grads.assign(torch.autograd.grad(loss, self.grads.params))
