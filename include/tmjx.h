@@ -55,6 +55,11 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out);
 void tmjx_model_destroy(tmjx_model *m);
 int tmjx_layout(const tmjx_model *m, tmjx_layout_t *out);
 
+/* Episode / auto-reset wrapper semantics of the handle: wrappers.wrap(env, episode_length, ...) (track_mjx/environment/wrappers.py:18-56:
+ * brax EpisodeWrapper's step counter / truncation at `episode_length`, and the (LSTM)AutoResetWrapperTracking restore on done).  Only
+ * the two constants change; the clip table of the handle stays resident.  Blocking; not to be called with launches in flight. */
+int tmjx_set_wrappers(tmjx_model *m, int episode_length, int auto_reset);
+
 /* Upload the ReferenceClip table (HOST pointers, float32, shapes (C,F,3) (C,F,4) (C,F,nq-7)
  * (C,F,nbody-1,3) (C,F,3)); the table becomes a resident device constant of the handle.
  * Replaces: the `reference_clip` constructor argument (task/multi_clip_tracking.py:16-72) whose
@@ -163,9 +168,22 @@ int tmjx_colsum(const float *src, float *out, float *scratch, int rows, int widt
 int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *grad_norm, long long n, float lr,
                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream);
 
+/* Observation normaliser update (brax running_statistics.update as called at track_mjx/agent/mlp_ppo/ppo.py:357-361; math:
+ * track_mjx/agent/masked_running_statistics.py:161-214) in one pass over src [rows][W] (W % 4 == 0):
+ *   tmjx_stats_sums:  sums[0..W) = sum_rows(x - mean), sums[W..2W) = sum_rows((x - mean)^2); scratch >= tmjx_stats_scratch_floats(W).
+ *   (multi-GPU: all-reduce `sums` here — replaces the reference's psums of mean_update and variance_update, same totals)
+ *   tmjx_stats_apply: count += n_added; mean += S1 / count; summed_variance += S2 - (S1 / count) S1; std = clip(sqrt(max(sv, 0) / count)).
+ * n_added = rows summed over all ranks. */
+int tmjx_stats_scratch_floats(int W);
+int tmjx_stats_sums(const float *src, const float *mean, float *sums, float *scratch, long long rows, int W, void *stream);
+int tmjx_stats_apply(const float *sums, float n_added, float *count, float *mean, float *summed_variance, float *std, int W, float std_min,
+                     float std_max, void *stream);
+
 /* Debug/test access: copy a named per-env workspace/intermediate array of the last tmjx_forward /
  * tmjx_physics call into `out` (device pointer, [count][n_env]); returns count or a negative code.
- * Names: "qM" (sparse rows), "qfrc_smooth", "qacc", "qacc_smooth", "efc_D", "efc_aref", "con_dist", ... */
+ * Names: "qM" (sparse rows), "qfrc_smooth", "qacc", "qacc_smooth", "efc_D", "efc_aref", "con_dist", ...;
+ * "solver_stats" = [CG iterations (mjx data.solver_niter), line-search iterations summed, constraint rows that entered the solver,
+ * of which joint limits] of the last substep; "efc_in" [nefc] = 1 for the original rows that entered the solver. */
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count);
 
 const char *tmjx_last_error(void);

@@ -57,3 +57,36 @@ def make_env_and_oracle(num_envs=64, n_clips=4, device="cuda:0", wrappers=True, 
 def rel_err(a, b, axis=None):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max(axis) / (np.abs(b).max(axis) + 1e-12)
+
+
+class StubEnv:
+    """Just enough of MultiClipTracking for PPOLearner on the CPU (tests of the learner's host logic and collectives): sizes and a
+    device; the roll-out buffers are filled by the test, no env is ever stepped."""
+
+    class _Layout:
+        ref_obs_size = 470
+
+    def __init__(self, num_envs: int, obs: int = 696, ref: int = 470, nu: int = 38):
+        import torch
+        self.num_envs, self.device = num_envs, torch.device("cpu")
+        self.observation_size, self.action_size = obs, nu
+        self.layout = StubEnv._Layout()
+        self.layout.ref_obs_size = ref
+
+
+def torch_gae(truncation, termination, rewards, values, bootstrap_value, lambda_=1.0, discount=0.99):
+    """compute_gae (track_mjx/agent/mlp_ppo/losses.py:39-100) in torch, for CPU tests of the learner (the product runs tmjx_gae)."""
+    import torch
+    T = rewards.shape[0]
+    tm = 1 - truncation
+    v1 = torch.cat([values[1:], bootstrap_value[None]], 0)
+    deltas = (rewards + discount * (1 - termination) * v1 - values) * tm
+    acc = torch.zeros_like(bootstrap_value)
+    out = []
+    for t in range(T - 1, -1, -1):
+        acc = deltas[t] + discount * (1 - termination[t]) * tm[t] * lambda_ * acc
+        out.append(acc)
+    vs = torch.stack(out[::-1], 0) + values
+    vs1 = torch.cat([vs[1:], bootstrap_value[None]], 0)
+    adv = (rewards + discount * (1 - termination) * vs1 - values) * tm
+    return vs.detach(), adv.detach()

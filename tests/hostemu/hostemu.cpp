@@ -14,6 +14,7 @@
 #include <string>
 
 #include "../../track_mjx_amd/csrc/env_core.h"
+#include "../../track_mjx_amd/csrc/physics_core.h"
 #include "../../track_mjx_amd/csrc/model_host.h"
 #include "../../track_mjx_amd/csrc/wave_physics.h"
 #include <algorithm>

@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     fg.all_reduce_mean()
     norm = fg.clip_by_global_norm(1e-3)
     rs = RunningStatistics(12, "cpu")
-    rs.update(x[lo:hi], group=dist.group.WORLD)
+    rs.update(x[lo:hi])                      # default process group, as PPOLearner.update calls it (group=None)
     rs.update(x[lo:hi] * 2 + 1, group=dist.group.WORLD)
     if rank == 0:
         q.put((fg.flat.clone().numpy(), float(norm), rs.mean.numpy(), rs.std.numpy(), float(rs.count)))
@@ -70,3 +70,105 @@ def test_shard_range_partitions_envs():
         assert False
     except ValueError:
         pass
+
+
+# ---- a full PPOLearner.update over 2 gloo ranks: normaliser (C2), per-minibatch loss -> gradients -> all-reduce-mean (C1) ->
+# clip_by_global_norm -> Adam, against one process that computes every shard's gradients itself and averages them
+_T, _NLOC, _OBS, _REF, _NU = 3, 4, 24, 16, 3
+_NETS = dict(encoder_layers=(12,), decoder_layers=(10,), critic_layers=(8,), latents=4)
+
+
+def _shard_data(rank):
+    g = torch.Generator().manual_seed(77 + rank)
+    rows = 2 * _NLOC
+    return {"observation": torch.randn((_T, rows, _OBS), generator=g) * 2 + 0.5, "raw_action": torch.randn((_T, rows, _NU), generator=g),
+            "log_prob": torch.randn((_T, rows), generator=g) * 0.1 - 2, "reward": torch.randn((_T, rows), generator=g),
+            "discount": (torch.rand((_T, rows), generator=g) > 0.1).float(), "truncation": (torch.rand((_T, rows), generator=g) > 0.9).float(),
+            "next_observation_last": torch.randn((rows, _OBS), generator=g)}
+
+
+def _perm(rank):
+    return lambda upd, rows: torch.randperm(rows, generator=torch.Generator().manual_seed(1000 + 10 * rank + upd))
+
+
+def _make_learner(world_batch):
+    from tests.common import StubEnv, torch_gae
+    from track_mjx_amd.agent.ppo import PPOLearner
+    ln = PPOLearner(StubEnv(_NLOC, _OBS, _REF, _NU), **_NETS, unroll_length=_T, batch_size=world_batch, num_minibatches=2, num_updates_per_batch=2,
+                    learning_rate=1e-2, use_graph=False, seed=3)
+    ln.gae_fn = torch_gae
+    return ln
+
+
+def _seeded(ln, rank):
+    """The loss draws fresh noise (entropy sample, latent eps) from torch's global generator: seed it per (rank, call) so that the
+    worker processes and the single reference process see the same draws."""
+    orig, calls = ln._minibatch_grads, [0]
+
+    def f(idx, kl_w):
+        torch.manual_seed(9000 + 100 * rank + calls[0])
+        calls[0] += 1
+        return orig(idx, kl_w)
+    ln._minibatch_grads = f
+
+
+def _learner_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ln = _make_learner(4 * world)                 # global batch_size; every rank takes batch_size / world rows of each minibatch
+    assert ln.world == 2 and ln.local_batch == 4 and ln.unrolls == 2
+    for k, v in _shard_data(rank).items():
+        ln.buf[k].copy_(v)
+    ln.perm_fn = _perm(rank)
+    _seeded(ln, rank)
+    ln.update()
+    n = ln.normalizer
+    q.put((rank, ln.opt.flat.clone().numpy(), n.mean.numpy().copy(), n.std.numpy().copy(), float(n.count)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_learner_update_matches_manual_gradient_average():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r = q.get(timeout=180)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # replicas stay identical (the reference asserts this: ppo.py:805 pmap.assert_is_replicated)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]) and got[0][3] == got[1][3] == 2 * _T * 2 * _NLOC
+    # one process: a learner per shard (same init), normaliser over both shards' observations, gradients averaged by hand
+    L = [_make_learner(4) for _ in range(2)]
+    data = [_shard_data(r) for r in range(2)]
+    for r, (ln, d) in enumerate(zip(L, data)):
+        for k, v in d.items():
+            ln.buf[k].copy_(v)
+        _seeded(ln, r)
+    allobs = torch.cat([d["observation"].reshape(-1, _OBS) for d in data], 0)
+    for ln in L:
+        ln.normalizer.update(allobs, distributed=False)
+    np.testing.assert_allclose(got[0][1], L[0].normalizer.mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[0][2], L[0].normalizer.std.numpy(), rtol=1e-5, atol=1e-6)
+    rows = 2 * _NLOC
+    for upd in range(2):
+        perms = [_perm(r)(upd, rows) for r in range(2)]
+        for mb in range(2):
+            flats = []
+            for r, ln in enumerate(L):
+                ln._minibatch_grads(perms[r][mb * 4:(mb + 1) * 4], ln.kl_weight)
+                flats.append(ln.grads.flat.clone())
+            mean = (flats[0] + flats[1]) / 2
+            for ln in L:
+                ln.grads.flat.copy_(mean)
+                ln.opt.step()
+    ref = L[0].opt.flat.numpy()
+    np.testing.assert_allclose(got[0][0], ref, rtol=2e-4, atol=2e-6)
+    moved = np.abs(ref - _make_learner(4).opt.flat.numpy()).max()
+    assert moved > 1e-3, "the update must have moved the parameters"

@@ -84,6 +84,12 @@ def test_substep_teacher_forced(variant, monkeypatch):
     if variant == "generic-tree":
         monkeypatch.setenv("TMJX_WAVE_DYNAMIC", "1")
     elif variant == "lane-per-env":
+        # the cross-check build (-DTMJX_LANE_IMPL, built next to the tests by __graft_entry__.build(); NOT the product library)
+        from track_mjx_amd import hip
+        lane_so = Path(__file__).parent / "lane" / "libtmjx_hip_lane.so"
+        if not lane_so.exists():
+            pytest.skip("tests/lane/libtmjx_hip_lane.so not built")
+        monkeypatch.setattr(hip, "_lib", hip.load(lane_so))
         monkeypatch.setenv("TMJX_IMPL", "lane")
     n = 64
     env, O32, cl = make_env_and_oracle(num_envs=n, wrappers=False)

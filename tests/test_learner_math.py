@@ -161,3 +161,36 @@ def test_flax_named_checkpoint_round_trip(tmp_path):
     n1.update(torch.randn(50, 696))
     ck.normalizer_from_flax(n2, ck.normalizer_to_flax(n1))
     assert torch.equal(n1.std, n2.std) and float(n2.count) == 50.0
+
+
+def test_full_learner_checkpoint_round_trip(tmp_path):
+    """save_npz / load_npz on a whole learner: normaliser, policy, VALUE network, Adam moments and step count come back (a resumed
+    run must not pair a trained policy with a fresh critic and zero optimiser state), in place (flat-buffer views stay valid)."""
+    from tests.common import StubEnv, torch_gae
+    from track_mjx_amd.agent import checkpoint as ck
+    from track_mjx_amd.agent.ppo import PPOLearner
+
+    def make(seed):
+        ln = PPOLearner(StubEnv(4, 24, 16, 3), encoder_layers=(12,), decoder_layers=(10,), critic_layers=(8,), latents=4, unroll_length=3,
+                        batch_size=4, num_minibatches=2, num_updates_per_batch=1, learning_rate=1e-2, use_graph=False, seed=seed)
+        ln.gae_fn = torch_gae
+        return ln
+    a = make(3)
+    g = torch.Generator().manual_seed(0)
+    for k, v in a.buf.items():
+        v.copy_(torch.rand(v.shape, generator=g))
+    a.update()
+    path = tmp_path / "PPONetwork_0.npz"
+    ck.save_npz(path, a, config={"train_setup": {"seed": 3}}, step=123)
+    b = make(4)
+    ptrs = [p.data_ptr() for p in b.params]
+    extra = ck.load_npz(path, b)
+    assert extra["env_steps"] == 123 and extra["config"]["train_setup"]["seed"] == 3
+    assert torch.equal(a.opt.flat, b.opt.flat) and torch.equal(a.opt.exp_avg, b.opt.exp_avg) and torch.equal(a.opt.exp_avg_sq, b.opt.exp_avg_sq)
+    assert a.opt.t == b.opt.t == 2
+    assert torch.equal(a.normalizer.mean, b.normalizer.mean) and float(b.normalizer.count) == float(a.normalizer.count)
+    x = torch.randn(5, 24)
+    assert torch.equal(a.value(x), b.value(x))
+    assert [p.data_ptr() for p in b.params] == ptrs          # loaded in place
+    assert sorted(k for k in ck.flatten(ck.learner_tree(a)) if k.startswith("value/")) == [
+        "value/params/hidden_0/bias", "value/params/hidden_0/kernel", "value/params/hidden_1/bias", "value/params/hidden_1/kernel"]

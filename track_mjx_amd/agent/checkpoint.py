@@ -76,6 +76,19 @@ def normalizer_from_flax(n: RunningStatistics, tree: dict) -> None:
         getattr(n, k).copy_(torch.as_tensor(np.asarray(tree[k]), dtype=torch.float32, device=n.mean.device).reshape(getattr(n, k).shape))
 
 
+@torch.no_grad()
+def value_from_flax(value: ValueNet, tree: dict) -> None:
+    """brax value MLP {'params': {hidden_i: {kernel [in, out], bias}}} -> the Linear layers of ValueNet, in place (flat-buffer views
+    and hipGraph pointers of a live learner stay valid)."""
+    p = tree["params"]
+    dense = [m for m in value.net if isinstance(m, torch.nn.Linear)]
+    if len(dense) != len(p):
+        raise ValueError(f"value tree has {len(p)} layers, the network {len(dense)}")
+    for i, lin in enumerate(dense):
+        lin.weight.copy_(torch.as_tensor(np.asarray(p[f"hidden_{i}"]["kernel"]).T.copy(), dtype=lin.weight.dtype, device=lin.weight.device))
+        lin.bias.copy_(torch.as_tensor(np.asarray(p[f"hidden_{i}"]["bias"]), dtype=lin.bias.dtype, device=lin.bias.device))
+
+
 def flatten(tree: dict, prefix: str = "") -> dict:
     out = {}
     for k, v in tree.items():
@@ -98,14 +111,45 @@ def unflatten(flat: dict) -> dict:
     return tree
 
 
-def save_npz(path, learner) -> None:
-    """(normalizer, policy, value) of a PPOLearner as one flat .npz in the reference's tree naming."""
-    tree = {"normalizer": normalizer_to_flax(learner.normalizer), "policy": policy_to_flax(learner.policy), "value": value_to_flax(learner.value)}
-    np.savez(path, **flatten(tree))
+def learner_tree(learner) -> dict:
+    """Everything a resumed run needs, in the reference's tree naming: (normalizer, policy, value) as the reference checkpoints them
+    (checkpointing.py:280-299: `policy` = (normalizer_params, policy_params), `train_state` also holds the value params and the
+    optimizer state) plus the Adam moments / step count of the flat optimiser (optax ScaleByAdamState: count, mu, nu)."""
+    opt = learner.opt
+    return {"normalizer": normalizer_to_flax(learner.normalizer), "policy": policy_to_flax(learner.policy), "value": value_to_flax(learner.value),
+            "optimizer": {"count": np.asarray(opt.t, dtype=np.int64), "mu": _np(opt.exp_avg), "nu": _np(opt.exp_avg_sq)}}
 
 
-def load_npz(path, learner) -> None:
+def save_npz(path, learner, config: dict | None = None, step: int | None = None) -> None:
+    """One flat .npz: learner_tree() + optionally the run's config as JSON (the reference embeds it: checkpointing.py:292-296) and
+    the env-step counter."""
+    import json
+    flat = flatten(learner_tree(learner))
+    if config is not None:
+        flat["config_json"] = np.frombuffer(json.dumps(config, default=str).encode(), dtype=np.uint8)
+    if step is not None:
+        flat["env_steps"] = np.asarray(step, dtype=np.int64)
+    np.savez(path, **flat)
+
+
+def load_npz(path, learner, load_optimizer: bool = True) -> dict:
+    """Restore normaliser, policy, value and (if present) the optimiser moments of a learner IN PLACE; returns {config, env_steps}."""
+    import json
     with np.load(path) as z:
-        tree = unflatten({k: z[k] for k in z.files})
+        flat = {k: z[k] for k in z.files}
+    extra = {"config": json.loads(bytes(flat.pop("config_json")).decode()) if "config_json" in flat else None,
+             "env_steps": int(flat.pop("env_steps")) if "env_steps" in flat else None}
+    tree = unflatten(flat)
     normalizer_from_flax(learner.normalizer, tree["normalizer"])
     policy_from_flax(learner.policy, tree["policy"])
+    if "value" in tree:
+        value_from_flax(learner.value, tree["value"])
+    if load_optimizer and "optimizer" in tree:
+        o = tree["optimizer"]
+        with torch.no_grad():
+            learner.opt.exp_avg.copy_(torch.as_tensor(o["mu"], device=learner.opt.exp_avg.device))
+            learner.opt.exp_avg_sq.copy_(torch.as_tensor(o["nu"], device=learner.opt.exp_avg_sq.device))
+        learner.opt.t = int(o["count"])
+    if hasattr(learner, "_refresh_padded_weights"):
+        learner._refresh_padded_weights()
+    return extra

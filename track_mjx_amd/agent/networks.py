@@ -369,7 +369,7 @@ class NormalTanh:
 class RunningStatistics:
     """Batched Welford observation normaliser (reference math: agent/masked_running_statistics.py:95-236;
     the learner calls brax's copy of the same code at mlp_ppo/ppo.py:357-361,503-505).
-    With `group` set, count / mean_update / variance_update are summed across ranks (the reference's three psums)."""
+    Across ranks the per-column sums are all-reduced once per update (same totals as the reference's three psums)."""
 
     def __init__(self, size: int, device, std_min: float = 1e-6, std_max: float = 1e6):
         self.count = torch.zeros((), dtype=torch.float32, device=device)
@@ -379,24 +379,47 @@ class RunningStatistics:
         self.std_min, self.std_max = std_min, std_max
 
     @torch.no_grad()
-    def update(self, batch: torch.Tensor, group=None) -> None:
+    def update(self, batch: torch.Tensor, group=None, distributed: bool | None = None) -> None:
+        """One pass over the batch: per column S1 = sum(x - mean_old), S2 = sum((x - mean_old)^2); then
+        mean_update = S1 / count_new and variance_update = sum((x - mean_old)(x - mean_new)) = S2 - mean_update * S1 — the
+        reference's update (masked_running_statistics.py:161-214) with its second pass over the data folded into the first.
+        `distributed` (default: a process group is initialised with more than one rank): S1 | S2 are summed across the ranks of
+        `group` (None = the default group) in ONE all-reduce — the same totals as the reference's psums of the count, mean_update
+        and variance_update (ppo.py:357-361).  On the GPU the sums and the in-place update are HIP kernels (tmjx_stats_sums /
+        tmjx_stats_apply, K6); CPU tensors (tests, gloo) take the same formulas in torch."""
         import torch.distributed as dist
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         flat = batch.reshape(-1, batch.shape[-1])
-        inc = torch.tensor(float(flat.shape[0]), device=flat.device)
-        if group is not None:
-            dist.all_reduce(inc, group=group)
-        count = self.count + inc
-        diff_old = flat - self.mean
-        mean_update = diff_old.sum(0) / count
-        if group is not None:
-            dist.all_reduce(mean_update, group=group)
-        mean = self.mean + mean_update
-        var_update = (diff_old * (flat - mean)).sum(0)
-        if group is not None:
-            dist.all_reduce(var_update, group=group)
+        if not flat.is_contiguous():
+            flat = flat.contiguous()
+        rows, W = flat.shape
+        n_added = float(rows * (dist.get_world_size(group) if distributed else 1))      # equal shards (shard_range)
+        if flat.is_cuda and flat.dtype == torch.float32 and W % 4 == 0:
+            import ctypes as C
+            from .. import hip as _hip
+            L = _hip.lib()
+            p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            if getattr(self, "_sums", None) is None:
+                self._sums = torch.empty(2 * W, dtype=torch.float32, device=flat.device)
+                self._scratch = torch.empty(L.tmjx_stats_scratch_floats(W), dtype=torch.float32, device=flat.device)
+            with torch.cuda.device(flat.device):
+                stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+                _hip.check(L.tmjx_stats_sums(p(flat), p(self.mean), p(self._sums), p(self._scratch), rows, W, stream), "tmjx_stats_sums")
+                if distributed:
+                    dist.all_reduce(self._sums, group=group)
+                _hip.check(L.tmjx_stats_apply(p(self._sums), n_added, p(self.count), p(self.mean), p(self.summed_variance), p(self.std), W,
+                                              float(self.std_min), float(self.std_max), stream), "tmjx_stats_apply")
+            return
+        d = flat - self.mean
+        sums = torch.cat([d.sum(0), (d * d).sum(0)])
+        if distributed:
+            dist.all_reduce(sums, group=group)
+        count = self.count + n_added
+        upd = sums[:W] / count
         # in place: the SGD-loop graph (PPOLearner) holds pointers to these buffers
-        self.summed_variance.add_(var_update)
-        self.mean.copy_(mean); self.count.copy_(count)
+        self.summed_variance.add_(sums[W:] - upd * sums[:W])
+        self.mean.add_(upd); self.count.copy_(count)
         self.std.copy_(torch.sqrt(torch.clamp(self.summed_variance, min=0) / count).clamp(self.std_min, self.std_max))
 
     def normalize(self, x: torch.Tensor) -> torch.Tensor:

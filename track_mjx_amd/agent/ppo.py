@@ -381,11 +381,18 @@ class PPOLearner:
                     torch.cuda.current_stream(self.dev).wait_stream(self._sgd_side)     # the value net's backward ran there
                 self.grads.assign(grads)
                 return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
-            loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp)
+            loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp,
+                                               **({"gae_fn": self.gae_fn} if self.gae_fn is not None else {}))
         self.grads.assign(torch.autograd.grad(loss, self.grads.params))
         return torch.stack([m[k].float() for k in self.METRIC_KEYS])
 
     METRIC_KEYS = ("total_loss", "policy_loss", "v_loss", "kl_latent_loss", "entropy_loss")
+    # tests of the torch (CPU) branch only: a GAE implementation for hosts without the HIP kernel (the product default, tmjx_gae, raises there)
+    gae_fn = None
+    # minibatch shuffle (ppo.py:304-311: jax.random.permutation(key_perm, x), one permutation for every leaf): None = torch.randperm of the
+    # learner's generator; otherwise a callable (update_index, rows) -> int64 permutation on the learner's device, e.g. the reference's own
+    # draws from a jax key (jax_random.py: sgd_permutations)
+    perm_fn = None
 
     def _capture(self, kl_w: float):
         """hipGraph of _minibatch_grads (torch.cuda.graphs): ~250 launches of the SGD step replayed as one graph launch.
@@ -406,7 +413,7 @@ class PPOLearner:
 
     def update(self, it: int = 0, kl_schedule: Callable | None = None) -> dict:
         if self.normalize_observations:
-            self.normalizer.update(self.buf["observation"], self.group if self.world > 1 else None)
+            self.normalizer.update(self.buf["observation"], group=self.group, distributed=self.world > 1)     # C2 (group None = default group)
         kl_w = kl_schedule(it) if kl_schedule is not None else self.kl_weight
         rows = self.buf["reward"].shape[1]
         use_graph = self.use_graph and self.dev.type == "cuda"
@@ -418,8 +425,9 @@ class PPOLearner:
                 self.use_graph = use_graph = False
                 torch.cuda.synchronize(self.dev)
         acc = torch.zeros(len(self.METRIC_KEYS), dtype=torch.float32, device=self.dev)
-        for _ in range(self.num_updates):
-            perm = torch.randperm(rows, generator=self.gen, device=self.dev)  # one permutation for every leaf (ppo.py:306-311)
+        for upd in range(self.num_updates):
+            # one permutation for every leaf (ppo.py:306-311)
+            perm = torch.randperm(rows, generator=self.gen, device=self.dev) if self.perm_fn is None else self.perm_fn(upd, rows).to(self.dev)
             for mb in range(self.num_minibatches):
                 idx = perm[mb * self.local_batch:(mb + 1) * self.local_batch]
                 if use_graph:
@@ -432,6 +440,7 @@ class PPOLearner:
                 self.opt.step()                               # clip_by_global_norm(10.0) -> adam (ppo.py:517-520), one fused launch
                 acc += out
         acc /= self.num_updates * self.num_minibatches
+        self._refresh_padded_weights()       # act() / the evaluator right after this update must not see last step's zero-padded copies
         res = {k: acc[i] for i, k in enumerate(self.METRIC_KEYS)}
         res["kl_weight"] = torch.as_tensor(kl_w)
         return res
@@ -449,11 +458,17 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
           encoder_hidden_layer_sizes=(1024, 1024), decoder_hidden_layer_sizes=(1024, 1024), value_hidden_layer_sizes=(1024, 1024),
           intention_latent_size: int = 60, progress_fn: Callable[[int, dict], None] = lambda *a: None,
           max_training_steps: int | None = None, eval_env=None, num_eval_envs: int = 128, deterministic_eval: bool = False,
+          matmul_dtype: torch.dtype | None = None, group=None, checkpoint_path: str | None = None, restore_from: str | None = None,
           **unused):
     """ppo.train(environment, num_timesteps, episode_length, ...) -> (make_policy, params, metrics)  (ppo.py:128-172,809).
 
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
-    ppo.py:469-475 (wrappers.wrap with the default use_lstm=True wrapper semantics)."""
+    ppo.py:469-475 (wrappers.wrap with the default use_lstm=True wrapper semantics).
+
+    Checkpoints (reference: process 0 saves at step 0 and after every eval epoch, ppo.py:700-711,787-795): `checkpoint_path` = a
+    directory; rank 0 writes `PPONetwork_{env_steps}.npz` (agent/checkpoint.py: normaliser, policy, value, Adam moments, config JSON)
+    there.  `ckpt_mgr` may be any object with `.directory` (an orbax CheckpointManager has one) or a path; orbax itself is not in
+    this image.  `restore_from` = such a file: parameters and optimiser state are loaded before the first roll-out."""
     from ..environment import wrap
     # a list of environments = equal groups of this rank's envs whose roll-outs are pipelined on separate HIP streams (collect())
     env_list = [wrap(e, episode_length=int(episode_length), action_repeat=1) for e in (environment if isinstance(environment, (list, tuple)) else [environment])]
@@ -463,7 +478,20 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
                          entropy_cost=entropy_cost, discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
                          clipping_epsilon=clipping_epsilon, unroll_length=unroll_length, batch_size=batch_size,
                          num_minibatches=num_minibatches, num_updates_per_batch=num_updates_per_batch,
-                         normalize_observations=normalize_observations, kl_weight=kl_weight, seed=seed)
+                         normalize_observations=normalize_observations, kl_weight=kl_weight, seed=seed, matmul_dtype=matmul_dtype, group=group)
+    from . import checkpoint as _ckpt
+    if checkpoint_path is None and ckpt_mgr is not None:
+        checkpoint_path = str(getattr(ckpt_mgr, "directory", ckpt_mgr))
+    if restore_from is not None:
+        _ckpt.load_npz(restore_from, learner)
+
+    def save_checkpoint(env_steps: int):
+        if checkpoint_path is None or learner.rank != 0:
+            return None
+        os.makedirs(checkpoint_path, exist_ok=True)
+        path = os.path.join(checkpoint_path, f"PPONetwork_{env_steps}.npz")
+        _ckpt.save_npz(path, learner, config=config_dict, step=env_steps)
+        return path
     env_step_per_training_step = learner.env_steps_per_training_step
     num_evals_after_init = max(num_evals - 1, 1)
     steps_per_epoch = int(math.ceil(num_timesteps / (num_evals_after_init * env_step_per_training_step * max(num_resets_per_eval, 1))))
@@ -483,6 +511,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
                               lambda obs: learner.act(obs, deterministic=deterministic_eval, gen=eval_gen), episode_length=int(episode_length), seed=seed + 7)
     metrics: dict = {}
     total_steps, done_steps = 0, 0
+    save_checkpoint(0)                                    # ppo.py:700-711: the initial parameters
     for it in range(1, num_evals_after_init + 1):
         for _ in range(max(num_resets_per_eval, 1)):
             t0 = time.time()
@@ -508,11 +537,27 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
             if evaluator is not None:
                 metrics = evaluator.run_evaluation(metrics)
             progress_fn(total_steps, metrics)
+        save_checkpoint(total_steps)                      # ppo.py:787-795: after every eval epoch, process 0
         if max_training_steps is not None and done_steps >= max_training_steps:
             break
 
     def make_policy(params=None, deterministic: bool = False):
+        """make_inference_fn(params) (ppo_networks.py:34-100).  `params` = None: the live learner; otherwise the (normalizer, policy[, value])
+        state dicts returned by train(), or a checkpoint file — loaded into the learner's networks IN PLACE first."""
+        if params is not None:
+            if isinstance(params, (str, os.PathLike)):
+                _ckpt.load_npz(params, learner, load_optimizer=False)
+            else:
+                norm_sd, pol_sd = params[0], params[1]
+                with torch.no_grad():
+                    for k, v in norm_sd.items():
+                        getattr(learner.normalizer, k).copy_(v)
+                    learner.policy.load_state_dict(pol_sd)     # copies into the existing (flat-buffer) parameters
+                    if len(params) > 2 and params[2] is not None:
+                        learner.value.load_state_dict(params[2])
+                learner._refresh_padded_weights()
         return lambda obs, key=None: learner.act(obs, deterministic=deterministic)
 
-    params = (learner.normalizer.state_dict(), learner.policy.state_dict(), learner.value.state_dict())
+    params = ({k: v.clone() for k, v in learner.normalizer.state_dict().items()}, {k: v.clone() for k, v in learner.policy.state_dict().items()},
+              {k: v.clone() for k, v in learner.value.state_dict().items()})
     return make_policy, params, metrics

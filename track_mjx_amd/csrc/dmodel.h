@@ -60,7 +60,7 @@ struct DModel {
   int w_ctrl, w_xquat, w_xanchor, w_xaxis, w_xipos, w_cinert, w_cdof, w_crb, w_M, w_LD, w_Dinv, w_cvel, w_cdof_dot, w_cacc,
       w_cfrc, w_qfrc_smooth, w_qacc_smooth, w_act_dot, w_con_dist, w_con_off, w_con_frame, w_efc_D, w_efc_aref,
       w_efc_Jaref, w_efc_jv, w_lim_sign, w_qacc, w_Ma, w_grad, w_Mgrad, w_search, w_mv, w_qfrc_constraint, w_tmp,
-      w_efc_force, w_com, w_rows;
+      w_efc_force, w_com, w_solver_stats, w_efc_in, w_rows;
 
   // ================= tables and LDS map of the wave-per-env physics kernel (csrc/wave_physics.h) =================
   // bodies

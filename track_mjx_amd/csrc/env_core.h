@@ -11,7 +11,7 @@
 #pragma once
 #include <float.h>
 
-#include "physics_core.h"
+#include "tm_common.h"
 
 #define IS(off) r_is[(size_t)(off) * (size_t)r.n + (size_t)r.e]
 #define OUTROW(buf, row) (buf)[(size_t)(row) * (size_t)r.n + (size_t)r.e]

@@ -205,7 +205,7 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
   WROW(w_con_dist, m.ncon); WROW(w_con_off, m.ncon * 3); WROW(w_con_frame, m.ncon * 9);
   WROW(w_efc_D, m.nefc); WROW(w_efc_aref, m.nefc); WROW(w_efc_Jaref, m.nefc); WROW(w_efc_jv, m.nefc); WROW(w_lim_sign, m.nlim);
   WROW(w_qacc, m.nv); WROW(w_Ma, m.nv); WROW(w_grad, m.nv); WROW(w_Mgrad, m.nv); WROW(w_search, m.nv); WROW(w_mv, m.nv);
-  WROW(w_qfrc_constraint, m.nv); WROW(w_tmp, m.nefc > m.nv ? m.nefc : m.nv); WROW(w_efc_force, m.nefc); WROW(w_com, 3);
+  WROW(w_qfrc_constraint, m.nv); WROW(w_tmp, m.nefc > m.nv ? m.nefc : m.nv); WROW(w_efc_force, m.nefc); WROW(w_com, 3); WROW(w_solver_stats, 4); WROW(w_efc_in, m.nefc);
 #undef WROW
   m.w_rows = w;
 
@@ -361,7 +361,7 @@ inline std::vector<NamedRows> debug_rows(const DModel &m) {
       {"qacc", m.w_qacc, m.nv, false}, {"qfrc_constraint", m.w_qfrc_constraint, m.nv, false},
       {"con_dist", m.w_con_dist, m.ncon, false}, {"con_frame", m.w_con_frame, m.ncon * 9, false},
       {"efc_D", m.w_efc_D, m.nefc, false}, {"efc_aref", m.w_efc_aref, m.nefc, false}, {"efc_force", m.w_efc_force, m.nefc, false},
-      {"subtree_com", m.w_com, 3, false},
+      {"subtree_com", m.w_com, 3, false}, {"solver_stats", m.w_solver_stats, 4, false}, {"efc_in", m.w_efc_in, m.nefc, false},
   };
 }
 

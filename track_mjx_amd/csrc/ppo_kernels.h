@@ -586,3 +586,58 @@ __global__ __launch_bounds__(256) void k_colsum_rows(const float *__restrict__ s
   __syncthreads();
   if (ry == 0 && col < width) { float s = 0.f; for (int j = 0; j < 8; j++) s += lds[j][cx]; partial[(size_t)blockIdx.y * width + col] = s; }
 }
+
+
+// ---- K6: observation normaliser update (brax running_statistics.update, reference math track_mjx/agent/masked_running_statistics.py:161-214)
+// ONE pass over the roll-out observations [rows][W]: per column S1 = sum(x - mean_old), S2 = sum((x - mean_old)^2).  The reference's
+//   mean_update = S1 / count_new,  variance_update = sum((x - mean_old)(x - mean_new)) = S2 - mean_update * S1
+// follow from the two sums (same numbers up to fp32 rounding), and across ranks S1 and S2 are what is summed: the reference's three
+// psums (count, mean_update, variance_update) become ONE all-reduce of 2 W floats (the count increment is known on the host).
+// Stage 1: block = 256 lanes = 64 float4 column groups x 4 row slices, one slab of rows per blockIdx.y; the reads of a row are
+// contiguous (W floats), eight rows in flight per lane.  HBM-bound: rows * W * 4 bytes read once.
+#define STATS_SLABS 512
+__global__ __launch_bounds__(256) void k_stats_partial(const float *__restrict__ src, const float *__restrict__ mean, float *__restrict__ partial,
+                                                       long long rows, int W) {
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  __shared__ f4 lds[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c4 = blockIdx.x * 64 + cx, W4 = W >> 2;
+  const long long per = (rows + STATS_SLABS - 1) / STATS_SLABS, r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < W4) {
+    const f4 m = ((const f4 *)mean)[c4];
+    const f4 *p = (const f4 *)src + c4;
+    long long r = r0 + ry;
+    for (; r + 28 < r1; r += 32) {
+      f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(r + 4 * u) * W4];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { f4 d = v[u] - m; s1 += d; s2 += d * d; }
+    }
+    for (; r < r1; r += 4) { f4 d = p[(size_t)r * W4] - m; s1 += d; s2 += d * d; }
+  }
+  lds[0][ry][cx] = s1; lds[1][ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c4 < W4) {
+    f4 a = (lds[0][0][cx] + lds[0][1][cx]) + (lds[0][2][cx] + lds[0][3][cx]), b = (lds[1][0][cx] + lds[1][1][cx]) + (lds[1][2][cx] + lds[1][3][cx]);
+    ((f4 *)(partial + (size_t)blockIdx.y * 2 * W))[c4] = a;
+    ((f4 *)(partial + (size_t)blockIdx.y * 2 * W + W))[c4] = b;
+  }
+}
+// Stage 3 (after the optional cross-rank sum of sums[2][W]): count, mean, summed_variance and std in place, one lane per column
+__global__ void k_stats_finalize(const float *__restrict__ sums, float n_added, float *count, float *mean, float *summed_variance, float *std,
+                                 int W, float std_min, float std_max) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const float cnt = *count + n_added;
+  if (c < W) {
+    const float s1 = sums[c], s2 = sums[W + c];
+    const float upd = s1 / cnt;
+    const float sv = summed_variance[c] + (s2 - upd * s1);
+    mean[c] += upd;
+    summed_variance[c] = sv;
+    std[c] = fminf(fmaxf(sqrtf(fmaxf(sv, 0.f) / cnt), std_min), std_max);
+  }
+  // every block read the old count above; the last lane of the grid to get here would race with slower blocks' reads, so the count is
+  // written by a second tiny launch (k_stats_count) — stream order makes it safe
+}
+__global__ void k_stats_count(float *count, float n_added) { *count += n_added; }

@@ -1,7 +1,9 @@
 // csrc/tmjx_hip.hip — kernels and C-ABI of libtmjx_hip.so (gfx950 / MI355X only).
 //
-// v1 mapping: one lane per env, env index = coalesced axis of every buffer (include/tmjx.h layout rules).
-// The per-env bodies live in physics_core.h (K2) and env_core.h (K1/K3); this file launches them.
+// The per-env bodies live in wave_physics.h (K2: one wavefront per env), env_core.h (K1 / K3: one lane per env or per (env, part), env
+// index = coalesced axis of every buffer, include/tmjx.h layout rules) and ppo_kernels.h (learner); this file launches them.
+// -DTMJX_LANE_IMPL additionally compiles the lane-per-env physics (physics_core.h; TMJX_IMPL=lane selects it): a second, independent
+// HIP implementation used by the tests as a cross-check — the product library is built without it.
 #include <hip/hip_runtime.h>
 
 #include <stdlib.h>
@@ -13,6 +15,9 @@
 #include "env_core.h"
 #include "model_host.h"
 #include "wave_physics.h"
+#ifdef TMJX_LANE_IMPL
+#include "physics_core.h"
+#endif
 
 struct tmjx_model {
   DModel h;           // host copy (clip pointers are device pointers)
@@ -32,8 +37,8 @@ struct tmjx_model {
 #define WAVE_REC_STRIDE(m) ((((m)->h.s_prev_ctrl + (m)->h.nu) + 15) & ~15)
 // workspace words in front of the record: window partials (2 nu rows) + post partials (16 rows), each n_env wide
 #define WAVE_REC_OFFSET(m, n) ((size_t)(2 * (m)->h.nu + 16) * (size_t)(n))
-static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream,
-                        float *rec = nullptr);
+static int launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream,
+                       float *rec = nullptr);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -44,6 +49,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
   } while (0)
 
 // ----------------------------------------------------------------------------------------------- kernels
+#ifdef TMJX_LANE_IMPL
 __global__ void k_reset(const DModel *__restrict__ mp, float *st, int *is, const int *clip, const int *start,
                         const float *qn, const float *vn, float *obs, float *ws, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,6 +81,8 @@ __global__ void k_physics(const DModel *__restrict__ mp, float *st, const float 
   for (int a = 0; a < m.nu; a++) WS(m.w_ctrl, a) = action ? action[(size_t)a * n + e] : 0.f;
   for (int f = 0; f < nsub; f++) { tm_forward(m, r); if (do_euler) tm_euler(m, r); }
 }
+
+#endif  // TMJX_LANE_IMPL
 
 // window statistics, one lane per (action dim, env): 38x more parallelism than lane-per-env for the 50x38 ring buffer
 __global__ void k_window(const DModel *__restrict__ mp, float *st, const int *is, const float *action, float *win, int n) {
@@ -245,7 +253,7 @@ __global__ void k_gae(const float *__restrict__ trunc, const float *__restrict__
 extern "C" {
 
 const char *tmjx_last_error(void) { return g_err.c_str(); }
-const char *tmjx_version(void) { return "tmjx-hip 0.2 (gfx950, wave-per-env LDS physics)"; }
+const char *tmjx_version(void) { return "tmjx-hip 0.3 (gfx950, wave-per-env LDS physics)"; }
 
 int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
   if (!blob || !out) return fail(TMJX_EINVAL, "null argument");
@@ -254,8 +262,10 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
   if (!tmjx_host::build_dmodel(blob, nbytes, m->h, err)) { delete m; return fail(TMJX_EINVAL, err); }
   const char *bs = getenv("TMJX_BLOCK");
   if (bs) { int v = atoi(bs); if (v >= 1 && v <= 256) m->block = v; }
+#ifdef TMJX_LANE_IMPL
   const char *impl = getenv("TMJX_IMPL");
   if (impl && !strcmp(impl, "lane")) m->wave = 0;
+#endif
   if (m->wave) {
     size_t lds_bytes = (size_t)tmjx_host::make_wave_layout(m->h, false).lds_floats * sizeof(float);   // the larger (generic) layout
     if (lds_bytes > 160 * 1024) { delete m; return fail(TMJX_EINVAL, "model does not fit the 160 KiB LDS of a CU"); }
@@ -298,6 +308,17 @@ int tmjx_layout(const tmjx_model *mm, tmjx_layout_t *o) {
   return TMJX_OK;
 }
 
+int tmjx_set_wrappers(tmjx_model *m, int episode_length, int auto_reset) {
+  if (!m) return fail(TMJX_EINVAL, "null argument");
+  if (episode_length < 1) return fail(TMJX_EINVAL, "episode_length must be >= 1");
+  m->h.episode_length = episode_length;
+  m->h.auto_reset = auto_reset ? 1 : 0;
+  // a blocking copy of the constants: called between roll-outs (wrappers.wrap, before the first reset), never while launches of this
+  // handle are in flight; the clip table stays where it is (re-creating the handle re-uploaded it: 631 MB at 1024 clips)
+  HIP_TRY(hipMemcpy(m->d, &m->h, sizeof(DModel), hipMemcpyHostToDevice));
+  return TMJX_OK;
+}
+
 int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quaternion, const float *joints,
                       const float *body_positions, const float *angular_velocity, int n_clips, int n_frames) {
   if (!m || !position || !quaternion || !joints || !body_positions || !angular_velocity) return fail(TMJX_EINVAL, "null argument");
@@ -317,8 +338,8 @@ int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quatern
   return TMJX_OK;
 }
 
-static void launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream,
-                        float *rec) {
+static int launch_wave(const tmjx_model *m, float *state, const float *action, int nsub, int do_euler, float *ws, int n_env, hipStream_t stream,
+                       float *rec) {
   // the compile-time (rodent) kernel uses the chain layout, the run-time one the generic layout of the same dims
   size_t lds = (size_t)(m->rodent ? m->h.lds_floats : tmjx_host::make_wave_layout(m->h, false).lds_floats) * sizeof(float);
   if (const char *pad = getenv("TMJX_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;  // occupancy experiments only
@@ -326,8 +347,14 @@ static void launch_wave(const tmjx_model *m, float *state, const float *action, 
   if (m->rodent && m->mspill_envs < n_env) {
     if (m->mspill) hipFree(m->mspill);            // (hipFree waits for the launches that may still read the old block)
     m->mspill = nullptr; m->mspill_envs = 0;
-    if (hipMalloc((void **)&m->mspill, ((size_t)n_env * sstride + 64) * sizeof(float)) == hipSuccess) m->mspill_envs = n_env;
-    else { m->mspill = nullptr; return; }         // reported by the caller's check_launch via hipGetLastError
+    hipError_t me = hipMalloc((void **)&m->mspill, ((size_t)n_env * sstride + 64) * sizeof(float));
+    if (me != hipSuccess) {                         // nothing was launched: the caller returns this code (no silent skip of the physics)
+      m->mspill = nullptr;
+      (void)hipGetLastError();
+      return fail(TMJX_ENOMEM, std::string("hipMalloc of the physics kernel's per-env inertia-matrix scratch (") +
+                                   std::to_string(((size_t)n_env * sstride + 64) * sizeof(float)) + " bytes): " + hipGetErrorString(me));
+    }
+    m->mspill_envs = n_env;
   }
   float *spill = m->rodent ? m->mspill : nullptr;
   int parts = 1;
@@ -341,6 +368,7 @@ static void launch_wave(const tmjx_model *m, float *state, const float *action, 
     else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs, spill, sstride);
   }
   if (rec) hipLaunchKernelGGL(k_rec_out, dim3((n_env + 63) / 64, (m->h.s_prev_ctrl - m->h.s_qpos + REC_ROWS_PER_THREAD - 1) / REC_ROWS_PER_THREAD), dim3(64), 0, stream, m->d, state, (const float *)rec, n_env, rs);
+  return TMJX_OK;
 }
 // env-major physics record inside the caller's workspace (behind the K3 partial rows), or nullptr = direct [row][n_env] access
 // (TMJX_NO_RECORD=1, or a workspace too small for it)
@@ -365,13 +393,17 @@ int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip
   if (m->wave) {
     hipLaunchKernelGGL(k_reset_pre, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, clip_idx, start_frame, qpos_noise,
                        qvel_noise, workspace, n_env);
-    launch_wave(m, state, (const float *)nullptr, 1, 0, (float *)nullptr, n_env, (hipStream_t)stream);
+    if (int rc = launch_wave(m, state, (const float *)nullptr, 1, 0, (float *)nullptr, n_env, (hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(k_reset_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, obs, n_env);
     return check_launch("k_reset(wave)");
   }
+#ifdef TMJX_LANE_IMPL
   hipLaunchKernelGGL(k_reset, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, clip_idx, start_frame, qpos_noise,
                      qvel_noise, obs, workspace, n_env);
   return check_launch("k_reset");
+#else
+  return fail(TMJX_EINVAL, "lane-per-env implementation not built");
+#endif
 }
 
 // K3 as four launches: observation parts, reward / termination, auto-reset copies (the window statistics were launched before)
@@ -394,7 +426,7 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
   if (m->wave) {
-    launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env));
+    if (int rc = launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env))) return rc;
     // 64-lane workgroups like the other K3 kernels: next to the other env group's physics kernel (up to 3 waves of 168 VGPRs per SIMD) a
     // 256-lane workgroup had to wait for four wave slots WITH registers on one CU — 245 us on average instead of 30
     hipLaunchKernelGGL(k_window, dim3((n_env + 63) / 64, m->h.nu), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action,
@@ -402,20 +434,26 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
     launch_post_split(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
     return check_launch("k_step(wave)");
   }
+#ifdef TMJX_LANE_IMPL
   hipLaunchKernelGGL(k_step, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
                      metrics, workspace, n_env);
   return check_launch("k_step");
+#else
+  return fail(TMJX_EINVAL, "lane-per-env implementation not built");
+#endif
 }
 
 // the physics part of tmjx_step alone (record transposes + K2 with the configured n_frames): what bench.py brackets with HIP events
 int tmjx_physics_step(tmjx_model *m, float *state, const float *action, float *workspace, int n_env, void *stream) {
   if (!m || !state || !action || !workspace) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+#ifdef TMJX_LANE_IMPL
   if (!m->wave) {
     hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, action, m->h.n_frames, 1, workspace, n_env);
     return check_launch("k_physics");
   }
-  launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env));
+#endif
+  if (int rc = launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env))) return rc;
   return check_launch("k_physics_wave");
 }
 
@@ -423,22 +461,30 @@ int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substep
   if (!m || !state || (!workspace && !m->wave)) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1 || n_substeps < 0) return fail(TMJX_EINVAL, "bad n_env / n_substeps");
   if (m->wave) {
-    launch_wave(m, state, action, n_substeps, 1, workspace, n_env, (hipStream_t)stream);
+    if (int rc = launch_wave(m, state, action, n_substeps, 1, workspace, n_env, (hipStream_t)stream)) return rc;
     return check_launch("k_physics_wave");
   }
+#ifdef TMJX_LANE_IMPL
   hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, action, n_substeps, 1, workspace, n_env);
   return check_launch("k_physics");
+#else
+  return fail(TMJX_EINVAL, "lane-per-env implementation not built");
+#endif
 }
 
 int tmjx_forward(tmjx_model *m, float *state, float *workspace, int n_env, void *stream) {
   if (!m || !state || !workspace) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (m->wave) {
-    launch_wave(m, state, (const float *)nullptr, 1, 0, workspace, n_env, (hipStream_t)stream);
+    if (int rc = launch_wave(m, state, (const float *)nullptr, 1, 0, workspace, n_env, (hipStream_t)stream)) return rc;
     return check_launch("k_forward(wave)");
   }
+#ifdef TMJX_LANE_IMPL
   hipLaunchKernelGGL(k_physics, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, (const float *)nullptr, 1, 0, workspace, n_env);
   return check_launch("k_forward");
+#else
+  return fail(TMJX_EINVAL, "lane-per-env implementation not built");
+#endif
 }
 
 int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
@@ -596,6 +642,28 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
   else { if (V == 4) TMJX_NL(4, false); else if (V == 2) TMJX_NL(2, false); else TMJX_NL(1, false); }
 #undef TMJX_NL
   return check_launch("k_linear_nolds");
+}
+
+int tmjx_stats_scratch_floats(int W) { return STATS_SLABS * 2 * W; }
+
+int tmjx_stats_sums(const float *src, const float *mean, float *sums, float *scratch, long long rows, int W, void *stream) {
+  if (!src || !mean || !sums || !scratch) return fail(TMJX_EINVAL, "null argument");
+  if (rows < 1 || W < 4 || (W & 3)) return fail(TMJX_EINVAL, "rows must be >= 1 and W a positive multiple of 4");
+  if (((uintptr_t)src | (uintptr_t)mean | (uintptr_t)scratch) & 15) return fail(TMJX_EINVAL, "src, mean and scratch must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_stats_partial, dim3(((W >> 2) + 63) / 64, STATS_SLABS), dim3(256), 0, s, src, mean, scratch, rows, W);
+  hipLaunchKernelGGL(k_colsum, dim3((2 * W + 31) / 32), dim3(256), 0, s, (const float *)scratch, sums, STATS_SLABS, 2 * W);
+  return check_launch("k_stats_partial");
+}
+
+int tmjx_stats_apply(const float *sums, float n_added, float *count, float *mean, float *summed_variance, float *std, int W, float std_min,
+                     float std_max, void *stream) {
+  if (!sums || !count || !mean || !summed_variance || !std) return fail(TMJX_EINVAL, "null argument");
+  if (W < 1 || !(n_added > 0.f)) return fail(TMJX_EINVAL, "W must be >= 1 and n_added > 0");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_stats_finalize, dim3((W + 255) / 256), dim3(256), 0, s, sums, n_added, count, mean, summed_variance, std, W, std_min, std_max);
+  hipLaunchKernelGGL(k_stats_count, dim3(1), dim3(1), 0, s, count, n_added);
+  return check_launch("k_stats_finalize");
 }
 
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {

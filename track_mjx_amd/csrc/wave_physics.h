@@ -26,7 +26,7 @@
 // TMW_FOR loops lane = 0..63.  Lane-private values that live across blocks are declared with TMW_REG (one slot on the
 // GPU, 64 in emulation).
 #pragma once
-#include "physics_core.h"
+#include "tm_common.h"
 #include "wave_layout.h"
 
 #ifdef TM_HOST_EMU
@@ -75,6 +75,9 @@ struct WCtx {
   unsigned kmask[TMW_NL];     // lane = (subset, component) of tmw_jt_force: contact mask (slots 0..31) of the subset (valid if n_wsub * 6 <= 64)
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
+// solver statistics of the last substep, kept in the spare LDS word behind the centre of mass (registers are what this kernel has none
+// left of): 64 * CG iterations (MJX data.solver_niter) + line-search iterations summed over them; tmw_dump unpacks it for the tests
+#define TMW_STATS(K) L[(K).l_com + 3]
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
 #define TMW_TICK2(idx) TMW_TICK(idx)
@@ -1705,7 +1708,7 @@ TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const f
 // the wave reductions: WIDTH = 16 / 32 when all active rows sit in the first 16 / 32 lanes (the usual case), else 64
 template <int WIDTH>
 TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0, float g1, float g2, float gtol) {
-  const DModel &m = *c.mp;
+  const DModel &m = *c.mp; float *L = c.L;
   TmwLS pt[3];
   float al[3] = {0.f, 0.f, 0.f};
   tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
@@ -1716,7 +1719,8 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
   bool lesser = lo0.d0 < p0.d0;
   TmwLS hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
   bool swap = true;
-  for (int it = 0; it < m.ls_iterations; it++) {
+  int it = 0;
+  for (; it < m.ls_iterations; it++) {
     bool done = !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
     if (done) break;
     al[0] = lo.alpha - lo.d0 * tmw_rcp(lo.d1); al[1] = hi.alpha - hi.d0 * tmw_rcp(hi.d1); al[2] = 0.5f * (lo.alpha + hi.alpha);
@@ -1732,6 +1736,7 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
     if (s4) hi = mid;
     swap = s1 || s2 || s3 || s4;
   }
+  TMW_STATS(K) += (float)it;
   bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
   return improved ? alpha : 0.f;
@@ -1822,7 +1827,9 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_mv + i] = -L[K.l_Mgrad + i]; }
   TMW_SYNC();
   TMW_TICK(6);
-  for (int it = 0; it < m.iterations; it++) {
+  TMW_STATS(K) = 0.f;
+  int it = 0;
+  for (; it < m.iterations; it++) {
     if (m.iterations != 1) {
       // MJX tests |grad_q| / scale; grad_q = L^T ghat is not formed here: its M^-1-norm (gn, at hand) scaled by the mean inertia
       // stands in for it — both only detect an already converged iterate (tolerance 1e-8)
@@ -1843,6 +1850,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     TMW_SYNC();
     TMW_TICK(8);
   }
+  TMW_STATS(K) += 64.f * (float)it;
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_warm + i] = L[K.l_qacc + i]; }
   TMW_SYNC();
 }
@@ -1960,6 +1968,13 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
       WDUMP(m.w_efc_force, r) = ja < 0.f ? -L[K.l_efc_D + kr] * ja : 0.f;
     }
     if (lane < 3) WDUMP(m.w_com, lane) = L[K.l_com + lane];
+    // solver statistics of the last substep: CG iterations, line-search iterations (summed), rows that entered the solver, of which limits
+    if (lane < 4) { int pk = (int)TMW_STATS(K); WDUMP(m.w_solver_stats, lane) = (float)(lane == 0 ? pk >> 6 : lane == 1 ? (pk & 63) : lane == 2 ? c.nact : c.nla); }
+    // which ORIGINAL constraint rows entered the solver (violated limits, the four pyramid rows of penetrating contacts): 1 / 0
+    for (int r = lane; r < K.nefc; r += 64) {
+      bool in = r < K.nlim ? L[K.l_lim_sign + r] != 0.f : TMW_CCROW(K)[(r - K.nlim) >> 2] != 255;
+      WDUMP(m.w_efc_in, r) = in ? 1.f : 0.f;
+    }
   }
 #undef WDUMP
   TMW_SYNC();

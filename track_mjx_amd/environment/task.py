@@ -16,6 +16,7 @@ Differences that are inherent to the platform, not to the maths:
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass, field
 from typing import Any
 
@@ -173,6 +174,7 @@ class MultiClipTracking:
             "qacc_warmstart": sb[L.qacc_warmstart:L.qacc_warmstart + L.nv].t(), "time": sb[L.time],
             "xpos": sb[L.xpos:L.xpos + 3 * L.nbody].t().reshape(self.num_envs, L.nbody, 3),
             "qfrc_actuator": sb[L.qfrc_actuator:L.qfrc_actuator + L.nv].t(),
+            "_env": weakref.ref(self),        # environment/reward.py: compute_tracking_rewards(data, ...) finds the handle through it
         }
         info = {
             "truncation": self.trunc_buf, "steps": sb[L.steps_f], "clip_idx": self.istate_buf[L.i_clip_idx],
@@ -298,6 +300,13 @@ class MultiClipTracking:
         return torch.floor(t + self.istate_buf[L.i_start_frame].float()).to(torch.int32)
 
     def configure_wrappers(self, episode_length: int, auto_reset: bool) -> None:
-        """(Re)build the handle with the Episode/AutoReset wrapper semantics switched on (wrappers.wrap)."""
+        """Switch the Episode / AutoReset wrapper semantics of the handle (wrappers.wrap): two constants of the device model change,
+        the clip table stays resident (tmjx_set_wrappers)."""
         self._episode_length, self._auto_reset = int(episode_length), bool(auto_reset)
-        self._create_handle()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)        # no launch of this handle may be in flight while its constants change
+            _hip.check(self._L.tmjx_set_wrappers(self._handle, self._episode_length, int(self._auto_reset)), "tmjx_set_wrappers")
+        self._blob = build_blob(self.walker, n_frames=self._n_frames, mocap_hz=self._mocap_hz, clip_length=self._clip_length,
+                                traj_length=self._ref_len, window=int(self._reward_config.var_window_size),
+                                episode_length=self._episode_length, reward_f=self._reward_config.vector(),
+                                auto_reset=self._auto_reset, **self._opts)      # what a handle with these semantics is created from (tests: the oracle)

@@ -31,6 +31,7 @@ class Layout(C.Structure):
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
+           "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
 
@@ -43,31 +44,40 @@ class PpoCfg(C.Structure):
 _lib = None
 
 
-def build(verbose: bool = False) -> Path:
-    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -> Path:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU).  `out` / `defines`: alternative builds for
+    tests (-DTMJX_LANE_IMPL: with the lane-per-env cross-check kernels) and profiling (-DTMW_PROFILE)."""
     # -fno-slp-vectorize: the SLP vectoriser packs the two dof slots of the row products into v_pk_* with more v_mov shuffles than
     # it saves (measured 1.8 % on the physics kernel); the explicitly packed FMAs of the chain kernels are not affected
+    out = SO_PATH if out is None else Path(out)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", str(SO_PATH), str(CSRC / "tmjx_hip.hip")]
+           *[f"-D{d}" for d in defines], "-o", str(out), str(CSRC / "tmjx_hip.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise TmjxError("hipcc failed:\n" + res.stderr[-4000:])
     if verbose:
         print(" ".join(cmd))
-    return SO_PATH
+    return out
 
 
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not SO_PATH.exists():
-        raise TmjxError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    _lib = load(SO_PATH)
+    return _lib
+
+
+def load(path: Path):
+    """dlopen a build of the library and declare its entry points (lib() = the product build; tests load the lane cross-check build)."""
+    path = Path(path)
+    if not path.exists():
+        raise TmjxError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
     try:
-        L = C.CDLL(str(SO_PATH))
+        L = C.CDLL(str(path))
     except OSError as e:  # e.g. no ROCm runtime on this machine
-        raise TmjxError(f"cannot load {SO_PATH}: {e}") from e
+        raise TmjxError(f"cannot load {path}: {e}") from e
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
     L.tmjx_model_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
     L.tmjx_model_destroy.argtypes = [vp]
@@ -94,10 +104,13 @@ def lib():
     L.tmjx_colsum_scratch_floats.argtypes = [C.c_int]
     L.tmjx_colsum.argtypes = [fp, fp, fp, C.c_int, C.c_int, vp]
     L.tmjx_adam_clip.argtypes = [fp] * 5 + [C.c_longlong] + [C.c_float] * 7 + [vp]
+    L.tmjx_set_wrappers.argtypes = [vp, C.c_int, C.c_int]
+    L.tmjx_stats_scratch_floats.argtypes = [C.c_int]
+    L.tmjx_stats_sums.argtypes = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]
+    L.tmjx_stats_apply.argtypes = [fp, C.c_float, fp, fp, fp, fp, C.c_int, C.c_float, C.c_float, vp]
     L.tmjx_debug_rows.argtypes = [vp, C.c_char_p, ip, ip]
     L.tmjx_last_error.restype = C.c_char_p
     L.tmjx_version.restype = C.c_char_p
-    _lib = L
     return L
 
 
