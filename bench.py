@@ -148,74 +148,130 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    ranks_seen = 1
+    if world > 1:      # one RCCL all-reduce before the timed region: every rank contributes 1 (and the communicator is warm)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     sync()
+    # roll-out / SGD split of the timed steps: HIP events on the learner's main stream around collect() and update()
+    split_ev = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        learner.training_step(1)
+        ev3 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev3[0].record(); learner.collect(); ev3[1].record(); learner.update(1); ev3[2].record()
+        split_ev.append(ev3)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # d1 of the measurement contract also asks for the ROLL-OUT-ONLY rate (random actions, no policy, no learner): the same env
-    # groups stepped on their own streams, outside the timed region of the training metric
-    rollout_only = None
-    try:
-        if args.no_rollout_only:
-            raise RuntimeError("skipped")
-        gen = torch.Generator(device=device).manual_seed(5)
-        acts = [torch.randn((38, e.num_envs), generator=gen, device=device).clamp(-1, 1) * 0.3 for e in envs]
-        streams = [torch.cuda.Stream(device=device) for _ in envs]
-        sts = list(learner.states)
-        saved_events = [e._physics_events for e in envs]
-        for e in envs:
-            e._physics_events = None          # the per-launch HIP events of the timed region stay as they are
-        nroll = 40
-        for _rep in range(2):                 # first repetition = warm-up
-            torch.cuda.synchronize(device)
-            tr0 = time.perf_counter()
-            for _ in range(nroll):
-                for k, e in enumerate(envs):
-                    with torch.cuda.stream(streams[k]):
-                        sts[k] = e.step(sts[k], acts[k])
-            torch.cuda.synchronize(device)
-            rollout_only = n_local * nroll / (time.perf_counter() - tr0)
-        for e, ev_ in zip(envs, saved_events):
-            e._physics_events = ev_
-    except Exception:
-        rollout_only = None
+    rollout_ms = sum(a.elapsed_time(b) for a, b, _ in split_ev) / args.steps
+    sgd_ms = sum(b.elapsed_time(c) for _, b, c in split_ev) / args.steps
     env_steps = learner.env_steps_per_training_step * args.steps
     ev = [p for e in envs for p in e._physics_events]
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)      # per launch (n_local / ngrp envs each)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)      # per launch (n_local / ngrp envs each), launches of the groups overlap
     per_launch = n_local // ngrp
+    for e in envs:
+        e._physics_events = None
+    # d1 of the measurement contract also asks for the ROLL-OUT-ONLY rate (random actions, no policy, no learner): the same env
+    # groups stepped on their own streams, outside the timed region of the training metric; and the physics kernel ALONE on an
+    # otherwise idle GPU (one group's launches back to back): the isolated per-launch duration next to the shared-GPU one above
+    rollout_only = rollout_err = isolated_ms = None
+    if not args.no_rollout_only:
+        try:
+            gen = torch.Generator(device=device).manual_seed(5)
+            acts = [torch.randn((38, e.num_envs), generator=gen, device=device).clamp(-1, 1) * 0.3 for e in envs]
+            streams = [torch.cuda.Stream(device=device) for _ in envs]
+            sts = list(learner.states)
+            nroll = 40
+            for _rep in range(2):                 # first repetition = warm-up
+                torch.cuda.synchronize(device)
+                tr0 = time.perf_counter()
+                for _ in range(nroll):
+                    for k, e in enumerate(envs):
+                        with torch.cuda.stream(streams[k]):
+                            sts[k] = e.step(sts[k], acts[k])
+                torch.cuda.synchronize(device)
+                rollout_only = n_local * nroll / (time.perf_counter() - tr0)
+            e0 = envs[0]
+            e0._physics_events = []
+            for _ in range(20):
+                sts[0] = e0.step(sts[0], acts[0])
+            torch.cuda.synchronize(device)
+            iso = [a.elapsed_time(b) for a, b in e0._physics_events[4:]]
+            isolated_ms = sum(iso) / len(iso)
+            e0._physics_events = None
+        except Exception as ex:  # noqa: BLE001 — reported in the JSON line and on stderr, never silently dropped
+            import traceback
+            traceback.print_exc()
+            rollout_err = f"{type(ex).__name__}: {ex}"
 
     if rank == 0:
-        achieved = K2_ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
+        def prof(name):
+            f = ROOT / "profiles" / name
             try:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch") * per_launch / ENVS_PER_GPU   # measured at 4096 envs per launch
+                return json.loads(f.read_text()) if f.exists() else None
             except Exception:
-                traffic = None
+                return None
+        achieved = ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
+        k2_achieved = K2_ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
+        pmc, sq, flc, mf = prof("pmc_traffic.json"), prof("sq_counters.json"), prof("oracle_flop_count.json"), prof("mfma_counters.json")
+        traffic = pmc.get("hbm_bytes_per_launch") * per_launch / pmc.get("envs_per_launch", ENVS_PER_GPU) if pmc else None
+        rate_rollout = rollout_only if rollout_only else env_steps / elapsed / world
+        flops_env_step = flc["flops_per_env_step"] if flc else None
+        # MLP GEMM flops of one minibatch step: forward + d input + d weight = 3 x 2 x rows x weights (policy and value), plus the
+        # bootstrap value forward
+        Pw = sum(p.numel() for p in learner.policy.parameters() if p.dim() == 2)
+        Vw = sum(p.numel() for p in learner.value.parameters() if p.dim() == 2)
+        rows_mb = learner.local_batch * learner.T
+        sgd_steps = learner.num_updates * learner.num_minibatches
+        gemm_flops_step = 6.0 * (Pw + Vw) * rows_mb + 2.0 * Vw * learner.local_batch
+        mfma_peak = 2500.0 if bc["matmul_dtype"] == "bf16" else 157.3
+        mfma_ach = gemm_flops_step * sgd_steps / (sgd_ms * 1e-3) / 1e12
         out = {
             "metric": "env-steps/sec (whole node), rodent task @ 4096 envs/GPU", "value": env_steps / elapsed,
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"rodent tracking PPO training step ({args.config}): {n_local} envs/GPU, {learner.env_steps_per_training_step // (n_local * learner.T)}x{learner.T}-step unrolls (10 physics substeps each) + 64 minibatch updates, {bc['label']}",
+            "config": {"workload": f"rodent tracking PPO training step ({args.config}): {n_local} envs/GPU, {learner.env_steps_per_training_step // (n_local * learner.T * world)}x{learner.T}-step unrolls (10 physics substeps each) + {sgd_steps} minibatch updates, {bc['label']}",
                        "n_clips": bc["n_clips"], "mlp_gemm_inputs": bc["matmul_dtype"] or "f32",
                        "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
-                       "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}",
-                       "policy_params": learner.n_params(), "physics_kernel_ms": kernel_ms, "envs_per_physics_launch": per_launch,
-                       "concurrent_physics_launches": ngrp,
-                       "rollout_only_env_steps_per_s_per_gpu": rollout_only},
+                       "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
+                       "policy_params": learner.n_params(), "envs_per_physics_launch": per_launch, "concurrent_physics_launches": ngrp,
+                       "rollout_ms_per_step": rollout_ms, "sgd_ms_per_step": sgd_ms, "sgd_ms_per_minibatch_step": sgd_ms / sgd_steps,
+                       "rollout_only_env_steps_per_s_per_gpu": rollout_only, "rollout_only_error": rollout_err,
+                       "note": "one box of the pool differs from the next by about 3 % on this line (1.17-1.22 M env-steps/s seen for the same build in round 1)"},
+            # 15 644 algorithmic bytes per env-step (K2 + K3 together) x the envs of one physics launch / that
+            # launch's average duration (HIP events on its launch stream; with --pipeline 2 the two groups' launches share the GPU)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env; the HIP events also span its two record-transpose launches, < 1 % of the time; with --pipeline 2 two such launches of 2048 envs run concurrently, each sharing the GPU)",
-                         "algorithmic_bytes_per_launch": K2_ALGO_BYTES_PER_ENV_STEP * per_launch, "avg_launch_ms": kernel_ms,
-                         "whole_step_algorithmic_bytes_per_env": ALGO_BYTES_PER_ENV_STEP,
-                         "whole_step_hbm_frac_at_training_rate": ALGO_BYTES_PER_ENV_STEP * (env_steps / elapsed) / 1e9 / HBM_PEAK_GBS},
+                         "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (FETCH_SIZE doubled, the gfx950 correction), NOT collected by this run; bytes per launch scaled to this launch's env count",
+                         "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env)",
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * per_launch,
+                         "avg_launch_ms": kernel_ms, "avg_launch_ms_is": f"shared-GPU duration: {ngrp} launches of {per_launch} envs run concurrently (plus the other group's K3 / inference); the HIP events also span the two record-transpose launches (< 1 %)",
+                         "avg_launch_ms_isolated": isolated_ms,
+                         "frac_isolated": (ALGO_BYTES_PER_ENV_STEP * per_launch / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if isolated_ms else None,
+                         "k2_only": {"algorithmic_bytes_per_env_step": K2_ALGO_BYTES_PER_ENV_STEP, "achieved": k2_achieved, "frac": k2_achieved / HBM_PEAK_GBS},
+                         "chip_level_frac_at_rollout_only_rate": ALGO_BYTES_PER_ENV_STEP * rate_rollout / 1e9 / HBM_PEAK_GBS,
+                         "chip_level_frac_at_training_rate": ALGO_BYTES_PER_ENV_STEP * (env_steps / elapsed / world) / 1e9 / HBM_PEAK_GBS},
+            # what actually binds K2: the vector ALU / latency (about 660 flop per algorithmic byte).  Numerator: the instrumented operation
+            # count of the reference's (dense MJX) algorithm, frozen in profiles/oracle_flop_count.json; pipe occupancy and lane use from
+            # the SQ counters of the same kernel (profiles/sq_counters.json: SQ_INSTS_VALU x 2 cycles / SIMD-cycles)
+            "roofline_valu": {"bound": "valu", "unit": "TFLOP/s", "peak": 157.3,
+                              "achieved": (flops_env_step * rate_rollout / 1e12) if flops_env_step else None,
+                              "frac": (flops_env_step * rate_rollout / 1e12 / 157.3) if flops_env_step else None,
+                              "at": "roll-out-only rate" if rollout_only else "training rate",
+                              "flops_per_env_step": flops_env_step,
+                              "flops_source": "profiles/oracle_flop_count.json: flop-counting build of the CPU oracle (dense MJX formulation: 1.03 Mflop per substep); the kernel's tree-sparse / matrix-free formulation executes fewer",
+                              "valu_pipe_busy": sq.get("valu_pipe_busy") if sq else None, "lane_occupancy": sq.get("lane_occupancy") if sq else None,
+                              "valu_insts_per_wave_substep": sq.get("SQ_INSTS_VALU_per_wave_substep") if sq else None,
+                              "counters_source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes, tools/sq_counters.sh), not collected by this run"},
+            "roofline_mfma": {"bound": "mfma", "unit": "TFLOP/s", "peak": mfma_peak, "achieved": mfma_ach, "frac": mfma_ach / mfma_peak,
+                              "what": f"{sgd_steps} minibatch SGD steps of {rows_mb} rows: GEMM flops (forward + d input + d weight, policy + value nets) / the whole SGD half's time incl. gathers, epilogues, loss head and optimiser (HIP events around update())",
+                              "gemm_flops_per_minibatch_step": gemm_flops_step, "sgd_ms_per_minibatch_step": sgd_ms / sgd_steps,
+                              "mfma_util_inside_gemm_kernels": mf.get("mfma_util") if mf else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

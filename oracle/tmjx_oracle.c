@@ -12,7 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifdef ORACLE_DOUBLE
+#if defined(ORACLE_COUNT)
+/* flop-counting build: the R_* wrappers come from counted_real.hpp */
+#elif defined(ORACLE_DOUBLE)
 #define R_SQRT sqrt
 #define R_SIN sin
 #define R_COS cos
@@ -276,7 +278,7 @@ static void com_pos(const OModel *m, OData *d) {
     }
     /* h = cross(off, -eye(3)); h @ h.T * mass  ==  mass * (|off|^2 I - off off^T) */
     real oo = dot3(off, off);
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[i * 3 + j] += ((i == j ? oo : 0) - off[i] * off[j]) * mass;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[i * 3 + j] += ((i == j ? oo : (real)0) - off[i] * off[j]) * mass;
     real *c = d->cinert[b];
     c[0] = I[0]; c[1] = I[4]; c[2] = I[8]; c[3] = I[1]; c[4] = I[2]; c[5] = I[5];
     c[6] = off[0] * mass; c[7] = off[1] * mass; c[8] = off[2] * mass; c[9] = mass;

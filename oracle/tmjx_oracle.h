@@ -21,7 +21,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#ifdef ORACLE_DOUBLE
+#if defined(ORACLE_COUNT)
+#include "counted_real.hpp"   /* C++ build: `real` counts its own arithmetic (oracle/count_flops.py) */
+#elif defined(ORACLE_DOUBLE)
 typedef double real;
 #else
 typedef float real;

@@ -18,7 +18,9 @@
 #include <omp.h>
 #endif
 
-#ifdef ORACLE_DOUBLE
+#if defined(ORACLE_COUNT)
+/* flop-counting build: the R_* wrappers come from counted_real.hpp */
+#elif defined(ORACLE_DOUBLE)
 #define R_SQRT sqrt
 #define R_EXP exp
 #define R_ACOS acos
@@ -253,7 +255,7 @@ void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_p
   /* brax EpisodeWrapper */
   e->steps += 1;
   int over = e->steps >= (real)m->episode_length;
-  e->truncation = over ? 1 - done : 0;
+  e->truncation = over ? 1 - done : (real)0;
   if (over) done = 1;
   e->done = done;
   /* auto-reset epilogue: pipeline_state, obs, prev_ctrl <- first_*; nothing else */
