@@ -168,6 +168,19 @@ int tmjx_colsum(const float *src, float *out, float *scratch, int rows, int widt
 int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *grad_norm, long long n, float lr,
                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream);
 
+/* Dense layers of the learner on the matrix cores, fp32 in / fp32 accumulate (flax nn.Dense of the intention network,
+ * track_mjx/agent/mlp_ppo/intention_network.py:32-44,68-76, and brax's value MLP, ppo_networks.py:180-184; the gradients are those of
+ * compute_ppo_loss, losses.py:103-245).  Row-major device matrices with leading dimensions (floats); any sizes; 16-byte aligned rows
+ * (pointer and leading dimension multiples of 4 floats) take the vector-load path.
+ *   tmjx_gemm_nt: C[M][N] = A[M][K] W[N][K]^T + bias[N] (bias may be NULL)      y = x W^T + b
+ *   tmjx_gemm_nn: C[M][N] = A[M][K] W[K][N]                                     dx = dy W
+ *   tmjx_gemm_dw: dW[N][K] = dY[M][N]^T X[M][K] (dW dense, leading dimension K) and, if db != NULL, db[N] = column sums of dY;
+ *                 scratch >= tmjx_gemm_dw_scratch_floats(M, N, K) floats (row-range slabs, reduced by a second launch). */
+int tmjx_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream);
+int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, void *stream);
+long long tmjx_gemm_dw_scratch_floats(int M, int N, int K);
+int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream);
+
 /* Observation normaliser update (brax running_statistics.update as called at track_mjx/agent/mlp_ppo/ppo.py:357-361; math:
  * track_mjx/agent/masked_running_statistics.py:161-214) in one pass over src [rows][W] (W % 4 == 0):
  *   tmjx_stats_sums:  sums[0..W) = sum_rows(x - mean), sums[W..2W) = sum_rows((x - mean)^2); scratch >= tmjx_stats_scratch_floats(W).

@@ -1,0 +1,87 @@
+"""GPU: the learner's MFMA GEMM kernels (csrc/gemm_kernels.h through the C-ABI: tmjx_gemm_nt / _nn / _dw) against float64 torch
+on the shapes the PPO step uses (rows = 20 x 1024; widths of the 2x256 and rodent-mc-intention nets incl. the odd ones: 470 / 286
+inputs with a leading dimension of 696, 120 / 76 / 1 outputs) and on ragged small shapes.  fp32 MFMA = a k-ordered fmaf chain, so
+the error bound is the fp32 dot-product one: |err| <= c * eps * sum |a||b|."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EPS = 2.0 ** -24
+
+
+def _bound(a64, b64_t, K):
+    return (a64.abs() @ b64_t.abs()) * EPS * (K ** 0.5 + 4) * 2 + 1e-30
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(20480, 256, 470, 696), (20480, 256, 256, 256), (20480, 120, 256, 256), (20480, 76, 256, 256), (20480, 1, 256, 256),
+                                       (20480, 512, 1024, 1024), (1000, 256, 286, 288), (37, 5, 7, 7), (81, 130, 33, 36), (1, 1, 1, 1)])
+def test_gemm_nt_forward(M, N, K, lda):
+    from track_mjx_amd.agent.networks import gemm_nt
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    buf = torch.randn((M, lda), generator=g, device=DEV)
+    x = buf[:, :K]
+    w = torch.randn((N, K), generator=g, device=DEV) / K ** 0.5
+    b = torch.randn(N, generator=g, device=DEV)
+    y = gemm_nt(x, w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    assert y.shape == (M, N)
+    assert ((y.double() - ref).abs() <= _bound(x.double(), w.double().t(), K) + EPS * b.abs().double()).all(), float((y.double() - ref).abs().max())
+    y0 = gemm_nt(x, w, None)
+    assert torch.equal(y0 + b, y) or (y0.double() + b.double() - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,cols", [(20480, 256, 256, None), (20480, 120, 256, None), (20480, 256, 286, 60), (20480, 1, 256, None), (20480, 76, 256, None),
+                                        (20480, 1024, 512, None), (53, 9, 21, None), (53, 9, 21, 5)])
+def test_gemm_nn_input_gradient(M, N, K, cols):
+    from track_mjx_amd.agent.networks import gemm_nn
+    g = torch.Generator(device=DEV).manual_seed(7 * M + N + K)
+    dy = torch.randn((M, N), generator=g, device=DEV)
+    w = torch.randn((N, K), generator=g, device=DEV) / N ** 0.5
+    dx = gemm_nn(dy, w, cols)
+    c = K if cols is None else cols
+    ref = dy.double() @ w.double()
+    assert dx.shape == (M, K)
+    assert ((dx[:, :c].double() - ref[:, :c]).abs() <= _bound(dy.double(), w.double(), N)[:, :c]).all()
+
+
+@pytest.mark.parametrize("M,N,K,ldx,bias", [(20480, 256, 470, 696, True), (20480, 256, 256, 256, True), (20480, 120, 256, 256, True), (20480, 1, 256, 256, True),
+                                            (20480, 256, 696, 696, True), (20480, 76, 256, 256, False), (40960, 512, 1024, 1024, True), (333, 76, 286, 288, True),
+                                            (31, 3, 5, 5, True), (20480, 256, 286, 288, True)])
+def test_gemm_dw_weight_and_bias_gradient(M, N, K, ldx, bias):
+    from track_mjx_amd.agent.networks import gemm_dw
+    g = torch.Generator(device=DEV).manual_seed(3 * M + N + K)
+    xb = torch.randn((M, ldx), generator=g, device=DEV)
+    x = xb[:, :K]
+    dy = torch.randn((M, N), generator=g, device=DEV)
+    dw, db = gemm_dw(dy, x, bias)
+    ref = dy.double().t() @ x.double()
+    bound = (dy.double().abs().t() @ x.double().abs()) * EPS * (M ** 0.5 + 4) * 2
+    assert dw.shape == (N, K) and ((dw.double() - ref).abs() <= bound).all(), float(((dw.double() - ref).abs() / bound).max())
+    if bias:
+        refb = dy.double().sum(0)
+        assert ((db.double() - refb).abs() <= dy.double().abs().sum(0) * EPS * (M ** 0.5 + 4) * 2).all()
+    else:
+        assert db is None
+
+
+def test_dense_layers_use_no_library_gemm_and_match_torch_gradients():
+    """A Dense -> SiLU -> LayerNorm block and a bias layer under autograd: outputs and all gradients against plain torch in float64."""
+    from track_mjx_amd.agent.networks import _Block, _dense
+    torch.manual_seed(0)
+    blk, lin = _Block(470, 256).to(DEV), _dense(256, 120).to(DEV)
+    obs = torch.randn((20, 1024, 696), device=DEV)
+    x = obs[..., :470]
+    y = lin(blk(x))
+    gy = torch.randn_like(y)
+    grads = torch.autograd.grad(y, [blk.dense.weight, blk.dense.bias, blk.norm.weight, blk.norm.bias, lin.weight, lin.bias], gy)
+    xd = x.double()
+    W0, b0, gam, bet, W1, b1 = [p.detach().double().requires_grad_() for p in (blk.dense.weight, blk.dense.bias, blk.norm.weight, blk.norm.bias, lin.weight, lin.bias)]
+    z = torch.nn.functional.silu(xd @ W0.t() + b0)
+    h = torch.nn.functional.layer_norm(z, (256,), gam, bet, 1e-6)
+    yr = h @ W1.t() + b1
+    gr = torch.autograd.grad(yr, [W0, b0, gam, bet, W1, b1], gy.double())
+    assert (y.double() - yr).abs().max() < 1e-4
+    for a, b in zip(grads, gr):
+        assert (a.double() - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, float((a.double() - b).abs().max() / b.abs().max())

@@ -8,9 +8,12 @@ Mirrors (paths relative to /root/reference/track_mjx/agent/mlp_ppo):
                                 make_intention_ppo_networks (value net = brax make_value_network: swish MLP -> 1)
   brax.training.distribution.NormalTanhDistribution (third-party, restated from its published definition):
                                 loc, raw = split(logits); scale = softplus(raw) + 0.001; tanh bijector
-The dense contractions go to the matrix cores through rocBLAS/hipBLASLt (plain library GEMMs); everything is fp32
-as in the reference unless `matmul_dtype=torch.bfloat16` is requested (BASELINE config 5): then the GEMM INPUTS are bf16
-(`gemm_inputs`), accumulation, outputs and everything around the GEMMs stay fp32.
+The dense contractions run on the matrix cores through the library's own kernels (csrc/gemm_kernels.h: tmjx_gemm_nt / _nn / _dw,
+fp32 in / fp32 accumulate v_mfma_f32_16x16x4_f32, 80-row tiles = one workgroup per CU at 20 480 rows, bias gradient fused into the
+weight-gradient kernel) — forward, input gradient and weight gradient alike, under autograd and in inference.  Everything is fp32 as
+in the reference unless `matmul_dtype=torch.bfloat16` is requested (BASELINE config 5): then the GEMM INPUTS are bf16
+(`gemm_inputs`, library bf16 GEMMs), accumulation, outputs and everything around the GEMMs stay fp32.  CPU tensors (host-logic
+tests) take plain torch ops.
 """
 from __future__ import annotations
 
@@ -54,9 +57,72 @@ class gemm_inputs:
         return False
 
 
+def _hip_gemm_ok(*ts) -> bool:
+    """fp32 CUDA operands and no reduced-precision GEMM-input mode: the hand-written MFMA kernels take the contraction."""
+    return gemm_inputs.dtype is None and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+def _rows2d(x: torch.Tensor) -> torch.Tensor:
+    """[.., K] -> [rows, K] with unit column stride (a view whenever the leading dims collapse, e.g. the [T, B, :470] slice of the
+    observation buffer keeps its row stride of 696: the kernels take a leading dimension, no copy)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    return x2 if x2.stride(1) == 1 and (x2.shape[0] == 1 or x2.stride(0) >= x2.shape[1]) else x2.contiguous()
+
+
+def _launch(fn_name: str, dev, *args):
+    import ctypes as C
+    from .. import hip as _hip
+    L = _hip.lib()
+    with torch.cuda.device(dev):
+        _hip.check(getattr(L, fn_name)(*args, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), fn_name)
+
+
+def _p(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """y[rows, N] = x[rows, K] w[N, K]^T + bias  (tmjx_gemm_nt)."""
+    x = _rows2d(x)
+    w = w if w.stride(1) == 1 else w.contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _launch("tmjx_gemm_nt", x.device, _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, K)
+    return y
+
+
+def gemm_nn(dy: torch.Tensor, w: torch.Tensor, cols: int | None = None) -> torch.Tensor:
+    """dx[rows, K] = dy[rows, N] w[N, K]  (tmjx_gemm_nn); `cols`: only the first `cols` columns of dx are computed (the rest of the
+    [rows, K] buffer is left unwritten: a caller that needs the gradient of a column prefix only)."""
+    dy = _rows2d(dy)
+    w = w if w.stride(1) == 1 else w.contiguous()
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    _launch("tmjx_gemm_nn", dy.device, _p(dy), dy.stride(0), _p(w), w.stride(0), _p(dx), K, M, K if cols is None else int(cols), N)
+    return dx
+
+
+def gemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool):
+    """(dw[N, K], db[N] or None) = (dy^T x, column sums of dy)  (tmjx_gemm_dw: row-range slabs + one reduction launch)."""
+    from .. import hip as _hip
+    dy, x = _rows2d(dy), _rows2d(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias else None
+    scratch = torch.empty(int(_hip.lib().tmjx_gemm_dw_scratch_floats(M, N, K)), dtype=torch.float32, device=dy.device)
+    _launch("tmjx_gemm_dw", dy.device, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(db), _p(scratch), M, N, K)
+    return dw, db
+
+
 def _mm_nt(x, w):
     """x [m, k] @ w[n, k]^T -> fp32 [m, n] in the current GEMM-input dtype; also returns the operands as they went into the GEMM."""
     dt = gemm_inputs.dtype
+    if _hip_gemm_ok(x, w):
+        return gemm_nt(x, w), x, w
     if dt is None or not x.is_cuda:
         return x @ w.t(), x, w
     xb, wb = x.to(dt), w.to(dt)
@@ -81,7 +147,7 @@ def _colsum(dy: torch.Tensor) -> torch.Tensor:
 
 
 def _splitk_dw(dy, x, s):
-    """dy^T x as SPLIT row slabs (one batched GEMM) + a sum; operands in their stored dtype, fp32 result."""
+    """dy^T x as SPLIT row slabs (one batched GEMM) + a sum; operands in their stored dtype, fp32 result (bf16 GEMM-input mode)."""
     m = x.shape[0]
     a, b = dy.view(s, m // s, dy.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])
     if x.dtype != torch.float32 and x.dtype != torch.float64:
@@ -89,19 +155,32 @@ def _splitk_dw(dy, x, s):
     return torch.bmm(a, b).sum(0)
 
 
-class _SplitKLinearFn(torch.autograd.Function):
-    """y = x W^T + b with a weight gradient computed as a split-K batched GEMM.
+class _HipDenseFn(torch.autograd.Function):
+    """y = x W^T (+ b) with all three contractions on the library's MFMA kernels: forward tmjx_gemm_nt, input gradient tmjx_gemm_nn,
+    weight + bias gradient tmjx_gemm_dw.  `dx_cols`: the caller only needs the gradient of the first dx_cols input columns."""
 
-    dW = dy^T x contracts over the ROWS (T*B = 20 480 per minibatch) into a small [out, in] matrix: as one GEMM it has
-    too few output tiles for 256 CUs and no split-K in the library heuristics (25 TFLOP/s measured on MI355X); cut into
-    SPLIT row slabs -> one batched GEMM + a tiny sum it runs ~3x faster (tools/scratch/gemm_bench2.py)."""
+    @staticmethod
+    def forward(ctx, x, w, b, dx_cols):
+        x2 = _rows2d(x)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias, ctx.dx_cols, ctx.x_shape = b is not None, dx_cols, x.shape
+        return gemm_nt(x2, w, b).view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = _rows2d(dy)
+        dx = gemm_nn(dy2, w, ctx.dx_cols).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dw, db = gemm_dw(dy2, x2, ctx.has_bias)
+        return dx, dw, db, None
+
+
+class _SplitKLinearFn(torch.autograd.Function):
+    """bf16 GEMM-input mode (BASELINE config 5) only: y = x W^T + b with a weight gradient computed as a split-K batched library GEMM."""
     SPLIT = 8
 
     @staticmethod
     def forward(ctx, x, w, b):
-        if gemm_inputs.dtype is None or not x.is_cuda:
-            ctx.save_for_backward(x, w)
-            return torch.addmm(b, x, w.t())
         y, xs, ws = _mm_nt(x, w)
         ctx.save_for_backward(xs, ws)          # the operands as they went into the GEMM (bf16 copies)
         return y + b
@@ -122,6 +201,10 @@ class _SplitKLinearFn(torch.autograd.Function):
 class _Dense(nn.Linear):
     def forward(self, x):
         rows = x.numel() // x.shape[-1]
+        if _hip_gemm_ok(x, self.weight):
+            if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+                return _HipDenseFn.apply(x, self.weight, self.bias, None)
+            return gemm_nt(x, self.weight, self.bias).view(*x.shape[:-1], self.out_features)
         if torch.is_grad_enabled() and self.weight.requires_grad and rows >= 4096 and rows % _SplitKLinearFn.SPLIT == 0 and x.is_cuda:
             y = _SplitKLinearFn.apply(x.reshape(rows, x.shape[-1]), self.weight, self.bias)
             return y.view(*x.shape[:-1], self.out_features)
@@ -139,7 +222,7 @@ def _dense(i: int, o: int, init=_lecun_uniform_) -> nn.Linear:
 
 
 class _SplitKMatmulFn(torch.autograd.Function):
-    """z = x W^T (no bias) with the split-K weight gradient of _SplitKLinearFn."""
+    """bf16 GEMM-input mode only: z = x W^T (no bias) with the split-K weight gradient of _SplitKLinearFn."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -212,11 +295,17 @@ class _Block(nn.Module):
         super().__init__()
         self.dense = _dense(i, o)
         self.norm = nn.LayerNorm(o, eps=1e-6)
+        self.dx_cols = None       # set when only a column prefix of the input needs a gradient (the decoder's first block: the latent)
 
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and self.dense.out_features in self.FUSED_WIDTHS and not torch.is_autocast_enabled():
-            x2 = x.reshape(-1, x.shape[-1])
-            z = _SplitKMatmulFn.apply(x2, self.dense.weight) if torch.is_grad_enabled() else _mm_nt(x2, self.dense.weight)[0]
+            x2 = _rows2d(x)
+            if not torch.is_grad_enabled():
+                z = _mm_nt(x2, self.dense.weight)[0]
+            elif _hip_gemm_ok(x2, self.dense.weight):
+                z = _HipDenseFn.apply(x2, self.dense.weight, None, self.dx_cols)     # (the bias lives in the fused epilogue below)
+            else:
+                z = _SplitKMatmulFn.apply(x2, self.dense.weight)
             y = _SiluLayerNormFn.apply(z, self.dense.bias, self.norm.weight, self.norm.bias, self.norm.eps)
             return y.view(*x.shape[:-1], self.dense.out_features)
         return self.norm(F.silu(self.dense(x)))
@@ -274,6 +363,7 @@ class IntentionPolicy(nn.Module):
         for h in decoder_layers:
             dec.append(_Block(d, h)); d = h
         self.decoder = nn.Sequential(*dec)
+        dec[0].dx_cols = latents      # the decoder input is [latent sample | proprioception]: only the latent part is differentiated
         self.head = _dense(d, 2 * action_size)
 
     def forward(self, obs: torch.Tensor, eps: torch.Tensor | None = None, deterministic: bool = False, return_fc2: bool = False):

@@ -1,0 +1,251 @@
+// csrc/gemm_kernels.h — the dense contractions of the PPO learner (K4 / K5 / K8) on the matrix cores, fp32 in / fp32 accumulate
+// (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fmaf chain, MI355X_MICROARCH.md), written for the shapes this path has:
+// a tall activation matrix (rows = unroll_length x minibatch rows = 20 480 per GPU, 40 960 in BASELINE config 5) against small
+// weight matrices (64 .. 1024 wide).  Reference layers: flax nn.Dense in track_mjx/agent/mlp_ppo/intention_network.py:32-44,68-76
+// and brax's value MLP (ppo_networks.py:180-184); their gradients are what jax.grad derives for losses.py:103-245.
+//
+//   k_gemm_act<NIW, BT>   C[M][N] = A[M][K] . op(W) (+ bias):  BT = true  W is [N][K] (y = x W^T + b, the forward pass)
+//                                                              BT = false W is [K][N] (dx = dy W, the input gradient)
+//       Workgroup tile 80 rows x 64 NIW columns, 4 waves side by side along N, each 5 x NIW tiles of 16 x 16.  80 rows because
+//       20 480 = 256 x 80: one workgroup per CU, no tail wave (a 128-row tile leaves 320 workgroups on 256 CUs: 62 % of the chip).
+//       K is walked in steps of 32 through two LDS stages; the next stage's global loads are issued before this stage's MFMAs
+//       and written to LDS behind them (register staging: one barrier per step).  A lane's float4 along K feeds four MFMAs (any
+//       assignment of the k of a step to the MFMAs is valid as long as both operands use the same one), so the activation
+//       fragments — and for BT the weight fragments — are ds_read_b128; rows are padded to 40 floats, which makes every 16-lane
+//       group of a b128 read hit 16 distinct 16-byte slots (row stride 10 slots: rows of the even-kq lanes land on even slots, of
+//       the odd-kq lanes on odd slots).  BT = false reads the weight fragment as ds_read_b32 from a [k][n] image whose row stride
+//       is 4 mod 8 floats (lanes of kq and kq + 1 then sit 16 banks apart).
+//   k_gemm_dw             dW[N][K] = dY[M][N]^T . X[M][K] and db[N] = column sums of dY, as slabs over row ranges of M
+//       (the contraction runs over the 20 480 rows: 4 .. 24 output tiles of 128 x 128 would leave the chip idle, so the rows are
+//       split until there are about 256 workgroups) + k_dw_reduce.  The bias gradient rides along: every thread adds up the dY
+//       values it stages (its four columns, all its rows), the eight partial sums per column meet in LDS after the loop and land in
+//       column K of the slab: no separate column-sum launches.
+#pragma once
+
+typedef float __attribute__((ext_vector_type(4))) gf4;
+
+#define GEMM_BM 80
+#define GEMM_BK 32
+#define GEMM_LDA 40          // floats per LDS row of a [rows][k] image (32 + 8 pad)
+
+__device__ __forceinline__ gf4 gemm_ld4(const float *__restrict__ p, long long row_off, int k, int K, bool row_ok, bool vec) {
+  // four consecutive k of one row, zero beyond K (and for rows outside the matrix); `vec`: the row base is 16-byte aligned
+  gf4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!row_ok || k >= K) return v;
+  const float *q = p + row_off + k;
+  if (vec && k + 3 < K) return *reinterpret_cast<const gf4 *>(q);
+  v.x = q[0];
+  if (k + 1 < K) v.y = q[1];
+  if (k + 2 < K) v.z = q[2];
+  if (k + 3 < K) v.w = q[3];
+  return v;
+}
+
+template <int NIW, bool BT>
+__global__ __launch_bounds__(256) void k_gemm_act(const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
+                                                  float *__restrict__ C, int ldc, int M, int N, int K, int avec, int wvec) {
+  constexpr int BN = 64 * NIW;
+  constexpr int LDB_T = GEMM_LDA;            // BT: [n][k] image, 40 floats per row
+  constexpr int LDB_N = BN + 4;              // !BT: [k][n] image, row stride 4 mod 8
+  constexpr int A_FLOATS = GEMM_BM * GEMM_LDA, B_FLOATS = BT ? BN * LDB_T : GEMM_BK * LDB_N, STAGE = A_FLOATS + B_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * BN, nw = wave * 16 * NIW;      // this wave's first column inside the tile
+  // ---- global -> register staging (float4 per thread): A 80 x 8 float4 (3 passes, the last one half empty), B BN x 8 or 32 x BN / 4
+  constexpr int A_PASS = (GEMM_BM * 8 + 255) / 256, B_PASS = BT ? (BN * 8) / 256 : (GEMM_BK * (BN / 4)) / 256;
+  gf4 ra[A_PASS], rb[B_PASS];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; p++) {
+      const int f = t + 256 * p, r = f >> 3, c4 = f & 7;
+      ra[p] = gemm_ld4(A, (long long)(m0 + r) * lda, k0 + 4 * c4, K, f < GEMM_BM * 8 && m0 + r < M, avec != 0);
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; p++) {
+      const int f = t + 256 * p;
+      if (BT) {
+        const int r = f >> 3, c4 = f & 7;
+        rb[p] = gemm_ld4(W, (long long)(n0 + r) * ldw, k0 + 4 * c4, K, n0 + r < N, wvec != 0);
+      } else {
+        const int r = f / (BN / 4), c4 = f % (BN / 4);               // row = k, four consecutive output columns
+        rb[p] = gemm_ld4(W, (long long)(k0 + r) * ldw + n0, 4 * c4, N - n0, k0 + r < K, wvec != 0);
+      }
+    }
+  };
+  auto swrite = [&](int stage) {
+    float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
+#pragma unroll
+    for (int p = 0; p < A_PASS; p++) {
+      const int f = t + 256 * p, r = f >> 3, c4 = f & 7;
+      if (f < GEMM_BM * 8) *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; p++) {
+      const int f = t + 256 * p;
+      if (BT) { const int r = f >> 3, c4 = f & 7; *reinterpret_cast<gf4 *>(sb + r * LDB_T + 4 * c4) = rb[p]; }
+      else { const int r = f / (BN / 4), c4 = f % (BN / 4); *reinterpret_cast<gf4 *>(sb + r * LDB_N + 4 * c4) = rb[p]; }
+    }
+  };
+  gf4 acc[5][NIW];
+#pragma unroll
+  for (int a = 0; a < 5; a++)
+#pragma unroll
+    for (int b = 0; b < NIW; b++) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int stage) {
+    const float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
+#pragma unroll
+    for (int c = 0; c < GEMM_BK / 16; c++) {
+      gf4 fa[5], fb[NIW];
+#pragma unroll
+      for (int a = 0; a < 5; a++) fa[a] = *reinterpret_cast<const gf4 *>(sa + (16 * a + li) * GEMM_LDA + 16 * c + 4 * kq);
+      if (BT) {
+#pragma unroll
+        for (int b = 0; b < NIW; b++) fb[b] = *reinterpret_cast<const gf4 *>(sb + (nw + 16 * b + li) * LDB_T + 16 * c + 4 * kq);
+      } else {
+#pragma unroll
+        for (int b = 0; b < NIW; b++) {
+          const float *q = sb + (16 * c + 4 * kq) * LDB_N + nw + 16 * b + li;
+          fb[b] = gf4{q[0], q[LDB_N], q[2 * LDB_N], q[3 * LDB_N]};
+        }
+      }
+      // e outermost: 5 NIW independent accumulators between two uses of the same one (dependent latency 40 cycles > issue 32)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+          for (int b = 0; b < NIW; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+    }
+  };
+  const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk) gload((kt + 1) * GEMM_BK);          // in flight during this stage's MFMAs
+    compute(kt & 1);
+    if (kt + 1 < nk) swrite((kt + 1) & 1);               // the other stage: last read before the previous barrier
+    __syncthreads();
+  }
+  // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile
+#pragma unroll
+  for (int b = 0; b < NIW; b++) {
+    const int col = n0 + nw + 16 * b + li;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * a + 4 * kq + r;
+        if (row < M && col < N) C[(long long)row * ldc + col] = acc[a][b][r] + bv;
+      }
+  }
+}
+
+// ---- dW = dY^T X (+ db as the column of ones): slabs over row ranges
+#define DW_BT 128            // output tile: 128 (n) x 128 (k)
+#define DW_BM 32             // rows of M per LDS stage
+#define DW_LD (DW_BT + 16)   // floats per LDS row: 16 mod 32, lanes of kq and kq + 1 read banks 16 apart
+__global__ __launch_bounds__(256) void k_gemm_dw(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx, float *__restrict__ slabs,
+                                                 int M, int N, int K, int with_bias, int rows_per_split, int ld_slab, int yvec, int xvec) {
+  constexpr int STAGE = 2 * DW_BM * DW_LD;
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * DW_BT, k0 = blockIdx.y * DW_BT, split = blockIdx.z;
+  const int r_begin = split * rows_per_split, r_end = min(M, r_begin + rows_per_split);
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  gf4 ry[4], rx[4], colacc = {0.f, 0.f, 0.f, 0.f};      // colacc: sum over this thread's rows of its four dY columns (bias gradient)
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int f = t + 256 * p, r = f >> 5, c4 = f & 31;           // 32 rows x 32 float4
+      const bool ok = r0 + r < r_end;
+      ry[p] = gemm_ld4(dY, (long long)(r0 + r) * ldy + n0, 4 * c4, N - n0, ok, yvec != 0);
+      rx[p] = gemm_ld4(X, (long long)(r0 + r) * ldx + k0, 4 * c4, K - k0, ok, xvec != 0);
+      colacc += ry[p];
+    }
+  };
+  auto swrite = [&](int stage) {
+    float *sy = gemm_lds + stage * STAGE, *sx = sy + DW_BM * DW_LD;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int f = t + 256 * p, r = f >> 5, c4 = f & 31;
+      *reinterpret_cast<gf4 *>(sy + r * DW_LD + 4 * c4) = ry[p];
+      *reinterpret_cast<gf4 *>(sx + r * DW_LD + 4 * c4) = rx[p];
+    }
+  };
+  gf4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int stage) {
+    const float *sy = gemm_lds + stage * STAGE, *sx = sy + DW_BM * DW_LD;
+#pragma unroll
+    for (int s = 0; s < DW_BM / 4; s++) {
+      float fa[4], fb[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) fa[a] = sy[(4 * s + kq) * DW_LD + wn + 16 * a + li];
+#pragma unroll
+      for (int b = 0; b < 4; b++) fb[b] = sx[(4 * s + kq) * DW_LD + wk + 16 * b + li];
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  };
+  const int nt = (r_end - r_begin + DW_BM - 1) / DW_BM;
+  if (nt > 0) {
+    gload(r_begin);
+    swrite(0);
+    __syncthreads();
+    for (int it = 0; it < nt; it++) {
+      if (it + 1 < nt) gload(r_begin + (it + 1) * DW_BM);
+      compute(it & 1);
+      if (it + 1 < nt) swrite((it + 1) & 1);
+      __syncthreads();
+    }
+  }
+  float *out = slabs + (size_t)split * (size_t)N * ld_slab;
+  if (with_bias && blockIdx.y == 0) {          // (uniform per workgroup) thread t holds columns 4 (t & 31) .. + 3 for the rows t / 32 + 8 j
+    float *red = gemm_lds;                     // the stages are dead: the loop ended with a barrier
+    *reinterpret_cast<gf4 *>(red + (t >> 5) * DW_BT + 4 * (t & 31)) = colacc;
+    __syncthreads();
+    if (t < DW_BT) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v += red[j * DW_BT + t];
+      if (n0 + t < N) out[(size_t)(n0 + t) * ld_slab + K] = v;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int col = k0 + wk + 16 * b + li;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = n0 + wn + 16 * a + 4 * kq + r;
+        if (row < N && col < K) out[(size_t)row * ld_slab + col] = acc[a][b][r];
+      }
+    }
+}
+// dW[n][k] = sum over slabs; db[n] = the slabs' column K.  One lane per output element, slabs walked with 8 loads in flight.
+__global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ slabs, float *__restrict__ dW, float *__restrict__ db, int S, int N, int K,
+                                                   int with_bias, int ld_slab) {
+  const int Kx = K + (with_bias ? 1 : 0);
+  const long long total = (long long)N * Kx, i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i / Kx), k = (int)(i % Kx);
+  const float *p = slabs + (size_t)n * ld_slab + k;
+  const size_t step = (size_t)N * ld_slab;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] += p[(size_t)(s + u) * step];
+  }
+  for (; s < S; s++) a[0] += p[(size_t)s * step];
+  const float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (k < K) dW[(size_t)n * K + k] = v; else db[n] = v;
+}

@@ -248,6 +248,7 @@ __global__ void k_gae(const float *__restrict__ trunc, const float *__restrict__
 }
 
 #include "ppo_kernels.h"
+#include "gemm_kernels.h"
 
 // ----------------------------------------------------------------------------------------------- C-ABI
 extern "C" {
@@ -642,6 +643,76 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
   else { if (V == 4) TMJX_NL(4, false); else if (V == 2) TMJX_NL(2, false); else TMJX_NL(1, false); }
 #undef TMJX_NL
   return check_launch("k_linear_nolds");
+}
+
+}  // extern "C" (the templates below need C++ linkage)
+// ---- dense layers of the learner on the matrix cores (csrc/gemm_kernels.h)
+static bool aligned16(const void *p, long long ld) { return !((uintptr_t)p & 15) && !(ld & 3); }
+template <int NIW, bool BT>
+static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
+  constexpr int BN = 64 * NIW;
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_BM * GEMM_LDA + (BT ? BN * GEMM_LDA : GEMM_BK * (BN + 4)));
+  static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid((M + GEMM_BM - 1) / GEMM_BM, (N + BN - 1) / BN);
+  hipLaunchKernelGGL((k_gemm_act<NIW, BT>), grid, dim3(256), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K, (int)aligned16(A, lda), (int)aligned16(W, ldw));
+  return check_launch("k_gemm_act");
+}
+template <bool BT>
+static int gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream) {
+  if (!A || !W || !C) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1 || lda < K || ldc < N || ldw < (BT ? K : N)) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 64) return launch_gemm_act<1, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  if (N <= 128) return launch_gemm_act<2, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  return launch_gemm_act<4, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+}
+extern "C" {
+int tmjx_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream) {
+  return gemm_act<true>(A, lda, W, ldw, bias, C, ldc, M, N, K, stream);
+}
+int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, void *stream) {
+  return gemm_act<false>(A, lda, W, ldw, nullptr, C, ldc, M, N, K, stream);
+}
+// rows of M per slab and number of slabs so that tiles x slabs is about the number of CUs (256)
+static void dw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab) {
+  const int tiles = ((N + DW_BT - 1) / DW_BT) * ((K + DW_BT - 1) / DW_BT);
+  int want = (256 + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  int rps = (((M + want - 1) / want) + DW_BM - 1) / DW_BM * DW_BM;
+  if (rps < DW_BM) rps = DW_BM;
+  *rows_per_split = rps;
+  *S = (M + rps - 1) / rps;
+  *ld_slab = ((K + DW_BT - 1) / DW_BT) * DW_BT + 4;
+}
+long long tmjx_gemm_dw_scratch_floats(int M, int N, int K) {
+  if (M < 1 || N < 1 || K < 1) return 0;
+  int rps, S, ld;
+  dw_split(M, N, K, &rps, &S, &ld);
+  return (long long)S * N * ld;
+}
+int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream) {
+  if (!dY || !X || !dW || !scratch) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1 || ldy < N || ldx < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  int rps, S, ld;
+  dw_split(M, N, K, &rps, &S, &ld);
+  constexpr size_t lds = 2 * sizeof(float) * 2 * DW_BM * DW_LD;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_dw): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((N + DW_BT - 1) / DW_BT, (K + DW_BT - 1) / DW_BT, S);
+  hipLaunchKernelGGL(k_gemm_dw, grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, db ? 1 : 0, rps, ld, (int)aligned16(dY, ldy), (int)aligned16(X, ldx));
+  const long long total = (long long)N * (K + (db ? 1 : 0));
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)scratch, dW, db, S, N, K, db ? 1 : 0, ld);
+  return check_launch("k_gemm_dw");
 }
 
 int tmjx_stats_scratch_floats(int W) { return STATS_SLABS * 2 * W; }
