@@ -28,110 +28,196 @@ typedef float __attribute__((ext_vector_type(4))) gf4;
 #define GEMM_BK 32
 #define GEMM_LDA 40          // floats per LDS row of a [rows][k] image (32 + 8 pad)
 
-__device__ __forceinline__ gf4 gemm_ld4(const float *__restrict__ p, long long row_off, int k, int K, bool row_ok, bool vec) {
-  // four consecutive k of one row, zero beyond K (and for rows outside the matrix); `vec`: the row base is 16-byte aligned
-  gf4 v = {0.f, 0.f, 0.f, 0.f};
-  if (!row_ok || k >= K) return v;
-  const float *q = p + row_off + k;
-  if (vec && k + 3 < K) return *reinterpret_cast<const gf4 *>(q);
-  v.x = q[0];
-  if (k + 1 < K) v.y = q[1];
-  if (k + 2 < K) v.z = q[2];
-  if (k + 3 < K) v.w = q[3];
+// Four consecutive elements k .. k + 3 of one matrix row, zero beyond `K` and for rows outside the matrix.  BRANCH-FREE on purpose:
+// every load is issued unconditionally from a clamped (valid) address and masked afterwards, so the compiler can leave the loads
+// of the next K step in flight across this step's MFMAs (a load inside a divergent branch is waited for at the end of the branch:
+// the first version of these kernels ran at 40 % of the MFMA rate for exactly that reason).
+//   VEC  : the row base is 16-byte aligned AND the row's allocation reaches the end of the last float4 (ld >= K rounded up to 4):
+//          one dwordx4 load, elements beyond K zeroed;  otherwise four dword loads.
+// The masking is a SEPARATE step (gemm_mask4, applied when the staged registers are written to LDS, behind the MFMAs of the current
+// step): applied right at the load it makes the loaded value live — and waited for — before the MFMAs start.
+template <bool VEC>
+__device__ __forceinline__ gf4 gemm_ld4(const float *__restrict__ p, long long row_off, int k, int K, bool row_ok, int &mask) {
+  const float *q = p + (row_ok ? row_off : 0ll);
+  const bool any = row_ok && k < K;
+  const int left = any ? K - k : 0;                    // valid elements from k on
+  mask = left >= 4 ? 15 : (1 << (left > 0 ? left : 0)) - 1;
+  gf4 v;
+  if (VEC) {                                  // compile time: a run-time flag here puts every load behind a branch and its vmcnt(0)
+    v = *reinterpret_cast<const gf4 *>(q + (any ? k : 0));
+  } else {
+    const int last = K - 1;
+    v.x = q[any ? k : 0];
+    v.y = q[any ? min(k + 1, last) : 0];
+    v.z = q[any ? min(k + 2, last) : 0];
+    v.w = q[any ? min(k + 3, last) : 0];
+  }
   return v;
 }
+__device__ __forceinline__ gf4 gemm_mask4(gf4 v, int mask) {
+  return gf4{(mask & 1) ? v.x : 0.f, (mask & 2) ? v.y : 0.f, (mask & 4) ? v.z : 0.f, (mask & 8) ? v.w : 0.f};
+}
 
-template <int NIW, bool BT>
-__global__ __launch_bounds__(256) void k_gemm_act(const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
-                                                  float *__restrict__ C, int ldc, int M, int N, int K, int avec, int wvec) {
+// LLVM SchedGroupMask values for __builtin_amdgcn_sched_group_barrier
+#define SG_VALU 0x2
+#define SG_MFMA 0x8
+#define SG_DS_READ 0x100
+#define SG_DS_WRITE 0x200
+
+template <int NIW> struct GemmCfg { static constexpr int NWAVE = NIW >= 2 ? 8 : 4, THREADS = 64 * NWAVE, NI = 4 * NIW / NWAVE; };
+template <int NIW, bool BT, bool AVEC, bool WVEC>
+__global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
+                                                  float *__restrict__ C, int ldc, int M, int N, int K) {
   constexpr int BN = 64 * NIW;
   constexpr int LDB_T = GEMM_LDA;            // BT: [n][k] image, 40 floats per row
   constexpr int LDB_N = BN + 4;              // !BT: [k][n] image, row stride 4 mod 8
   constexpr int A_FLOATS = GEMM_BM * GEMM_LDA, B_FLOATS = BT ? BN * LDB_T : GEMM_BK * LDB_N, STAGE = A_FLOATS + B_FLOATS;
   extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
+  // TWO waves per SIMD (8 per workgroup) once the tile is 128 columns or wider: with one wave per SIMD everything that is not an
+  // MFMA (address arithmetic, masks, LDS traffic, the barrier) idles the matrix pipe — measured 52 % MFMA-busy; the second wave's
+  // MFMAs fill those gaps.  The waves sit side by side along N: 16 NI columns each.
+  constexpr int NT = GemmCfg<NIW>::THREADS, NI = GemmCfg<NIW>::NI;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * BN, nw = wave * 16 * NIW;      // this wave's first column inside the tile
-  // ---- global -> register staging (float4 per thread): A 80 x 8 float4 (3 passes, the last one half empty), B BN x 8 or 32 x BN / 4
-  constexpr int A_PASS = (GEMM_BM * 8 + 255) / 256, B_PASS = BT ? (BN * 8) / 256 : (GEMM_BK * (BN / 4)) / 256;
-  gf4 ra[A_PASS], rb[B_PASS];
-  auto gload = [&](int k0) {
+  const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * BN, nw = wave * 16 * NI;      // this wave's first column inside the tile
+  // ---- global -> register staging (float4 per thread): A 80 x 8 float4 (the last pass partly empty), B BN x 8 or 32 x BN / 4
+  constexpr int A_PASS = (GEMM_BM * 8 + NT - 1) / NT, B_PASS = BT ? (BN * 8) / NT : (GEMM_BK * (BN / 4)) / NT, NPASS = A_PASS + B_PASS;
+  // TWO register sets: tile j travels in set j & 1, loaded a whole K step before it is written to LDS (the write sits between the
+  // MFMAs of the step in between, so nothing waits for memory)
+  struct Stage { gf4 v[NPASS]; int m[NPASS]; };
+  auto gload = [&](Stage &R, int k0) {
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
-      const int f = t + 256 * p, r = f >> 3, c4 = f & 7;
-      ra[p] = gemm_ld4(A, (long long)(m0 + r) * lda, k0 + 4 * c4, K, f < GEMM_BM * 8 && m0 + r < M, avec != 0);
+      const int f = t + NT * p, r = f >> 3, c4 = f & 7;
+      const bool ok = f < GEMM_BM * 8 && m0 + r < M;
+      R.v[p] = gemm_ld4<AVEC>(A, (long long)(m0 + (ok ? r : 0)) * lda, k0 + 4 * c4, K, ok, R.m[p]);
     }
 #pragma unroll
     for (int p = 0; p < B_PASS; p++) {
-      const int f = t + 256 * p;
+      const int f = t + NT * p;
       if (BT) {
         const int r = f >> 3, c4 = f & 7;
-        rb[p] = gemm_ld4(W, (long long)(n0 + r) * ldw, k0 + 4 * c4, K, n0 + r < N, wvec != 0);
+        const bool ok = n0 + r < N;
+        R.v[A_PASS + p] = gemm_ld4<WVEC>(W, (long long)(n0 + (ok ? r : 0)) * ldw, k0 + 4 * c4, K, ok, R.m[A_PASS + p]);
       } else {
         const int r = f / (BN / 4), c4 = f % (BN / 4);               // row = k, four consecutive output columns
-        rb[p] = gemm_ld4(W, (long long)(k0 + r) * ldw + n0, 4 * c4, N - n0, k0 + r < K, wvec != 0);
+        const bool ok = k0 + r < K;
+        R.v[A_PASS + p] = gemm_ld4<WVEC>(W, (long long)(ok ? k0 + r : 0) * ldw + n0, 4 * c4, N - n0, ok, R.m[A_PASS + p]);
       }
     }
   };
-  auto swrite = [&](int stage) {
+  auto swrite = [&](const Stage &R, int stage) {
     float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
-      const int f = t + 256 * p, r = f >> 3, c4 = f & 7;
-      if (f < GEMM_BM * 8) *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = ra[p];
+      const int f = t + NT * p, r = f >> 3, c4 = f & 7;
+      if (f < GEMM_BM * 8) *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = gemm_mask4(R.v[p], R.m[p]);
     }
 #pragma unroll
     for (int p = 0; p < B_PASS; p++) {
-      const int f = t + 256 * p;
-      if (BT) { const int r = f >> 3, c4 = f & 7; *reinterpret_cast<gf4 *>(sb + r * LDB_T + 4 * c4) = rb[p]; }
-      else { const int r = f / (BN / 4), c4 = f % (BN / 4); *reinterpret_cast<gf4 *>(sb + r * LDB_N + 4 * c4) = rb[p]; }
+      const int f = t + NT * p;
+      const gf4 v = gemm_mask4(R.v[A_PASS + p], R.m[A_PASS + p]);
+      if (BT) { const int r = f >> 3, c4 = f & 7; *reinterpret_cast<gf4 *>(sb + r * LDB_T + 4 * c4) = v; }
+      else { const int r = f / (BN / 4), c4 = f % (BN / 4); *reinterpret_cast<gf4 *>(sb + r * LDB_N + 4 * c4) = v; }
     }
   };
-  gf4 acc[5][NIW];
+  struct Frag { gf4 a[5], b[NI]; };
+  auto fread = [&](Frag &F, int stage, int c) {
+    const float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
+#pragma unroll
+    for (int a = 0; a < 5; a++) F.a[a] = *reinterpret_cast<const gf4 *>(sa + (16 * a + li) * GEMM_LDA + 16 * c + 4 * kq);
+    if (BT) {
+#pragma unroll
+      for (int b = 0; b < NI; b++) F.b[b] = *reinterpret_cast<const gf4 *>(sb + (nw + 16 * b + li) * LDB_T + 16 * c + 4 * kq);
+    } else {
+#pragma unroll
+      for (int b = 0; b < NI; b++) {
+        const float *q = sb + (16 * c + 4 * kq) * LDB_N + nw + 16 * b + li;
+        F.b[b] = gf4{q[0], q[LDB_N], q[2 * LDB_N], q[3 * LDB_N]};
+      }
+    }
+  };
+  gf4 acc[5][NI];
 #pragma unroll
   for (int a = 0; a < 5; a++)
 #pragma unroll
-    for (int b = 0; b < NIW; b++) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](int stage) {
-    const float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
+    for (int b = 0; b < NI; b++) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](const Frag &F) {
+    // e outermost: 5 NI independent accumulators between two uses of the same one (dependent latency 40 cycles > issue 32)
 #pragma unroll
-    for (int c = 0; c < GEMM_BK / 16; c++) {
-      gf4 fa[5], fb[NIW];
+    for (int e = 0; e < 4; e++)
 #pragma unroll
-      for (int a = 0; a < 5; a++) fa[a] = *reinterpret_cast<const gf4 *>(sa + (16 * a + li) * GEMM_LDA + 16 * c + 4 * kq);
-      if (BT) {
+      for (int a = 0; a < 5; a++)
 #pragma unroll
-        for (int b = 0; b < NIW; b++) fb[b] = *reinterpret_cast<const gf4 *>(sb + (nw + 16 * b + li) * LDB_T + 16 * c + 4 * kq);
-      } else {
+        for (int b = 0; b < NI; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[a][e], F.b[b][e], acc[a][b], 0, 0, 0);
+  };
+  constexpr int NMFMA = 20 * NI;                       // MFMAs per 16-deep chunk and wave
+  constexpr int NFR = 5 + (BT ? NI : 4 * NI);          // LDS reads per chunk
+  // One K step (32 deep = two chunks of 16) of tile k in stage s, ONE barrier in its middle and MFMAs on both sides of it:
+  //   phase A: chunk 0's MFMAs, between them the fragment reads of chunk 1 and the LDS writes of tile k + 1 (register set RW, in
+  //            flight since a step and a half) into the other stage — last read before the previous barrier;
+  //   barrier: the other stage is complete;
+  //   phase B: chunk 1's MFMAs (fragments already in registers: no LDS latency behind the barrier), between them the first
+  //            fragments of tile k + 1 and the global loads of tile k + 3 into RW's registers (free again).
+  // Branch-free: past the last tile the loads are fully masked and the writes go to a stage nobody reads any more.
+  auto kstep = [&](Frag &F0, Frag &F1, Stage &RW, int stage, int k_next3) {
+    fread(F1, stage, 1);
+    swrite(RW, stage ^ 1);
+    mma(F0);
 #pragma unroll
-        for (int b = 0; b < NIW; b++) {
-          const float *q = sb + (16 * c + 4 * kq) * LDB_N + nw + 16 * b + li;
-          fb[b] = gf4{q[0], q[LDB_N], q[2 * LDB_N], q[3 * LDB_N]};
-        }
-      }
-      // e outermost: 5 NIW independent accumulators between two uses of the same one (dependent latency 40 cycles > issue 32)
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-#pragma unroll
-        for (int a = 0; a < 5; a++)
-#pragma unroll
-          for (int b = 0; b < NIW; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+    for (int i = 0; i < NFR; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
     }
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, (NMFMA - NFR) / (NPASS + 1), 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DS_WRITE, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, NMFMA, 0);
+    __syncthreads();
+    fread(F0, stage ^ 1, 0);
+    gload(RW, k_next3);
+    mma(F1);
+#pragma unroll
+    for (int i = 0; i < NFR; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, NMFMA, 0);
   };
   const int nk = (K + GEMM_BK - 1) / GEMM_BK;
-  gload(0);
-  swrite(0);
+#ifdef GEMM_PROF
+  unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+  Stage R0, R1;
+  Frag F0, F1;
+  gload(R0, 0);
+  swrite(R0, 0);
+  gload(R1, GEMM_BK);
+  gload(R0, 2 * GEMM_BK);
   __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk) gload((kt + 1) * GEMM_BK);          // in flight during this stage's MFMAs
-    compute(kt & 1);
-    if (kt + 1 < nk) swrite((kt + 1) & 1);               // the other stage: last read before the previous barrier
-    __syncthreads();
+  fread(F0, 0, 0);
+#ifdef GEMM_PROF
+  unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(F0, F1, R1, 0, (kt + 3) * GEMM_BK);          // tile kt in stage 0; tile kt + 1 (R1) goes to stage 1; tile kt + 3 is loaded into R1
+    if (kt + 1 < nk) kstep(F0, F1, R0, 1, (kt + 4) * GEMM_BK);
   }
-  // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile
+#ifdef GEMM_PROF
+  unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
+  // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile: stored straight from the registers (64-byte
+  // pieces; routing the tile through LDS to store whole rows as dwordx4 was tried and is 6 % SLOWER for these 80 x 256 tiles)
 #pragma unroll
-  for (int b = 0; b < NIW; b++) {
+  for (int b = 0; b < NI; b++) {
     const int col = n0 + nw + 16 * b + li;
+#ifdef GEMM_PROF
+    const float bv = 0.f;
+#else
     const float bv = (bias && col < N) ? bias[col] : 0.f;
+#endif
 #pragma unroll
     for (int a = 0; a < 5; a++)
 #pragma unroll
@@ -140,29 +226,37 @@ __global__ __launch_bounds__(256) void k_gemm_act(const float *__restrict__ A, i
         if (row < M && col < N) C[(long long)row * ldc + col] = acc[a][b][r] + bv;
       }
   }
+#ifdef GEMM_PROF
+  if (lane == 0) {
+    unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+    unsigned long long *o = (unsigned long long *)bias + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * (NT / 64) + wave) * 4;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+  }
+#endif
 }
 
 // ---- dW = dY^T X (+ db as the column of ones): slabs over row ranges
 #define DW_BT 128            // output tile: 128 (n) x 128 (k)
 #define DW_BM 32             // rows of M per LDS stage
 #define DW_LD (DW_BT + 16)   // floats per LDS row: 16 mod 32, lanes of kq and kq + 1 read banks 16 apart
+template <bool YVEC, bool XVEC>
 __global__ __launch_bounds__(256) void k_gemm_dw(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx, float *__restrict__ slabs,
-                                                 int M, int N, int K, int with_bias, int rows_per_split, int ld_slab, int yvec, int xvec) {
+                                                 int M, int N, int K, int with_bias, int rows_per_split, int ld_slab) {
   constexpr int STAGE = 2 * DW_BM * DW_LD;
   extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * DW_BT, k0 = blockIdx.y * DW_BT, split = blockIdx.z;
   const int r_begin = split * rows_per_split, r_end = min(M, r_begin + rows_per_split);
   const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  int my[4], mx[4];
   gf4 ry[4], rx[4], colacc = {0.f, 0.f, 0.f, 0.f};      // colacc: sum over this thread's rows of its four dY columns (bias gradient)
   auto gload = [&](int r0) {
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int f = t + 256 * p, r = f >> 5, c4 = f & 31;           // 32 rows x 32 float4
       const bool ok = r0 + r < r_end;
-      ry[p] = gemm_ld4(dY, (long long)(r0 + r) * ldy + n0, 4 * c4, N - n0, ok, yvec != 0);
-      rx[p] = gemm_ld4(X, (long long)(r0 + r) * ldx + k0, 4 * c4, K - k0, ok, xvec != 0);
-      colacc += ry[p];
+      ry[p] = gemm_ld4<YVEC>(dY, (long long)(ok ? r0 + r : r_begin) * ldy + n0, 4 * c4, N - n0, ok, my[p]);
+      rx[p] = gemm_ld4<XVEC>(X, (long long)(ok ? r0 + r : r_begin) * ldx + k0, 4 * c4, K - k0, ok, mx[p]);
     }
   };
   auto swrite = [&](int stage) {
@@ -170,8 +264,10 @@ __global__ __launch_bounds__(256) void k_gemm_dw(const float *__restrict__ dY, i
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int f = t + 256 * p, r = f >> 5, c4 = f & 31;
-      *reinterpret_cast<gf4 *>(sy + r * DW_LD + 4 * c4) = ry[p];
-      *reinterpret_cast<gf4 *>(sx + r * DW_LD + 4 * c4) = rx[p];
+      const gf4 vy = gemm_mask4(ry[p], my[p]);
+      colacc += vy;
+      *reinterpret_cast<gf4 *>(sy + r * DW_LD + 4 * c4) = vy;
+      *reinterpret_cast<gf4 *>(sx + r * DW_LD + 4 * c4) = gemm_mask4(rx[p], mx[p]);
     }
   };
   gf4 acc[4][4];

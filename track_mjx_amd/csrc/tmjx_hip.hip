@@ -647,29 +647,52 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
 
 }  // extern "C" (the templates below need C++ linkage)
 // ---- dense layers of the learner on the matrix cores (csrc/gemm_kernels.h)
+// vector (dwordx4) loads of a row-major operand: 16-byte aligned rows (pointer and leading dimension) — then ld >= cols rounded up to 4
+// holds by itself (ld is a multiple of 4 and >= cols), i.e. the last float4 of a row stays inside the row's allocation
 static bool aligned16(const void *p, long long ld) { return !((uintptr_t)p & 15) && !(ld & 3); }
-template <int NIW, bool BT>
+template <int NIW, bool BT, bool AVEC, bool WVEC>
 static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
   constexpr int BN = 64 * NIW;
   constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_BM * GEMM_LDA + (BT ? BN * GEMM_LDA : GEMM_BK * (BN + 4)));
   static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT, AVEC, WVEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act): ") + hipGetErrorString(e));
     attr_set = true;
   }
   dim3 grid((M + GEMM_BM - 1) / GEMM_BM, (N + BN - 1) / BN);
-  hipLaunchKernelGGL((k_gemm_act<NIW, BT>), grid, dim3(256), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K, (int)aligned16(A, lda), (int)aligned16(W, ldw));
+  hipLaunchKernelGGL((k_gemm_act<NIW, BT, AVEC, WVEC>), grid, dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K);
   return check_launch("k_gemm_act");
+}
+template <int NIW, bool BT>
+static int gemm_act_vec(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
+  const bool av = aligned16(A, lda), wv = aligned16(W, ldw);
+  if (av && wv) return launch_gemm_act<NIW, BT, true, true>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  if (av) return launch_gemm_act<NIW, BT, true, false>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  if (wv) return launch_gemm_act<NIW, BT, false, true>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  return launch_gemm_act<NIW, BT, false, false>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
 }
 template <bool BT>
 static int gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream) {
   if (!A || !W || !C) return fail(TMJX_EINVAL, "null argument");
   if (M < 1 || N < 1 || K < 1 || lda < K || ldc < N || ldw < (BT ? K : N)) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
   hipStream_t s = (hipStream_t)stream;
-  if (N <= 64) return launch_gemm_act<1, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
-  if (N <= 128) return launch_gemm_act<2, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
-  return launch_gemm_act<4, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  if (N <= 64) return gemm_act_vec<1, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  if (N <= 128) return gemm_act_vec<2, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  return gemm_act_vec<4, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+}
+template <bool YVEC, bool XVEC>
+static int launch_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *scratch, int M, int N, int K, int with_bias, int rps, int S, int ld, hipStream_t s) {
+  constexpr size_t lds = 2 * sizeof(float) * 2 * DW_BM * DW_LD;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_dw<YVEC, XVEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_dw): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid((N + DW_BT - 1) / DW_BT, (K + DW_BT - 1) / DW_BT, S);
+  hipLaunchKernelGGL((k_gemm_dw<YVEC, XVEC>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, with_bias, rps, ld);
+  return TMJX_OK;
 }
 extern "C" {
 int tmjx_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream) {
@@ -681,7 +704,7 @@ int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int
 // rows of M per slab and number of slabs so that tiles x slabs is about the number of CUs (256)
 static void dw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab) {
   const int tiles = ((N + DW_BT - 1) / DW_BT) * ((K + DW_BT - 1) / DW_BT);
-  int want = (256 + tiles - 1) / tiles;
+  int want = (512 + tiles - 1) / tiles;      // two workgroups per CU (74 KB of LDS, < 256 registers each): one fills the other's non-MFMA gaps
   if (want < 1) want = 1;
   int rps = (((M + want - 1) / want) + DW_BM - 1) / DW_BM * DW_BM;
   if (rps < DW_BM) rps = DW_BM;
@@ -700,16 +723,14 @@ int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, f
   if (M < 1 || N < 1 || K < 1 || ldy < N || ldx < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
   int rps, S, ld;
   dw_split(M, N, K, &rps, &S, &ld);
-  constexpr size_t lds = 2 * sizeof(float) * 2 * DW_BM * DW_LD;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_dw): ") + hipGetErrorString(e));
-    attr_set = true;
-  }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((N + DW_BT - 1) / DW_BT, (K + DW_BT - 1) / DW_BT, S);
-  hipLaunchKernelGGL(k_gemm_dw, grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, db ? 1 : 0, rps, ld, (int)aligned16(dY, ldy), (int)aligned16(X, ldx));
+  const bool yv = aligned16(dY, ldy), xv = aligned16(X, ldx);
+  int rc;
+  if (yv && xv) rc = launch_gemm_dw<true, true>(dY, ldy, X, ldx, scratch, M, N, K, db ? 1 : 0, rps, S, ld, s);
+  else if (yv) rc = launch_gemm_dw<true, false>(dY, ldy, X, ldx, scratch, M, N, K, db ? 1 : 0, rps, S, ld, s);
+  else if (xv) rc = launch_gemm_dw<false, true>(dY, ldy, X, ldx, scratch, M, N, K, db ? 1 : 0, rps, S, ld, s);
+  else rc = launch_gemm_dw<false, false>(dY, ldy, X, ldx, scratch, M, N, K, db ? 1 : 0, rps, S, ld, s);
+  if (rc) return rc;
   const long long total = (long long)N * (K + (db ? 1 : 0));
   hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)scratch, dW, db, S, N, K, db ? 1 : 0, ld);
   return check_launch("k_gemm_dw");
