@@ -1,0 +1,144 @@
+"""The oracle behind the same C-ABI as the product (oracle/liboracle_abi.so): ONE harness — the ctypes binding
+of track_mjx_amd/hip.py — drives both libraries.  CPU part: the ABI twin against the oracle's native API (the buffer packing / layout
+is the only thing in between).  GPU part: the identical call sequence on libtmjx_hip.so and on the twin, layouts field by field,
+outputs buffer against buffer."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.common import default_blob, default_walker, make_oracle, rel_err
+from track_mjx_amd import clips as _clips
+from track_mjx_amd import hip
+
+ROOT = Path(__file__).resolve().parents[1]
+ABI_SO = ROOT / "oracle" / "liboracle_abi.so"
+
+
+class Harness:
+    """reset + steps through the C-ABI of `L`; `alloc(shape, dtype)` -> (array-like, pointer): numpy for the twin, torch.cuda for HIP."""
+
+    def __init__(self, L, blob, clip, n, alloc, ptr, to_np, stream=None):
+        self.L, self.n, self.ptr, self.to_np, self.stream = L, n, ptr, to_np, stream
+        self.h = C.c_void_p()
+        assert L.tmjx_model_create(blob, len(blob), C.byref(self.h)) == 0
+        self.lay = hip.Layout()
+        assert L.tmjx_layout(self.h, C.byref(self.lay)) == 0
+        arrs = [np.ascontiguousarray(getattr(clip, k), dtype=np.float32) for k in ("position", "quaternion", "joints", "body_positions", "angular_velocity")]
+        assert L.tmjx_clips_upload(self.h, *[a.ctypes.data_as(C.c_void_p) for a in arrs], arrs[0].shape[0], arrs[0].shape[1]) == 0
+        assert L.tmjx_set_wrappers(self.h, 195, 1) == 0
+        y = self.lay
+        self.state, self.istate = alloc((y.state_rows, n), np.float32), alloc((y.istate_rows, n), np.int32)
+        self.ws = alloc((max(y.ws_rows, 1), n), np.float32)
+        self.obs, self.metrics = alloc((y.obs_size, n), np.float32), alloc((y.n_metrics, n), np.float32)
+        self.reward, self.done, self.trunc = alloc((n,), np.float32), alloc((n,), np.float32), alloc((n,), np.float32)
+        self.alloc = alloc
+
+    def put(self, arr):
+        a = self.alloc(arr.shape, arr.dtype)
+        a[...] = arr if isinstance(a, np.ndarray) else __import__("torch").from_numpy(arr)
+        return a
+
+    def reset(self, clip_idx, start, qn, vn):
+        self._in = [self.put(x) for x in (clip_idx, start, qn, vn)]
+        p = self.ptr
+        assert self.L.tmjx_reset(self.h, p(self.state), p(self.istate), *[p(x) for x in self._in], p(self.obs), p(self.ws), self.n, self.stream) == 0
+
+    def step(self, action):
+        a = self.put(action)
+        p = self.ptr
+        rc = self.L.tmjx_step(self.h, p(self.state), p(self.istate), p(a), p(self.obs), p(self.reward), p(self.done), p(self.trunc), p(self.metrics),
+                              p(self.ws), self.n, self.stream)
+        assert rc == 0, self.L.tmjx_last_error()
+        self._a = a
+
+    def out(self):
+        t = self.to_np
+        return {"obs": t(self.obs), "reward": t(self.reward), "done": t(self.done), "trunc": t(self.trunc), "metrics": t(self.metrics),
+                "state": t(self.state), "istate": t(self.istate)}
+
+    def close(self):
+        self.L.tmjx_model_destroy(self.h)
+
+
+def _np_harness(blob, clip, n):
+    if not ABI_SO.exists():
+        import subprocess
+        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    L = hip.load(ABI_SO)
+    return Harness(L, blob, clip, n, lambda s, d: np.zeros(s, dtype=d), lambda a: a.ctypes.data_as(C.c_void_p), lambda a: np.array(a))
+
+
+def _inputs(n, seed=3):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 4, n).astype(np.int32), rng.integers(0, 44, n).astype(np.int32),
+            rng.uniform(-1e-3, 1e-3, (74, n)).astype(np.float32), rng.uniform(-1e-3, 1e-3, (73, n)).astype(np.float32),
+            [np.clip(rng.normal(size=(38, n)) * 0.03, -1, 1).astype(np.float32) for _ in range(3)])
+
+
+def test_abi_twin_exports_the_env_entry_points_and_matches_the_native_oracle():
+    import subprocess
+    w, cfg = default_walker()
+    blob = default_blob(w, cfg)
+    clip = _clips.make_synthetic_clips(w.model, 4, seed=0)
+    n = 6
+    H = _np_harness(blob, clip, n)
+    sym = subprocess.run(["nm", "-D", "--defined-only", str(ABI_SO)], capture_output=True, text=True, check=True).stdout
+    for name in ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_set_wrappers", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
+                 "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_last_error", "tmjx_version"):
+        assert f" T {name}" in sym, name
+    ci, sf, qn, vn, acts = _inputs(n)
+    H.reset(ci, sf, qn, vn)
+    O = make_oracle(blob, clip, "f32")
+    envs = O.new_envs(n)
+    for e in range(n):
+        O.env_reset(envs, e, int(ci[e]), int(sf[e]), qn[:, e], vn[:, e])
+    obs0 = np.stack([O.env_get(envs, e, "obs") for e in range(n)], 1)
+    np.testing.assert_array_equal(H.out()["obs"], obs0.astype(np.float32))
+    y = H.lay
+    assert (y.nq, y.nv, y.nu, y.obs_size, y.ref_obs_size, y.state_rows) == (74, 73, 38, 696, 470, 3478)
+    for a in acts:
+        H.step(a)
+        for e in range(n):
+            O.env_step(envs, e, a[:, e])
+        o = H.out()
+        # the twin round-trips the state through float32 buffers between steps, the native API keeps its struct: same float32 numbers
+        assert rel_err(o["obs"], np.stack([O.env_get(envs, e, "obs") for e in range(n)], 1)) < 1e-5
+        assert np.abs(o["reward"] - np.array([O.env_get(envs, e, "reward")[0] for e in range(n)])).max() < 1e-5
+        assert np.array_equal(o["done"], np.array([O.env_get(envs, e, "done")[0] for e in range(n)], dtype=np.float32))
+        assert np.array_equal(o["istate"][y.i_buffer_index], np.array([O.env_get(envs, e, "buffer_index")[0] for e in range(n)], dtype=np.int32))
+    H.close()
+
+
+@pytest.mark.gpu
+def test_one_harness_drives_the_hip_library_and_the_oracle_twin():
+    import torch
+    w, cfg = default_walker()
+    blob = default_blob(w, cfg)
+    clip = _clips.make_synthetic_clips(w.model, 4, seed=0)
+    n = 64
+    T = {np.float32: torch.float32, np.int32: torch.int32, np.dtype("float32"): torch.float32, np.dtype("int32"): torch.int32}
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    G = Harness(hip.lib(), blob, clip, n, lambda s, d: torch.zeros(s, dtype=T[d], device="cuda:0"), lambda a: C.c_void_p(a.data_ptr()),
+                lambda a: a.cpu().numpy(), stream)
+    H = _np_harness(blob, clip, n)
+    for f, _ in hip.Layout._fields_:
+        if f != "ws_rows":                      # the scratch workspace is each library's own business
+            assert getattr(G.lay, f) == getattr(H.lay, f), f
+    ci, sf, qn, vn, acts = _inputs(n)
+    G.reset(ci, sf, qn, vn); H.reset(ci, sf, qn, vn)
+    torch.cuda.synchronize()
+    y = G.lay
+    a, b = G.out(), H.out()
+    assert rel_err(a["obs"], b["obs"]) < 1e-5 and np.array_equal(a["istate"][:3], b["istate"][:3])
+    assert rel_err(a["state"][y.first_obs:y.first_obs + y.obs_size], b["state"][y.first_obs:y.first_obs + y.obs_size]) < 1e-5
+    for k, act in enumerate(acts[:2]):          # gentle, pre-contact steps: free-running comparison is meaningful
+        G.step(act); H.step(act)
+        torch.cuda.synchronize()
+        a, b = G.out(), H.out()
+        assert rel_err(a["obs"], b["obs"]) < 2e-4 and np.abs(a["reward"] - b["reward"]).max() < 1e-4
+        assert np.array_equal(a["done"], b["done"]) and np.array_equal(a["trunc"], b["trunc"])
+        assert np.array_equal(a["istate"][y.i_buffer_index], b["istate"][y.i_buffer_index])
+        assert rel_err(a["state"][y.qpos:y.qpos + 74], b["state"][y.qpos:y.qpos + 74]) < 1e-5
+    G.close(); H.close()

@@ -49,3 +49,42 @@ def test_reset_draws_batch_matches_scalar_path():
         c1, s1, q1, v1 = jr.reset_draws(keys[e], 64, 74, 73, 1e-3)
         assert (int(ci[e]), int(sf[e])) == (c1, s1)
         assert np.array_equal(qn[:, e], q1) and np.array_equal(vn[:, e], v1)
+
+
+def test_sgd_key_plumbing_and_permutation_hook():
+    """SgdKeys walks ppo.py:443-451 -> :729-730 -> :324 -> :303-307 exactly as composed by hand from split / fold_in / permutation, rank r
+    = the reference's local device r; the learner's perm_fn hook hands those permutations to the SGD loop."""
+    import torch
+    from tests.common import StubEnv
+    from track_mjx_amd import jax_random as jr
+    from track_mjx_amd.agent.ppo import PPOLearner
+    seed, world, rank, rows = 7, 4, 2, 64
+    _g, local = jr.split(jr.PRNGKey(seed), 2)
+    local = jr.fold_in(local, 0)
+    local, _env, _eval = jr.split(local, 3)
+    epoch_key, local = jr.split(local, 2)
+    key = jr.split(epoch_key, world)[rank]
+    expect = []
+    for _step in range(2):
+        key_sgd, _unroll, key = jr.split(key, 3)
+        carry = key_sgd
+        for _upd in range(3):
+            carry, key_perm, _grad = jr.split(carry, 3)
+            expect.append(jr.permutation(key_perm, rows))
+    sk = jr.SgdKeys(seed, 0, rank, world)
+    sk.start_epoch()
+    got = []
+    for _step in range(2):
+        sk.start_training_step()
+        got += [sk.permutation(rows) for _ in range(3)]
+    assert all(np.array_equal(a, b) for a, b in zip(got, expect))
+    assert all(sorted(p.tolist()) == list(range(rows)) for p in got) and not np.array_equal(got[0], got[1])
+    # another device of the same process shuffles differently (ppo.py:730: one key per local device)
+    other = jr.SgdKeys(seed, 0, rank + 1, world); other.start_training_step()
+    assert not np.array_equal(other.permutation(rows), expect[0])
+    ln = PPOLearner(StubEnv(4, 24, 16, 3), encoder_layers=(8,), decoder_layers=(8,), critic_layers=(8,), latents=4, unroll_length=2, batch_size=4,
+                    num_minibatches=2, num_updates_per_batch=3, use_graph=False, seed=seed, shuffle_rng="jax")
+    ln.sgd_keys = jr.SgdKeys(seed, 0, rank, world)
+    ln.start_epoch(); ln.sgd_keys.start_training_step()
+    p0 = ln.perm_fn(0, rows)
+    assert p0.dtype == torch.int64 and np.array_equal(p0.numpy(), expect[0])

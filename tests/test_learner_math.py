@@ -194,3 +194,32 @@ def test_full_learner_checkpoint_round_trip(tmp_path):
     assert [p.data_ptr() for p in b.params] == ptrs          # loaded in place
     assert sorted(k for k in ck.flatten(ck.learner_tree(a)) if k.startswith("value/")) == [
         "value/params/hidden_0/bias", "value/params/hidden_0/kernel", "value/params/hidden_1/bias", "value/params/hidden_1/kernel"]
+
+
+def test_flat_buffers_pad_odd_row_lengths_and_keep_pads_zero():
+    """Weight matrices whose row length is not a multiple of 4 (the 470- / 286-wide first layers) live in the flat buffers with rows padded
+    to one (16-byte aligned rows for the GEMM kernels' vector loads): the parameter is a strided view, the pad stays exactly zero through
+    optimiser steps, and the step equals torch's Adam with global-norm clipping on the unpadded tensors."""
+    from track_mjx_amd.agent.ppo import FlatAdam, FlatGrads
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.SiLU(), torch.nn.Linear(5, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.SiLU(), torch.nn.Linear(5, 3))
+    ref.load_state_dict(net.state_dict())
+    fg = FlatGrads(list(net.parameters()))
+    opt = FlatAdam(fg, lr=1e-2, max_norm=0.05)
+    w0 = net[0].weight
+    assert w0.shape == (5, 7) and w0.stride() == (8, 1) and w0.data_ptr() % 16 == 0 and net[2].weight.stride() == (8, 1)
+    assert all(p.data_ptr() % 16 == 0 for p in net.parameters())
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, eps=1e-8)
+    x = torch.randn(11, 7)
+    for _ in range(3):
+        fg.assign(torch.autograd.grad((net(x) ** 2).sum(), fg.params))
+        opt.step()
+        ropt.zero_grad()
+        (ref(x) ** 2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+        ropt.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    pad = opt.flat[:40].view(5, 8)[:, 7]
+    assert (pad == 0).all() and (opt.exp_avg[:40].view(5, 8)[:, 7] == 0).all()

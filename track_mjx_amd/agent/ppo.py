@@ -26,6 +26,29 @@ import os
 _nullctx = contextlib.nullcontext
 
 
+def _flat_layout(params):
+    """Segments of the flat parameter / gradient / moment buffers: every tensor starts on a 16-byte boundary and a weight matrix whose
+    row length is not a multiple of 4 (the 470- and 286-wide first layers) gets its rows padded to one: the MFMA GEMM kernels then
+    take the parameter itself through their vector-load path (leading dimension 472 / 288, the true K masks the pad), and the pad
+    columns stay exactly zero (zero gradient, zero moments).  Returns [(offset, rows, cols, padded_cols)], total floats."""
+    segs, off = [], 0
+    for p in params:
+        if p.dim() == 2 and p.shape[1] % 4 and not os.environ.get("TMJX_NO_PAD"):
+            rows, cols, pc = p.shape[0], p.shape[1], (p.shape[1] + 3) // 4 * 4
+        else:
+            rows, cols, pc = 1, p.numel(), p.numel()
+        segs.append((off, rows, cols, pc))
+        off += (rows * pc + 3) // 4 * 4
+    return segs, off
+
+
+def _flat_view(flat, seg, like):
+    off, rows, cols, pc = seg
+    if pc == cols:
+        return flat[off:off + rows * cols].view_as(like)
+    return flat[off:off + rows * pc].view(rows, pc)[:, :cols]
+
+
 class FlatGrads:
     """All parameter gradients live in ONE contiguous fp32 buffer, so the data-parallel mean is a single
     all-reduce of 2.5-17 MB (sized for the 7 x 153 GB/s xGMI links: one large message instead of per-tensor
@@ -33,12 +56,10 @@ class FlatGrads:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        self.segs, n = _flat_layout(self.params)
         self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for p, seg in zip(self.params, self.segs):
+            p.grad = _flat_view(self.flat, seg, p)
 
     def zero(self):
         self.flat.zero_()
@@ -46,7 +67,14 @@ class FlatGrads:
     def assign(self, grads):
         """Write freshly computed gradients (torch.autograd.grad) into the flat buffer with one multi-tensor copy: no
         zero-fill and no per-parameter `grad += new` kernels as with loss.backward() into pre-existing .grad views."""
-        torch._foreach_copy_([p.grad for p in self.params], list(grads))
+        grads = list(grads)
+        dense = [i for i, p in enumerate(self.params) if p.grad.is_contiguous()]
+        # one multi-tensor kernel for the dense views; the row-padded (strided) ones separately — a single strided destination sends the
+        # WHOLE foreach call down its per-tensor runtime-copy path (25 copyBuffer nodes per SGD step, +0.12 ms)
+        torch._foreach_copy_([self.params[i].grad for i in dense], [grads[i] for i in dense])
+        for i, p in enumerate(self.params):
+            if not p.grad.is_contiguous():
+                p.grad.copy_(grads[i])
 
     def all_reduce_mean(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -61,20 +89,18 @@ class FlatGrads:
 
 class FlatAdam:
     """optax.chain(clip_by_global_norm(max_norm), adam(lr)) (reference: ppo.py:517-520) on the flat buffers: the parameters are
-    re-seated as views of ONE contiguous fp32 buffer (like the gradients of FlatGrads), so the optimiser step is a norm reduction
+    re-seated as views of ONE contiguous fp32 buffer (same layout as the gradients of FlatGrads), so the optimiser step is a norm reduction
     plus one launch of tmjx_adam_clip instead of the clip kernels, a multi-tensor scale and a multi-tensor Adam over ~30 tensors.
     Must be built before any hipGraph captures the parameters' addresses.  CPU tensors (tests) take the same maths in torch."""
 
     def __init__(self, grads: FlatGrads, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 10.0):
         self.grads, self.lr, self.betas, self.eps, self.max_norm = grads, lr, betas, eps, max_norm
-        flat = torch.empty_like(grads.flat)
-        off = 0
+        flat = torch.zeros_like(grads.flat)
         with torch.no_grad():
-            for p in grads.params:
-                n = p.numel()
-                flat[off:off + n].copy_(p.detach().reshape(-1))
-                p.data = flat[off:off + n].view_as(p)
-                off += n
+            for p, seg in zip(grads.params, grads.segs):
+                view = _flat_view(flat, seg, p)
+                view.copy_(p.detach())
+                p.data = view
         self.flat = flat
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
         self.t = 0
@@ -117,7 +143,7 @@ class PPOLearner:
                  entropy_cost: float = 1e-2, discounting: float = 0.98, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
                  clipping_epsilon: float = 0.2, unroll_length: int = 20, batch_size: int = 1024, num_minibatches: int = 16,
                  num_updates_per_batch: int = 4, normalize_observations: bool = True, kl_weight: float = 0.1,
-                 seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None, use_graph: bool = True):
+                 seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None, use_graph: bool = True, shuffle_rng: str = "torch"):
         # `env` may be a LIST of envs (equal halves of this rank's envs): their roll-outs are then pipelined on one HIP stream
         # each (collect()), so that the tail of one half's physics kernel, its reward / observation kernels and its policy
         # inference run next to the other half's physics kernel
@@ -167,6 +193,15 @@ class PPOLearner:
         self._act_graphs: dict = {}
         self._wpad: dict = {}
         self.lds_free = len(self.envs) > 1 and dev.type == "cuda"   # pipelined roll-outs: LDS-free inference kernels (see _act_fused)
+        # minibatch shuffle: "torch" = torch.randperm on the device (default, nothing leaves the GPU); "jax" = the reference's own draws from
+        # the seed (jax_random.SgdKeys: key plumbing of ppo.py:443-451,303-307,324 + jax.random.permutation), computed on the host
+        self.sgd_keys = None
+        if shuffle_rng == "jax":
+            from ..jax_random import SgdKeys
+            self.sgd_keys = SgdKeys(seed, process_id=0, device_index=self.rank, local_devices=self.world)
+            self.perm_fn = lambda upd, rows: torch.from_numpy(self.sgd_keys.permutation(rows).astype("int64"))
+        elif shuffle_rng != "torch":
+            raise ValueError("shuffle_rng must be 'torch' or 'jax'")
         self.states = [None] * len(self.envs)
         self._streams = [torch.cuda.Stream(device=dev) for _ in self.envs] if (len(self.envs) > 1 and dev.type == "cuda") else None
 
@@ -179,7 +214,7 @@ class PPOLearner:
         self.states[0] = st
 
     def n_params(self) -> int:
-        return int(self.grads.flat.numel())
+        return int(sum(p.numel() for p in self.grads.params))
 
     # ---- acting (brax acting.generate_unroll / actor_step through make_inference_fn, ppo_networks.py:46-96)
     @torch.no_grad()
@@ -445,7 +480,14 @@ class PPOLearner:
         res["kl_weight"] = torch.as_tensor(kl_w)
         return res
 
+    def start_epoch(self) -> None:
+        """A new training epoch begins (ppo.py:729-730: fresh per-device keys); only matters with shuffle_rng="jax"."""
+        if self.sgd_keys is not None:
+            self.sgd_keys.start_epoch()
+
     def training_step(self, it: int = 0, kl_schedule=None) -> dict:
+        if self.sgd_keys is not None:
+            self.sgd_keys.start_training_step()
         self.collect()
         return self.update(it, kl_schedule)
 
@@ -459,7 +501,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
           intention_latent_size: int = 60, progress_fn: Callable[[int, dict], None] = lambda *a: None,
           max_training_steps: int | None = None, eval_env=None, num_eval_envs: int = 128, deterministic_eval: bool = False,
           matmul_dtype: torch.dtype | None = None, group=None, checkpoint_path: str | None = None, restore_from: str | None = None,
-          **unused):
+          shuffle_rng: str = "torch", **unused):
     """ppo.train(environment, num_timesteps, episode_length, ...) -> (make_policy, params, metrics)  (ppo.py:128-172,809).
 
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
@@ -478,7 +520,8 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
                          entropy_cost=entropy_cost, discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
                          clipping_epsilon=clipping_epsilon, unroll_length=unroll_length, batch_size=batch_size,
                          num_minibatches=num_minibatches, num_updates_per_batch=num_updates_per_batch,
-                         normalize_observations=normalize_observations, kl_weight=kl_weight, seed=seed, matmul_dtype=matmul_dtype, group=group)
+                         normalize_observations=normalize_observations, kl_weight=kl_weight, seed=seed, matmul_dtype=matmul_dtype, group=group,
+                         shuffle_rng=shuffle_rng)
     from . import checkpoint as _ckpt
     if checkpoint_path is None and ckpt_mgr is not None:
         checkpoint_path = str(getattr(ckpt_mgr, "directory", ckpt_mgr))
@@ -516,6 +559,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
         for _ in range(max(num_resets_per_eval, 1)):
             t0 = time.time()
             acc: dict = {}
+            learner.start_epoch()
             for s in range(steps_per_epoch):
                 m = learner.training_step(it, kl_schedule)
                 for k, v in m.items():

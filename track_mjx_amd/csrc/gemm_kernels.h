@@ -240,84 +240,122 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #define DW_BM 32             // rows of M per LDS stage
 #define DW_LD (DW_BT + 16)   // floats per LDS row: 16 mod 32, lanes of kq and kq + 1 read banks 16 apart
 template <bool YVEC, bool XVEC>
-__global__ __launch_bounds__(256) void k_gemm_dw(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx, float *__restrict__ slabs,
+__global__ __launch_bounds__(512) void k_gemm_dw(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx, float *__restrict__ slabs,
                                                  int M, int N, int K, int with_bias, int rows_per_split, int ld_slab) {
+  // 8 waves (two per SIMD), each 64 (n) x 32 (k) of the 128 x 128 tile: 4 x 2 tiles of 16 x 16.  Same pipeline as k_gemm_act: two register
+  // sets for the staged rows, ONE barrier in the middle of a 32-row step, MFMAs on both sides of it with the fragment reads, the
+  // masking + LDS writes and the global loads spread between them.
   constexpr int STAGE = 2 * DW_BM * DW_LD;
   extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * DW_BT, k0 = blockIdx.y * DW_BT, split = blockIdx.z;
   const int r_begin = split * rows_per_split, r_end = min(M, r_begin + rows_per_split);
-  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
-  int my[4], mx[4];
-  gf4 ry[4], rx[4], colacc = {0.f, 0.f, 0.f, 0.f};      // colacc: sum over this thread's rows of its four dY columns (bias gradient)
-  auto gload = [&](int r0) {
+  const int wn = (wave >> 2) * 64, wk = (wave & 3) * 32;
+  struct Stage { gf4 y[2], x[2]; int my[2], mx[2]; };
+  gf4 colacc = {0.f, 0.f, 0.f, 0.f};        // sum over this thread's rows of its four dY columns (bias gradient)
+  auto gload = [&](Stage &R, int r0) {
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int f = t + 256 * p, r = f >> 5, c4 = f & 31;           // 32 rows x 32 float4
+    for (int p = 0; p < 2; p++) {
+      const int f = t + 512 * p, r = f >> 5, c4 = f & 31;           // 32 rows x 32 float4
       const bool ok = r0 + r < r_end;
-      ry[p] = gemm_ld4<YVEC>(dY, (long long)(ok ? r0 + r : r_begin) * ldy + n0, 4 * c4, N - n0, ok, my[p]);
-      rx[p] = gemm_ld4<XVEC>(X, (long long)(ok ? r0 + r : r_begin) * ldx + k0, 4 * c4, K - k0, ok, mx[p]);
+      R.y[p] = gemm_ld4<YVEC>(dY, (long long)(ok ? r0 + r : r_begin) * ldy + n0, 4 * c4, N - n0, ok, R.my[p]);
+      R.x[p] = gemm_ld4<XVEC>(X, (long long)(ok ? r0 + r : r_begin) * ldx + k0, 4 * c4, K - k0, ok, R.mx[p]);
     }
   };
-  auto swrite = [&](int stage) {
+  auto swrite = [&](const Stage &R, int stage) {
     float *sy = gemm_lds + stage * STAGE, *sx = sy + DW_BM * DW_LD;
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int f = t + 256 * p, r = f >> 5, c4 = f & 31;
-      const gf4 vy = gemm_mask4(ry[p], my[p]);
+    for (int p = 0; p < 2; p++) {
+      const int f = t + 512 * p, r = f >> 5, c4 = f & 31;
+      const gf4 vy = gemm_mask4(R.y[p], R.my[p]);
       colacc += vy;
       *reinterpret_cast<gf4 *>(sy + r * DW_LD + 4 * c4) = vy;
-      *reinterpret_cast<gf4 *>(sx + r * DW_LD + 4 * c4) = gemm_mask4(rx[p], mx[p]);
+      *reinterpret_cast<gf4 *>(sx + r * DW_LD + 4 * c4) = gemm_mask4(R.x[p], R.mx[p]);
     }
   };
-  gf4 acc[4][4];
+  struct Frag { float a[4][4], b[4][2]; };      // [s-step][tile]
+  auto fread = [&](Frag &F, int stage, int half) {
+    const float *sy = gemm_lds + stage * STAGE, *sx = sy + DW_BM * DW_LD;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int row = 16 * half + 4 * s + kq;
+#pragma unroll
+      for (int a = 0; a < 4; a++) F.a[s][a] = sy[row * DW_LD + wn + 16 * a + li];
+#pragma unroll
+      for (int b = 0; b < 2; b++) F.b[s][b] = sx[row * DW_LD + wk + 16 * b + li];
+    }
+  };
+  gf4 acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](int stage) {
-    const float *sy = gemm_lds + stage * STAGE, *sx = sy + DW_BM * DW_LD;
+    for (int b = 0; b < 2; b++) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](const Frag &F) {
 #pragma unroll
-    for (int s = 0; s < DW_BM / 4; s++) {
-      float fa[4], fb[4];
-#pragma unroll
-      for (int a = 0; a < 4; a++) fa[a] = sy[(4 * s + kq) * DW_LD + wn + 16 * a + li];
-#pragma unroll
-      for (int b = 0; b < 4; b++) fb[b] = sx[(4 * s + kq) * DW_LD + wk + 16 * b + li];
+    for (int s = 0; s < 4; s++)
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s][a], F.b[s][b], acc[a][b], 0, 0, 0);
+  };
+  auto mstep = [&](Frag &F0, Frag &F1, Stage &RW, int stage, int r_next3) {
+    fread(F1, stage, 1);
+    swrite(RW, stage ^ 1);
+    mma(F0);
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DS_WRITE, 1, 0);
+    }
+    __syncthreads();
+    fread(F0, stage ^ 1, 0);
+    gload(RW, r_next3);
+    mma(F1);
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 8, 0);
   };
   const int nt = (r_end - r_begin + DW_BM - 1) / DW_BM;
   if (nt > 0) {
-    gload(r_begin);
-    swrite(0);
+    Stage R0, R1;
+    Frag F0, F1;
+    gload(R0, r_begin);
+    swrite(R0, 0);
+    gload(R1, r_begin + DW_BM);
+    gload(R0, r_begin + 2 * DW_BM);
     __syncthreads();
-    for (int it = 0; it < nt; it++) {
-      if (it + 1 < nt) gload(r_begin + (it + 1) * DW_BM);
-      compute(it & 1);
-      if (it + 1 < nt) swrite((it + 1) & 1);
-      __syncthreads();
+    fread(F0, 0, 0);
+    for (int it = 0; it < nt; it += 2) {
+      mstep(F0, F1, R1, 0, r_begin + (it + 3) * DW_BM);
+      if (it + 1 < nt) mstep(F0, F1, R0, 1, r_begin + (it + 4) * DW_BM);
     }
   }
   float *out = slabs + (size_t)split * (size_t)N * ld_slab;
-  if (with_bias && blockIdx.y == 0) {          // (uniform per workgroup) thread t holds columns 4 (t & 31) .. + 3 for the rows t / 32 + 8 j
-    float *red = gemm_lds;                     // the stages are dead: the loop ended with a barrier
+  if (with_bias && blockIdx.y == 0) {          // (uniform per workgroup) thread t holds columns 4 (t & 31) .. + 3 of the rows t / 32 + 16 j
+    __syncthreads();                           // every wave is done with the stages
+    float *red = gemm_lds;
     *reinterpret_cast<gf4 *>(red + (t >> 5) * DW_BT + 4 * (t & 31)) = colacc;
     __syncthreads();
     if (t < DW_BT) {
       float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; j++) v += red[j * DW_BT + t];
+      for (int j = 0; j < 16; j++) v += red[j * DW_BT + t];
       if (n0 + t < N) out[(size_t)(n0 + t) * ld_slab + K] = v;
     }
   }
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < 2; b++) {
       const int col = k0 + wk + 16 * b + li;
 #pragma unroll
       for (int r = 0; r < 4; r++) {

@@ -691,7 +691,7 @@ static int launch_gemm_dw(const float *dY, int ldy, const float *X, int ldx, flo
     attr_set = true;
   }
   dim3 grid((N + DW_BT - 1) / DW_BT, (K + DW_BT - 1) / DW_BT, S);
-  hipLaunchKernelGGL((k_gemm_dw<YVEC, XVEC>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, with_bias, rps, ld);
+  hipLaunchKernelGGL((k_gemm_dw<YVEC, XVEC>), grid, dim3(512), lds, s, dY, ldy, X, ldx, scratch, M, N, K, with_bias, rps, ld);
   return TMJX_OK;
 }
 extern "C" {
@@ -704,7 +704,8 @@ int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int
 // rows of M per slab and number of slabs so that tiles x slabs is about the number of CUs (256)
 static void dw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab) {
   const int tiles = ((N + DW_BT - 1) / DW_BT) * ((K + DW_BT - 1) / DW_BT);
-  int want = (512 + tiles - 1) / tiles;      // two workgroups per CU (74 KB of LDS, < 256 registers each): one fills the other's non-MFMA gaps
+  static const int target = getenv("TMJX_DW_WGS") ? atoi(getenv("TMJX_DW_WGS")) : 256;      // tuning knob
+  int want = (target + tiles - 1) / tiles;      // one workgroup per CU: twice as many slabs (two per CU) ran the kernel no faster and doubled the reduction's traffic
   if (want < 1) want = 1;
   int rps = (((M + want - 1) / want) + DW_BM - 1) / DW_BM * DW_BM;
   if (rps < DW_BM) rps = DW_BM;

@@ -79,43 +79,53 @@ def load(path: Path):
     except OSError as e:  # e.g. no ROCm runtime on this machine
         raise TmjxError(f"cannot load {path}: {e}") from e
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p
-    L.tmjx_model_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
-    L.tmjx_model_destroy.argtypes = [vp]
-    L.tmjx_model_destroy.restype = None
-    L.tmjx_layout.argtypes = [vp, C.POINTER(Layout)]
-    L.tmjx_clips_upload.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
-    L.tmjx_reset.argtypes = [vp, fp, vp, vp, vp, fp, fp, fp, fp, C.c_int, vp]
-    L.tmjx_step.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
-    L.tmjx_physics.argtypes = [vp, fp, fp, C.c_int, fp, C.c_int, vp]
-    L.tmjx_physics_step.argtypes = [vp, fp, fp, fp, C.c_int, vp]
-    L.tmjx_forward.argtypes = [vp, fp, fp, C.c_int, vp]
-    L.tmjx_reward_obs.argtypes = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
-    L.tmjx_gae.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, vp]
-    L.tmjx_ppo_scratch_floats.argtypes = [C.c_int, C.c_int]
-    L.tmjx_ppo_loss.argtypes = [C.POINTER(PpoCfg)] + [fp] * 15 + [vp]
-    L.tmjx_silu_ln_partial_floats.argtypes = [C.c_int, C.c_int]
-    L.tmjx_silu_ln_fwd.argtypes = [fp] * 6 + [C.c_int, C.c_int, C.c_float, vp]
-    L.tmjx_silu_ln_bwd.argtypes = [fp] * 8 + [C.c_int, C.c_int, vp]
-    L.tmjx_gather_normalize.argtypes = [fp] * 5 + [C.c_int] * 4 + [vp]
-    L.tmjx_latent_concat.argtypes = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, C.c_int, vp]
-    L.tmjx_latent_concat_bwd.argtypes = [fp] * 4 + [C.c_int] * 3 + [vp]
-    L.tmjx_sample_action.argtypes = [fp] * 5 + [C.c_int, C.c_int, vp]
-    L.tmjx_linear_nolds.argtypes = [fp, C.c_int64, C.c_int64, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
-    L.tmjx_colsum_scratch_floats.argtypes = [C.c_int]
-    L.tmjx_colsum.argtypes = [fp, fp, fp, C.c_int, C.c_int, vp]
-    L.tmjx_adam_clip.argtypes = [fp] * 5 + [C.c_longlong] + [C.c_float] * 7 + [vp]
-    L.tmjx_gemm_nt.argtypes = [fp, C.c_int, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-    L.tmjx_gemm_nn.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-    L.tmjx_gemm_dw_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
-    L.tmjx_gemm_dw_scratch_floats.restype = C.c_longlong
-    L.tmjx_gemm_dw.argtypes = [fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
-    L.tmjx_set_wrappers.argtypes = [vp, C.c_int, C.c_int]
-    L.tmjx_stats_scratch_floats.argtypes = [C.c_int]
-    L.tmjx_stats_sums.argtypes = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]
-    L.tmjx_stats_apply.argtypes = [fp, C.c_float, fp, fp, fp, fp, C.c_int, C.c_float, C.c_float, vp]
-    L.tmjx_debug_rows.argtypes = [vp, C.c_char_p, ip, ip]
-    L.tmjx_last_error.restype = C.c_char_p
-    L.tmjx_version.restype = C.c_char_p
+    sig: dict = {}      # entry point -> (argtypes, restype or None for the default int return code)
+    sig.setdefault("tmjx_model_create", [None, None])[0] = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    sig.setdefault("tmjx_model_destroy", [None, None])[0] = [vp]
+    sig.setdefault("tmjx_model_destroy", [None, None])[1] = None
+    sig.setdefault("tmjx_layout", [None, None])[0] = [vp, C.POINTER(Layout)]
+    sig.setdefault("tmjx_clips_upload", [None, None])[0] = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
+    sig.setdefault("tmjx_reset", [None, None])[0] = [vp, fp, vp, vp, vp, fp, fp, fp, fp, C.c_int, vp]
+    sig.setdefault("tmjx_step", [None, None])[0] = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
+    sig.setdefault("tmjx_physics", [None, None])[0] = [vp, fp, fp, C.c_int, fp, C.c_int, vp]
+    sig.setdefault("tmjx_physics_step", [None, None])[0] = [vp, fp, fp, fp, C.c_int, vp]
+    sig.setdefault("tmjx_forward", [None, None])[0] = [vp, fp, fp, C.c_int, vp]
+    sig.setdefault("tmjx_reward_obs", [None, None])[0] = [vp, fp, vp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
+    sig.setdefault("tmjx_gae", [None, None])[0] = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_ppo_scratch_floats", [None, None])[0] = [C.c_int, C.c_int]
+    sig.setdefault("tmjx_ppo_loss", [None, None])[0] = [C.POINTER(PpoCfg)] + [fp] * 15 + [vp]
+    sig.setdefault("tmjx_silu_ln_partial_floats", [None, None])[0] = [C.c_int, C.c_int]
+    sig.setdefault("tmjx_silu_ln_fwd", [None, None])[0] = [fp] * 6 + [C.c_int, C.c_int, C.c_float, vp]
+    sig.setdefault("tmjx_silu_ln_bwd", [None, None])[0] = [fp] * 8 + [C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_gather_normalize", [None, None])[0] = [fp] * 5 + [C.c_int] * 4 + [vp]
+    sig.setdefault("tmjx_latent_concat", [None, None])[0] = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, C.c_int, vp]
+    sig.setdefault("tmjx_latent_concat_bwd", [None, None])[0] = [fp] * 4 + [C.c_int] * 3 + [vp]
+    sig.setdefault("tmjx_sample_action", [None, None])[0] = [fp] * 5 + [C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_linear_nolds", [None, None])[0] = [fp, C.c_int64, C.c_int64, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_colsum_scratch_floats", [None, None])[0] = [C.c_int]
+    sig.setdefault("tmjx_colsum", [None, None])[0] = [fp, fp, fp, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_adam_clip", [None, None])[0] = [fp] * 5 + [C.c_longlong] + [C.c_float] * 7 + [vp]
+    sig.setdefault("tmjx_gemm_nt", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_gemm_nn", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_gemm_dw_scratch_floats", [None, None])[0] = [C.c_int, C.c_int, C.c_int]
+    sig.setdefault("tmjx_gemm_dw_scratch_floats", [None, None])[1] = C.c_longlong
+    sig.setdefault("tmjx_gemm_dw", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_set_wrappers", [None, None])[0] = [vp, C.c_int, C.c_int]
+    sig.setdefault("tmjx_stats_scratch_floats", [None, None])[0] = [C.c_int]
+    sig.setdefault("tmjx_stats_sums", [None, None])[0] = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]
+    sig.setdefault("tmjx_stats_apply", [None, None])[0] = [fp, C.c_float, fp, fp, fp, fp, C.c_int, C.c_float, C.c_float, vp]
+    sig.setdefault("tmjx_debug_rows", [None, None])[0] = [vp, C.c_char_p, ip, ip]
+    sig.setdefault("tmjx_last_error", [None, None])[1] = C.c_char_p
+    sig.setdefault("tmjx_version", [None, None])[1] = C.c_char_p
+    restype_set = {"tmjx_model_destroy"}
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(L, name, None)      # a library may export a subset (the oracle's ABI twin has no learner kernels): calling a missing one raises
+        if fn is None:
+            continue
+        if argtypes is not None:
+            fn.argtypes = argtypes
+        if restype is not None or name in restype_set:
+            fn.restype = restype
     return L
 
 

@@ -203,3 +203,39 @@ def reset_draws_batch(keys, n_clips: int, nq: int, nv: int, noise_scale: float):
     lo, hi = np.float32(-noise_scale), np.float32(noise_scale)
     u = np.maximum(lo, f * (hi - lo) + lo).astype(np.float32)
     return clip_idx, start_frame, np.ascontiguousarray(u[:, :nq].T), np.ascontiguousarray(u[:, :nv].T)
+
+
+class SgdKeys:
+    """The learner's key plumbing for ONE device, from the seed down to the minibatch shuffles (track_mjx/agent/mlp_ppo/ppo.py):
+         train          :443-451  key = PRNGKey(seed); global_key, local_key = split(key); local_key = fold_in(local_key, process_id);
+                                   local_key, key_env, eval_key = split(local_key, 3)
+         epoch loop     :729-730  epoch_key, local_key = split(local_key); epoch_keys = split(epoch_key, local_devices_to_use)
+         training_step  :324      key_sgd, key_generate_unroll, new_key = split(key, 3)            (carry: new_key)
+         sgd_step       :303-307  key, key_perm, key_grad = split(key, 3); x = permutation(key_perm, x) for every leaf
+       One process per GPU here: rank r plays local device r of the reference's single process (process_id 0, local_devices = world size),
+       so a run with the same seed shuffles every device's roll-out rows exactly as the reference's pmap replica r does."""
+
+    def __init__(self, seed: int, process_id: int = 0, device_index: int = 0, local_devices: int = 1, partitionable: bool | None = None):
+        self.part = partitionable
+        _global_key, local_key = split(PRNGKey(seed), 2, self.part)
+        local_key = fold_in(local_key, process_id)
+        self.local_key, self.key_env, self.eval_key = split(local_key, 3, self.part)
+        self.device_index, self.local_devices = int(device_index), int(local_devices)
+        self.key = None          # the training_step carry of the current epoch
+        self.key_sgd = None
+        self.key_generate_unroll = None
+
+    def start_epoch(self) -> None:
+        epoch_key, self.local_key = split(self.local_key, 2, self.part)
+        self.key = split(epoch_key, self.local_devices, self.part)[self.device_index]
+
+    def start_training_step(self) -> None:
+        if self.key is None:
+            self.start_epoch()
+        self.key_sgd, self.key_generate_unroll, self.key = split(self.key, 3, self.part)
+        self._sgd_carry = self.key_sgd
+
+    def permutation(self, n: int) -> np.ndarray:
+        """The next sgd_step's row permutation (call once per update, in order)."""
+        self._sgd_carry, key_perm, _key_grad = split(self._sgd_carry, 3, self.part)
+        return permutation(key_perm, n, self.part)
