@@ -1,30 +1,38 @@
 #!/usr/bin/env python3
-"""profiles/r01_mfma_counters.txt from the PMC runs of tools/run_cfgs.sh (MFMA counters of the SGD half of a training step).
-Usage: python tools/mfma_summary.py gpurun_out/cfgs  > profiles/r01_mfma_counters.txt"""
+"""profiles/mfma_counters.json from tools/mfma_counters.sh: matrix-pipe utilisation inside the learner's GEMM kernels (k_gemm_act / k_gemm_dw)
+over the SGD half of a training step.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) (gfx94x MfmaUtil formula,
+per-kernel sums).  usage: python tools/mfma_summary.py gpurun_out/mfma_<tag>"""
 import collections
 import csv
 import glob
+import json
 import sys
+from pathlib import Path
 
-src = sys.argv[1]
-print("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace")
-print("  -- python3 tools/sgd_step.py --config <cfg>   (the SGD half of a training step, eager launches; tools/run_cfgs.sh)")
-print("MFMA utilisation of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)  (gfx94x MfmaUtil formula, per-kernel sums)\n")
-for c, label in (("cfg2", "2x256 nets, fp32 GEMMs (hipBLASLt v_mfma_f32_16x16x4_f32)"), ("cfg5", "rodent-mc-intention nets, bf16 GEMM inputs / fp32 accumulate and output (agent/networks.py: gemm_inputs)")):
-    fs = glob.glob(f"{src}/pmc_mfma_{c}/*/*_counter_collection.csv")
+src = Path(sys.argv[1])
+res = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA ... over tools/sgd_step.py --config <cfg> (eager launches); "
+               "utilisation = MFMA busy cycles / (4 x CU busy cycles), summed per kernel family"}
+for cfg in ("cfg2", "cfg4"):
+    fs = glob.glob(str(src / cfg / "*" / "*_counter_collection.csv"))
     if not fs:
         continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(fs[0])):
-        k = r["Kernel_Name"][:72]; agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Counter_Name"] == "SQ_INSTS_MFMA":
-            calls[k] += 1
-    print(f"== {c}: {label}")
-    tot = collections.defaultdict(float)
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)):
-        if not k.startswith("Cijk"):
-            continue
-        for n, x in v.items():
-            tot[n] += x
-        print(f"  {k:72s} calls={calls[k]:5d} mfma_util={v['SQ_VALU_MFMA_BUSY_CYCLES'] / max(4 * v['SQ_BUSY_CU_CYCLES'], 1):.3f} mfma_insts={v['SQ_INSTS_MFMA']:.3g}")
-    print(f"  all library GEMM kernels: MFMA utilisation {tot['SQ_VALU_MFMA_BUSY_CYCLES'] / max(4 * tot['SQ_BUSY_CU_CYCLES'], 1):.3f}  (MFMA instructions {tot['SQ_INSTS_MFMA']:.4g}, MOPS f32 {tot['SQ_INSTS_VALU_MFMA_MOPS_F32']:.4g}, bf16 {tot['SQ_INSTS_VALU_MFMA_MOPS_BF16']:.4g})\n")
+        k = r["Kernel_Name"]
+        fam = "k_gemm_act (forward / input gradient)" if "k_gemm_act" in k else "k_gemm_dw (weight gradient)" if "k_gemm_dw" in k else ("library GEMM" if k.startswith("Cijk") else None)
+        if fam:
+            agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+    out, tot = {}, collections.defaultdict(float)
+    for fam, v in agg.items():
+        out[fam] = {"mfma_util": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / max(4 * v["SQ_BUSY_CU_CYCLES"], 1), 4), "mfma_insts": v["SQ_INSTS_MFMA"],
+                    "wave_parked_fraction": round(v["SQ_WAIT_ANY"] / max(v["SQ_WAVE_CYCLES"], 1), 4),
+                    "issue_stall_fraction": round(v["SQ_WAIT_INST_ANY"] / max(v["SQ_WAVE_CYCLES"], 1), 4)}
+        if not fam.startswith("library"):
+            for n, x in v.items():
+                tot[n] += x
+    out["all_hand_written_gemm_kernels"] = round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / max(4 * tot["SQ_BUSY_CU_CYCLES"], 1), 4)
+    out["library_gemm_kernels_in_timed_region"] = int(any(f.startswith("library") for f in agg))
+    res[cfg] = out
+res["mfma_util"] = res.get("cfg2", {}).get("all_hand_written_gemm_kernels")
+(Path(__file__).resolve().parents[1] / "profiles" / "mfma_counters.json").write_text(json.dumps(res, indent=1) + "\n")
+print(json.dumps(res, indent=1))
