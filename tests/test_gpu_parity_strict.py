@@ -293,3 +293,45 @@ def test_compute_tracking_rewards_entry_is_side_effect_free():
     assert torch.equal(terms[16], -env.metrics_buf[18]) and torch.equal(terms[17], -env.metrics_buf[19])
     ref_ctrl = 0.02 * 0 + env._reward_config.ctrl_cost_weight * (a2 ** 2).sum(1)      # reward.py:219-232: w * sum(a^2)
     assert torch.allclose(terms[6], ref_ctrl, rtol=1e-5, atol=1e-7)
+
+
+def test_same_seed_rng_mode_rollout_noise_and_shuffles():
+    """shuffle_rng = act_rng = "jax": the roll-out's latent / action noise and the minibatch permutations are the reference's own draws
+    from the seed (jax_random.SgdKeys) — the raw actions stored in the roll-out buffer are loc + scale * that noise, the shuffles are
+    the key plumbing's permutations, two learners with the same seed collect identical roll-outs, and a different seed differs."""
+    from track_mjx_amd import jax_random as jr
+    from track_mjx_amd.agent import ppo
+    from track_mjx_amd.agent.networks import NormalTanh
+
+    def make(seed):
+        envs = [make_env_and_oracle(num_envs=32, n_clips=4, wrappers=True, seed=0)[0] for _ in range(2)]
+        L = ppo.PPOLearner(envs, encoder_layers=(64,), decoder_layers=(64,), critic_layers=(64,), latents=60, unroll_length=4, batch_size=32,
+                           num_minibatches=4, num_updates_per_batch=2, seed=seed, shuffle_rng="jax", act_rng="jax", use_graph=False)
+        for k, e in enumerate(envs):
+            L.states[k] = e.reset(torch.Generator().manual_seed(10 + k))
+        return L
+    A, B, Cc = make(5), make(5), make(6)
+    perms = []
+    for L in (A, B, Cc):
+        L.start_epoch()
+        L.sgd_keys.start_training_step()
+        L.collect()
+    torch.cuda.synchronize()
+    assert A.unrolls == 2
+    assert torch.equal(A.buf["raw_action"], B.buf["raw_action"]) and torch.equal(A.buf["observation"], B.buf["observation"])
+    assert not torch.equal(A.buf["raw_action"], Cc.buf["raw_action"])
+    # first control step of the first unroll: raw = loc + (softplus(raw_scale) + 0.001) * noise with the reference's noise for all 64 envs
+    sk = jr.SgdKeys(5, 0, 0, 1)
+    sk.start_epoch(); sk.start_training_step(); sk.start_unrolls(); sk.start_unroll()
+    eps, noise = sk.act_noise(64, 60, 38)
+    obs0 = A.buf["observation"][0, :64]
+    with torch.no_grad():
+        logits, _, _ = A.policy(A.normalizer.normalize(obs0), eps=torch.from_numpy(eps).to(DEV))
+        raw = NormalTanh.sample_no_postprocessing(logits.float(), torch.from_numpy(noise).to(DEV))
+    assert torch.allclose(raw, A.buf["raw_action"][0, :64], rtol=1e-4, atol=1e-5)
+    # the SGD shuffles of this training step are the key plumbing's permutations
+    rows = A.buf["reward"].shape[1]
+    expect = sk.permutation(rows)
+    assert np.array_equal(A.perm_fn(0, rows).numpy(), expect)
+    m = A.update(1)
+    assert all(bool(torch.isfinite(v).all()) for v in m.values())

@@ -88,3 +88,26 @@ def test_sgd_key_plumbing_and_permutation_hook():
     ln.start_epoch(); ln.sgd_keys.start_training_step()
     p0 = ln.perm_fn(0, rows)
     assert p0.dtype == torch.int64 and np.array_equal(p0.numpy(), expect[0])
+
+
+def test_acting_noise_key_plumbing():
+    """SgdKeys.act_noise follows training_step's unroll scan (ppo.py:333-348) -> brax generate_unroll's per-step split -> the policy's
+    key_sample / key_network split (ppo_networks.py:50) -> the network's encoder_rng (intention_network.py:104) as composed by hand."""
+    from track_mjx_amd import jax_random as jr
+    sk = jr.SgdKeys(3, 0, 1, 2)
+    sk.start_epoch(); sk.start_training_step()
+    carry = sk.key_generate_unroll
+    sk.start_unrolls()
+    for _unroll in range(2):
+        cur, carry = jr.split(carry, 2)
+        sk.start_unroll()
+        step_carry = cur
+        for _t in range(3):
+            current, step_carry = jr.split(step_carry, 2)
+            key_sample, key_network = jr.split(current, 2)
+            _, enc = jr.split(key_network, 2)
+            eps, noise = sk.act_noise(8, 60, 38)
+            assert eps.shape == (8, 60) and noise.shape == (8, 38) and eps.dtype == np.float32
+            assert np.array_equal(eps, jr.normal(enc, (8, 60))) and np.array_equal(noise, jr.normal(key_sample, (8, 38)))
+    big = np.concatenate([sk.act_noise(512, 60, 38)[0].ravel() for _ in range(4)])
+    assert abs(big.mean()) < 0.02 and abs(big.std() - 1) < 0.02

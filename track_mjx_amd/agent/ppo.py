@@ -143,7 +143,8 @@ class PPOLearner:
                  entropy_cost: float = 1e-2, discounting: float = 0.98, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
                  clipping_epsilon: float = 0.2, unroll_length: int = 20, batch_size: int = 1024, num_minibatches: int = 16,
                  num_updates_per_batch: int = 4, normalize_observations: bool = True, kl_weight: float = 0.1,
-                 seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None, use_graph: bool = True, shuffle_rng: str = "torch"):
+                 seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None, use_graph: bool = True, shuffle_rng: str = "torch",
+                 act_rng: str = "torch"):
         # `env` may be a LIST of envs (equal halves of this rank's envs): their roll-outs are then pipelined on one HIP stream
         # each (collect()), so that the tail of one half's physics kernel, its reward / observation kernels and its policy
         # inference run next to the other half's physics kernel
@@ -196,6 +197,9 @@ class PPOLearner:
         # minibatch shuffle: "torch" = torch.randperm on the device (default, nothing leaves the GPU); "jax" = the reference's own draws from
         # the seed (jax_random.SgdKeys: key plumbing of ppo.py:443-451,303-307,324 + jax.random.permutation), computed on the host
         self.sgd_keys = None
+        self.act_rng = act_rng          # "jax" (needs shuffle_rng="jax"): the roll-outs' latent / action noise = the reference's draws too
+        if act_rng not in ("torch", "jax") or (act_rng == "jax" and shuffle_rng != "jax"):
+            raise ValueError("act_rng must be 'torch' or 'jax' (the latter together with shuffle_rng='jax')")
         if shuffle_rng == "jax":
             from ..jax_random import SgdKeys
             self.sgd_keys = SgdKeys(seed, process_id=0, device_index=self.rank, local_devices=self.world)
@@ -218,8 +222,17 @@ class PPOLearner:
 
     # ---- acting (brax acting.generate_unroll / actor_step through make_inference_fn, ppo_networks.py:46-96)
     @torch.no_grad()
-    def act(self, obs: torch.Tensor, deterministic: bool = False, gen: torch.Generator | None = None):
+    def act(self, obs: torch.Tensor, deterministic: bool = False, gen: torch.Generator | None = None, draws=None):
+        """`draws` = (eps [n, latents], noise [n, A]) replaces the generator's normal draws (same-seed mode: the reference's own noise)."""
         gen = self.gen if gen is None else gen
+        if draws is not None:
+            x = self.normalizer.normalize(obs) if self.normalize_observations else obs
+            with gemm_inputs(self.matmul_dtype):
+                logits, mean, logvar = self.policy(x, eps=draws[0], deterministic=False)
+            logits = logits.float()
+            raw = NormalTanh.sample_no_postprocessing(logits, draws[1])
+            return NormalTanh.postprocess(raw), {"raw_action": raw, "log_prob": NormalTanh.log_prob(logits, raw), "logits": logits,
+                                                 "latent_mean": mean, "latent_logvar": logvar}
         if (not deterministic and self.dev.type == "cuda" and self.matmul_dtype is None and obs.dim() == 2 and obs.dtype == torch.float32):
             if self.lds_free and obs.shape[0] % 4 == 0 and obs.stride(0) == 1:     # K-major float4 loads need 4 | n_env
                 return self._act_fused(None, obs_raw=obs, gen=gen)
@@ -361,14 +374,25 @@ class PPOLearner:
         if self._streams:
             for sg in self._streams:
                 sg.wait_stream(cur)        # parameters / normaliser written by the previous update()
+        jax_noise = self.sgd_keys is not None and self.act_rng == "jax"
+        if jax_noise:
+            self.sgd_keys.start_unrolls()
         for u in range(self.unrolls):
+            if jax_noise:
+                self.sgd_keys.start_unroll()
             for t in range(T):
+                if jax_noise:      # the reference's own draws for all envs of this device, sliced per env group below (host-side: parity mode)
+                    eps_np, noise_np = self.sgd_keys.act_noise(n_local, self.policy.latents, self.policy.action_size)
+                    eps_all, noise_all = torch.from_numpy(eps_np).to(self.dev), torch.from_numpy(noise_np).to(self.dev)
                 for g, env in enumerate(self.envs):
                     sl = slice(u * n_local + offs[g], u * n_local + offs[g + 1])
                     with torch.cuda.stream(self._streams[g]) if self._streams else _nullctx():
                         st = self.states[g]
                         self.buf["observation"][t, sl] = st.obs
-                        action, extra = self._act_graphed(st.obs, g)
+                        if jax_noise:
+                            action, extra = self.act(st.obs, draws=(eps_all[offs[g]:offs[g + 1]], noise_all[offs[g]:offs[g + 1]]))
+                        else:
+                            action, extra = self._act_graphed(st.obs, g)
                         self.buf["raw_action"][t, sl] = extra["raw_action"]     # before env.step: the graph's outputs are re-used next step
                         self.buf["log_prob"][t, sl] = extra["log_prob"]
                         st = env.step(st, action)
@@ -501,7 +525,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
           intention_latent_size: int = 60, progress_fn: Callable[[int, dict], None] = lambda *a: None,
           max_training_steps: int | None = None, eval_env=None, num_eval_envs: int = 128, deterministic_eval: bool = False,
           matmul_dtype: torch.dtype | None = None, group=None, checkpoint_path: str | None = None, restore_from: str | None = None,
-          shuffle_rng: str = "torch", **unused):
+          shuffle_rng: str = "torch", act_rng: str = "torch", **unused):
     """ppo.train(environment, num_timesteps, episode_length, ...) -> (make_policy, params, metrics)  (ppo.py:128-172,809).
 
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
@@ -521,7 +545,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
                          clipping_epsilon=clipping_epsilon, unroll_length=unroll_length, batch_size=batch_size,
                          num_minibatches=num_minibatches, num_updates_per_batch=num_updates_per_batch,
                          normalize_observations=normalize_observations, kl_weight=kl_weight, seed=seed, matmul_dtype=matmul_dtype, group=group,
-                         shuffle_rng=shuffle_rng)
+                         shuffle_rng=shuffle_rng, act_rng=act_rng)
     from . import checkpoint as _ckpt
     if checkpoint_path is None and ckpt_mgr is not None:
         checkpoint_path = str(getattr(ckpt_mgr, "directory", ckpt_mgr))

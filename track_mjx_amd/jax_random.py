@@ -235,6 +235,26 @@ class SgdKeys:
         self.key_sgd, self.key_generate_unroll, self.key = split(self.key, 3, self.part)
         self._sgd_carry = self.key_sgd
 
+    # ---- acting noise of the roll-outs (parity mode: two normal() draws per control step on the host)
+    def start_unrolls(self) -> None:
+        """training_step's scan over the unrolls starts from key_generate_unroll (ppo.py:343-348)."""
+        self._unroll_carry = self.key_generate_unroll
+
+    def start_unroll(self) -> None:
+        """ppo.py:333-340: current_key, next_key = split(current_key); generate_unroll(env, state, policy, current_key, unroll_length)."""
+        self._step_carry, self._unroll_carry = split(self._unroll_carry, 2, self.part)
+
+    def act_noise(self, n_env: int, latents: int, action_size: int):
+        """One actor_step of brax's generate_unroll (third-party, restated: `current_key, next_key = split(current_key)` per step; the policy
+        gets current_key) through make_inference_fn.policy (ppo_networks.py:46-96: key_sample, key_network = split(key_sample)) and
+        IntentionNetwork.__call__ (intention_network.py:104,78-81: _, encoder_rng = split(key); eps = normal(encoder_rng, logvar.shape))
+        and NormalTanhDistribution.sample_no_postprocessing (normal(key_sample, loc.shape)).  Returns (eps [n, latents], noise [n, A])
+        for ALL envs of this device, float32."""
+        current, self._step_carry = split(self._step_carry, 2, self.part)
+        key_sample, key_network = split(current, 2, self.part)
+        _, encoder_rng = split(key_network, 2, self.part)
+        return normal(encoder_rng, (n_env, latents), self.part), normal(key_sample, (n_env, action_size), self.part)
+
     def permutation(self, n: int) -> np.ndarray:
         """The next sgd_step's row permutation (call once per update, in order)."""
         self._sgd_carry, key_perm, _key_grad = split(self._sgd_carry, 3, self.part)
