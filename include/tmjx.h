@@ -180,6 +180,15 @@ int tmjx_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *
 int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, void *stream);
 long long tmjx_gemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream);
+/* All weight (+ bias) gradients of one backward pass as ONE launch + one reduction launch: up to 16 independent problems of tmjx_gemm_dw,
+ * each with its own scratch (>= tmjx_gemm_dw_scratch_floats(M, N, K) floats) and a leading dimension `lddw` for dW (so the result can land
+ * in a row-padded view of a flat gradient buffer); dY and X need 16-byte aligned rows.  `problems` is a HOST array (copied into the launch). */
+typedef struct tmjx_dw_problem_t {
+  const float *dY, *X;
+  float *dW, *db, *scratch;       /* db may be NULL */
+  int32_t ldy, ldx, lddw, M, N, K;
+} tmjx_dw_problem_t;
+int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *problems, int n, void *stream);
 
 /* Observation normaliser update (brax running_statistics.update as called at track_mjx/agent/mlp_ppo/ppo.py:357-361; math:
  * track_mjx/agent/masked_running_statistics.py:161-214) in one pass over src [rows][W] (W % 4 == 0):

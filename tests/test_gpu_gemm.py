@@ -85,3 +85,37 @@ def test_dense_layers_use_no_library_gemm_and_match_torch_gradients():
     assert (y.double() - yr).abs().max() < 1e-4
     for a, b in zip(grads, gr):
         assert (a.double() - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, float((a.double() - b).abs().max() / b.abs().max())
+
+
+def test_grouped_weight_gradients_match_individual_problems():
+    """tmjx_gemm_dw_grouped: several layers' (dW, db) in one launch + one reduction, results written with a leading dimension (row-padded
+    flat-buffer views), against float64 — through the same recording context the learner uses."""
+    from track_mjx_amd.agent.networks import deferred_weight_grads
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M = 20480
+    shapes = [(256, 470, 696, True), (256, 256, 256, True), (120, 256, 256, True), (76, 256, 256, False), (256, 286, 288, True)]
+    probs = []
+    with deferred_weight_grads() as d:
+        for N, K, ldx, bias in shapes:
+            xb = torch.randn((M, ldx), generator=g, device=DEV)
+            x, dy = xb[:, :K], torch.randn((M, N), generator=g, device=DEV)
+            w = torch.nn.Parameter(torch.zeros((N, (K + 3) // 4 * 4), device=DEV)[:, :K])
+            w.grad = torch.full((N, (K + 3) // 4 * 4), 7.0, device=DEV)[:, :K]         # a strided destination, pre-filled: pads must stay untouched
+            b = torch.nn.Parameter(torch.zeros(N, device=DEV)) if bias else None
+            if b is not None:
+                b.grad = torch.zeros(N, device=DEV)
+            assert d.try_add(dy, x, w, b) is not None
+            probs.append((dy, x, w, b))
+        # unaligned operands are refused (the caller computes them individually)
+        assert d.try_add(torch.randn((M, 1), device=DEV), probs[1][1], torch.nn.Parameter(torch.zeros((1, 256), device=DEV)), None) is None
+    d.launch()
+    torch.cuda.synchronize()
+    for dy, x, w, b in probs:
+        ref = dy.double().t() @ x.double()
+        bound = (dy.double().abs().t() @ x.double().abs()) * EPS * (M ** 0.5 + 4) * 2
+        assert ((w.grad.double() - ref).abs() <= bound).all()
+        if w.grad.stride(0) != w.shape[1]:
+            full = torch.as_strided(w.grad, (w.shape[0], w.grad.stride(0)), (w.grad.stride(0), 1))
+            assert (full[:, w.shape[1]:] == 7.0).all()
+        if b is not None:
+            assert ((b.grad.double() - dy.double().sum(0)).abs() <= dy.double().abs().sum(0) * EPS * (M ** 0.5 + 4) * 2).all()

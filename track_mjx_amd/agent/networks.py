@@ -155,6 +155,57 @@ def _splitk_dw(dy, x, s):
     return torch.bmm(a, b).sum(0)
 
 
+class deferred_weight_grads:
+    """`with deferred_weight_grads() as d: grads = torch.autograd.grad(...)` then `d.launch()`: inside the block every dense layer's
+    backward only RECORDS its weight-gradient problem (dY, X and the parameter's flat-buffer gradient views as destinations) and hands those
+    views back to autograd as the gradients; `launch()` then computes all of them with ONE grouped launch + one reduction launch
+    (tmjx_gemm_dw_grouped), stream-ordered behind the backward pass — nothing reads the views before that.  Layers whose operands are not
+    16-byte aligned (the 1-wide value head) and parameters without a flat gradient view compute their gradient on the spot as usual."""
+    active = None
+
+    def __enter__(self):
+        self.problems, self.keep = [], []
+        deferred_weight_grads.active = self
+        return self
+
+    def __exit__(self, *a):
+        deferred_weight_grads.active = None
+        return False
+
+    @staticmethod
+    def _aligned(t):
+        return t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1
+
+    def try_add(self, dy2, x2, w, b):
+        gw, gb = w.grad, (b.grad if b is not None else None)
+        if gw is None or (b is not None and gb is None) or len(self.problems) >= 16:
+            return None
+        if not (self._aligned(dy2) and self._aligned(x2) and gw.stride(1) == 1 and gw.shape == w.shape):
+            return None
+        self.problems.append((dy2, x2, gw, gb))
+        return gw, gb
+
+    def launch(self):
+        if not self.problems:
+            return
+        import ctypes as C
+        from .. import hip as _hip
+        L = _hip.lib()
+        dev = self.problems[0][0].device
+        sizes = [int(L.tmjx_gemm_dw_scratch_floats(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _, _ in self.problems]
+        scratch = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), dtype=torch.float32, device=dev)
+        arr = (_hip.DwProblem * len(self.problems))()
+        off = 0
+        for i, (dy, x, gw, gb) in enumerate(self.problems):
+            arr[i] = _hip.DwProblem(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
+                                    scratch.data_ptr() + 4 * off, dy.stride(0), x.stride(0), gw.stride(0), dy.shape[0], dy.shape[1], x.shape[1])
+            off += (sizes[i] + 3) // 4 * 4
+        with torch.cuda.device(dev):
+            _hip.check(L.tmjx_gemm_dw_grouped(arr, len(self.problems), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_gemm_dw_grouped")
+        self.keep = [scratch]
+        self.problems = []
+
+
 class _HipDenseFn(torch.autograd.Function):
     """y = x W^T (+ b) with all three contractions on the library's MFMA kernels: forward tmjx_gemm_nt, input gradient tmjx_gemm_nn,
     weight + bias gradient tmjx_gemm_dw.  `dx_cols`: the caller only needs the gradient of the first dx_cols input columns."""
@@ -164,6 +215,7 @@ class _HipDenseFn(torch.autograd.Function):
         x2 = _rows2d(x)
         ctx.save_for_backward(x2, w)
         ctx.has_bias, ctx.dx_cols, ctx.x_shape = b is not None, dx_cols, x.shape
+        ctx.params = (w, b)                    # the Parameter objects (their .grad = the flat-buffer views a deferred gradient lands in)
         return gemm_nt(x2, w, b).view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
@@ -171,7 +223,9 @@ class _HipDenseFn(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         dy2 = _rows2d(dy)
         dx = gemm_nn(dy2, w, ctx.dx_cols).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
-        dw, db = gemm_dw(dy2, x2, ctx.has_bias)
+        d = deferred_weight_grads.active
+        got = d.try_add(dy2, x2, *ctx.params) if d is not None else None
+        dw, db = got if got is not None else gemm_dw(dy2, x2, ctx.has_bias)
         return dx, dw, db, None
 
 

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import losses as _losses
-from .networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet, gemm_inputs
+from .networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet, deferred_weight_grads, gemm_inputs
 
 
 import contextlib
@@ -68,13 +68,15 @@ class FlatGrads:
         """Write freshly computed gradients (torch.autograd.grad) into the flat buffer with one multi-tensor copy: no
         zero-fill and no per-parameter `grad += new` kernels as with loss.backward() into pre-existing .grad views."""
         grads = list(grads)
-        dense = [i for i, p in enumerate(self.params) if p.grad.is_contiguous()]
+        todo = [i for i, p in enumerate(self.params) if grads[i].data_ptr() != p.grad.data_ptr()]     # (deferred weight gradients are already in place)
+        dense = [i for i in todo if self.params[i].grad.is_contiguous()]
         # one multi-tensor kernel for the dense views; the row-padded (strided) ones separately — a single strided destination sends the
         # WHOLE foreach call down its per-tensor runtime-copy path (25 copyBuffer nodes per SGD step, +0.12 ms)
-        torch._foreach_copy_([self.params[i].grad for i in dense], [grads[i] for i in dense])
-        for i, p in enumerate(self.params):
-            if not p.grad.is_contiguous():
-                p.grad.copy_(grads[i])
+        if dense:
+            torch._foreach_copy_([self.params[i].grad for i in dense], [grads[i] for i in dense])
+        for i in todo:
+            if not self.params[i].grad.is_contiguous():
+                self.params[i].grad.copy_(grads[i])
 
     def all_reduce_mean(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -435,9 +437,12 @@ class PPOLearner:
                 # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
                 m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,
                                                                          side_stream=self._sgd_side, **self.hp)
-                grads = torch.autograd.grad(outs, self.grads.params, grad_outputs=gouts)
+                with deferred_weight_grads() as dwg:
+                    grads = torch.autograd.grad(outs, self.grads.params, grad_outputs=gouts)
                 if self._sgd_side is not None:
                     torch.cuda.current_stream(self.dev).wait_stream(self._sgd_side)     # the value net's backward ran there
+                dwg.launch()             # every layer's (dW, db) in one grouped launch, straight into the flat gradient buffer
+                self._dwg = dwg          # (keeps the slab scratch alive until the next step)
                 self.grads.assign(grads)
                 return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
             loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp,

@@ -59,6 +59,7 @@ __device__ __forceinline__ gf4 gemm_mask4(gf4 v, int mask) {
 }
 
 // LLVM SchedGroupMask values for __builtin_amdgcn_sched_group_barrier
+#define GEMM_SGB(a, b, c) __builtin_amdgcn_sched_group_barrier(a, b, c)
 #define SG_VALU 0x2
 #define SG_MFMA 0x8
 #define SG_DS_READ 0x100
@@ -165,26 +166,26 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     mma(F0);
 #pragma unroll
     for (int i = 0; i < NFR; i++) {
-      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+      GEMM_SGB(SG_MFMA, 1, 0);
+      GEMM_SGB(SG_DS_READ, 1, 0);
     }
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
-      __builtin_amdgcn_sched_group_barrier(SG_MFMA, (NMFMA - NFR) / (NPASS + 1), 0);
-      __builtin_amdgcn_sched_group_barrier(SG_VALU, 12, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DS_WRITE, 1, 0);
+      GEMM_SGB(SG_MFMA, (NMFMA - NFR) / (NPASS + 1), 0);
+      GEMM_SGB(SG_VALU, 12, 0);
+      GEMM_SGB(SG_DS_WRITE, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(SG_MFMA, NMFMA, 0);
+    GEMM_SGB(SG_MFMA, NMFMA, 0);
     __syncthreads();
     fread(F0, stage ^ 1, 0);
     gload(RW, k_next3);
     mma(F1);
 #pragma unroll
     for (int i = 0; i < NFR; i++) {
-      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+      GEMM_SGB(SG_MFMA, 1, 0);
+      GEMM_SGB(SG_DS_READ, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(SG_MFMA, NMFMA, 0);
+    GEMM_SGB(SG_MFMA, NMFMA, 0);
   };
   const int nk = (K + GEMM_BK - 1) / GEMM_BK;
 #ifdef GEMM_PROF
@@ -240,15 +241,15 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #define DW_BM 32             // rows of M per LDS stage
 #define DW_LD (DW_BT + 16)   // floats per LDS row: 16 mod 32, lanes of kq and kq + 1 read banks 16 apart
 template <bool YVEC, bool XVEC>
-__global__ __launch_bounds__(512) void k_gemm_dw(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx, float *__restrict__ slabs,
-                                                 int M, int N, int K, int with_bias, int rows_per_split, int ld_slab) {
+__device__ __forceinline__ void gemm_dw_tile(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx, float *__restrict__ slabs,
+                                             int M, int N, int K, int with_bias, int rows_per_split, int ld_slab, int tile_n, int tile_k, int split) {
   // 8 waves (two per SIMD), each 64 (n) x 32 (k) of the 128 x 128 tile: 4 x 2 tiles of 16 x 16.  Same pipeline as k_gemm_act: two register
   // sets for the staged rows, ONE barrier in the middle of a 32-row step, MFMAs on both sides of it with the fragment reads, the
   // masking + LDS writes and the global loads spread between them.
   constexpr int STAGE = 2 * DW_BM * DW_LD;
   extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * DW_BT, k0 = blockIdx.y * DW_BT, split = blockIdx.z;
+  const int n0 = tile_n * DW_BT, k0 = tile_k * DW_BT;
   const int r_begin = split * rows_per_split, r_end = min(M, r_begin + rows_per_split);
   const int wn = (wave >> 2) * 64, wk = (wave & 3) * 32;
   struct Stage { gf4 y[2], x[2]; int my[2], mx[2]; };
@@ -298,31 +299,15 @@ __global__ __launch_bounds__(512) void k_gemm_dw(const float *__restrict__ dY, i
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s][a], F.b[s][b], acc[a][b], 0, 0, 0);
   };
+  // (no sched_group_barrier pinning here: measured 4-9 % faster with the compiler's own interleave of these six-read steps)
   auto mstep = [&](Frag &F0, Frag &F1, Stage &RW, int stage, int r_next3) {
     fread(F1, stage, 1);
     swrite(RW, stage ^ 1);
     mma(F0);
-#pragma unroll
-    for (int i = 0; i < 24; i++) {
-      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_VALU, 12, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DS_WRITE, 1, 0);
-    }
     __syncthreads();
     fread(F0, stage ^ 1, 0);
     gload(RW, r_next3);
     mma(F1);
-#pragma unroll
-    for (int i = 0; i < 24; i++) {
-      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 8, 0);
   };
   const int nt = (r_end - r_begin + DW_BM - 1) / DW_BM;
   if (nt > 0) {
@@ -340,7 +325,7 @@ __global__ __launch_bounds__(512) void k_gemm_dw(const float *__restrict__ dY, i
     }
   }
   float *out = slabs + (size_t)split * (size_t)N * ld_slab;
-  if (with_bias && blockIdx.y == 0) {          // (uniform per workgroup) thread t holds columns 4 (t & 31) .. + 3 of the rows t / 32 + 16 j
+  if (with_bias && tile_k == 0) {          // (uniform per workgroup) thread t holds columns 4 (t & 31) .. + 3 of the rows t / 32 + 16 j
     __syncthreads();                           // every wave is done with the stages
     float *red = gemm_lds;
     *reinterpret_cast<gf4 *>(red + (t >> 5) * DW_BT + 4 * (t & 31)) = colacc;
@@ -364,12 +349,16 @@ __global__ __launch_bounds__(512) void k_gemm_dw(const float *__restrict__ dY, i
       }
     }
 }
+template <bool YVEC, bool XVEC>
+__global__ __launch_bounds__(512) void k_gemm_dw(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx, float *__restrict__ slabs,
+                                                 int M, int N, int K, int with_bias, int rows_per_split, int ld_slab) {
+  gemm_dw_tile<YVEC, XVEC>(dY, ldy, X, ldx, slabs, M, N, K, with_bias, rows_per_split, ld_slab, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 // dW[n][k] = sum over slabs; db[n] = the slabs' column K.  One lane per output element, slabs walked with 8 loads in flight.
-__global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ slabs, float *__restrict__ dW, float *__restrict__ db, int S, int N, int K,
-                                                   int with_bias, int ld_slab) {
+__device__ __forceinline__ void dw_reduce_elem(const float *__restrict__ slabs, float *__restrict__ dW, float *__restrict__ db, int S, int N, int K,
+                                               int with_bias, int ld_slab, int lddw, long long i) {
   const int Kx = K + (with_bias ? 1 : 0);
-  const long long total = (long long)N * Kx, i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  if (i >= (long long)N * Kx) return;
   const int n = (int)(i / Kx), k = (int)(i % Kx);
   const float *p = slabs + (size_t)n * ld_slab + k;
   const size_t step = (size_t)N * ld_slab;
@@ -381,5 +370,35 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ sla
   }
   for (; s < S; s++) a[0] += p[(size_t)s * step];
   const float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  if (k < K) dW[(size_t)n * K + k] = v; else db[n] = v;
+  if (k < K) dW[(size_t)n * lddw + k] = v; else db[n] = v;
+}
+__global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ slabs, float *__restrict__ dW, float *__restrict__ db, int S, int N, int K,
+                                                   int with_bias, int ld_slab, int lddw) {
+  dw_reduce_elem(slabs, dW, db, S, N, K, with_bias, ld_slab, lddw, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// ---- all weight gradients of a backward pass as ONE launch (+ one reduction launch): the per-layer problems are independent once the
+// backward chain has produced every dY, each is a single round of workgroups with a short K loop (5 .. 20 row tiles), so launched one by
+// one their fixed costs (launch gap, pipeline fill, drain, the reduction's own launch) add up to a third of the time; side by side the
+// workgroups of one problem fill the gaps of the next.  The problem table travels BY VALUE in the kernel arguments (hipGraph-safe).
+#define DW_GROUP_MAX 16
+struct DwProblem {
+  const float *dY, *X;
+  float *dW, *db, *slabs;
+  int ldy, ldx, lddw, M, N, K, rows_per_split, S, ld_slab, tiles_n, tiles_k;
+  int wg_begin, red_begin;          // first workgroup of this problem in the grouped launch / in the grouped reduction
+};
+struct DwGroup { DwProblem p[DW_GROUP_MAX]; int n; };
+__global__ __launch_bounds__(512) void k_gemm_dw_grouped(const DwGroup G) {
+  int i = 0;
+  for (int j = 1; j < G.n; j++) if ((int)blockIdx.x >= G.p[j].wg_begin) i = j;       // uniform
+  const DwProblem &P = G.p[i];
+  const int local = blockIdx.x - P.wg_begin, tiles = P.tiles_n * P.tiles_k, split = local / tiles, tl = local % tiles;
+  gemm_dw_tile<true, true>(P.dY, P.ldy, P.X, P.ldx, P.slabs, P.M, P.N, P.K, P.db != nullptr, P.rows_per_split, P.ld_slab, tl / P.tiles_k, tl % P.tiles_k, split);
+}
+__global__ __launch_bounds__(256) void k_dw_reduce_grouped(const DwGroup G) {
+  int i = 0;
+  for (int j = 1; j < G.n; j++) if ((int)blockIdx.x >= G.p[j].red_begin) i = j;
+  const DwProblem &P = G.p[i];
+  dw_reduce_elem(P.slabs, P.dW, P.db, P.S, P.N, P.K, P.db != nullptr, P.ld_slab, P.lddw, (long long)(blockIdx.x - P.red_begin) * 256 + threadIdx.x);
 }

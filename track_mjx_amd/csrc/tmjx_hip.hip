@@ -733,8 +733,40 @@ int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, f
   else rc = launch_gemm_dw<false, false>(dY, ldy, X, ldx, scratch, M, N, K, db ? 1 : 0, rps, S, ld, s);
   if (rc) return rc;
   const long long total = (long long)N * (K + (db ? 1 : 0));
-  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)scratch, dW, db, S, N, K, db ? 1 : 0, ld);
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)scratch, dW, db, S, N, K, db ? 1 : 0, ld, K);
   return check_launch("k_gemm_dw");
+}
+
+int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
+  if (!probs) return fail(TMJX_EINVAL, "null argument");
+  if (n < 1 || n > DW_GROUP_MAX) return fail(TMJX_EINVAL, "1 .. 16 problems per group");
+  DwGroup G;
+  G.n = n;
+  int wg = 0, red = 0;
+  for (int i = 0; i < n; i++) {
+    const tmjx_dw_problem_t &q = probs[i];
+    if (!q.dY || !q.X || !q.dW || !q.scratch) return fail(TMJX_EINVAL, "null pointer in a problem");
+    if (q.M < 1 || q.N < 1 || q.K < 1 || q.ldy < q.N || q.ldx < q.K || q.lddw < q.K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions in a problem");
+    if (!aligned16(q.dY, q.ldy) || !aligned16(q.X, q.ldx)) return fail(TMJX_EINVAL, "grouped weight gradients need 16-byte aligned rows of dY and X");
+    DwProblem &P = G.p[i];
+    P.dY = q.dY; P.X = q.X; P.dW = q.dW; P.db = q.db; P.slabs = q.scratch;
+    P.ldy = q.ldy; P.ldx = q.ldx; P.lddw = q.lddw; P.M = q.M; P.N = q.N; P.K = q.K;
+    dw_split(q.M, q.N, q.K, &P.rows_per_split, &P.S, &P.ld_slab);
+    P.tiles_n = (q.N + DW_BT - 1) / DW_BT; P.tiles_k = (q.K + DW_BT - 1) / DW_BT;
+    P.wg_begin = wg; wg += P.tiles_n * P.tiles_k * P.S;
+    P.red_begin = red; red += (int)(((long long)q.N * (q.K + (q.db ? 1 : 0)) + 255) / 256);
+  }
+  constexpr size_t lds = 2 * sizeof(float) * 2 * DW_BM * DW_LD;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_dw_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_dw_grouped): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(wg), dim3(512), lds, s, G);
+  hipLaunchKernelGGL(k_dw_reduce_grouped, dim3(red), dim3(256), 0, s, G);
+  return check_launch("k_gemm_dw_grouped");
 }
 
 int tmjx_stats_scratch_floats(int W) { return STATS_SLABS * 2 * W; }

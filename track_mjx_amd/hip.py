@@ -31,8 +31,14 @@ class Layout(C.Structure):
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
-           "tmjx_gemm_nt", "tmjx_gemm_nn", "tmjx_gemm_dw", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
+           "tmjx_gemm_nt", "tmjx_gemm_nn", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
+
+
+class DwProblem(C.Structure):
+    """tmjx_dw_problem_t (include/tmjx.h)."""
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("scratch", C.c_void_p),
+                ("ldy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
 
 
 class PpoCfg(C.Structure):
@@ -110,6 +116,7 @@ def load(path: Path):
     sig.setdefault("tmjx_gemm_dw_scratch_floats", [None, None])[0] = [C.c_int, C.c_int, C.c_int]
     sig.setdefault("tmjx_gemm_dw_scratch_floats", [None, None])[1] = C.c_longlong
     sig.setdefault("tmjx_gemm_dw", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_gemm_dw_grouped", [None, None])[0] = [C.POINTER(DwProblem), C.c_int, vp]
     sig.setdefault("tmjx_set_wrappers", [None, None])[0] = [vp, C.c_int, C.c_int]
     sig.setdefault("tmjx_stats_scratch_floats", [None, None])[0] = [C.c_int]
     sig.setdefault("tmjx_stats_sums", [None, None])[0] = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]
