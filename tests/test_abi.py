@@ -80,3 +80,27 @@ def test_physics_kernel_resources_allow_ten_envs_per_cu(tmp_path):
     sp = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", after).group(1))
     scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", after).group(1))
     assert vg <= 168 and sp == 0 and scratch == 0, (vg, sp, scratch)
+
+
+def test_argument_validation_of_the_learner_entry_points_without_gpu():
+    """Every entry point validates before it launches: null pointers, empty or inconsistent sizes and group counts return TMJX_EINVAL
+    (-22) with a message — no compute call is made (runs in the GPU-less build container)."""
+    L = hip.lib()
+    vp = ctypes.c_void_p
+    one = vp(16)            # a non-null, 16-byte aligned dummy that is never dereferenced: validation fails first
+    assert L.tmjx_gemm_nt(None, 4, one, 4, None, one, 4, 1, 1, 1, None) == -22
+    assert L.tmjx_gemm_nt(one, 4, one, 4, None, one, 4, 0, 4, 4, None) == -22            # M = 0: empty input
+    assert L.tmjx_gemm_nt(one, 2, one, 4, None, one, 4, 4, 4, 4, None) == -22            # lda < K
+    assert L.tmjx_gemm_nn(one, 4, one, 2, one, 4, 4, 4, 4, None) == -22                  # ldw < N
+    assert L.tmjx_gemm_dw(one, 4, one, 4, None, None, one, 4, 4, 4, None) == -22
+    assert L.tmjx_gemm_dw_scratch_floats(0, 4, 4) == 0 and L.tmjx_gemm_dw_scratch_floats(20480, 256, 256) > 0
+    assert L.tmjx_gemm_dw_grouped(None, 1, None) == -22
+    arr = (hip.DwProblem * 1)()
+    assert L.tmjx_gemm_dw_grouped(arr, 0, None) == -22 and L.tmjx_gemm_dw_grouped(arr, 17, None) == -22
+    assert L.tmjx_gemm_dw_grouped(arr, 1, None) == -22                                   # null pointers inside the problem
+    arr[0] = hip.DwProblem(8, 16, 16, None, 16, 4, 4, 4, 4, 4, 4)                        # dY not 16-byte aligned
+    assert L.tmjx_gemm_dw_grouped(arr, 1, None) == -22 and b"aligned" in L.tmjx_last_error()
+    assert L.tmjx_stats_sums(one, one, one, one, 10, 6, None) == -22                     # W not a multiple of 4
+    assert L.tmjx_stats_apply(one, 0.0, one, one, one, one, 4, 1e-6, 1e6, None) == -22   # n_added must be positive
+    assert L.tmjx_set_wrappers(None, 195, 1) == -22
+    assert L.tmjx_last_error()

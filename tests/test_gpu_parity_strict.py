@@ -335,3 +335,30 @@ def test_same_seed_rng_mode_rollout_noise_and_shuffles():
     assert np.array_equal(A.perm_fn(0, rows).numpy(), expect)
     m = A.update(1)
     assert all(bool(torch.isfinite(v).all()) for v in m.values())
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 65, 100])
+def test_ragged_env_counts_match_oracle(n):
+    """Env counts that are not multiples of the wavefront / vector widths (1, 3, 63, 65, 100): reset, two gentle steps and one violent step
+    through the C-ABI against the oracle — every env, no padding artefacts at the tail of a launch."""
+    env, O, cl = make_env_and_oracle(num_envs=n, wrappers=True)
+    g = torch.Generator().manual_seed(n)
+    clip = torch.randint(0, 4, (n,), generator=g, dtype=torch.int32); start = torch.randint(0, 44, (n,), generator=g, dtype=torch.int32)
+    qn = (torch.rand((74, n), generator=g) * 2 - 1) * 1e-3; vn = (torch.rand((73, n), generator=g) * 2 - 1) * 1e-3
+    st = env.reset(g, clip, start_frame=start, qpos_noise=qn, qvel_noise=vn)
+    envs = O.new_envs(n)
+    for e in range(n):
+        O.env_reset(envs, e, int(clip[e]), int(start[e]), qn[:, e].numpy(), vn[:, e].numpy())
+    assert rel_err(st.obs.cpu().numpy(), np.stack([O.env_get(envs, e, "obs") for e in range(n)], 0)) < 1e-5
+    for s in range(2):
+        a = (torch.randn((38, n), generator=g) * 0.03).clamp(-1, 1)
+        st = env.step(st, a.to(DEV)); torch.cuda.synchronize()
+        for e in range(n):
+            O.env_step(envs, e, a[:, e].numpy())
+        obs_o = np.stack([O.env_get(envs, e, "obs") for e in range(n)], 0)
+        assert st.obs.shape == (n, 696) and rel_err(st.obs.cpu().numpy(), obs_o) < 2e-4
+        assert np.abs(st.reward.cpu().numpy() - np.array([O.env_get(envs, e, "reward")[0] for e in range(n)])).max() < 1e-4
+        assert np.array_equal(st.done.cpu().numpy(), np.array([O.env_get(envs, e, "done")[0] for e in range(n)], dtype=np.float32))
+    a = torch.randn((38, n), generator=g).clamp(-1, 1)
+    st = env.step(st, a.to(DEV)); torch.cuda.synchronize()
+    assert torch.isfinite(st.obs).all() and torch.isfinite(st.reward).all() and st.done.shape == (n,)
