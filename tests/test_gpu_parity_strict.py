@@ -362,3 +362,41 @@ def test_ragged_env_counts_match_oracle(n):
     a = torch.randn((38, n), generator=g).clamp(-1, 1)
     st = env.step(st, a.to(DEV)); torch.cuda.synchronize()
     assert torch.isfinite(st.obs).all() and torch.isfinite(st.reward).all() and st.done.shape == (n,)
+
+
+def test_free_running_statistics_in_the_bench_regime():
+    """Free-running (NOT teacher-forced) roll-out under policy-scale actions, 256 envs x 12 control steps: trajectories diverge chaotically
+    env by env, so what is compared is the POPULATION — episode-end rate per step, reward quantiles, mean tracking
+    distances — between the HIP path and the float32 oracle on identical inputs (observed: episode ends per step 0.155 / 0.157, reward median 0.416 / 0.429).  After the first control step the typical env is
+    still compared one to one."""
+    n, steps = 256, 12
+    env, O, cl = make_env_and_oracle(num_envs=n, wrappers=True)
+    g = torch.Generator().manual_seed(21)
+    clip = torch.randint(0, 4, (n,), generator=g, dtype=torch.int32); start = torch.randint(0, 44, (n,), generator=g, dtype=torch.int32)
+    qn = (torch.rand((74, n), generator=g) * 2 - 1) * 1e-3; vn = (torch.rand((73, n), generator=g) * 2 - 1) * 1e-3
+    st = env.reset(g, clip, start_frame=start, qpos_noise=qn, qvel_noise=vn)
+    envs = O.new_envs(n)
+    for e in range(n):
+        O.env_reset(envs, e, int(clip[e]), int(start[e]), qn[:, e].numpy(), vn[:, e].numpy())
+    done_h, done_o, rew_h, rew_o, jd_h, jd_o = [], [], [], [], [], []
+    for s in range(steps):
+        a = (torch.randn((38, n), generator=g) * 0.3).clamp(-1, 1)
+        st = env.step(st, a.to(DEV)); torch.cuda.synchronize()
+        O.env_step_batch(envs, n, np.ascontiguousarray(a.t().numpy(), dtype=np.float64), 8)
+        r_o = np.array([O.env_get(envs, e, "reward")[0] for e in range(n)])
+        d_o = np.array([O.env_get(envs, e, "done")[0] for e in range(n)])
+        m_o = np.stack([O.env_get(envs, e, "metrics") for e in range(n)], 0)
+        if s == 0:      # one control step from identical states: the typical env still agrees closely even at this action scale
+            dr = np.abs(st.reward.cpu().numpy() - r_o)
+            print(f"\nstep 1 reward |diff|: median {np.median(dr):.2e} 90th pct {np.quantile(dr, .9):.2e} max {dr.max():.2e}; done flags differing: {int((st.done.cpu().numpy() != d_o).sum())}")
+            assert np.median(dr) < 1e-3 and (st.done.cpu().numpy() != d_o).mean() <= 0.02
+        done_h.append(float(st.done.mean())); done_o.append(float(d_o.mean()))
+        rew_h.append(st.reward.cpu().numpy()); rew_o.append(r_o)
+        jd_h.append(float(np.nanmedian(env.metrics_buf[15].cpu().numpy()))); jd_o.append(float(np.nanmedian(m_o[:, 15])))      # (median: exploding envs carry inf / NaN distances on both sides)
+    rew_h, rew_o = np.concatenate(rew_h), np.concatenate(rew_o)
+    print(f"\\nfree-running, 0.3-scaled actions: episode ends per step HIP {np.mean(done_h):.4f} oracle {np.mean(done_o):.4f}; reward median {np.median(rew_h):.4f} / {np.median(rew_o):.4f}, "
+          f"10th pct {np.quantile(rew_h, .1):.4f} / {np.quantile(rew_o, .1):.4f}; median joint distance {np.mean(jd_h):.4f} / {np.mean(jd_o):.4f}")
+    assert abs(np.mean(done_h) - np.mean(done_o)) <= 0.02 + 0.25 * np.mean(done_o)
+    for q in (0.1, 0.5, 0.9):
+        assert abs(np.quantile(rew_h, q) - np.quantile(rew_o, q)) <= 0.05 * (abs(np.quantile(rew_o, q)) + 1)
+    assert abs(np.mean(jd_h) - np.mean(jd_o)) <= 0.05 * np.mean(jd_o) + 1e-3

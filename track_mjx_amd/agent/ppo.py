@@ -337,7 +337,7 @@ class PPOLearner:
         """act() replayed as one hipGraph per env group.  Valid while `obs` is the group's persistent observation buffer (same
         pointer every step); falls back to eager launches otherwise."""
         gen = self.gens[g]
-        if not (self.use_graph and self.dev.type == "cuda"):
+        if not (self.use_graph and self.dev.type == "cuda") or os.environ.get("TMJX_NO_ACT_GRAPH"):
             return self.act(obs, gen=gen)
         key = (obs.data_ptr(), tuple(obs.shape), tuple(obs.stride()))
         ent = self._act_graphs.get(g)
