@@ -103,7 +103,10 @@ def main():
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    if world > 1:
+    # TMJX_COLLECTIVES_ALWAYS=1 under torch.distributed.run with ONE rank: RCCL is initialised and C1 / C2 / the timing reductions are
+    # issued on the one-rank group — the multi-GPU call path on a single-GPU box (the numbers equal the plain N=1 run's)
+    use_dist = world > 1 or ("RANK" in os.environ and bool(os.environ.get("TMJX_COLLECTIVES_ALWAYS")))
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     cfg = _config.default_config()
@@ -144,12 +147,12 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
     ranks_seen = 1
-    if world > 1:      # one RCCL all-reduce before the timed region: every rank contributes 1 (and the communicator is warm)
+    if use_dist:      # one RCCL all-reduce before the timed region: every rank contributes 1 (and the communicator is warm)
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
@@ -163,7 +166,7 @@ def main():
         split_ev.append(ev3)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -279,7 +282,7 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

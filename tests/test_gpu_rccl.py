@@ -1,0 +1,65 @@
+"""RCCL on the hardware that is there: a ONE-rank nccl (= RCCL) process group with the collectives of the training step forced on
+(TMJX_COLLECTIVES_ALWAYS=1).  All-reduces over one rank are identities, so the learner must end up where the plain single-process learner
+does — what this covers is the call path no CPU test can: RCCL initialisation on the GPU, C1 (the flat-gradient all-reduce) issued between
+replays of the captured SGD-step hipGraph with the RCCL watchdog thread alive (capture_error_mode="thread_local"), and C2 (the running
+statistics' sums) between the two K6 kernels.  Reference: track_mjx/agent/mlp_ppo/ppo.py:357-361 (pmean of the statistics), :409 (pmean of
+the gradients).  The N > 1 arithmetic is covered on CPU by tests/test_distributed_cpu.py (gloo, world_size 2)."""
+import os
+import socket
+
+import pytest
+import torch
+
+from tests.common import make_env_and_oracle
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _learner(seed_env):
+    from track_mjx_amd.agent import ppo
+    envs = [make_env_and_oracle(num_envs=64, n_clips=4, wrappers=True, seed=seed_env + k)[0] for k in range(2)]
+    L = ppo.PPOLearner(envs, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=5,
+                       batch_size=32, num_minibatches=4, num_updates_per_batch=2, seed=3, normalize_observations=True)
+    for k, e in enumerate(envs):
+        L.states[k] = e.reset(torch.Generator().manual_seed(10 + k))
+    return L
+
+
+@pytest.mark.gpu
+def test_training_step_with_rccl_collectives_on_one_rank(monkeypatch):
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    plain = _learner(0)
+    assert not plain.collectives
+    for it in range(2):
+        plain.training_step(it)
+    torch.cuda.synchronize()
+    want = plain.opt.flat.clone()
+    want_mean = plain.normalizer.mean.clone()
+
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        monkeypatch.setenv("TMJX_COLLECTIVES_ALWAYS", "1")
+        ones = torch.ones(4, device=dev)
+        dist.all_reduce(ones)
+        assert ones.tolist() == [1.0] * 4
+        L = _learner(0)
+        assert L.collectives and L.world == 1 and L.use_graph
+        for it in range(2):
+            m = L.training_step(it)
+        torch.cuda.synchronize()
+        assert L._graph is not None, "the SGD step must still run as a captured graph with RCCL initialised"
+        assert all(bool(torch.isfinite(v).all()) for v in m.values())
+        dp = (L.opt.flat - want).abs().max().item()
+        dm = (L.normalizer.mean - want_mean).abs().max().item()
+        print(f"\n[rccl one rank] max |param diff| vs plain learner {dp:.3e}, max |obs-mean diff| {dm:.3e}")
+        assert dm <= 1e-6 * (1 + want_mean.abs().max().item())
+        assert dp <= 1e-5, "identity collectives changed the training step"
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -78,8 +78,9 @@ class FlatGrads:
             if not self.params[i].grad.is_contiguous():
                 self.params[i].grad.copy_(grads[i])
 
-    def all_reduce_mean(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def all_reduce_mean(self, group=None, force: bool = False):
+        """`force`: issue the collective on a one-rank group too (identity) — lets a single-GPU box exercise the RCCL call path."""
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
 
@@ -155,6 +156,9 @@ class PPOLearner:
         self.env, self.group = env, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # C1 / C2 are issued when there is more than one rank; TMJX_COLLECTIVES_ALWAYS=1 also issues them on a one-rank process group
+        # (identities), so that the RCCL + hipGraph interplay of the training step can be run on a single-GPU box (tests/test_gpu_rccl.py)
+        self.collectives = self.world > 1 or bool(dist.is_available() and dist.is_initialized() and os.environ.get("TMJX_COLLECTIVES_ALWAYS"))
         dev = env.device
         self.dev = dev
         n_local = sum(e.num_envs for e in self.envs)
@@ -477,7 +481,7 @@ class PPOLearner:
 
     def update(self, it: int = 0, kl_schedule: Callable | None = None) -> dict:
         if self.normalize_observations:
-            self.normalizer.update(self.buf["observation"], group=self.group, distributed=self.world > 1)     # C2 (group None = default group)
+            self.normalizer.update(self.buf["observation"], group=self.group, distributed=self.collectives)     # C2 (group None = default group)
         kl_w = kl_schedule(it) if kl_schedule is not None else self.kl_weight
         rows = self.buf["reward"].shape[1]
         use_graph = self.use_graph and self.dev.type == "cuda"
@@ -500,7 +504,7 @@ class PPOLearner:
                     out = self._g_out
                 else:
                     out = self._minibatch_grads(idx, kl_w)
-                self.grads.all_reduce_mean(self.group)       # C1: one RCCL all-reduce per minibatch step
+                self.grads.all_reduce_mean(self.group, force=self.collectives)       # C1: one RCCL all-reduce per minibatch step
                 self.opt.step()                               # clip_by_global_norm(10.0) -> adam (ppo.py:517-520), one fused launch
                 acc += out
         acc /= self.num_updates * self.num_minibatches
