@@ -178,6 +178,13 @@ int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_a
  *                 scratch >= tmjx_gemm_dw_scratch_floats(M, N, K) floats (row-range slabs, reduced by a second launch). */
 int tmjx_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream);
 int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, void *stream);
+/* One Dense -> SiLU -> LayerNorm block of the intention network (intention_network.py:32-40,68-74) forward in ONE launch, for layers exactly
+ * one tile wide (N = 64, 128 or 256) with 16-byte aligned operand rows (tmjx_gemm_nt_silu_ln_ok says whether a call qualifies):
+ *   Z = A W^T (no bias: the operand of tmjx_silu_ln_bwd), Y = LayerNorm(silu(Z + bias)) * gamma + beta, stats[row] = (mean, 1 / std).
+ * Same arithmetic as tmjx_gemm_nt followed by tmjx_silu_ln_fwd. */
+int tmjx_gemm_nt_silu_ln_ok(const float *A, int lda, const float *W, int ldw, int N);
+int tmjx_gemm_nt_silu_ln(const float *A, int lda, const float *W, int ldw, const float *bias, const float *gamma, const float *beta, float *Z, float *Y,
+                         int ldc, float *stats, int M, int N, int K, float eps, void *stream);
 long long tmjx_gemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream);
 /* All weight (+ bias) gradients of one backward pass as ONE launch + one reduction launch: up to 16 independent problems of tmjx_gemm_dw,

@@ -119,3 +119,44 @@ def test_grouped_weight_gradients_match_individual_problems():
             assert (full[:, w.shape[1]:] == 7.0).all()
         if b is not None:
             assert ((b.grad.double() - dy.double().sum(0)).abs() <= dy.double().abs().sum(0) * EPS * (M ** 0.5 + 4) * 2).all()
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(20480, 256, 470, 696), (20480, 256, 286, 288), (20480, 128, 256, 256), (1000, 64, 100, 100), (77, 256, 36, 36)])
+def test_fused_dense_silu_layernorm_block(M, N, K, lda, monkeypatch):
+    """tmjx_gemm_nt_silu_ln (the SiLU + LayerNorm epilogue on the GEMM tile) against the two-launch path (tmjx_gemm_nt + tmjx_silu_ln_fwd)
+    and against float64 torch, forward and every gradient (reference block: intention_network.py:32-40 Dense -> silu -> LayerNorm)."""
+    from track_mjx_amd.agent import networks as nw
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    buf = torch.randn((M, lda), generator=g, device=DEV)
+    blk = nw._Block(K, N).to(DEV)
+    with torch.no_grad():
+        wpad = torch.zeros((N, (K + 3) // 4 * 4), device=DEV)          # rows 16-byte aligned, as in the learner's flat parameter buffer
+        wpad[:, :K] = blk.dense.weight
+        blk.dense.weight.data = wpad[:, :K]
+        blk.dense.bias.copy_(torch.randn(N, generator=g, device=DEV) * 0.3)
+        blk.norm.weight.copy_(1 + 0.2 * torch.randn(N, generator=g, device=DEV))
+        blk.norm.bias.copy_(0.2 * torch.randn(N, generator=g, device=DEV))
+    cot = torch.randn((M, N), generator=g, device=DEV)
+
+    def run(fused):
+        if fused:
+            monkeypatch.setenv("TMJX_FUSED_BLOCK", "1")
+        else:
+            monkeypatch.delenv("TMJX_FUSED_BLOCK", raising=False)
+        x = buf[:, :K].detach().requires_grad_(True)
+        assert nw._block_fusable(x, blk.dense.weight) == fused
+        y = blk(x)
+        grads = torch.autograd.grad(y, [x, blk.dense.weight, blk.dense.bias, blk.norm.weight, blk.norm.bias], cot)
+        return [y.detach()] + [t.detach() for t in grads]
+
+    got, two = run(True), run(False)
+    x64 = buf[:, :K].double().detach().requires_grad_(True)
+    p64 = [p.detach().double().requires_grad_(True) for p in (blk.dense.weight, blk.dense.bias, blk.norm.weight, blk.norm.bias)]
+    y64 = torch.nn.functional.layer_norm(torch.nn.functional.silu(x64 @ p64[0].t() + p64[1]), (N,), p64[2], p64[3], 1e-6)
+    ref = [y64.detach()] + list(torch.autograd.grad(y64, [x64] + p64, cot.double()))
+    names = ["y", "dx", "dW", "db", "dgamma", "dbeta"]
+    for name, a, b, r in zip(names, got, two, ref):
+        scale = r.abs().max().item() + 1e-30
+        e_f, e_t = (a.double() - r).abs().max().item() / scale, (b.double() - r).abs().max().item() / scale
+        print(f"{name}: fused {e_f:.2e}  two-launch {e_t:.2e} (rel. to max |ref|)")
+        assert e_f <= max(3 * e_t, 2e-6), name

@@ -1,0 +1,7 @@
+# usage: tools/_ab_env.sh "<ENV=1 ...>" "<ENV=...>" ... : bench line per environment setting
+for cfg in "$@"; do
+  echo "== [$cfg]"; env $cfg python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rollout-only 2>gpurun_out/err.txt | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']
+print('value %.0f rollout_ms %.1f sgd_ms %.1f' % (d['value'], c['rollout_ms_per_step'], c['sgd_ms_per_step']))" || tail -5 gpurun_out/err.txt
+done

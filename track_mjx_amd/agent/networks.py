@@ -18,6 +18,7 @@ tests) take plain torch ops.
 from __future__ import annotations
 
 import math
+import os
 from typing import Sequence
 
 import torch
@@ -341,6 +342,62 @@ class _SiluLayerNormFn(torch.autograd.Function):
         return dz, grads[2], grads[0], grads[1], None
 
 
+def _block_fusable(x2, w) -> bool:
+    """One-launch forward of a Dense -> SiLU -> LayerNorm block: layers exactly one GEMM tile wide (64 / 128 / 256) with aligned operands.
+    OPT-IN (TMJX_FUSED_BLOCK=1): measured on MI355X the fused launch is SLOWER than GEMM + tmjx_silu_ln_fwd (47.1 vs 44.9 us at 20480 x 256 x 256,
+    76.3 vs 68.8 us at K = 470; SGD half 84.5 vs 81.6 ms): all 256 workgroups reach the epilogue together, so its 40 exp + divisions per lane and the
+    second 21 MB store run with the matrix pipe idle, while the separate memory-bound kernel (9 us) overlaps the value network's GEMMs on the other
+    stream.  Kept (and tested) as the one-launch form of the block."""
+    if not _hip_gemm_ok(x2, w) or not os.environ.get("TMJX_FUSED_BLOCK"):
+        return False
+    from .. import hip as _hip
+    import ctypes as C
+    return bool(_hip.lib().tmjx_gemm_nt_silu_ln_ok(C.c_void_p(x2.data_ptr()), x2.stride(0), C.c_void_p(w.data_ptr()), w.stride(0), w.shape[0]))
+
+
+class _HipBlockFn(torch.autograd.Function):
+    """y = LayerNorm(silu(x W^T + b)): forward ONE launch (tmjx_gemm_nt_silu_ln: the SiLU + LayerNorm epilogue on the accumulators of the
+    MFMA tile, which spans whole rows); backward tmjx_silu_ln_bwd, then the input gradient (tmjx_gemm_nn) and the weight gradient
+    (deferred into the grouped launch, or tmjx_gemm_dw).  Same saved tensors and arithmetic as _HipDenseFn + _SiluLayerNormFn."""
+
+    @staticmethod
+    def forward(ctx, x2, w, b, gamma, beta, eps, dx_cols):
+        import ctypes as C
+        from .. import hip as _hip
+        M, K = x2.shape
+        N = w.shape[0]
+        z = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+        y = torch.empty_like(z)
+        stats = torch.empty((M, 2), dtype=torch.float32, device=x2.device)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(x2.device):
+            _hip.check(_hip.lib().tmjx_gemm_nt_silu_ln(p(x2), x2.stride(0), p(w), w.stride(0), p(b), p(gamma), p(beta), p(z), p(y), N, p(stats), M, N, K,
+                                                       float(eps), C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)), "tmjx_gemm_nt_silu_ln")
+        ctx.save_for_backward(x2, w, z, b, gamma, stats)
+        ctx.dx_cols, ctx.param = dx_cols, w
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from .. import hip as _hip
+        x2, w, z, b, gamma, stats = ctx.saved_tensors
+        M, N = z.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        grads = torch.empty((3, N), dtype=torch.float32, device=z.device)
+        L = _hip.lib()
+        partial = torch.empty(L.tmjx_silu_ln_partial_floats(M, N), dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _hip.check(L.tmjx_silu_ln_bwd(*[C.c_void_p(t.data_ptr()) for t in (dy, z, b, gamma, stats, dz, grads, partial)], M, N,
+                                          C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)), "tmjx_silu_ln_bwd")
+        dx = gemm_nn(dz, w, ctx.dx_cols) if ctx.needs_input_grad[0] else None
+        d = deferred_weight_grads.active
+        got = d.try_add(dz, x2, ctx.param, None) if d is not None else None
+        dw = got[0] if got is not None else gemm_dw(dz, x2, False)[0]
+        return dx, dw, grads[2], grads[0], grads[1], None, None
+
+
 class _Block(nn.Module):
     """Dense -> SiLU -> LayerNorm (flax LayerNorm defaults: eps 1e-6, scale + bias)."""
     FUSED_WIDTHS = (64, 128, 256, 512, 1024)
@@ -354,6 +411,9 @@ class _Block(nn.Module):
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and self.dense.out_features in self.FUSED_WIDTHS and not torch.is_autocast_enabled():
             x2 = _rows2d(x)
+            if torch.is_grad_enabled() and _block_fusable(x2, self.dense.weight):
+                y = _HipBlockFn.apply(x2, self.dense.weight, self.dense.bias, self.norm.weight, self.norm.bias, self.norm.eps, self.dx_cols)
+                return y.view(*x.shape[:-1], self.dense.out_features)
             if not torch.is_grad_enabled():
                 z = _mm_nt(x2, self.dense.weight)[0]
             elif _hip_gemm_ok(x2, self.dense.weight):

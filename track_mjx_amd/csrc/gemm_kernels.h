@@ -65,10 +65,23 @@ __device__ __forceinline__ gf4 gemm_mask4(gf4 v, int mask) {
 #define SG_DS_READ 0x100
 #define SG_DS_WRITE 0x200
 
+// Fused forward epilogue of a Dense -> SiLU -> LayerNorm block (LN = true; the tile must span the whole row: N == 64 NIW, one column
+// block): z = A W^T goes to C as before (WITHOUT the bias: what k_silu_ln_bwd expects), y = LayerNorm(silu(z + bias)) to `y`, the row's
+// (mean, 1 / std) to `stats` — the arithmetic of k_silu_ln_fwd (two-pass variance), without its launch and its re-read of z.
+struct GemmLN { const float *gamma, *beta; float *y, *stats; float eps; };
+// sum over the 16 lanes of a DPP row (all 16 lanes get it): quad xor 1, quad xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float gemm_row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+  return x;
+}
+
 template <int NIW> struct GemmCfg { static constexpr int NWAVE = NIW >= 2 ? 8 : 4, THREADS = 64 * NWAVE, NI = 4 * NIW / NWAVE; };
-template <int NIW, bool BT, bool AVEC, bool WVEC>
+template <int NIW, bool BT, bool AVEC, bool WVEC, bool LN = false>
 __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
-                                                  float *__restrict__ C, int ldc, int M, int N, int K) {
+                                                  float *__restrict__ C, int ldc, int M, int N, int K, GemmLN ln = GemmLN{}) {
   constexpr int BN = 64 * NIW;
   constexpr int LDB_T = GEMM_LDA;            // BT: [n][k] image, 40 floats per row
   constexpr int LDB_N = BN + 4;              // !BT: [k][n] image, row stride 4 mod 8
@@ -209,6 +222,84 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #ifdef GEMM_PROF
   unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (LN) {
+    // rows of the tile are whole rows of the layer (N == BN): lane (kq, li) of wave w holds, per row 16 a + 4 kq + r, the NI columns
+    // nw + 16 b + li.  Row sums: over b in registers, over li by DPP, over the waves through LDS (the K loop's stages are dead).
+    constexpr int NW = GemmCfg<NIW>::NWAVE;
+    static_assert(2 * GEMM_BM * NW <= 2 * STAGE, "reduction scratch must fit the K loop's LDS");
+    float *red1 = gemm_lds, *red2 = gemm_lds + GEMM_BM * NW;
+    float bv[NI], gv[NI], bev[NI];
+#pragma unroll
+    for (int b = 0; b < NI; b++) { const int col = nw + 16 * b + li; bv[b] = bias[col]; gv[b] = ln.gamma[col]; bev[b] = ln.beta[col]; }
+    // z first (straight from the accumulators), then the accumulators are overwritten by silu(z + bias): 40 live registers fewer
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * a + 4 * kq + r;
+        if (row < M) {
+#pragma unroll
+          for (int b = 0; b < NI; b++) C[(long long)row * ldc + nw + 16 * b + li] = acc[a][b][r];
+        }
+      }
+    float stat[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float p = 0.f;
+#pragma unroll
+        for (int b = 0; b < NI; b++) { const float v = acc[a][b][r] + bv[b]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
+        stat[a][r] = gemm_row16_sum(p);
+      }
+    __syncthreads();                   // every wave has read its last fragments
+    auto exchange = [&](float *red) {  // stat[a][r] <- sum over the waves
+      if (li == 0) {
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) red[(16 * a + 4 * kq + r) * NW + wave] = stat[a][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const gf4 *q = reinterpret_cast<const gf4 *>(red + (16 * a + 4 * kq + r) * NW);
+          float m = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < NW / 4; w4++) { const gf4 v = q[w4]; m += (v.x + v.y) + (v.z + v.w); }
+          stat[a][r] = m;
+        }
+    };
+    exchange(red1);
+    const float inv_n = 1.f / (float)BN;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float mean = stat[a][r] * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int b = 0; b < NI; b++) { acc[a][b][r] -= mean; q += acc[a][b][r] * acc[a][b][r]; }      // centred from here on
+        if (wave == 0 && li == 0 && m0 + 16 * a + 4 * kq + r < M) ln.stats[2 * (long long)(m0 + 16 * a + 4 * kq + r)] = mean;
+        stat[a][r] = gemm_row16_sum(q);
+      }
+    exchange(red2);
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * a + 4 * kq + r;
+        const float rstd = rsqrtf(stat[a][r] * inv_n + ln.eps);
+        if (row < M) {
+#pragma unroll
+          for (int b = 0; b < NI; b++) ln.y[(long long)row * ldc + nw + 16 * b + li] = acc[a][b][r] * rstd * gv[b] + bev[b];
+          if (wave == 0 && li == 0) ln.stats[2 * (long long)row + 1] = rstd;
+        }
+      }
+    return;
+  }
   // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile: stored straight from the registers (64-byte
   // pieces; routing the tile through LDS to store whole rows as dwordx4 was tried and is 6 % SLOWER for these 80 x 256 tiles)
 #pragma unroll

@@ -661,7 +661,7 @@ static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, con
     attr_set = true;
   }
   dim3 grid((M + GEMM_BM - 1) / GEMM_BM, (N + BN - 1) / BN);
-  hipLaunchKernelGGL((k_gemm_act<NIW, BT, AVEC, WVEC>), grid, dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K);
+  hipLaunchKernelGGL((k_gemm_act<NIW, BT, AVEC, WVEC>), grid, dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K, GemmLN{});
   return check_launch("k_gemm_act");
 }
 template <int NIW, bool BT>
@@ -681,6 +681,20 @@ static int gemm_act(const float *A, int lda, const float *W, int ldw, const floa
   if (N <= 128) return gemm_act_vec<2, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
   return gemm_act_vec<4, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
 }
+// Dense -> SiLU -> LayerNorm forward in one launch (k_gemm_act<.., LN = true>): the layer must be exactly one tile wide
+template <int NIW>
+static int launch_gemm_ln(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, int ldc, int M, int N, int K, GemmLN ln, hipStream_t s) {
+  constexpr int BN = 64 * NIW;
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_BM * GEMM_LDA + BN * GEMM_LDA);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act LN): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, true>), dim3((M + GEMM_BM - 1) / GEMM_BM, 1), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
+  return check_launch("k_gemm_act(LN)");
+}
 template <bool YVEC, bool XVEC>
 static int launch_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *scratch, int M, int N, int K, int with_bias, int rps, int S, int ld, hipStream_t s) {
   constexpr size_t lds = 2 * sizeof(float) * 2 * DW_BM * DW_LD;
@@ -697,6 +711,20 @@ static int launch_gemm_dw(const float *dY, int ldy, const float *X, int ldx, flo
 extern "C" {
 int tmjx_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream) {
   return gemm_act<true>(A, lda, W, ldw, bias, C, ldc, M, N, K, stream);
+}
+int tmjx_gemm_nt_silu_ln_ok(const float *A, int lda, const float *W, int ldw, int N) {
+  return (N == 64 || N == 128 || N == 256) && aligned16(A, lda) && aligned16(W, ldw);
+}
+int tmjx_gemm_nt_silu_ln(const float *A, int lda, const float *W, int ldw, const float *bias, const float *gamma, const float *beta, float *Z, float *Y,
+                         int ldc, float *stats, int M, int N, int K, float eps, void *stream) {
+  if (!A || !W || !bias || !gamma || !beta || !Z || !Y || !stats) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || K < 1 || lda < K || ldc < N || ldw < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  if (!tmjx_gemm_nt_silu_ln_ok(A, lda, W, ldw, N)) return fail(TMJX_EINVAL, "tmjx_gemm_nt_silu_ln: N must be 64, 128 or 256 and the operands' rows 16-byte aligned");
+  GemmLN ln{gamma, beta, Y, stats, eps};
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 64) return launch_gemm_ln<1>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+  if (N == 128) return launch_gemm_ln<2>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+  return launch_gemm_ln<4>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
 }
 int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, void *stream) {
   return gemm_act<false>(A, lda, W, ldw, nullptr, C, ldc, M, N, K, stream);
