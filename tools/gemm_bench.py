@@ -38,13 +38,14 @@ def main():
     for N, K, ld in layers:
         xb = torch.randn((M, ld), device=DEV)
         x = xb[:, :K]
-        w = torch.randn((N, K), device=DEV)
+        w = torch.randn((N, (K + 3) // 4 * 4), device=DEV)[:, :K]       # rows 16-byte aligned, as in the learner's flat parameter buffer
+        wc = w.contiguous()                                              # (the library's operand)
         b = torch.randn(N, device=DEV)
         dy = torch.randn((M, N), device=DEV)
         fl = 2.0 * M * N * K
         xc = x.contiguous()
-        r = {"nt": (timeit(lambda: gemm_nt(x, w, b)), timeit(lambda: torch.addmm(b, xc, w.t()))),
-             "nn": (timeit(lambda: gemm_nn(dy, w)), timeit(lambda: dy @ w)),
+        r = {"nt": (timeit(lambda: gemm_nt(x, w, b)), timeit(lambda: torch.addmm(b, xc, wc.t()))),
+             "nn": (timeit(lambda: gemm_nn(dy, w)), timeit(lambda: dy @ wc)),
              "dw": (timeit(lambda: gemm_dw(dy, x, True)), timeit(lambda: (dy.t() @ xc, dy.sum(0))))}
         print(f"N={N:5d} K={K:5d}: " + "  ".join(f"{k} {a * 1e6:7.1f} us {fl / a / 1e12:6.1f} TF (torch {t * 1e6:7.1f} us {fl / t / 1e12:6.1f} TF)" for k, (a, t) in r.items()), flush=True)
         for k, (a, t) in r.items():

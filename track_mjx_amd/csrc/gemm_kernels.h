@@ -21,11 +21,13 @@
 //       values it stages (its four columns, all its rows), the eight partial sums per column meet in LDS after the loop and land in
 //       column K of the slab: no separate column-sum launches.
 #pragma once
+#include <type_traits>
 
 typedef float __attribute__((ext_vector_type(4))) gf4;
 
 #define GEMM_BM 80
 #define GEMM_BK 32
+#define GEMM_A_ROWS (GEMM_BM + 8)   // LDS rows of the A image: the tile + 8 dump rows (see k_gemm_act)
 #define GEMM_LDA 40          // floats per LDS row of a [rows][k] image (32 + 8 pad)
 
 // Four consecutive elements k .. k + 3 of one matrix row, zero beyond `K` and for rows outside the matrix.  BRANCH-FREE on purpose:
@@ -62,6 +64,7 @@ __device__ __forceinline__ gf4 gemm_mask4(gf4 v, int mask) {
 #define GEMM_SGB(a, b, c) __builtin_amdgcn_sched_group_barrier(a, b, c)
 #define SG_VALU 0x2
 #define SG_MFMA 0x8
+#define SG_VMEM_READ 0x20
 #define SG_DS_READ 0x100
 #define SG_DS_WRITE 0x200
 
@@ -85,7 +88,9 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
   constexpr int BN = 64 * NIW;
   constexpr int LDB_T = GEMM_LDA;            // BT: [n][k] image, 40 floats per row
   constexpr int LDB_N = BN + 4;              // !BT: [k][n] image, row stride 4 mod 8
-  constexpr int A_FLOATS = GEMM_BM * GEMM_LDA, B_FLOATS = BT ? BN * LDB_T : GEMM_BK * LDB_N, STAGE = A_FLOATS + B_FLOATS;
+  // (8 extra rows behind the A tile: the lanes of the partly empty last staging pass write THERE instead of sitting out a divergent
+  // branch — a branch in the K step splits its basic block, which voids the sched_group_barrier interleave and costs a waitcnt)
+  constexpr int A_FLOATS = GEMM_A_ROWS * GEMM_LDA, B_FLOATS = BT ? BN * LDB_T : GEMM_BK * LDB_N, STAGE = A_FLOATS + B_FLOATS;
   extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
   // TWO waves per SIMD (8 per workgroup) once the tile is 128 columns or wider: with one wave per SIMD everything that is not an
   // MFMA (address arithmetic, masks, LDS traffic, the barrier) idles the matrix pipe — measured 52 % MFMA-busy; the second wave's
@@ -123,8 +128,8 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
-      const int f = t + NT * p, r = f >> 3, c4 = f & 7;
-      if (f < GEMM_BM * 8) *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = gemm_mask4(R.v[p], R.m[p]);
+      const int f = t + NT * p, r = f < GEMM_BM * 8 ? f >> 3 : GEMM_BM + ((f >> 3) & 7), c4 = f & 7;
+      *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = gemm_mask4(R.v[p], R.m[p]);
     }
 #pragma unroll
     for (int p = 0; p < B_PASS; p++) {
@@ -132,6 +137,45 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       const gf4 v = gemm_mask4(R.v[A_PASS + p], R.m[A_PASS + p]);
       if (BT) { const int r = f >> 3, c4 = f & 7; *reinterpret_cast<gf4 *>(sb + r * LDB_T + 4 * c4) = v; }
       else { const int r = f / (BN / 4), c4 = f % (BN / 4); *reinterpret_cast<gf4 *>(sb + r * LDB_N + 4 * c4) = v; }
+    }
+  };
+  // FAST forms for the tiles that lie entirely inside K (all but the last one or two): no masks at all.  Rows / columns outside the
+  // matrix are CLAMPED to valid ones instead of zeroed — row m of C depends only on row m of A and column n only on row / column n of W,
+  // and rows >= M, columns >= N are never stored — so the only elements that must be exact zeros are those with k >= K, and those exist only
+  // in the last (partial) tile.  Loop-invariant per-pass pointers; the K offset is wave-uniform (scalar).  Measured: the address + mask
+  // arithmetic of the masked form (22 vector instructions per load) cost 14 % of the MFMA rate.
+  constexpr bool FAST = AVEC && WVEC;
+  const float *pa[A_PASS], *pb[B_PASS];
+#pragma unroll
+  for (int p = 0; p < A_PASS; p++) {
+    const int f = t + NT * p, r = f < GEMM_BM * 8 ? f >> 3 : 0, c4 = f & 7;
+    pa[p] = A + (long long)min(m0 + r, M - 1) * lda + 4 * c4;
+  }
+#pragma unroll
+  for (int p = 0; p < B_PASS; p++) {
+    const int f = t + NT * p;
+    if (BT) { const int r = f >> 3, c4 = f & 7; pb[p] = W + (long long)min(n0 + r, N - 1) * ldw + 4 * c4; }
+    else { const int r = f / (BN / 4), c4 = f % (BN / 4); pb[p] = W + (long long)r * ldw + min(n0 + 4 * c4, ((N + 3) & ~3) - 4); }
+  }
+  auto gload_fast = [&](Stage &R, int k0) {
+    const int k0c = k0 + GEMM_BK <= K ? k0 : 0;        // tiles past the end are never consumed: any valid address will do
+#pragma unroll
+    for (int p = 0; p < A_PASS; p++) R.v[p] = *reinterpret_cast<const gf4 *>(pa[p] + k0c);
+#pragma unroll
+    for (int p = 0; p < B_PASS; p++) R.v[A_PASS + p] = *reinterpret_cast<const gf4 *>(pb[p] + (BT ? (long long)k0c : (long long)k0c * ldw));
+  };
+  auto swrite_fast = [&](const Stage &R, int stage) {
+    float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
+#pragma unroll
+    for (int p = 0; p < A_PASS; p++) {
+      const int f = t + NT * p, r = f < GEMM_BM * 8 ? f >> 3 : GEMM_BM + ((f >> 3) & 7), c4 = f & 7;
+      *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = R.v[p];
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; p++) {
+      const int f = t + NT * p;
+      if (BT) { const int r = f >> 3, c4 = f & 7; *reinterpret_cast<gf4 *>(sb + r * LDB_T + 4 * c4) = R.v[A_PASS + p]; }
+      else { const int r = f / (BN / 4), c4 = f % (BN / 4); *reinterpret_cast<gf4 *>(sb + r * LDB_N + 4 * c4) = R.v[A_PASS + p]; }
     }
   };
   struct Frag { gf4 a[5], b[NI]; };
@@ -173,9 +217,16 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
   //   phase B: chunk 1's MFMAs (fragments already in registers: no LDS latency behind the barrier), between them the first
   //            fragments of tile k + 1 and the global loads of tile k + 3 into RW's registers (free again).
   // Branch-free: past the last tile the loads are fully masked and the writes go to a stage nobody reads any more.
-  auto kstep = [&](Frag &F0, Frag &F1, Stage &RW, int stage, int k_next3) {
-    fread(F1, stage, 1);
-    swrite(RW, stage ^ 1);
+#ifndef GEMM_LOAD_VALU
+#define GEMM_LOAD_VALU 16   // vector instructions (address + mask arithmetic) the scheduler may place in front of each pinned global load
+#endif
+#ifndef GEMM_ABL
+#define GEMM_ABL 0          // timing ablations (wrong results): 1 no global loads, 2 no LDS writes, 4 no barrier, 8 no fragment reads
+#endif
+  auto kstep = [&](auto fast_tag, Frag &F0, Frag &F1, Stage &RW, int stage, int k_next3) {
+    constexpr bool F = decltype(fast_tag)::value;
+    if (!(GEMM_ABL & 8)) fread(F1, stage, 1);
+    if (!(GEMM_ABL & 2)) { if constexpr (F) swrite_fast(RW, stage ^ 1); else swrite(RW, stage ^ 1); }
     mma(F0);
 #pragma unroll
     for (int i = 0; i < NFR; i++) {
@@ -185,18 +236,26 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
       GEMM_SGB(SG_MFMA, (NMFMA - NFR) / (NPASS + 1), 0);
-      GEMM_SGB(SG_VALU, 12, 0);
+      if (!F) GEMM_SGB(SG_VALU, 12, 0);
       GEMM_SGB(SG_DS_WRITE, 1, 0);
     }
     GEMM_SGB(SG_MFMA, NMFMA, 0);
-    __syncthreads();
-    fread(F0, stage ^ 1, 0);
-    gload(RW, k_next3);
+    if (!(GEMM_ABL & 4)) __syncthreads();
+    if (!(GEMM_ABL & 8)) fread(F0, stage ^ 1, 0);
+    if (!(GEMM_ABL & 1)) { if constexpr (F) gload_fast(RW, (GEMM_ABL & 16) ? 0 : k_next3); else gload(RW, (GEMM_ABL & 16) ? 0 : k_next3); }
     mma(F1);
 #pragma unroll
     for (int i = 0; i < NFR; i++) {
       GEMM_SGB(SG_MFMA, 1, 0);
       GEMM_SGB(SG_DS_READ, 1, 0);
+    }
+    // the global loads are pinned HERE: left to itself the scheduler sinks them (and their address arithmetic) to the end of the region,
+    // i.e. behind the NEXT step's LDS writes — half a step before their data is needed instead of a step and a half
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      GEMM_SGB(SG_MFMA, (NMFMA - NFR) / (NPASS + 1), 0);
+      GEMM_SGB(SG_VALU, F ? 2 : GEMM_LOAD_VALU, 0);
+      GEMM_SGB(SG_VMEM_READ, 1, 0);
     }
     GEMM_SGB(SG_MFMA, NMFMA, 0);
   };
@@ -215,10 +274,28 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #ifdef GEMM_PROF
   unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-  for (int kt = 0; kt < nk; kt += 2) {
-    kstep(F0, F1, R1, 0, (kt + 3) * GEMM_BK);          // tile kt in stage 0; tile kt + 1 (R1) goes to stage 1; tile kt + 3 is loaded into R1
-    if (kt + 1 < nk) kstep(F0, F1, R0, 1, (kt + 4) * GEMM_BK);
+  // two K steps per trip and the odd last one OUTSIDE the loop: with `if (kt + 1 < nk)` around the second step the waitcnt pass has to merge
+  // "second step skipped" into the loop head, where the loads of R1 are then the youngest in flight: it drained every load (vmcnt(0)) before
+  // the first step's LDS writes, i.e. waited for loads issued half a step earlier (measured: 102 -> see DESIGN.md TF at 20480 x 512 x 1024)
+  // Fast steps while neither the tile a step WRITES (kt + 1, and kt + 2 by the second step of a trip) nor the one it LOADS can be the
+  // partial tile nk - 1: all steps when K is a multiple of 32, all but the last four (rounded to whole trips) otherwise.  The masked
+  // steps behind them may write a fast-loaded register set: its masks are preset to "all valid".
+  constexpr std::true_type FAST_STEP{};
+  constexpr std::false_type MASKED_STEP{};
+  int kt = 0;
+  if (FAST) {
+    const int nfast = (K % GEMM_BK) == 0 ? nk : max(0, (nk - 4) & ~1);
+    for (; kt + 1 < nfast; kt += 2) {
+      kstep(FAST_STEP, F0, F1, R1, 0, (kt + 3) * GEMM_BK);          // tile kt in stage 0; tile kt + 1 (R1) goes to stage 1; tile kt + 3 is loaded into R1
+      kstep(FAST_STEP, F0, F1, R0, 1, (kt + 4) * GEMM_BK);
+    }
+    if (kt < nfast) { kstep(FAST_STEP, F0, F1, R1, 0, (kt + 3) * GEMM_BK); kt = nk; }      // (odd nfast only when nfast == nk: this was the last step)
   }
+  for (; kt + 1 < nk; kt += 2) {
+    kstep(MASKED_STEP, F0, F1, R1, 0, (kt + 3) * GEMM_BK);
+    kstep(MASKED_STEP, F0, F1, R0, 1, (kt + 4) * GEMM_BK);
+  }
+  if (kt < nk) kstep(MASKED_STEP, F0, F1, R1, 0, (kt + 3) * GEMM_BK);
 #ifdef GEMM_PROF
   unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -365,6 +442,36 @@ __device__ __forceinline__ void gemm_dw_tile(const float *__restrict__ dY, int l
       *reinterpret_cast<gf4 *>(sx + r * DW_LD + 4 * c4) = gemm_mask4(R.x[p], R.mx[p]);
     }
   };
+  // FAST forms for the 32-row steps that lie entirely inside the slab's row range (see k_gemm_act): no masks; columns outside the matrix are
+  // clamped to valid ones (their products land in tile entries that are never stored), only ROWS beyond r_end must be exact zeros (they are
+  // summed over) and those exist only in the slab's last, partial step.
+  constexpr bool FAST = YVEC && XVEC;
+  const float *py[2], *px[2];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int f = t + 512 * p, r = f >> 5, c4 = f & 31;
+    py[p] = dY + (long long)r * ldy + min(n0 + 4 * c4, ((N + 3) & ~3) - 4);
+    px[p] = X + (long long)r * ldx + min(k0 + 4 * c4, ((K + 3) & ~3) - 4);
+  }
+  auto gload_fast = [&](Stage &R, int r0) {
+    const int r0c = r0 + DW_BM <= r_end ? r0 : r_begin;      // steps past the end are never consumed: any valid rows will do
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      R.y[p] = *reinterpret_cast<const gf4 *>(py[p] + (long long)r0c * ldy);
+      R.x[p] = *reinterpret_cast<const gf4 *>(px[p] + (long long)r0c * ldx);
+    }
+  };
+  auto swrite_fast = [&](const Stage &R, int stage, bool live) {      // live (wave-uniform): the step written lies inside the row range
+    float *sy = gemm_lds + stage * STAGE, *sx = sy + DW_BM * DW_LD;
+    const float w = live ? 1.f : 0.f;          // (steps past the end hold clamped, i.e. real and finite, rows: they must not reach the bias sum)
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const int f = t + 512 * p, r = f >> 5, c4 = f & 31;
+      colacc += w * R.y[p];
+      *reinterpret_cast<gf4 *>(sy + r * DW_LD + 4 * c4) = R.y[p];
+      *reinterpret_cast<gf4 *>(sx + r * DW_LD + 4 * c4) = R.x[p];
+    }
+  };
   struct Frag { float a[4][4], b[4][2]; };      // [s-step][tile]
   auto fread = [&](Frag &F, int stage, int half) {
     const float *sy = gemm_lds + stage * STAGE, *sx = sy + DW_BM * DW_LD;
@@ -391,13 +498,14 @@ __device__ __forceinline__ void gemm_dw_tile(const float *__restrict__ dY, int l
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s][a], F.b[s][b], acc[a][b], 0, 0, 0);
   };
   // (no sched_group_barrier pinning here: measured 4-9 % faster with the compiler's own interleave of these six-read steps)
-  auto mstep = [&](Frag &F0, Frag &F1, Stage &RW, int stage, int r_next3) {
+  auto mstep = [&](auto fast_tag, Frag &F0, Frag &F1, Stage &RW, int stage, int r_next3) {
+    constexpr bool F = decltype(fast_tag)::value;
     fread(F1, stage, 1);
-    swrite(RW, stage ^ 1);
+    if constexpr (F) swrite_fast(RW, stage ^ 1, r_next3 - 2 * DW_BM < r_end); else swrite(RW, stage ^ 1);
     mma(F0);
     __syncthreads();
     fread(F0, stage ^ 1, 0);
-    gload(RW, r_next3);
+    if constexpr (F) gload_fast(RW, r_next3); else gload(RW, r_next3);
     mma(F1);
   };
   const int nt = (r_end - r_begin + DW_BM - 1) / DW_BM;
@@ -410,10 +518,23 @@ __device__ __forceinline__ void gemm_dw_tile(const float *__restrict__ dY, int l
     gload(R0, r_begin + 2 * DW_BM);
     __syncthreads();
     fread(F0, 0, 0);
-    for (int it = 0; it < nt; it += 2) {
-      mstep(F0, F1, R1, 0, r_begin + (it + 3) * DW_BM);
-      if (it + 1 < nt) mstep(F0, F1, R0, 1, r_begin + (it + 4) * DW_BM);
+    // (two steps per trip, the odd last one outside the loop, fast steps first: see k_gemm_act)
+    constexpr std::true_type FAST_STEP{};
+    constexpr std::false_type MASKED_STEP{};
+    int it = 0;
+    if (FAST) {
+      const int nfast = ((r_end - r_begin) % DW_BM) == 0 ? nt : max(0, (nt - 4) & ~1);
+      for (; it + 1 < nfast; it += 2) {
+        mstep(FAST_STEP, F0, F1, R1, 0, r_begin + (it + 3) * DW_BM);
+        mstep(FAST_STEP, F0, F1, R0, 1, r_begin + (it + 4) * DW_BM);
+      }
+      if (it < nfast) { mstep(FAST_STEP, F0, F1, R1, 0, r_begin + (it + 3) * DW_BM); it = nt; }
     }
+    for (; it + 1 < nt; it += 2) {
+      mstep(MASKED_STEP, F0, F1, R1, 0, r_begin + (it + 3) * DW_BM);
+      mstep(MASKED_STEP, F0, F1, R0, 1, r_begin + (it + 4) * DW_BM);
+    }
+    if (it < nt) mstep(MASKED_STEP, F0, F1, R1, 0, r_begin + (it + 3) * DW_BM);
   }
   float *out = slabs + (size_t)split * (size_t)N * ld_slab;
   if (with_bias && tile_k == 0) {          // (uniform per workgroup) thread t holds columns 4 (t & 31) .. + 3 of the rows t / 32 + 16 j

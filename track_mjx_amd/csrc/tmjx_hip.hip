@@ -653,7 +653,7 @@ static bool aligned16(const void *p, long long ld) { return !((uintptr_t)p & 15)
 template <int NIW, bool BT, bool AVEC, bool WVEC>
 static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
   constexpr int BN = 64 * NIW;
-  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_BM * GEMM_LDA + (BT ? BN * GEMM_LDA : GEMM_BK * (BN + 4)));
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + (BT ? BN * GEMM_LDA : GEMM_BK * (BN + 4)));
   static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT, AVEC, WVEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -685,7 +685,7 @@ static int gemm_act(const float *A, int lda, const float *W, int ldw, const floa
 template <int NIW>
 static int launch_gemm_ln(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, int ldc, int M, int N, int K, GemmLN ln, hipStream_t s) {
   constexpr int BN = 64 * NIW;
-  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_BM * GEMM_LDA + BN * GEMM_LDA);
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + BN * GEMM_LDA);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
