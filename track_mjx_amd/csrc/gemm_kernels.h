@@ -24,6 +24,7 @@
 #include <type_traits>
 
 typedef float __attribute__((ext_vector_type(4))) gf4;
+typedef float __attribute__((ext_vector_type(2))) gf2;
 
 #define GEMM_BM 80
 #define GEMM_BK 32
@@ -188,9 +189,17 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       for (int b = 0; b < NI; b++) F.b[b] = *reinterpret_cast<const gf4 *>(sb + (nw + 16 * b + li) * LDB_T + 16 * c + 4 * kq);
     } else {
 #pragma unroll
-      for (int b = 0; b < NI; b++) {
-        const float *q = sb + (16 * c + 4 * kq) * LDB_N + nw + 16 * b + li;
-        F.b[b] = gf4{q[0], q[LDB_N], q[2 * LDB_N], q[3 * LDB_N]};
+      // [k][n] image: lane (li, kq) needs W[k = 16 c + 4 kq + e][its column of tile b].  The tile's columns are INTERLEAVED — tile b holds
+      // columns nw + NI li + b — so that the NI tiles' values of one k are NI consecutive floats: one ds_read_b64 per k instead of NI
+      // ds_read_b32 (9 instead of 13 LDS reads per chunk; the input-gradient kernel ran 20 % behind the forward one for exactly these reads),
+      // and the epilogue stores NI consecutive floats per lane.
+      for (int e = 0; e < 4; e++) {
+        const float *q = sb + (16 * c + 4 * kq + e) * LDB_N + nw + NI * li;
+        if constexpr (NI == 2) { const gf2 v = *reinterpret_cast<const gf2 *>(q); F.b[0][e] = v.x; F.b[1][e] = v.y; }
+        else {
+#pragma unroll
+          for (int b = 0; b < NI; b++) F.b[b][e] = q[b];
+        }
       }
     }
   };
@@ -379,9 +388,25 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
   }
   // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile: stored straight from the registers (64-byte
   // pieces; routing the tile through LDS to store whole rows as dwordx4 was tried and is 6 % SLOWER for these 80 x 256 tiles)
+  if constexpr (!BT && NI == 2) {      // interleaved tile columns (see fread): lane holds columns n0 + nw + 2 li, + 1 of its rows
+    const int col = n0 + nw + 2 * li;
+    const bool pair = col + 1 < N && !(ldc & 1) && !((uintptr_t)C & 7);
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * a + 4 * kq + r;
+        if (row < M) {
+          float *o = C + (long long)row * ldc + col;
+          if (pair) *reinterpret_cast<gf2 *>(o) = gf2{acc[a][0][r], acc[a][1][r]};
+          else { if (col < N) o[0] = acc[a][0][r]; if (col + 1 < N) o[1] = acc[a][1][r]; }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < NI; b++) {
-    const int col = n0 + nw + 16 * b + li;
+    const int col = n0 + nw + (BT ? 16 * b + li : NI * li + b);
 #ifdef GEMM_PROF
     const float bv = 0.f;
 #else
@@ -478,10 +503,12 @@ __device__ __forceinline__ void gemm_dw_tile(const float *__restrict__ dY, int l
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       const int row = 16 * half + 4 * s + kq;
-#pragma unroll
-      for (int a = 0; a < 4; a++) F.a[s][a] = sy[row * DW_LD + wn + 16 * a + li];
-#pragma unroll
-      for (int b = 0; b < 2; b++) F.b[s][b] = sx[row * DW_LD + wk + 16 * b + li];
+      // INTERLEAVED tile columns: tile a of the dY side holds columns wn + 4 li + a, tile b of the X side columns wk + 2 li + b, so the
+      // four (two) tiles' values of one row are consecutive floats: one ds_read_b128 + one ds_read_b64 per row instead of six ds_read_b32
+      const gf4 va = *reinterpret_cast<const gf4 *>(sy + row * DW_LD + wn + 4 * li);
+      const gf2 vb = *reinterpret_cast<const gf2 *>(sx + row * DW_LD + wk + 2 * li);
+      F.a[s][0] = va.x; F.a[s][1] = va.y; F.a[s][2] = va.z; F.a[s][3] = va.w;
+      F.b[s][0] = vb.x; F.b[s][1] = vb.y;
     }
   };
   gf4 acc[4][2];
@@ -497,16 +524,35 @@ __device__ __forceinline__ void gemm_dw_tile(const float *__restrict__ dY, int l
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s][a], F.b[s][b], acc[a][b], 0, 0, 0);
   };
-  // (no sched_group_barrier pinning here: measured 4-9 % faster with the compiler's own interleave of these six-read steps)
+  // The same pinned interleave as k_gemm_act (32 MFMAs per half step and wave): the fragment reads of the other half one per MFMA, then the
+  // LDS writes (phase A) / global loads (phase B) spread over the next MFMAs.  Left to itself the compiler clusters the reads in front of
+  // their first use (lgkmcnt waits between the MFMA groups) and drains the writes right in front of the barrier.
+#ifndef DW_SGB
+#define DW_SGB 1
+#endif
   auto mstep = [&](auto fast_tag, Frag &F0, Frag &F1, Stage &RW, int stage, int r_next3) {
     constexpr bool F = decltype(fast_tag)::value;
     fread(F1, stage, 1);
     if constexpr (F) swrite_fast(RW, stage ^ 1, r_next3 - 2 * DW_BM < r_end); else swrite(RW, stage ^ 1);
     mma(F0);
+    if (DW_SGB) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) { GEMM_SGB(SG_MFMA, 1, 0); GEMM_SGB(SG_DS_READ, 1, 0); }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { GEMM_SGB(SG_MFMA, 4, 0); GEMM_SGB(SG_VALU, F ? 4 : 12, 0); GEMM_SGB(SG_DS_WRITE, 1, 0); }
+      GEMM_SGB(SG_MFMA, 32, 0);
+    }
     __syncthreads();
     fread(F0, stage ^ 1, 0);
     if constexpr (F) gload_fast(RW, r_next3); else gload(RW, r_next3);
     mma(F1);
+    if (DW_SGB) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) { GEMM_SGB(SG_MFMA, 1, 0); GEMM_SGB(SG_DS_READ, 1, 0); }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { GEMM_SGB(SG_MFMA, 4, 0); GEMM_SGB(SG_VALU, F ? 2 : GEMM_LOAD_VALU, 0); GEMM_SGB(SG_VMEM_READ, 1, 0); }
+      GEMM_SGB(SG_MFMA, 32, 0);
+    }
   };
   const int nt = (r_end - r_begin + DW_BM - 1) / DW_BM;
   if (nt > 0) {
@@ -549,15 +595,16 @@ __device__ __forceinline__ void gemm_dw_tile(const float *__restrict__ dY, int l
       if (n0 + t < N) out[(size_t)(n0 + t) * ld_slab + K] = v;
     }
   }
+  // accumulator register r of tile (a, b) holds output row n0 + wn + 4 (4 kq + r) + a, column k0 + wk + 2 li + b (interleaved tiles, see fread)
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
-      const int col = k0 + wk + 16 * b + li;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = n0 + wn + 16 * a + 4 * kq + r;
-        if (row < N && col < K) out[(size_t)row * ld_slab + col] = acc[a][b][r];
+    for (int r = 0; r < 4; r++) {
+      const int row = n0 + wn + 4 * (4 * kq + r) + a, col = k0 + wk + 2 * li;
+      if (row < N) {
+        float *o = out + (size_t)row * ld_slab + col;
+        if (col + 1 < K) *reinterpret_cast<gf2 *>(o) = gf2{acc[a][0][r], acc[a][1][r]};        // (slab rows and the tile origin are 8-byte aligned)
+        else if (col < K) o[0] = acc[a][0][r];
       }
     }
 }
