@@ -136,6 +136,12 @@ int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const f
  * out[t][b][:] = (src[t][idx[b]][:] - mean) / std; src [T][R][W], idx int64 [B], out [T][B][W], W % 4 == 0. */
 int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mean, const float *std, float *out, int T, int R, int B,
                           int W, void *stream);
+/* The whole minibatch of one SGD step in one launch (ppo.py:304-317: the same permutation slice indexes every leaf of the roll-out data):
+ * obs_n [T][B][W] = (obs[t][idx[b]] - mean) / std, next_n [B][W] likewise from next_last [R][W], raw_action_g [T][B][A] = raw_action[t][idx[b]],
+ * scalars_g [4][T][B] = (log_prob, reward, discount, truncation)[t][idx[b]].  idx: int64 [B] on the device, values in [0, R). */
+int tmjx_gather_minibatch(const float *obs, const float *next_last, const float *raw_action, const float *log_prob, const float *reward, const float *discount,
+                          const float *truncation, const int64_t *idx, const float *mean, const float *std, float *obs_n, float *next_n, float *raw_action_g,
+                          float *scalars_g, int T, int R, int B, int W, int A, void *stream);
 
 /* Backward of the latent sample inside tmjx_latent_concat (reparameterize, intention_network.py:78-88): from d x [n][dx_stride]
  * to d fc2 [n][2 Z] = [d mean | d logvar]. */

@@ -393,6 +393,30 @@ def test_gather_normalize_matches_torch():
 
 
 @pytest.mark.gpu
+def test_fused_minibatch_gather_matches_index_select():
+    """tmjx_gather_minibatch (every leaf of the roll-out data at the minibatch rows, one launch) is bit-identical to index_select per leaf
+    + the normaliser (ppo.py:304-317: x[perm] reshaped to minibatches, the same rows for every leaf)."""
+    import torch
+    from track_mjx_amd.agent import losses
+    from track_mjx_amd.agent.networks import RunningStatistics
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    T, R, W, A, B = 5, 300, 696, 38, 77
+    buf = {"observation": torch.randn(T, R, W, generator=g, device=dev), "raw_action": torch.randn(T, R, A, generator=g, device=dev),
+           "log_prob": torch.randn(T, R, generator=g, device=dev), "reward": torch.randn(T, R, generator=g, device=dev),
+           "discount": torch.rand(T, R, generator=g, device=dev), "truncation": torch.rand(T, R, generator=g, device=dev),
+           "next_observation_last": torch.randn(R, W, generator=g, device=dev)}
+    idx = torch.randint(0, R, (B,), generator=g, device=dev)
+    norm = RunningStatistics(W, dev)
+    norm.update(buf["observation"])
+    got = losses.gather_minibatch(buf, idx, norm)
+    assert torch.equal(got["observation_normalized"], norm.normalize(buf["observation"].index_select(1, idx)))
+    assert torch.equal(got["next_observation_last_normalized"], norm.normalize(buf["next_observation_last"].index_select(0, idx)))
+    for k in ("raw_action", "log_prob", "reward", "discount", "truncation"):
+        assert torch.equal(got[k], buf[k].index_select(1, idx)), k
+
+
+@pytest.mark.gpu
 def test_evaluator_first_episode_sums():
     """agent/evaluator.py (brax acting.Evaluator + EvalWrapper semantics, ppo.py:83-124,629-668): episode_* are sums over the FIRST
     episode of each env only, avg_episode_length counts its steps — checked against a numpy accumulation of the same roll-out."""

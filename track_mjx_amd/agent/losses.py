@@ -46,6 +46,24 @@ def gather_normalize(src: torch.Tensor, idx: torch.Tensor, normalizer) -> torch.
     return out[0] if squeeze else out
 
 
+def gather_minibatch(buf: dict, idx: torch.Tensor, normalizer) -> dict:
+    """Every leaf of the roll-out buffer at the minibatch rows `idx` (ppo.py:304-317), observations normalised, in ONE launch
+    (tmjx_gather_minibatch).  Returns the dict compute_ppo_loss / ppo_loss_and_output_grads take."""
+    obs, nxt, act = buf["observation"], buf["next_observation_last"], buf["raw_action"]
+    T, R, W = obs.shape
+    B, A = idx.shape[0], act.shape[-1]
+    f32 = dict(dtype=torch.float32, device=obs.device)
+    obs_n, next_n = torch.empty((T, B, W), **f32), torch.empty((B, W), **f32)
+    act_g, sc = torch.empty((T, B, A), **f32), torch.empty((4, T, B), **f32)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(obs.device):
+        _hip.check(_hip.lib().tmjx_gather_minibatch(p(obs), p(nxt), p(act), p(buf["log_prob"]), p(buf["reward"]), p(buf["discount"]), p(buf["truncation"]), p(idx),
+                                                    p(normalizer.mean), p(normalizer.std), p(obs_n), p(next_n), p(act_g), p(sc), T, R, B, W, A,
+                                                    C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)), "tmjx_gather_minibatch")
+    return {"observation_normalized": obs_n, "next_observation_last_normalized": next_n, "raw_action": act_g, "log_prob": sc[0], "reward": sc[1],
+            "discount": sc[2], "truncation": sc[3]}
+
+
 def create_ramp_schedule(max_value: float = 0.1, min_value: float = 0.0001, ramp_steps: int = 1000, warmup_steps: int = 0):
     """Linear ramp (losses.py:263-269): clip((step - warmup)/ramp_steps, min_value, 1) * max_value."""
     def schedule_fn(step: float) -> float:

@@ -418,24 +418,10 @@ class PPOLearner:
     def _minibatch_grads(self, idx: torch.Tensor, kl_w: float) -> torch.Tensor:
         """Gather one minibatch, loss, gradients into the flat buffer; returns the 5 loss terms as one tensor."""
         fused_gather = self.dev.type == "cuda" and self.normalize_observations and self.buf["observation"].shape[-1] % 4 == 0
-        small = [k for k in self.buf if not (fused_gather and k in ("observation", "next_observation_last"))]
-        data = {}
-        if fused_gather:
-            data["observation_normalized"] = _losses.gather_normalize(self.buf["observation"], idx, self.normalizer)
-            data["next_observation_last_normalized"] = _losses.gather_normalize(self.buf["next_observation_last"], idx, self.normalizer)
-        side = self._sgd_side if (fused_gather and self.dev.type == "cuda") else None
-        if side is not None:
-            # the five small gathers (actions, log-probs, rewards, flags) are needed by the loss head only: second stream, next to the
-            # policy's forward pass (joined there: losses.ppo_loss_and_output_grads waits for the side stream in front of the loss head)
-            cur = torch.cuda.current_stream(self.dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for k in small:
-                    data[k] = self.buf[k].index_select(1, idx)
-                    data[k].record_stream(cur)
+        if fused_gather and all(v.is_contiguous() for v in self.buf.values()):
+            data = _losses.gather_minibatch(self.buf, idx, self.normalizer)      # all seven leaves in one launch
         else:
-            for k in small:
-                data[k] = self.buf[k].index_select(1, idx) if k != "next_observation_last" else self.buf[k].index_select(0, idx)
+            data = {k: (self.buf[k].index_select(1, idx) if k != "next_observation_last" else self.buf[k].index_select(0, idx)) for k in self.buf}
         with gemm_inputs(self.matmul_dtype):
             if self.dev.type == "cuda":
                 # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs

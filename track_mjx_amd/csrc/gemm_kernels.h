@@ -215,7 +215,12 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
       for (int a = 0; a < 5; a++)
 #pragma unroll
-        for (int b = 0; b < NI; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[a][e], F.b[b][e], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NI; b++) {
+          // BT: the weight fragment goes in as the FIRST operand, i.e. the tile comes out transposed: register r of lane (li, kq) is
+          // C[16 a + li][16 b + 4 kq + r] — four consecutive columns of one row, stored as one dwordx4 (10 stores per wave instead of 40)
+          if constexpr (BT) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.b[b][e], F.a[a][e], acc[a][b], 0, 0, 0);
+          else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[a][e], F.b[b][e], acc[a][b], 0, 0, 0);
+        }
   };
   constexpr int NMFMA = 20 * NI;                       // MFMAs per 16-deep chunk and wave
   constexpr int NFR = 5 + (BT ? NI : 4 * NI);          // LDS reads per chunk
@@ -309,85 +314,77 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
   unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
   if constexpr (LN) {
-    // rows of the tile are whole rows of the layer (N == BN): lane (kq, li) of wave w holds, per row 16 a + 4 kq + r, the NI columns
-    // nw + 16 b + li.  Row sums: over b in registers, over li by DPP, over the waves through LDS (the K loop's stages are dead).
+    // rows of the tile are whole rows of the layer (N == BN).  Lane (li, kq) of wave w holds, of the rows 16 a + li, the columns
+    // nw + 16 b + 4 kq + r.  Row sums: over r and b in registers, over kq by two cross-lane adds, over the waves through LDS (the K loop's
+    // stages are dead).
     constexpr int NW = GemmCfg<NIW>::NWAVE;
     static_assert(2 * GEMM_BM * NW <= 2 * STAGE, "reduction scratch must fit the K loop's LDS");
     float *red1 = gemm_lds, *red2 = gemm_lds + GEMM_BM * NW;
-    float bv[NI], gv[NI], bev[NI];
+    gf4 bv[NI], gv[NI], bev[NI];
 #pragma unroll
-    for (int b = 0; b < NI; b++) { const int col = nw + 16 * b + li; bv[b] = bias[col]; gv[b] = ln.gamma[col]; bev[b] = ln.beta[col]; }
-    // z first (straight from the accumulators), then the accumulators are overwritten by silu(z + bias): 40 live registers fewer
+    for (int b = 0; b < NI; b++) {
+      const int col = nw + 16 * b + 4 * kq;
+      bv[b] = *reinterpret_cast<const gf4 *>(bias + col); gv[b] = *reinterpret_cast<const gf4 *>(ln.gamma + col); bev[b] = *reinterpret_cast<const gf4 *>(ln.beta + col);
+    }
+    // z first (straight from the accumulators), then the accumulators are overwritten by silu(z + bias)
+    float stat[5];
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < 5; a++) {
+      const int row = m0 + 16 * a + li;
+      float p = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = m0 + 16 * a + 4 * kq + r;
-        if (row < M) {
+      for (int b = 0; b < NI; b++) {
+        if (row < M) *reinterpret_cast<gf4 *>(C + (long long)row * ldc + nw + 16 * b + 4 * kq) = acc[a][b];
 #pragma unroll
-          for (int b = 0; b < NI; b++) C[(long long)row * ldc + nw + 16 * b + li] = acc[a][b][r];
-        }
+        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
       }
-    float stat[5][4];
-#pragma unroll
-    for (int a = 0; a < 5; a++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float p = 0.f;
-#pragma unroll
-        for (int b = 0; b < NI; b++) { const float v = acc[a][b][r] + bv[b]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
-        stat[a][r] = gemm_row16_sum(p);
-      }
+      p += __shfl_xor(p, 16);
+      stat[a] = p + __shfl_xor(p, 32);
+    }
     __syncthreads();                   // every wave has read its last fragments
-    auto exchange = [&](float *red) {  // stat[a][r] <- sum over the waves
-      if (li == 0) {
+    auto exchange = [&](float *red) {  // stat[a] <- sum over the waves
+      if (kq == 0) {
 #pragma unroll
-        for (int a = 0; a < 5; a++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) red[(16 * a + 4 * kq + r) * NW + wave] = stat[a][r];
+        for (int a = 0; a < 5; a++) red[(16 * a + li) * NW + wave] = stat[a];
       }
       __syncthreads();
 #pragma unroll
-      for (int a = 0; a < 5; a++)
+      for (int a = 0; a < 5; a++) {
+        const gf4 *q = reinterpret_cast<const gf4 *>(red + (16 * a + li) * NW);
+        float m = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const gf4 *q = reinterpret_cast<const gf4 *>(red + (16 * a + 4 * kq + r) * NW);
-          float m = 0.f;
-#pragma unroll
-          for (int w4 = 0; w4 < NW / 4; w4++) { const gf4 v = q[w4]; m += (v.x + v.y) + (v.z + v.w); }
-          stat[a][r] = m;
-        }
+        for (int w4 = 0; w4 < NW / 4; w4++) { const gf4 v = q[w4]; m += (v.x + v.y) + (v.z + v.w); }
+        stat[a] = m;
+      }
     };
     exchange(red1);
     const float inv_n = 1.f / (float)BN;
+    float mean[5];
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < 5; a++) {
+      mean[a] = stat[a] * inv_n;
+      float q = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float mean = stat[a][r] * inv_n;
-        float q = 0.f;
+      for (int b = 0; b < NI; b++)
 #pragma unroll
-        for (int b = 0; b < NI; b++) { acc[a][b][r] -= mean; q += acc[a][b][r] * acc[a][b][r]; }      // centred from here on
-        if (wave == 0 && li == 0 && m0 + 16 * a + 4 * kq + r < M) ln.stats[2 * (long long)(m0 + 16 * a + 4 * kq + r)] = mean;
-        stat[a][r] = gemm_row16_sum(q);
-      }
+        for (int r = 0; r < 4; r++) { acc[a][b][r] -= mean[a]; q += acc[a][b][r] * acc[a][b][r]; }      // centred from here on
+      q += __shfl_xor(q, 16);
+      stat[a] = q + __shfl_xor(q, 32);
+    }
     exchange(red2);
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < 5; a++) {
+      const int row = m0 + 16 * a + li;
+      const float rstd = rsqrtf(stat[a] * inv_n + ln.eps);
+      if (row < M) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = m0 + 16 * a + 4 * kq + r;
-        const float rstd = rsqrtf(stat[a][r] * inv_n + ln.eps);
-        if (row < M) {
-#pragma unroll
-          for (int b = 0; b < NI; b++) ln.y[(long long)row * ldc + nw + 16 * b + li] = acc[a][b][r] * rstd * gv[b] + bev[b];
-          if (wave == 0 && li == 0) ln.stats[2 * (long long)row + 1] = rstd;
-        }
+        for (int b = 0; b < NI; b++) *reinterpret_cast<gf4 *>(ln.y + (long long)row * ldc + nw + 16 * b + 4 * kq) = acc[a][b] * rstd * gv[b] + bev[b];
+        if (wave == 0 && kq == 0) { ln.stats[2 * (long long)row] = mean[a]; ln.stats[2 * (long long)row + 1] = rstd; }
       }
+    }
     return;
   }
-  // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile: stored straight from the registers (64-byte
-  // pieces; routing the tile through LDS to store whole rows as dwordx4 was tried and is 6 % SLOWER for these 80 x 256 tiles)
+  // stored straight from the accumulators (routing the tile through LDS to store whole rows was tried and is 6 % SLOWER for these tiles)
   if constexpr (!BT && NI == 2) {      // interleaved tile columns (see fread): lane holds columns n0 + nw + 2 li, + 1 of its rows
     const int col = n0 + nw + 2 * li;
     const bool pair = col + 1 < N && !(ldc & 1) && !((uintptr_t)C & 7);
@@ -404,9 +401,36 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       }
     return;
   }
+  if constexpr (BT) {                  // transposed tiles (see mma): one dwordx4 per tile and lane where the row is 16-byte aligned
+    const bool vec = !(ldc & 3) && !((uintptr_t)C & 15);
+#pragma unroll
+    for (int b = 0; b < NI; b++) {
+      const int col = n0 + nw + 16 * b + 4 * kq;
+      gf4 bv = {0.f, 0.f, 0.f, 0.f};
+#ifndef GEMM_PROF
+      if (bias) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) bv[r] = col + r < N ? bias[col + r] : 0.f;
+      }
+#endif
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+        const int row = m0 + 16 * a + li;
+        if (row < M) {
+          float *o = C + (long long)row * ldc + col;
+          const gf4 v = acc[a][b] + bv;
+          if (vec && col + 3 < N) *reinterpret_cast<gf4 *>(o) = v;
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (col + r < N) o[r] = v[r];
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int b = 0; b < NI; b++) {
-    const int col = n0 + nw + (BT ? 16 * b + li : NI * li + b);
+    const int col = n0 + nw + NI * li + b;
 #ifdef GEMM_PROF
     const float bv = 0.f;
 #else
@@ -419,6 +443,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
         const int row = m0 + 16 * a + 4 * kq + r;
         if (row < M && col < N) C[(long long)row * ldc + col] = acc[a][b][r] + bv;
       }
+  }
   }
 #ifdef GEMM_PROF
   if (lane == 0) {

@@ -413,6 +413,49 @@ __global__ __launch_bounds__(256) void k_gather_normalize(const float *__restric
   }
 }
 
+// The whole minibatch of one SGD step in ONE launch (ppo.py:304-317: every leaf of the roll-out data is indexed by the same permutation slice):
+// normalised observations [T][B][W] and bootstrap observations [B][W] (float4 lanes), raw actions [T][B][A] and the four per-step scalars
+// (log-prob, reward, discount, truncation) [4][T][B] — seven index_select / gather launches of 4-20 us each otherwise, serialised in front of
+// the first GEMM of the step.
+struct MinibatchGather {
+  const float *obs, *next_last, *raw_action, *scalar[4];
+  const long long *idx;
+  const float *mean, *stdv;
+  float *obs_n, *next_n, *raw_action_g, *scalars_g;
+  int T, R, B, W, A;
+};
+__global__ __launch_bounds__(256) void k_gather_minibatch(MinibatchGather g) {
+  const int w4 = g.W >> 2;
+  const size_t n_obs = (size_t)g.T * g.B * w4, n_next = (size_t)g.B * w4, n_act = (size_t)g.T * g.B * g.A, n_sc = (size_t)4 * g.T * g.B;
+  const size_t total = n_obs + n_next + n_act + n_sc;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    if (i < n_obs + n_next) {
+      const bool nx = i >= n_obs;
+      const size_t j = nx ? i - n_obs : i;
+      const int c = (int)(j % w4);
+      const size_t tb = j / w4;
+      const int b = (int)(tb % g.B), t = (int)(tb / g.B);
+      const float *src = nx ? g.next_last : g.obs;
+      const float4 v = reinterpret_cast<const float4 *>(src + ((size_t)t * g.R + (size_t)g.idx[b]) * g.W)[c];
+      const float4 m = reinterpret_cast<const float4 *>(g.mean)[c], s = reinterpret_cast<const float4 *>(g.stdv)[c];
+      const float4 o = {(v.x - m.x) / s.x, (v.y - m.y) / s.y, (v.z - m.z) / s.z, (v.w - m.w) / s.w};
+      reinterpret_cast<float4 *>((nx ? g.next_n : g.obs_n) + tb * g.W)[c] = o;
+    } else if (i < n_obs + n_next + n_act) {
+      const size_t j = i - n_obs - n_next;
+      const int c = (int)(j % g.A);
+      const size_t tb = j / g.A;
+      const int b = (int)(tb % g.B), t = (int)(tb / g.B);
+      g.raw_action_g[j] = g.raw_action[((size_t)t * g.R + (size_t)g.idx[b]) * g.A + c];
+    } else {
+      const size_t j = i - n_obs - n_next - n_act;
+      const int b = (int)(j % g.B);
+      const size_t kt = j / g.B;                      // k * T + t
+      const int t = (int)(kt % g.T), k = (int)(kt / g.T);
+      g.scalars_g[j] = g.scalar[k][(size_t)t * g.R + (size_t)g.idx[b]];
+    }
+  }
+}
+
 // ---- policy inference tails (make_inference_fn, ppo_networks.py:46-96; reparameterize, intention_network.py:78-88)
 // latent sample + decoder input in one pass:  x[i] = [ mean + eps * exp(logvar / 2)  |  obs[i][ref:] ]
 __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__ fc2, const float *__restrict__ eps, const float *__restrict__ obs,

@@ -572,6 +572,19 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
   return check_launch("k_gather_normalize");
 }
 
+int tmjx_gather_minibatch(const float *obs, const float *next_last, const float *raw_action, const float *log_prob, const float *reward, const float *discount,
+                          const float *truncation, const int64_t *idx, const float *mean, const float *std, float *obs_n, float *next_n, float *raw_action_g,
+                          float *scalars_g, int T, int R, int B, int W, int A, void *stream) {
+  if (!obs || !next_last || !raw_action || !log_prob || !reward || !discount || !truncation || !idx || !mean || !std || !obs_n || !next_n || !raw_action_g || !scalars_g)
+    return fail(TMJX_EINVAL, "null argument");
+  if (T < 1 || R < 1 || B < 1 || A < 1 || W < 4 || (W & 3)) return fail(TMJX_EINVAL, "bad T / R / B / A / W (W must be a multiple of 4)");
+  MinibatchGather g{obs, next_last, raw_action, {log_prob, reward, discount, truncation}, (const long long *)idx, mean, std, obs_n, next_n, raw_action_g, scalars_g, T, R, B, W, A};
+  const size_t total = (size_t)T * B * (W >> 2) + (size_t)B * (W >> 2) + (size_t)T * B * A + (size_t)4 * T * B;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_gather_minibatch, dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
+  return check_launch("k_gather_minibatch");
+}
+
 int tmjx_colsum_scratch_floats(int width) { return COLSUM_CHUNKS * width; }
 
 int tmjx_colsum(const float *src, float *out, float *scratch, int rows, int width, void *stream) {
