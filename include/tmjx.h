@@ -142,6 +142,26 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
 int tmjx_gather_minibatch(const float *obs, const float *next_last, const float *raw_action, const float *log_prob, const float *reward, const float *discount,
                           const float *truncation, const int64_t *idx, const float *mean, const float *std, float *obs_n, float *next_n, float *raw_action_g,
                           float *scalars_g, int T, int R, int B, int W, int A, void *stream);
+/* The same launch as the first kernel of a SELF-ADVANCING SGD step (a captured hipGraph replays it without any host input): the rows are
+ * perm[slot B .. slot B + B) with slot = state[1]; the launch also draws the step's two N(0, 1) arrays — eps [T B Z] (the latent sample of
+ * intention_network.py:78-88) and noise [T B A] (the entropy sample of losses.py:222) — from Philox4x32-10 keyed by `seed`, counter state[0],
+ * and, with `advance`, adds 1 to state[0] and state[1] once every workgroup is done (state: device int64[TMJX_MINIBATCH_STATE_WORDS], {draw counter, slot, 0, 0, ...}:
+ * words 2 .. are the launch's completion tickets and must be zero).
+ * The host resets state[1] and refills `perm` once per epoch (ppo.py:304-311: one permutation per update over the batch). */
+#define TMJX_MINIBATCH_STATE_WORDS (16 + 16 * 64)
+typedef struct tmjx_minibatch_t {
+  const float *obs, *next_last, *raw_action, *log_prob, *reward, *discount, *truncation;
+  const int64_t *perm;
+  const float *mean, *std;
+  float *obs_n, *next_n, *raw_action_g, *scalars_g;
+  float *eps, *noise;            /* may be NULL */
+  int64_t *state;                /* may be NULL when eps, noise are NULL and advance == 0 (then slot = 0) */
+  uint64_t seed;
+  int32_t T, R, B, W, A, Z, advance;
+} tmjx_minibatch_t;
+int tmjx_minibatch_begin(const tmjx_minibatch_t *mb, void *stream);
+/* Philox4x32-10 of (counter[4], key[2]) = six device words -> four device words: the generator above, exposed for its known-answer test */
+int tmjx_philox4x32_10(const uint32_t *ctr_key_dev, uint32_t *out_dev, void *stream);
 
 /* Backward of the latent sample inside tmjx_latent_concat (reparameterize, intention_network.py:78-88): from d x [n][dx_stride]
  * to d fc2 [n][2 Z] = [d mean | d logvar]. */

@@ -11,14 +11,14 @@ ROOT = Path(__file__).resolve().parents[1]
 
 def _declared():
     text = (ROOT / "include" / "tmjx.h").read_text()
-    return sorted(set(re.findall(r"\b(tmjx_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(tmjx_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported():
     if not hip.SO_PATH.exists():
         hip.build()
     out = subprocess.run(["nm", "-D", "--defined-only", str(hip.SO_PATH)], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r"\bT (tmjx_[a-z_]+)", out))
+    exported = set(re.findall(r"\bT (tmjx_[a-z0-9_]+)", out))
     declared = _declared()
     assert len(declared) >= 12
     assert not [s for s in declared if s not in exported], exported

@@ -788,3 +788,60 @@ def test_lds_free_linear_matches_torch(M, N, K, kmajor, monkeypatch):
         _hip.check(L.tmjx_linear_nolds(p(A), A.stride(0), A.stride(1), p(W), p(b), p(out), M, N, K, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nolds")
         torch.cuda.synchronize()
         assert float((out.double() - ref).abs().max()) <= 5e-6 * float(ref.abs().max()), (valu, M, N, K)
+
+
+@pytest.mark.gpu
+def test_philox_known_answers_and_self_advancing_minibatch():
+    """The device-side noise of the SGD step: (1) Philox4x32-10 against the known-answer vectors of the Random123 distribution (kat_vectors:
+    zero, all-ones and pi-digit inputs); (2) tmjx_minibatch_begin: rows = the slot's slice of the permutation, bit-identical to index_select,
+    the state advanced exactly once per launch, draws N(0, 1) by their first four moments, reproducible for the same (seed, counter) and
+    different for the next counter."""
+    import ctypes as C
+    import torch
+    from track_mjx_amd import hip
+    from track_mjx_amd.agent import losses
+    from track_mjx_amd.agent.networks import RunningStatistics
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    kat = [([0, 0, 0, 0, 0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 6, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for inp, want in kat:
+        a = torch.tensor(np.array(inp, dtype=np.uint32).view(np.int32), device=dev)
+        o = torch.zeros(4, dtype=torch.int32, device=dev)
+        hip.check(L.tmjx_philox4x32_10(C.c_void_p(a.data_ptr()), C.c_void_p(o.data_ptr()), None), "tmjx_philox4x32_10")
+        torch.cuda.synchronize()
+        assert o.cpu().numpy().view(np.uint32).tolist() == want, [hex(v) for v in o.cpu().numpy().view(np.uint32)]
+
+    g = torch.Generator(device=dev).manual_seed(6)
+    T, R, W, A, B, Z = 20, 4096, 696, 38, 1024, 60
+    buf = {"observation": torch.randn(T, R, W, generator=g, device=dev), "raw_action": torch.randn(T, R, A, generator=g, device=dev),
+           "log_prob": torch.randn(T, R, generator=g, device=dev), "reward": torch.randn(T, R, generator=g, device=dev),
+           "discount": torch.rand(T, R, generator=g, device=dev), "truncation": torch.rand(T, R, generator=g, device=dev),
+           "next_observation_last": torch.randn(R, W, generator=g, device=dev), "_B": B}
+    perm = torch.randperm(R, generator=g, device=dev)
+    norm = RunningStatistics(W, dev)
+    norm.update(buf["observation"])
+    state = torch.zeros(16 + 16 * 64, dtype=torch.long, device=dev)          # TMJX_MINIBATCH_STATE_WORDS
+    state[0], state[1] = 7, 2
+    d1 = losses.minibatch_begin(buf, perm, state, 1234, norm, Z)
+    assert state[:2].tolist() == [8, 3] and not state[2:].any()
+    idx = perm[2 * B:3 * B]
+    assert torch.equal(d1["observation_normalized"], norm.normalize(buf["observation"].index_select(1, idx)))
+    assert torch.equal(d1["next_observation_last_normalized"], norm.normalize(buf["next_observation_last"].index_select(0, idx)))
+    for k in ("raw_action", "log_prob", "reward", "discount", "truncation"):
+        assert torch.equal(d1[k], buf[k].index_select(1, idx)), k
+    d2 = losses.minibatch_begin(buf, perm, state, 1234, norm, Z)                 # counter 8, slot 3
+    state[0], state[1] = 7, 2
+    d3 = losses.minibatch_begin(buf, perm, state, 1234, norm, Z, advance=False)  # counter 7 again
+    assert state[:2].tolist() == [7, 2] and not state[2:].any()
+    for k in ("latent_eps", "entropy_noise"):
+        x = d1[k].double().flatten()
+        n = x.numel()
+        m, v = x.mean().item(), x.var().item()
+        skew, kurt = ((x - m) ** 3).mean().item() / v ** 1.5, ((x - m) ** 4).mean().item() / v ** 2
+        print(f"{k}: n {n} mean {m:+.4f} var {v:.4f} skew {skew:+.4f} kurt {kurt:.4f} max |x| {x.abs().max().item():.2f}")
+        assert abs(m) < 5 / n ** 0.5 and abs(v - 1) < 5 * (2 / n) ** 0.5 and abs(skew) < 5 * (6 / n) ** 0.5 and abs(kurt - 3) < 5 * (24 / n) ** 0.5
+        assert torch.equal(d1[k], d3[k]) and not torch.equal(d1[k], d2[k])
+        assert abs(torch.corrcoef(torch.stack([d1[k].flatten(), d2[k].flatten()]))[0, 1].item()) < 5 / n ** 0.5
+    assert abs(torch.corrcoef(torch.stack([d1["latent_eps"].flatten()[:100000], d1["entropy_noise"].flatten()[:100000]]))[0, 1].item()) < 0.02

@@ -64,6 +64,26 @@ def gather_minibatch(buf: dict, idx: torch.Tensor, normalizer) -> dict:
             "discount": sc[2], "truncation": sc[3]}
 
 
+def minibatch_begin(buf: dict, perm: torch.Tensor, state: torch.Tensor, seed: int, normalizer, latents: int, advance: bool = True) -> dict:
+    """First launch of a self-advancing SGD step (tmjx_minibatch_begin): the minibatch rows perm[slot B : slot B + B] (slot = state[1], B =
+    perm.numel() // num_minibatches is implied by the caller through `buf["_B"]`) of every leaf, observations normalised, plus the step's two
+    N(0, 1) arrays ("latent_eps" [T, B, latents], "entropy_noise" [T, B, A]) from the device-side Philox stream; advances state[0:2]."""
+    obs, nxt, act = buf["observation"], buf["next_observation_last"], buf["raw_action"]
+    T, R, W = obs.shape
+    B, A = int(buf["_B"]), act.shape[-1]
+    f32 = dict(dtype=torch.float32, device=obs.device)
+    obs_n, next_n = torch.empty((T, B, W), **f32), torch.empty((B, W), **f32)
+    act_g, sc = torch.empty((T, B, A), **f32), torch.empty((4, T, B), **f32)
+    eps, noise = torch.empty((T, B, latents), **f32), torch.empty((T, B, A), **f32)
+    d = lambda t: t.data_ptr()  # noqa: E731
+    m = _hip.Minibatch(d(obs), d(nxt), d(act), d(buf["log_prob"]), d(buf["reward"]), d(buf["discount"]), d(buf["truncation"]), d(perm), d(normalizer.mean),
+                       d(normalizer.std), d(obs_n), d(next_n), d(act_g), d(sc), d(eps), d(noise), d(state), seed & (2 ** 64 - 1), T, R, B, W, A, latents, int(advance))
+    with torch.cuda.device(obs.device):
+        _hip.check(_hip.lib().tmjx_minibatch_begin(C.byref(m), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)), "tmjx_minibatch_begin")
+    return {"observation_normalized": obs_n, "next_observation_last_normalized": next_n, "raw_action": act_g, "log_prob": sc[0], "reward": sc[1],
+            "discount": sc[2], "truncation": sc[3], "latent_eps": eps, "entropy_noise": noise}
+
+
 def create_ramp_schedule(max_value: float = 0.1, min_value: float = 0.0001, ramp_steps: int = 1000, warmup_steps: int = 0):
     """Linear ramp (losses.py:263-269): clip((step - warmup)/ramp_steps, min_value, 1) * max_value."""
     def schedule_fn(step: float) -> float:
@@ -122,16 +142,16 @@ def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_
             baseline = value(obs)
             with torch.no_grad():
                 bootstrap = value(nxt)
-        logits, fc2 = policy(obs, return_fc2=True)
+        logits, fc2 = policy(obs, eps=data.get("latent_eps"), return_fc2=True)
         cur.wait_stream(side_stream)
         baseline.record_stream(cur); bootstrap.record_stream(cur)
     else:
-        logits, fc2 = policy(obs, return_fc2=True)
+        logits, fc2 = policy(obs, eps=data.get("latent_eps"), return_fc2=True)
         baseline = value(obs)
         with torch.no_grad():
             bootstrap = value(nxt)
     with torch.no_grad():
-        noise = torch.randn(data["raw_action"].shape, dtype=torch.float32, device=logits.device)   # entropy sample (randn_like(loc))
+        noise = data["entropy_noise"] if "entropy_noise" in data else torch.randn(data["raw_action"].shape, dtype=torch.float32, device=logits.device)   # entropy sample (randn_like(loc))
         T, B = data["reward"].shape
         dev = logits.device
         args = [a.detach().contiguous().float() for a in (logits, data["raw_action"], data["log_prob"], noise, baseline, bootstrap, data["reward"],

@@ -196,7 +196,12 @@ class PPOLearner:
         if self._sgd_side is not None and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)    # intentional: the value net's gradients arrive from the side stream
         self._metric_index = torch.tensor([0, 1, 2, 4, 3], dtype=torch.long, device=dev)    # METRIC_KEYS -> slots of tmjx_ppo_loss's output
-        self.use_graph, self._graph, self._graph_kl = use_graph, None, None
+        self.use_graph, self._graph, self._graph_kl, self._graph_selfadv = use_graph, None, None, None
+        # self-advancing SGD step (tmjx_minibatch_begin): the epoch's permutation, {draw counter, slot, ticket}, the metric accumulator
+        self._perm_static = torch.zeros(rows, dtype=torch.long, device=dev)
+        self._mb_state = torch.zeros(16 + 16 * 64, dtype=torch.long, device=dev)     # TMJX_MINIBATCH_STATE_WORDS: {draw counter, slot, tickets ...}
+        self._acc8 = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._noise_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * (self.rank + 1)) & (2 ** 64 - 1)      # one Philox key per rank
         self._act_graphs: dict = {}
         self._wpad: dict = {}
         self.lds_free = len(self.envs) > 1 and dev.type == "cuda"   # pipelined roll-outs: LDS-free inference kernels (see _act_fused)
@@ -415,10 +420,20 @@ class PPOLearner:
                 cur.wait_stream(sg)
 
     # ---- learning
-    def _minibatch_grads(self, idx: torch.Tensor, kl_w: float) -> torch.Tensor:
-        """Gather one minibatch, loss, gradients into the flat buffer; returns the 5 loss terms as one tensor."""
+    def _self_advancing(self) -> bool:
+        """The SGD step draws its rows and its noise on the device (tmjx_minibatch_begin): needs the fused gather's layout."""
+        return (self.dev.type == "cuda" and self.normalize_observations and self.buf["observation"].shape[-1] % 4 == 0
+                and all(v.is_contiguous() for v in self.buf.values()) and not os.environ.get("TMJX_NO_SELF_ADVANCE"))
+
+    def _minibatch_grads(self, idx: torch.Tensor | None, kl_w: float) -> torch.Tensor:
+        """Gather one minibatch, loss, gradients into the flat buffer; returns the 5 loss terms as one tensor.  idx None: the self-advancing
+        form — rows from the epoch's permutation at the device-side slot counter, noise from the device-side Philox stream, metrics added
+        to self._acc8: a captured graph of it replays with NO host input (no index copy, no torch generator state to refresh)."""
         fused_gather = self.dev.type == "cuda" and self.normalize_observations and self.buf["observation"].shape[-1] % 4 == 0
-        if fused_gather and all(v.is_contiguous() for v in self.buf.values()):
+        if idx is None:
+            data = _losses.minibatch_begin({**self.buf, "_B": self.local_batch}, self._perm_static, self._mb_state, self._noise_seed, self.normalizer,
+                                           self.policy.latents)
+        elif fused_gather and all(v.is_contiguous() for v in self.buf.values()):
             data = _losses.gather_minibatch(self.buf, idx, self.normalizer)      # all seven leaves in one launch
         else:
             data = {k: (self.buf[k].index_select(1, idx) if k != "next_observation_last" else self.buf[k].index_select(0, idx)) for k in self.buf}
@@ -434,6 +449,9 @@ class PPOLearner:
                 dwg.launch()             # every layer's (dW, db) in one grouped launch, straight into the flat gradient buffer
                 self._dwg = dwg          # (keeps the slab scratch alive until the next step)
                 self.grads.assign(grads)
+                if idx is None:
+                    self._acc8.add_(out8)                # (reordered to METRIC_KEYS once per update())
+                    return self._acc8
                 return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
             loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp,
                                                **({"gae_fn": self.gae_fn} if self.gae_fn is not None else {}))
@@ -452,18 +470,21 @@ class PPOLearner:
         """hipGraph of _minibatch_grads (torch.cuda.graphs): ~250 launches of the SGD step replayed as one graph launch.
         The minibatch row indices are a static device buffer; the optimiser and the gradient all-reduce stay eager, so the
         same graph serves any world size."""
-        self._g_idx = torch.zeros(self.local_batch, dtype=torch.long, device=self.dev)
+        selfadv = self._self_advancing()
+        self._g_idx = None if selfadv else torch.zeros(self.local_batch, dtype=torch.long, device=self.dev)
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
             for _ in range(3):
+                if selfadv:
+                    self._mb_state[1:].zero_()          # (warm-up runs read slot 0 of whatever the permutation buffer holds: valid rows)
                 self._minibatch_grads(self._g_idx, kl_w)
         torch.cuda.current_stream(self.dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread polls events concurrently (world > 1) and must not invalidate the capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._g_out = self._minibatch_grads(self._g_idx, kl_w)
-        self._graph, self._graph_kl = graph, kl_w
+        self._graph, self._graph_kl, self._graph_selfadv = graph, kl_w, selfadv
 
     def update(self, it: int = 0, kl_schedule: Callable | None = None) -> dict:
         if self.normalize_observations:
@@ -478,22 +499,34 @@ class PPOLearner:
                 print(f"[track_mjx_amd] hipGraph capture of the SGD step failed ({type(e).__name__}: {e}); running eagerly", flush=True)
                 self.use_graph = use_graph = False
                 torch.cuda.synchronize(self.dev)
+        selfadv = self._self_advancing()
+        if use_graph and self._graph_selfadv != selfadv:
+            self._capture(kl_w)
         acc = torch.zeros(len(self.METRIC_KEYS), dtype=torch.float32, device=self.dev)
+        if selfadv:
+            self._acc8.zero_()
         for upd in range(self.num_updates):
             # one permutation for every leaf (ppo.py:306-311)
             perm = torch.randperm(rows, generator=self.gen, device=self.dev) if self.perm_fn is None else self.perm_fn(upd, rows).to(self.dev)
+            if selfadv:
+                self._perm_static.copy_(perm)
+                self._mb_state[1:2].zero_()                   # slot 0 of the new permutation
             for mb in range(self.num_minibatches):
-                idx = perm[mb * self.local_batch:(mb + 1) * self.local_batch]
+                idx = None if selfadv else perm[mb * self.local_batch:(mb + 1) * self.local_batch]
                 if use_graph:
-                    self._g_idx.copy_(idx)
+                    if not selfadv:
+                        self._g_idx.copy_(idx)
                     self._graph.replay()
                     out = self._g_out
                 else:
                     out = self._minibatch_grads(idx, kl_w)
                 self.grads.all_reduce_mean(self.group, force=self.collectives)       # C1: one RCCL all-reduce per minibatch step
                 self.opt.step()                               # clip_by_global_norm(10.0) -> adam (ppo.py:517-520), one fused launch
-                acc += out
-        acc /= self.num_updates * self.num_minibatches
+                if not selfadv:
+                    acc += out
+        if selfadv:
+            acc = self._acc8[self._metric_index]
+        acc = acc / (self.num_updates * self.num_minibatches)
         self._refresh_padded_weights()       # act() / the evaluator right after this update must not see last step's zero-padded copies
         res = {k: acc[i] for i, k in enumerate(self.METRIC_KEYS)}
         res["kl_weight"] = torch.as_tensor(kl_w)

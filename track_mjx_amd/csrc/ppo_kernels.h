@@ -417,43 +417,109 @@ __global__ __launch_bounds__(256) void k_gather_normalize(const float *__restric
 // normalised observations [T][B][W] and bootstrap observations [B][W] (float4 lanes), raw actions [T][B][A] and the four per-step scalars
 // (log-prob, reward, discount, truncation) [4][T][B] — seven index_select / gather launches of 4-20 us each otherwise, serialised in front of
 // the first GEMM of the step.
+#define TM_MB_SUBTICKETS 64
+#define TM_MB_STATE_HEAD 16      // int64 words in front of the sub-tickets: {draw counter, slot, top ticket, ...}
+#define TM_MB_STATE_STRIDE 16    // one 128-byte line per sub-ticket
 struct MinibatchGather {
   const float *obs, *next_last, *raw_action, *scalar[4];
-  const long long *idx;
+  const long long *idx;       // the minibatch rows are idx[slot * B .. + B), slot = state[1] (0 without state)
   const float *mean, *stdv;
   float *obs_n, *next_n, *raw_action_g, *scalars_g;
-  int T, R, B, W, A;
+  float *eps, *noise;         // N(0, 1) draws [T B Z] / [T B A] (either may be null)
+  long long *state;           // device int64[TM_MB_STATE_HEAD + TM_MB_STATE_STRIDE * TM_MB_SUBTICKETS]: {draw counter, slot, ticket, .. | sub-tickets} or null
+  unsigned long long seed;
+  int T, R, B, W, A, Z, advance;
 };
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 constants)
+__device__ __forceinline__ void tm_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned *out) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// four N(0, 1) draws for elements 4 q .. 4 q + 3 of stream `sid` at draw counter `ctr` (Box-Muller on 24-bit uniforms in (0, 1))
+__device__ __forceinline__ void tm_normal4(unsigned long long seed, unsigned long long ctr, unsigned sid, unsigned q, float *n) {
+  unsigned x[4];
+  tm_philox4x32_10(q, sid, (unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)seed, (unsigned)(seed >> 32), x);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float u1 = ((float)(x[2 * h] >> 8) + 0.5f) * (1.f / 16777216.f), u2 = ((float)(x[2 * h + 1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float r = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincospif(2.f * u2, &sn, &cs);
+    n[2 * h] = r * cs; n[2 * h + 1] = r * sn;
+  }
+}
 __global__ __launch_bounds__(256) void k_gather_minibatch(MinibatchGather g) {
   const int w4 = g.W >> 2;
+  // every block reads the state before it can have been advanced: the advance is made by the block that FINISHES last (ticket below)
+  const unsigned long long ctr = g.state ? (unsigned long long)g.state[0] : 0ull;
+  const long long *idx = g.idx + (g.state ? g.state[1] * (long long)g.B : 0ll);
   const size_t n_obs = (size_t)g.T * g.B * w4, n_next = (size_t)g.B * w4, n_act = (size_t)g.T * g.B * g.A, n_sc = (size_t)4 * g.T * g.B;
-  const size_t total = n_obs + n_next + n_act + n_sc;
+  const size_t q_eps = g.eps ? ((size_t)g.T * g.B * g.Z + 3) / 4 : 0, q_noise = g.noise ? (n_act + 3) / 4 : 0;
+  const size_t e0 = n_obs + n_next, e1 = e0 + n_act, e2 = e1 + n_sc, e3 = e2 + q_eps, total = e3 + q_noise;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    if (i < n_obs + n_next) {
+    if (i < e0) {
       const bool nx = i >= n_obs;
       const size_t j = nx ? i - n_obs : i;
       const int c = (int)(j % w4);
       const size_t tb = j / w4;
       const int b = (int)(tb % g.B), t = (int)(tb / g.B);
       const float *src = nx ? g.next_last : g.obs;
-      const float4 v = reinterpret_cast<const float4 *>(src + ((size_t)t * g.R + (size_t)g.idx[b]) * g.W)[c];
+      const float4 v = reinterpret_cast<const float4 *>(src + ((size_t)t * g.R + (size_t)idx[b]) * g.W)[c];
       const float4 m = reinterpret_cast<const float4 *>(g.mean)[c], s = reinterpret_cast<const float4 *>(g.stdv)[c];
       const float4 o = {(v.x - m.x) / s.x, (v.y - m.y) / s.y, (v.z - m.z) / s.z, (v.w - m.w) / s.w};
       reinterpret_cast<float4 *>((nx ? g.next_n : g.obs_n) + tb * g.W)[c] = o;
-    } else if (i < n_obs + n_next + n_act) {
-      const size_t j = i - n_obs - n_next;
+    } else if (i < e1) {
+      const size_t j = i - e0;
       const int c = (int)(j % g.A);
       const size_t tb = j / g.A;
       const int b = (int)(tb % g.B), t = (int)(tb / g.B);
-      g.raw_action_g[j] = g.raw_action[((size_t)t * g.R + (size_t)g.idx[b]) * g.A + c];
-    } else {
-      const size_t j = i - n_obs - n_next - n_act;
+      g.raw_action_g[j] = g.raw_action[((size_t)t * g.R + (size_t)idx[b]) * g.A + c];
+    } else if (i < e2) {
+      const size_t j = i - e1;
       const int b = (int)(j % g.B);
       const size_t kt = j / g.B;                      // k * T + t
       const int t = (int)(kt % g.T), k = (int)(kt / g.T);
-      g.scalars_g[j] = g.scalar[k][(size_t)t * g.R + (size_t)g.idx[b]];
+      g.scalars_g[j] = g.scalar[k][(size_t)t * g.R + (size_t)idx[b]];
+    } else {
+      const bool second = i >= e3;
+      const size_t q = second ? i - e3 : i - e2, n = second ? n_act : (size_t)g.T * g.B * g.Z;
+      float v[4];
+      tm_normal4(g.seed, ctr, second ? 1u : 0u, (unsigned)q, v);
+      float *dst = second ? g.noise : g.eps;
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (4 * q + k < n) dst[4 * q + k] = v[k];
     }
   }
+  if (g.state && g.advance) {
+    // No fences: a block's reads of state[0 .. 1] are complete before its loop ends (their values were used), hence before its ticket; the
+    // write below happens after every ticket, and the kernel boundary publishes it.  (An agent-scope __threadfence() per block — an L2
+    // write-back on gfx950 — made this 20 us kernel take 370 us.)
+    // Two-level ticket: 8192 atomics on ONE address serialise in its L2 channel (~10 ns each: 80 us); 64 sub-tickets on separate cache
+    // lines take them in parallel, the last block of each sub-group then takes one of 64 top-level tickets.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned sub = blockIdx.x % TM_MB_SUBTICKETS, nsub = min((unsigned)gridDim.x, (unsigned)TM_MB_SUBTICKETS);
+      const unsigned members = (gridDim.x - sub + TM_MB_SUBTICKETS - 1) / TM_MB_SUBTICKETS;       // blocks with this residue
+      unsigned long long *st = (unsigned long long *)g.state, *subt = st + TM_MB_STATE_HEAD + (size_t)TM_MB_STATE_STRIDE * sub;
+      if (__hip_atomic_fetch_add(subt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)members - 1ull) {
+        __hip_atomic_store(subt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(st + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)nsub - 1ull) {
+          __hip_atomic_store(st + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every block has finished, i.e. has read state[0 .. 1]
+          g.state[0] += 1; g.state[1] += 1;
+        }
+      }
+    }
+  }
+}
+// raw Philox words for the known-answer test (tests/test_gpu_parity.py)
+__global__ void k_philox_kat(const unsigned *ctr_key, unsigned *out) {
+  if (threadIdx.x == 0) tm_philox4x32_10(ctr_key[0], ctr_key[1], ctr_key[2], ctr_key[3], ctr_key[4], ctr_key[5], out);
 }
 
 // ---- policy inference tails (make_inference_fn, ppo_networks.py:46-96; reparameterize, intention_network.py:78-88)

@@ -572,17 +572,38 @@ int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mea
   return check_launch("k_gather_normalize");
 }
 
+static int launch_minibatch(const MinibatchGather &g, hipStream_t s) {
+  if (!g.obs || !g.next_last || !g.raw_action || !g.scalar[0] || !g.scalar[1] || !g.scalar[2] || !g.scalar[3] || !g.idx || !g.mean || !g.stdv || !g.obs_n || !g.next_n ||
+      !g.raw_action_g || !g.scalars_g)
+    return fail(TMJX_EINVAL, "null argument");
+  if (g.T < 1 || g.R < 1 || g.B < 1 || g.A < 1 || g.W < 4 || (g.W & 3)) return fail(TMJX_EINVAL, "bad T / R / B / A / W (W must be a multiple of 4)");
+  if (g.eps && g.Z < 1) return fail(TMJX_EINVAL, "Z must be >= 1 with eps");
+  const size_t nact = (size_t)g.T * g.B * g.A;
+  const size_t total = (size_t)g.T * g.B * (g.W >> 2) + (size_t)g.B * (g.W >> 2) + nact + (size_t)4 * g.T * g.B + (g.eps ? ((size_t)g.T * g.B * g.Z + 3) / 4 : 0) +
+                       (g.noise ? (nact + 3) / 4 : 0);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_gather_minibatch, dim3(grid), dim3(256), 0, s, g);
+  return check_launch("k_gather_minibatch");
+}
 int tmjx_gather_minibatch(const float *obs, const float *next_last, const float *raw_action, const float *log_prob, const float *reward, const float *discount,
                           const float *truncation, const int64_t *idx, const float *mean, const float *std, float *obs_n, float *next_n, float *raw_action_g,
                           float *scalars_g, int T, int R, int B, int W, int A, void *stream) {
-  if (!obs || !next_last || !raw_action || !log_prob || !reward || !discount || !truncation || !idx || !mean || !std || !obs_n || !next_n || !raw_action_g || !scalars_g)
-    return fail(TMJX_EINVAL, "null argument");
-  if (T < 1 || R < 1 || B < 1 || A < 1 || W < 4 || (W & 3)) return fail(TMJX_EINVAL, "bad T / R / B / A / W (W must be a multiple of 4)");
-  MinibatchGather g{obs, next_last, raw_action, {log_prob, reward, discount, truncation}, (const long long *)idx, mean, std, obs_n, next_n, raw_action_g, scalars_g, T, R, B, W, A};
-  const size_t total = (size_t)T * B * (W >> 2) + (size_t)B * (W >> 2) + (size_t)T * B * A + (size_t)4 * T * B;
-  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_gather_minibatch, dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
-  return check_launch("k_gather_minibatch");
+  MinibatchGather g{obs, next_last, raw_action, {log_prob, reward, discount, truncation}, (const long long *)idx, mean, std, obs_n, next_n, raw_action_g, scalars_g,
+                    nullptr, nullptr, nullptr, 0ull, T, R, B, W, A, 0, 0};
+  return launch_minibatch(g, (hipStream_t)stream);
+}
+int tmjx_minibatch_begin(const tmjx_minibatch_t *m, void *stream) {
+  if (!m) return fail(TMJX_EINVAL, "null argument");
+  if ((m->eps || m->noise || m->advance) && !m->state) return fail(TMJX_EINVAL, "tmjx_minibatch_begin: draws / advance need the device state");
+  MinibatchGather g{m->obs, m->next_last, m->raw_action, {m->log_prob, m->reward, m->discount, m->truncation}, (const long long *)m->perm, m->mean, m->std, m->obs_n,
+                    m->next_n, m->raw_action_g, m->scalars_g, m->eps, m->noise, (long long *)m->state, (unsigned long long)m->seed, m->T, m->R, m->B, m->W, m->A,
+                    m->Z, m->advance};
+  return launch_minibatch(g, (hipStream_t)stream);
+}
+int tmjx_philox4x32_10(const uint32_t *ctr_key_dev, uint32_t *out_dev, void *stream) {
+  if (!ctr_key_dev || !out_dev) return fail(TMJX_EINVAL, "null argument");
+  hipLaunchKernelGGL(k_philox_kat, dim3(1), dim3(64), 0, (hipStream_t)stream, ctr_key_dev, out_dev);
+  return check_launch("k_philox_kat");
 }
 
 int tmjx_colsum_scratch_floats(int width) { return COLSUM_CHUNKS * width; }

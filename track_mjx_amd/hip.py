@@ -31,8 +31,15 @@ class Layout(C.Structure):
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
-           "tmjx_gather_minibatch", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
+           "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
+
+
+class Minibatch(C.Structure):
+    """tmjx_minibatch_t (include/tmjx.h)."""
+    _fields_ = ([(k, C.c_void_p) for k in ("obs", "next_last", "raw_action", "log_prob", "reward", "discount", "truncation", "perm", "mean", "std", "obs_n", "next_n",
+                                           "raw_action_g", "scalars_g", "eps", "noise", "state")] + [("seed", C.c_uint64)] +
+                [(k, C.c_int32) for k in ("T", "R", "B", "W", "A", "Z", "advance")])
 
 
 class DwProblem(C.Structure):
@@ -105,6 +112,8 @@ def load(path: Path):
     sig.setdefault("tmjx_silu_ln_bwd", [None, None])[0] = [fp] * 8 + [C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_gather_normalize", [None, None])[0] = [fp] * 5 + [C.c_int] * 4 + [vp]
     sig.setdefault("tmjx_gather_minibatch", [None, None])[0] = [fp] * 14 + [C.c_int] * 5 + [vp]
+    sig.setdefault("tmjx_minibatch_begin", [None, None])[0] = [C.POINTER(Minibatch), vp]
+    sig.setdefault("tmjx_philox4x32_10", [None, None])[0] = [fp, fp, vp]
     sig.setdefault("tmjx_latent_concat", [None, None])[0] = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, C.c_int, vp]
     sig.setdefault("tmjx_latent_concat_bwd", [None, None])[0] = [fp] * 4 + [C.c_int] * 3 + [vp]
     sig.setdefault("tmjx_sample_action", [None, None])[0] = [fp] * 5 + [C.c_int, C.c_int, vp]
