@@ -140,9 +140,9 @@ def test_fused_dense_silu_layernorm_block(M, N, K, lda, monkeypatch):
 
     def run(fused):
         if fused:
-            monkeypatch.setenv("TMJX_FUSED_BLOCK", "1")
+            monkeypatch.delenv("TMJX_NO_FUSED_BLOCK", raising=False)
         else:
-            monkeypatch.delenv("TMJX_FUSED_BLOCK", raising=False)
+            monkeypatch.setenv("TMJX_NO_FUSED_BLOCK", "1")
         x = buf[:, :K].detach().requires_grad_(True)
         assert nw._block_fusable(x, blk.dense.weight) == fused
         y = blk(x)

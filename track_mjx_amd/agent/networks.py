@@ -344,11 +344,10 @@ class _SiluLayerNormFn(torch.autograd.Function):
 
 def _block_fusable(x2, w) -> bool:
     """One-launch forward of a Dense -> SiLU -> LayerNorm block: layers exactly one GEMM tile wide (64 / 128 / 256) with aligned operands.
-    OPT-IN (TMJX_FUSED_BLOCK=1): measured on MI355X the fused launch is SLOWER than GEMM + tmjx_silu_ln_fwd (47.1 vs 44.9 us at 20480 x 256 x 256,
-    76.3 vs 68.8 us at K = 470; SGD half 84.5 vs 81.6 ms): all 256 workgroups reach the epilogue together, so its 40 exp + divisions per lane and the
-    second 21 MB store run with the matrix pipe idle, while the separate memory-bound kernel (9 us) overlaps the value network's GEMMs on the other
-    stream.  Kept (and tested) as the one-launch form of the block."""
-    if not _hip_gemm_ok(x2, w) or not os.environ.get("TMJX_FUSED_BLOCK"):
+    Measured on MI355X (20480 rows): a first version that kept the accumulators' native layout (64-byte store pieces, 20 row statistics per lane)
+    was SLOWER than GEMM + tmjx_silu_ln_fwd (47.1 vs 44.9 us at 256 x 256); with the transposed tile (four consecutive columns per lane: dwordx4
+    stores of z and y, 5 row statistics per lane) the SGD half takes 69.9 ms against 70.4 ms.  TMJX_NO_FUSED_BLOCK=1 selects the two-launch form."""
+    if not _hip_gemm_ok(x2, w) or os.environ.get("TMJX_NO_FUSED_BLOCK"):
         return False
     from .. import hip as _hip
     import ctypes as C
