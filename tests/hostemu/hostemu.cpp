@@ -76,6 +76,7 @@ void emu_physics_wave(EmuModel *mm, float *st, const float *action, int nsub, in
     WCtx c{&mm->h, lds.data(), st, n, e, 0, nullptr, 0ull, ws_dump};
     std::vector<float> spill(mm->h.nnz + 64, 0.f);
     c.mspill = spill.data() + 64;
+    c.action = action;
     const WLayout K = tmjx_host::make_wave_layout(mm->h, !getenv("TMJX_EMU_GENERIC"));
     float time = tmw_load_state(c, K, action);
     for (int f = 0; f < nsub; f++) { tmw_forward(c, K, f == nsub - 1); if (do_euler) time = tmw_euler(c, K, time); }

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict
   WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x + e0, (int)threadIdx.x, nullptr, 0ull, nullptr};
   c.rs = rs;
   c.mspill = spill ? spill + 64 + (size_t)(blockIdx.x + e0) * (size_t)spill_stride : nullptr;
+  c.action = action;
 #ifndef TMW_PROFILE
   c.dump = ws_dump;
 #endif

@@ -9,8 +9,8 @@
 struct WLayout {
   int nbody, njnt, nq, nv, nu, ncon, nlim, nefc, ngroup, nnz, nphys, nround_body, nround_dof;
   // persistent part
-  int l_qpos, l_qvel, l_act, l_warm, l_ctrl, l_cdof, l_M, l_con_dist, l_con_off, l_con_frame, l_lim_sign, l_qfrc_smooth,
-      l_qfrc_actuator, l_act_dot, l_com, l_sv, l_wr, l_tdof, l_tgrp, l_hdamp, l_con_mu, l_con_grpb, l_rowmap, l_ccrow, l_dummy, l_alias0;
+  int l_qpos, l_qvel, l_act, l_cdof, l_M, l_con_dist, l_con_off, l_con_frame, l_lim_sign, l_qfrc_smooth,
+      l_com, l_sv, l_wr, l_tdof, l_tgrp, l_hdamp, l_con_mu, l_con_grpb, l_rowmap, l_ccrow, l_dummy, l_alias0;
   // aliased region A (solver stage)
   int l_LD, l_Dinv, l_efc_D, l_efc_aref, l_Jaref, l_jv, l_qacc_smooth, l_qacc, l_Ma, l_grad, l_Mgrad, l_search, l_mv,
       l_qfrc_constraint, l_tmp;
@@ -22,18 +22,22 @@ struct WLayout {
   constexpr WLayout(int nb, int nj, int nq_, int nv_, int nu_, int nc, int nl, int nnz_, int ng, int rb, int rd, int ch = 0)
       : nbody(nb), njnt(nj), nq(nq_), nv(nv_), nu(nu_), ncon(nc), nlim(nl), nefc(nl + 4 * nc), ngroup(ng), nnz(nnz_),
         nphys(nq_ + nv_ + nu_ + nv_ + 1), nround_body(rb), nround_dof(rd),
-        l_qpos(0), l_qvel(0), l_act(0), l_warm(0), l_ctrl(0), l_cdof(0), l_M(0), l_con_dist(0), l_con_off(0), l_con_frame(0),
-        l_lim_sign(0), l_qfrc_smooth(0), l_qfrc_actuator(0), l_act_dot(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_hdamp(0), l_con_mu(0), l_con_grpb(0), l_rowmap(0), l_ccrow(0), l_dummy(0),
+        l_qpos(0), l_qvel(0), l_act(0), l_cdof(0), l_M(0), l_con_dist(0), l_con_off(0), l_con_frame(0),
+        l_lim_sign(0), l_qfrc_smooth(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_hdamp(0), l_con_mu(0), l_con_grpb(0), l_rowmap(0), l_ccrow(0), l_dummy(0),
         l_alias0(0), l_LD(0), l_Dinv(0), l_efc_D(0), l_efc_aref(0), l_Jaref(0), l_jv(0), l_qacc_smooth(0), l_qacc(0), l_Ma(0),
         l_grad(0), l_Mgrad(0), l_search(0), l_mv(0), l_qfrc_constraint(0), l_tmp(0), l_scanA(0), l_scanB(0), l_jl_anchor(0),
         l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0), chains(ch) {
     int l = 0;
-    l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += nu; l_warm = l; l += nv; l_ctrl = l; l += nu;
+    // NOT here (they were, 295 words): the warm start, ctrl, act_dot, qfrc_actuator and timestep * damping.  LDS is granted in 1280-byte
+    // granules on gfx950 (tools/micro/lds_occupancy.hip): 16 284 bytes took 13 of the 128 granules of a CU, i.e. NINE resident envs, not the
+    // ten that "16 KB x 10 = 160 KB" suggests; 15 104 bytes take 12 -> ten.  Those five are touched once or twice per substep: they live in
+    // the env's global record (warm start, qfrc_actuator), are re-read from it (ctrl), recomputed (act_dot) or staged in a solver vector
+    // that is dead by then (l_hdamp = l_search during Euler).
+    l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += nu;
     l_cdof = l; l += nv * 6; l_M = l; l += nnz; l_con_dist = l; l += ncon; l_con_off = l; l += ncon * 3;
-    l_con_frame = l; l += ncon * 6; l_lim_sign = l; l += nlim; l_qfrc_smooth = l; l += nv; l_qfrc_actuator = l; l += nv;
-    l_act_dot = l; l += nu; l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_tdof = l; l += nv * 2;
+    l_con_frame = l; l += ncon * 6; l_lim_sign = l; l += nlim; l_qfrc_smooth = l; l += nv;
+    l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_tdof = l; l += nv * 2;
     l_tgrp = l; l += ngroup * 4;
-    l_hdamp = l; l += nv;     // timestep * joint damping (diagonal of Euler's M + h D), filled once per launch
     l_con_mu = l; l += ncon;  // friction coefficient and (bytes) paw group of every contact slot: model constants the products with
     l_con_grpb = l; l += (ncon + 3) / 4;   // J / J^T need on every call — kept here instead of being fetched from global memory each time
     // byte tables of the ACTIVE constraint rows (wave_physics.h: tmw_make_constraint): compact row -> original row, contact -> its
@@ -46,7 +50,7 @@ struct WLayout {
     // wrenches of J^T f (wr, 6*ncon <= nefc) are only live inside tmw_jt_force, never together with jv
     l_jv = l_efc_aref; l_wr = l_efc_aref;
     l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
-    l_Mgrad = l; l += nv; l_search = l; l += nv; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
+    l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
     l_dummy = l_mv;   // per-lane source of masked LDS READS (never written through; needs 64 <= nv words)
     int endA = l;
     l = l_alias0;
@@ -73,7 +77,7 @@ struct WLayout {
       l_Dinv = l; l += nv; l_efc_D = l; l += nefc; l_efc_aref = l; l += nefc; l_Jaref = l; l += nefc;
       l_jv = l_efc_aref; l_wr = l_efc_aref;
       l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
-      l_Mgrad = l; l += nv; l_search = l; l += nv; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
+      l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
       l_dummy = l_mv;
       int eA = l;
       // region B: xipos | joint anchors | joint axes; cinert overlays the joint frames (dead once cdof is built) but not xipos,

@@ -73,6 +73,7 @@ struct WCtx {
   int rs;                     // 0: `st` is the [row][n_env] state; > 0: `st` is the env-major physics record with this stride
   // per-lane model constants of the J / J^T products, fetched once per launch (a global load in every call left its latency exposed):
   unsigned kmask[TMW_NL];     // lane = (subset, component) of tmw_jt_force: contact mask (slots 0..31) of the subset (valid if n_wsub * 6 <= 64)
+  const float *action;        // [nu][n] action rows (direct mode, c.rs == 0) or null
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
 // solver statistics of the last substep, kept in the spare LDS word behind the centre of mass (registers are what this kernel has none
@@ -170,15 +171,12 @@ TM_DEV int tmw_prefix(const int *flag, int *excl) {
 TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int i = lane; i < K.nphys - 1; i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);
-    // (record mode: the action rows were transposed in behind the state + output rows)
-    for (int a = lane; a < K.nu; a += 64) L[K.l_ctrl + a] = c.rs ? c.st[(size_t)c.e * (size_t)c.rs + (size_t)(m.s_prev_ctrl + a)] : (action ? action[(size_t)a * c.n + c.e] : 0.f);
+    for (int i = lane; i < K.nq + K.nv + K.nu; i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel | act (the warm start stays in global memory)
     for (int i = lane; i < 2 * K.nv; i += 64) {   // index table of the sparse rows (+ the dof's limit row / wrench subset in the top bytes)
       int dof = i >> 1, extra = (i & 1) ? m.dof_wsub[dof] + 1 : m.dof_limrow[dof] + 1;
       L[K.l_tdof + i] = tm_i2f(m.tdof[i] | (extra << 24));
     }
     for (int g = lane; g < K.ngroup; g += 64) { L[K.l_tgrp + 4 * g] = tm_i2f(m.grp_lastdof[g]); L[K.l_tgrp + 4 * g + 1] = tm_i2f(m.grp_start[g]); L[K.l_tgrp + 4 * g + 2] = tm_i2f(m.grp_count[g]); }
-    for (int i = lane; i < K.nv; i += 64) L[K.l_hdamp + i] = m.timestep * m.dof_damping[i];
     for (int cc = lane; cc < K.ncon; cc += 64) { L[K.l_con_mu + cc] = m.con_mu[cc]; ((unsigned char *)(L + K.l_con_grpb))[cc] = (unsigned char)m.con_grp[cc]; }
     {
       int su = lane / 6;
@@ -207,8 +205,7 @@ TM_DEV int tmw_anc(int i, int q, int w1) {
 TM_DEV void tmw_store_state(WCtx &c, const WLayout &K, float time) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int i = lane; i < K.nphys - 1; i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];
-    for (int i = lane; i < K.nv; i += 64) WST(m.s_qfrc_actuator, i) = L[K.l_qfrc_actuator + i];
+    for (int i = lane; i < K.nq + K.nv + K.nu; i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];      // (warm start and qfrc_actuator are written where they arise)
     if (lane == 0) WST(m.s_time, 0) = time;
   }
   TMW_SYNC();
@@ -604,15 +601,12 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       for (int k = 0; k < 6; k++) bias += cd[k] * fb[k];
       float fa = 0.f;
       for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[K.l_act + u]); }
-      L[K.l_qfrc_actuator + i] = fa;
+      WST(m.s_qfrc_actuator, i) = fa;
       float f = -m.dof_damping[i] * L[K.l_qvel + i] - bias + fa;
       if (m.dof_stiffness[i] != 0.f) f += -m.dof_stiffness[i] * (L[K.l_qpos + m.dof_qposadr[i]] - m.dof_qspring[i]);
       L[K.l_qfrc_smooth + i] = f;
     }
-    for (int a = lane; a < K.nu; a += 64) {
-      float ctrl = fminf(fmaxf(L[K.l_ctrl + a], m.act_ctrlrange[a][0]), m.act_ctrlrange[a][1]);
-      L[K.l_act_dot + a] = (ctrl - L[K.l_act + a]) / fmaxf(TM_MINVAL, m.act_tau[a]);
-    }
+    // (act_dot = (clamp(ctrl) - act) / tau is formed in tmw_euler, where act is advanced: act does not change in between)
   }
   TMW_SYNC();
 }
@@ -1806,7 +1800,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
   if (c.prof && c.lane == 0) { c.prof[10] += (c.nact <= 16) ? 1000 : 0; c.prof[18] += (c.nact > 16 && c.nact <= 32) ? 1000 : 0; }   // histogram of active rows (x1000) in two unused slots
 #endif
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] = L[K.l_warm + i]; L[K.l_grad + i] = 1.f / L[K.l_Dinv + i]; L[K.l_tmp + i] = 0.f; } }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] = WST(m.s_warm, i); L[K.l_grad + i] = 1.f / L[K.l_Dinv + i]; L[K.l_tmp + i] = 0.f; } }
   TMW_SYNC();
   // start from the warm start unless the unconstrained acceleration has the lower cost (MJX evaluates warm, smooth and
   // then the winner again; evaluating smooth FIRST leaves M qacc / Jaref of the warm start — the usual winner — in place)
@@ -1851,7 +1845,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     TMW_TICK(8);
   }
   TMW_STATS(K) += 64.f * (float)it;
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_warm + i] = L[K.l_qacc + i]; }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) WST(m.s_warm, i) = L[K.l_qacc + i]; }
   TMW_SYNC();
 }
 
@@ -1871,8 +1865,15 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   if (K.m_spilled()) {
     // M is about to be factorised in place: keep a copy in global memory for Euler's factorisation of M + h D, and take the one
     // product with M the solver needs (M * warm start, tmw_solve_cg) now
+    // (the warm start comes from the env's global record into the solver's iterate vector — region A is free here, l_Ma below is written
+    // by the product anyway; its load is in flight across the copy loop)
+    const DModel &m = *c.mp;
+    TMW_REG(float, w0); TMW_REG(float, w1);
+    TMW_FOR { w0[TMW_LI] = WST(m.s_warm, lane); w1[TMW_LI] = lane + 64 < K.nv ? WST(m.s_warm, lane + 64) : 0.f; }
     TMW_FOR { for (int i = lane; i < K.nnz; i += 64) c.mspill[i] = L[K.l_M + i]; }
-    tmw_mul_m(c, K, K.l_warm, K.l_Ma);
+    TMW_FOR { L[K.l_qacc + lane] = w0[TMW_LI]; if (lane + 64 < K.nv) L[K.l_qacc + lane + 64] = w1[TMW_LI]; }
+    TMW_SYNC();
+    tmw_mul_m(c, K, K.l_qacc, K.l_Ma);
   }
   if (K.chains) tmw_factor_chains<false>(c, K, 0.f, -1); else tmw_factor(c, K, 0.f);
   TMW_TICK(2);
@@ -1894,6 +1895,17 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   float h = m.timestep;
   // qfrc_constraint of the final iterate is in LDS (last tmw_update_gradient); keep the rhs out of the LD alias
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_qfrc_smooth + i] + L[K.l_qfrc_constraint + i]; }
+  // timestep * damping (the diagonal Euler adds to M) into the dead search vector; the activation state is advanced here already — nothing
+  // reads act between tmw_velocity_inertia and the end of the substep — so that ctrl's global load sits next to the loads below
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) L[K.l_hdamp + i] = m.timestep * m.dof_damping[i];
+    for (int a = lane; a < K.nu; a += 64) {
+      // (record mode: the action rows were transposed in behind the state + output rows)
+      float ctrl = c.rs ? c.st[(size_t)c.e * (size_t)c.rs + (size_t)(m.s_prev_ctrl + a)] : (c.action ? c.action[(size_t)a * c.n + c.e] : 0.f);
+      ctrl = fminf(fmaxf(ctrl, m.act_ctrlrange[a][0]), m.act_ctrlrange[a][1]);
+      L[K.l_act + a] += ((ctrl - L[K.l_act + a]) / fmaxf(TM_MINVAL, m.act_tau[a])) * h;
+    }
+  }
   TMW_SYNC();
   TMW_TICK(8);
   if (K.m_spilled()) {
@@ -1914,7 +1926,6 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   if (K.chains) tmw_subst_chains(c, K, K.l_tmp); else tmw_subst_down(c, K, K.l_tmp);
   TMW_TICK(11);
   TMW_FOR {
-    for (int a = lane; a < K.nu; a += 64) L[K.l_act + a] += L[K.l_act_dot + a] * h;
     for (int i = lane; i < K.nv; i += 64) L[K.l_qvel + i] += L[K.l_tmp + i] * h;
   }
   TMW_SYNC();
