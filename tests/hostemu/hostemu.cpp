@@ -74,7 +74,7 @@ void emu_physics_wave(EmuModel *mm, float *st, const float *action, int nsub, in
   for (int e = 0; e < n; e++) {
     for (auto &v : lds) v = 0.f;
     WCtx c{&mm->h, lds.data(), st, n, e, 0, nullptr, 0ull, ws_dump};
-    std::vector<float> spill(mm->h.nnz + 64, 0.f);
+    std::vector<float> spill(mm->h.nnz + mm->h.nv + 64, 0.f);
     c.mspill = spill.data() + 64;
     c.action = action;
     const WLayout K = tmjx_host::make_wave_layout(mm->h, !getenv("TMJX_EMU_GENERIC"));

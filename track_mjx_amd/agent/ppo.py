@@ -395,6 +395,12 @@ class PPOLearner:
                 if jax_noise:      # the reference's own draws for all envs of this device, sliced per env group below (host-side: parity mode)
                     eps_np, noise_np = self.sgd_keys.act_noise(n_local, self.policy.latents, self.policy.action_size)
                     eps_all, noise_all = torch.from_numpy(eps_np).to(self.dev), torch.from_numpy(noise_np).to(self.dev)
+                    if self._streams:      # uploaded on the current stream, consumed on the groups' streams: order them and keep the blocks alive there
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(self.dev))
+                        for sg in self._streams:
+                            sg.wait_event(ev)
+                            eps_all.record_stream(sg); noise_all.record_stream(sg)
                 for g, env in enumerate(self.envs):
                     sl = slice(u * n_local + offs[g], u * n_local + offs[g + 1])
                     with torch.cuda.stream(self._streams[g]) if self._streams else _nullctx():

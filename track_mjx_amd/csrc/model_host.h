@@ -30,6 +30,13 @@ inline bool rodent_chains_match(const DModel &m) {
     if (m.dof_depth[i] != (parent[i] < 0 ? 0 : m.dof_depth[parent[i]] + 1)) return false;
     adr += m.dof_depth[i] + 1;
   }
+  // the lean LDS map stores ONE contact normal (wave_layout.h): every contact slot must be against the same plane geom of a body that does
+  // not move (outside the walker's tree)
+  for (int cc = 0; cc < m.ncon; cc++) {
+    if (m.con_body1[cc] != m.con_body1[0] || m.body_moving[m.con_body1[cc]]) return false;
+    for (int k = 0; k < 3; k++) if (m.con_g1_pos[cc][k] != m.con_g1_pos[0][k]) return false;
+    for (int k = 0; k < 4; k++) if (m.con_g1_quat[cc][k] != m.con_g1_quat[0][k]) return false;
+  }
   return adr == m.nnz;
 }
 inline WLayout make_wave_layout(const DModel &m, bool allow_chains = true) {

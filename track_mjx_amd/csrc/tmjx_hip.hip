@@ -32,7 +32,11 @@ struct tmjx_model {
   mutable float *mspill = nullptr;
   mutable int mspill_envs = 0;
 };
+#ifdef TMW_OLD_STRIDE
 #define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
+#else
+#define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz + (m)->h.nv) + 63) & ~63)
+#endif      // per env: the inertia matrix's copy | qfrc_smooth (wave_layout.h: lean)
 // record stride: state rows qpos .. qfrc_actuator, then the action, rounded up to 16 words
 #define WAVE_REC_STRIDE(m) ((((m)->h.s_prev_ctrl + (m)->h.nu) + 15) & ~15)
 // workspace words in front of the record: window partials (2 nu rows) + post partials (16 rows), each n_env wide
@@ -856,6 +860,13 @@ int tmjx_stats_apply(const float *sums, float n_added, float *count, float *mean
 
 int tmjx_debug_rows(const tmjx_model *m, const char *name, int *row0, int *count) {
   if (!m || !name || !row0 || !count) return fail(TMJX_EINVAL, "null argument");
+  // "k2_kernel": which physics kernel this handle launches — *row0 = 1 the compile-time (rodent chain) specialisation, 0 the generic one;
+  // *count = its dynamic LDS bytes per env (tests pin both: a model that silently fell back to the generic kernel ran 2.4 x slower)
+  if (!strcmp(name, "k2_kernel")) {
+    *row0 = m->rodent ? 1 : 0;
+    *count = (int)((m->rodent ? m->h.lds_floats : tmjx_host::make_wave_layout(m->h, false).lds_floats) * sizeof(float));
+    return 0;
+  }
   for (const auto &e : tmjx_host::debug_rows(m->h))
     if (!strcmp(e.name, name)) { *row0 = e.row0; *count = e.count; return e.in_state ? 1 : 0; }
   return fail(TMJX_EINVAL, std::string("unknown debug array: ") + name);

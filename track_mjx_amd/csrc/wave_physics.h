@@ -91,6 +91,11 @@ struct WCtx {
 // one-wavefront-per-env kernel moves full sectors instead of one 4-byte word per 32-byte sector
 #define WST(off, i) c.st[c.rs ? (size_t)c.e * (size_t)c.rs + (size_t)((off) + (i)) : (size_t)((off) + (i)) * (size_t)c.n + (size_t)c.e]
 
+// lean layout (K.lean, the rodent): the activation state stays in the env's global record, qfrc_smooth in the tail of the env's
+// inertia-matrix scratch, the contact frames share the floor's normal (wave_layout.h); the generic layout keeps all three in LDS
+#define TMW_ACT(a) (*(K.lean_act ? &WST(m.s_act, (a)) : &L[K.l_act + (a)]))
+#define TMW_QFS(i) (*(K.lean_qfs ? &c.mspill[K.nnz + (i)] : &L[K.l_qfrc_smooth + (i)]))
+#define TMW_LIMSIGN(K) ((signed char *)(L + (K).l_lim_sign))      /* sign * (compact row + 1) of a violated limit, 0 otherwise */
 TM_DEV int tm_f2i(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
 
@@ -166,18 +171,19 @@ TM_DEV int tmw_prefix(const int *flag, int *excl) {
 #endif
 #define TMW_ROWMAP(K) ((unsigned char *)(L + (K).l_rowmap))
 #define TMW_CCROW(K) ((unsigned char *)(L + (K).l_ccrow))
+#define TMW_CONGRP(K) ((unsigned char *)(L + (K).l_con_grpb) + (K).ncon)     /* paw group of a contact slot: behind the ccrow bytes */
 
 // ------------------------------------------------------------------------------------------ state in / out
 TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int i = lane; i < K.nq + K.nv + K.nu; i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel | act (the warm start stays in global memory)
+    for (int i = lane; i < K.nq + K.nv + (K.lean_act ? 0 : K.nu); i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel (| act); the warm start stays in global memory
     for (int i = lane; i < 2 * K.nv; i += 64) {   // index table of the sparse rows (+ the dof's limit row / wrench subset in the top bytes)
       int dof = i >> 1, extra = (i & 1) ? m.dof_wsub[dof] + 1 : m.dof_limrow[dof] + 1;
       L[K.l_tdof + i] = tm_i2f(m.tdof[i] | (extra << 24));
     }
-    for (int g = lane; g < K.ngroup; g += 64) { L[K.l_tgrp + 4 * g] = tm_i2f(m.grp_lastdof[g]); L[K.l_tgrp + 4 * g + 1] = tm_i2f(m.grp_start[g]); L[K.l_tgrp + 4 * g + 2] = tm_i2f(m.grp_count[g]); }
-    for (int cc = lane; cc < K.ncon; cc += 64) { L[K.l_con_mu + cc] = m.con_mu[cc]; ((unsigned char *)(L + K.l_con_grpb))[cc] = (unsigned char)m.con_grp[cc]; }
+    for (int g = lane; g < K.ngroup; g += 64) ((signed char *)(L + K.l_tgrp))[g] = (signed char)m.grp_lastdof[g];
+    for (int cc = lane; cc < K.ncon; cc += 64) { L[K.l_con_mu + cc] = m.con_mu[cc]; TMW_CONGRP(K)[cc] = (unsigned char)m.con_grp[cc]; }
     {
       int su = lane / 6;
       bool ok = lane < m.n_wsub * 6;
@@ -205,10 +211,20 @@ TM_DEV int tmw_anc(int i, int q, int w1) {
 TM_DEV void tmw_store_state(WCtx &c, const WLayout &K, float time) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int i = lane; i < K.nq + K.nv + K.nu; i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];      // (warm start and qfrc_actuator are written where they arise)
+    for (int i = lane; i < K.nq + K.nv + (K.lean_act ? 0 : K.nu); i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];      // (warm start and qfrc_actuator are written where they arise)
     if (lane == 0) WST(m.s_time, 0) = time;
   }
   TMW_SYNC();
+}
+
+// contact frame rows n, b of slot cc: 6 words per slot, or (chain layout) the shared normal + 3 words per slot
+TM_DEV void tmw_put_con_frame(float *L, const WLayout &K, int cc, const float *fr) {
+  if (K.lean_frame) { if (cc == 0) for (int k = 0; k < 3; k++) L[K.l_con_frame + k] = fr[k]; for (int k = 0; k < 3; k++) L[K.l_con_frame + 3 + cc * 3 + k] = fr[3 + k]; }
+  else for (int k = 0; k < 6; k++) L[K.l_con_frame + cc * 6 + k] = fr[k];
+}
+TM_DEV void tmw_get_con_frame(const float *L, const WLayout &K, int cc, float *fr) {
+  if (K.lean_frame) { for (int k = 0; k < 3; k++) { fr[k] = L[K.l_con_frame + k]; fr[3 + k] = L[K.l_con_frame + 3 + cc * 3 + k]; } }
+  else for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
 }
 
 // ------------------------------------------------------------------------------------------ fwd_position
@@ -336,7 +352,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
       }
       L[K.l_con_dist + cc] = dist;
       for (int k = 0; k < 3; k++) L[K.l_con_off + cc * 3 + k] = pos[k] - com[k];
-      for (int k = 0; k < 6; k++) L[K.l_con_frame + cc * 6 + k] = fr[k];   // rows n and b; the third row is n x b
+      tmw_put_con_frame(L, K, cc, fr);   // rows n and b; the third row is n x b
     }
   }
   TMW_TICK2(30);
@@ -578,6 +594,10 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
     }
     TMW_SYNC();
   }
+  // lean layout: the activation state lives in the env's global record, each value written and re-read by its OWN lane (tmw_euler) — a dof's
+  // lane needs other lanes' values, and global memory gives no ordering between the lanes of a wave: stage it through the paw-velocity
+  // buffer, which only the J products of the solver stage use (nu <= 6 ngroup: WLayout::lean)
+  if (K.lean_act) { TMW_FOR { for (int a = lane; a < K.nu; a += 64) L[K.l_sv + a] = WST(m.s_act, a); } }
   TMW_SYNC();
   TMW_TICK2(23);
   // M rows, bias, passive, actuation -> qfrc_smooth; act_dot
@@ -600,11 +620,11 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       float bias = 0.f;
       for (int k = 0; k < 6; k++) bias += cd[k] * fb[k];
       float fa = 0.f;
-      for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[K.l_act + u]); }
+      for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[(K.lean_act ? K.l_sv : K.l_act) + u]); }
       WST(m.s_qfrc_actuator, i) = fa;
       float f = -m.dof_damping[i] * L[K.l_qvel + i] - bias + fa;
       if (m.dof_stiffness[i] != 0.f) f += -m.dof_stiffness[i] * (L[K.l_qpos + m.dof_qposadr[i]] - m.dof_qspring[i]);
-      L[K.l_qfrc_smooth + i] = f;
+      TMW_QFS(i) = f;
     }
     // (act_dot = (clamp(ctrl) - act) / tau is formed in tmw_euler, where act is advanced: act does not change in between)
   }
@@ -1303,7 +1323,7 @@ TM_DEV void tmw_jmul_stage1(WCtx &c, const WLayout &K, int v) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     if (lane < K.ngroup * 6) {  // spatial velocity of each paw body, one lane per (group, component)
-      int g = lane / 6, k = lane - g * 6, ld = tm_f2i(L[K.l_tgrp + 4 * g]);
+      int g = lane / 6, k = lane - g * 6, ld = ((const signed char *)(L + K.l_tgrp))[g];
       float s = 0.f;
       if (ld >= 0) {
         int w1 = TMW_W1(ld), d = TMW_DEPTH(TMW_W0(ld));
@@ -1327,9 +1347,9 @@ TM_DEV void tmw_jmul_stage2(WCtx &c, const WLayout &K, int v, int out) {
         o = ((r & 0x80) ? -1.f : 1.f) * L[v + (r & 0x7f)];
       } else {
         int cc = (r - K.nlim) >> 2, e = (r - K.nlim) & 3;
-        const float *sv = L + K.l_sv + ((const unsigned char *)(L + K.l_con_grpb))[cc] * 6, *off = L + K.l_con_off + cc * 3;
+        const float *sv = L + K.l_sv + TMW_CONGRP(K)[cc] * 6, *off = L + K.l_con_off + cc * 3;
         float fr[9];
-        for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
+        tmw_get_con_frame(L, K, cc, fr);
         tm_cross(fr + 6, fr, fr + 3);
         float cr[3], vel[3];
         tm_cross(cr, sv, off);
@@ -1360,7 +1380,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
         float mu = L[K.l_con_mu + cc], c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
         const float *off = L + K.l_con_off + cc * 3;
         float fr[9];
-        for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
+        tmw_get_con_frame(L, K, cc, fr);
         tm_cross(fr + 6, fr, fr + 3);
         float F[3], T[3];
         for (int k = 0; k < 3; k++) F[k] = c0 * fr[k] + c1 * fr[3 + k] + c2 * fr[6 + k];
@@ -1406,7 +1426,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
       float s = 0.f;
       int lr = TMW_LIMROW1(TMW_W0(i)) - 1, su = TMW_WSUB1(TMW_W1(i)) - 1;
       if (lr >= 0) {     // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise
-        float sv = L[K.l_lim_sign + lr];
+        float sv = (float)TMW_LIMSIGN(K)[lr];
         if (sv != 0.f) { int kr = (int)fabsf(sv) - 1; float ja = L[K.l_Jaref + kr]; if (ja < 0.f) s = (sv > 0.f ? 1.f : -1.f) * (-L[K.l_efc_D + kr] * ja); }
       }
       if (su >= 0) { const float *w = L + K.l_wr + su * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
@@ -1464,8 +1484,8 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
   TMW_FOR {
     unsigned char *rm = TMW_ROWMAP(K), *cr = TMW_CCROW(K);
     // map byte of a limit row: its dof | (violated on the upper side) << 7 — all that J and J^T need; of a contact row: nlim + 4 cc + e
-    if (lane < K.nlim) { L[K.l_lim_sign + lane] = s0[TMW_LI] * (float)(x0[TMW_LI] + 1); if (f0[TMW_LI]) rm[x0[TMW_LI]] = (unsigned char)(d0[TMW_LI] | (s0[TMW_LI] < 0.f ? 0x80 : 0)); }
-    if (lane + 64 < K.nlim) { L[K.l_lim_sign + lane + 64] = s1[TMW_LI] * (float)(n0 + x1[TMW_LI] + 1); if (f1[TMW_LI]) rm[n0 + x1[TMW_LI]] = (unsigned char)(d1[TMW_LI] | (s1[TMW_LI] < 0.f ? 0x80 : 0)); }
+    if (lane < K.nlim) { TMW_LIMSIGN(K)[lane] = (signed char)(s0[TMW_LI] * (float)(x0[TMW_LI] + 1)); if (f0[TMW_LI]) rm[x0[TMW_LI]] = (unsigned char)(d0[TMW_LI] | (s0[TMW_LI] < 0.f ? 0x80 : 0)); }
+    if (lane + 64 < K.nlim) { TMW_LIMSIGN(K)[lane + 64] = (signed char)(s1[TMW_LI] * (float)(n0 + x1[TMW_LI] + 1)); if (f1[TMW_LI]) rm[n0 + x1[TMW_LI]] = (unsigned char)(d1[TMW_LI] | (s1[TMW_LI] < 0.f ? 0x80 : 0)); }
     if (lane < K.ncon) {
       int r0 = nla + 4 * xc[TMW_LI];
       cr[lane] = fc[TMW_LI] ? (unsigned char)r0 : (unsigned char)255;
@@ -1509,7 +1529,7 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
           pos = fminf(dmin, dmax) - m.jnt_margin[j];
           tm_kbi(m, m.jnt_solref[j], m.jnt_solimp[j], pos, k, b, imp);
           iw = m.dof_invweight0[m.jnt_dofadr[j]];
-          float sv = L[K.l_lim_sign + r];
+          float sv = (float)TMW_LIMSIGN(K)[r];
           if (sv != 0.f) kr = (int)fabsf(sv) - 1;
         } else {
           int cc = (r - K.nlim) >> 2;
@@ -1552,7 +1572,7 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool 
       L[K.l_Jaref + e] = ja;
       if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja;
     }
-    if (!jonly) for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - L[K.l_qfrc_smooth + i]) * (L[q + i] - L[K.l_qacc_smooth + i]);
+    if (!jonly) for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - TMW_QFS(i)) * (L[q + i] - L[K.l_qacc_smooth + i]);
     pc[TMW_LI] = sc; pg[TMW_LI] = sg;
   }
   TMW_SYNC();
@@ -1808,7 +1828,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   float cw = tmw_eval_cost(c, K, K.l_qacc, gauss, false, K.m_spilled());
   float cost = cw;
   if (cw < cs) {     // ut = y - y_s = D^-1 N^T (M qacc - qfrc_smooth)
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Ma + i] -= L[K.l_qfrc_smooth + i]; }
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Ma + i] -= TMW_QFS(i); }
     TMW_SYNC();
     tmw_solve_up(c, K, K.l_Ma, K.l_Ma);
   } else {
@@ -1884,7 +1904,7 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   tmw_make_constraint(c, K);
   TMW_TICK(4);
   if (TMW_STOP <= 4) return;
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = L[K.l_qfrc_smooth + i]; }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = TMW_QFS(i); }
   TMW_SYNC();
   tmw_solve(c, K, K.l_qacc_smooth);
   TMW_TICK(5);
@@ -1894,7 +1914,7 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float h = m.timestep;
   // qfrc_constraint of the final iterate is in LDS (last tmw_update_gradient); keep the rhs out of the LD alias
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_qfrc_smooth + i] + L[K.l_qfrc_constraint + i]; }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = TMW_QFS(i) + L[K.l_qfrc_constraint + i]; }
   // timestep * damping (the diagonal Euler adds to M) into the dead search vector; the activation state is advanced here already — nothing
   // reads act between tmw_velocity_inertia and the end of the substep — so that ctrl's global load sits next to the loads below
   TMW_FOR {
@@ -1903,7 +1923,8 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
       // (record mode: the action rows were transposed in behind the state + output rows)
       float ctrl = c.rs ? c.st[(size_t)c.e * (size_t)c.rs + (size_t)(m.s_prev_ctrl + a)] : (c.action ? c.action[(size_t)a * c.n + c.e] : 0.f);
       ctrl = fminf(fmaxf(ctrl, m.act_ctrlrange[a][0]), m.act_ctrlrange[a][1]);
-      L[K.l_act + a] += ((ctrl - L[K.l_act + a]) / fmaxf(TM_MINVAL, m.act_tau[a])) * h;
+      const float act = TMW_ACT(a);
+      TMW_ACT(a) = act + ((ctrl - act) / fmaxf(TM_MINVAL, m.act_tau[a])) * h;
     }
   }
   TMW_SYNC();
@@ -1961,19 +1982,19 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
     for (int i = lane; i < K.nnz; i += 64) WDUMP(m.w_M, i) = K.m_spilled() ? c.mspill[i] : L[K.l_M + i];
     for (int i = lane; i < K.nv * 6; i += 64) WDUMP(m.w_cdof, i) = L[K.l_cdof + i];
     for (int i = lane; i < K.nv; i += 64) {
-      WDUMP(m.w_qfrc_smooth, i) = L[K.l_qfrc_smooth + i]; WDUMP(m.w_qacc_smooth, i) = L[K.l_qacc_smooth + i];
+      WDUMP(m.w_qfrc_smooth, i) = TMW_QFS(i); WDUMP(m.w_qacc_smooth, i) = L[K.l_qacc_smooth + i];
       WDUMP(m.w_qacc, i) = L[K.l_qacc + i]; WDUMP(m.w_qfrc_constraint, i) = L[K.l_qfrc_constraint + i];
     }
     for (int i = lane; i < K.ncon; i += 64) WDUMP(m.w_con_dist, i) = L[K.l_con_dist + i];
     for (int cc = lane; cc < K.ncon; cc += 64) {
       float fr[9];
-      for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
+      tmw_get_con_frame(L, K, cc, fr);
       tm_cross(fr + 6, fr, fr + 3);
       for (int k = 0; k < 9; k++) WDUMP(m.w_con_frame, cc * 9 + k) = fr[k];
     }
     for (int r = lane; r < K.nefc; r += 64) {   // efc_D / efc_aref were written by tmw_make_constraint; force per ORIGINAL row
       int kr = -1;
-      if (r < K.nlim) { float sv = L[K.l_lim_sign + r]; if (sv != 0.f) kr = (int)fabsf(sv) - 1; }
+      if (r < K.nlim) { float sv = (float)TMW_LIMSIGN(K)[r]; if (sv != 0.f) kr = (int)fabsf(sv) - 1; }
       else if (TMW_CCROW(K)[(r - K.nlim) >> 2] != 255) kr = TMW_CCROW(K)[(r - K.nlim) >> 2] + ((r - K.nlim) & 3);
       float ja = kr >= 0 ? L[K.l_Jaref + kr] : 0.f;
       WDUMP(m.w_efc_force, r) = ja < 0.f ? -L[K.l_efc_D + kr] * ja : 0.f;
@@ -1983,7 +2004,7 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
     if (lane < 4) { int pk = (int)TMW_STATS(K); WDUMP(m.w_solver_stats, lane) = (float)(lane == 0 ? pk >> 6 : lane == 1 ? (pk & 63) : lane == 2 ? c.nact : c.nla); }
     // which ORIGINAL constraint rows entered the solver (violated limits, the four pyramid rows of penetrating contacts): 1 / 0
     for (int r = lane; r < K.nefc; r += 64) {
-      bool in = r < K.nlim ? L[K.l_lim_sign + r] != 0.f : TMW_CCROW(K)[(r - K.nlim) >> 2] != 255;
+      bool in = r < K.nlim ? TMW_LIMSIGN(K)[r] != 0 : TMW_CCROW(K)[(r - K.nlim) >> 2] != 255;
       WDUMP(m.w_efc_in, r) = in ? 1.f : 0.f;
     }
   }
