@@ -83,8 +83,8 @@ struct WLayout {
       // rows are in registers before its first row of L is stored), so l_LD == l_M; M itself goes to a per-env global scratch right
       // after it is built (Euler's second factorisation reads it back from there, M * warm start is taken before the first one).
       // Between Euler and the next "M rows" step the region is dead and hosts the transform / dof scan buffers.  With that the
-      // solver-stage region A loses LD and the kinematics region B its scan buffers: 15.9 KB per env instead of 20.4 KB, i.e. 10
-      // instead of 8 envs per CU.
+      // solver-stage region A loses LD and the kinematics region B its scan buffers: 15.9 KB per env instead of 20.4 KB (13 instead
+      // of 17 LDS granules of 1280 bytes: 9 instead of 7 envs per CU; the cuts listed above bring it to 11 granules).
       l_LD = l_M;
       l_scanA = l_M; l_scanB = l_M + nbody * 8; l_dscanA = l_scanA; l_dscanB = l_scanB;
       l = l_alias0;

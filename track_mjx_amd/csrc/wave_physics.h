@@ -1,5 +1,5 @@
 // csrc/wave_physics.h — K2, wave-per-env: one 64-lane wavefront integrates one env; every per-env array of a
-// substep lives in LDS (wave_layout.h: 16 KB per env for the rodent's chain layout => 10 envs per CU = 2-3 waves per SIMD; the
+// substep lives in LDS (wave_layout.h: 14 080 bytes per env for the rodent's chain layout = 11 LDS granules => 11 envs per CU = 2-3 waves per SIMD; the
 // inertia matrix is additionally kept in a per-env global copy between its two factorisations), the 64 lanes split bodies /
 // dofs / constraint rows / matrix columns between them.
 //
