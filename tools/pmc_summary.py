@@ -30,9 +30,10 @@ dom = "k_physics_wave<true>"
 res = {
     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_gpu.sh) over tools/time_step.py --steps 4, 4096 envs; "
             "KB per dispatch -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950. K2 reads and writes the env-major physics "
-            "record (13.8 MB algorithmic per launch) and, since the one-matrix-region LDS layout (10 envs per CU), writes every substep's inertia "
-            "matrix to a per-env global copy and reads it back for Euler's factorisation: 89.5 KB per env-step at the L2 (367 MB per launch), of "
-            "which the write-back L2 / MALL absorb all but the bytes counted here.",
+            "record (13.8 MB algorithmic per launch) and — the price of eleven resident envs per CU (LDS granules, wave_layout.h) — keeps what it touches "
+            "once or twice per substep in global memory: every substep's inertia matrix (written, read back for Euler's factorisation: 89.5 KB per "
+            "env-step at the L2), the warm start, qfrc_smooth, qfrc_actuator and the activation state (another ~25 KB per env-step at the L2); the "
+            "write-back L2 / MALL absorb all but the bytes counted here (mostly writes).  In time: ~50 GB/s, 0.6 % of the HBM bandwidth.",
     "kernels": kern, "dominant_kernel": dom, "envs_per_launch": ENVS,
     "hbm_bytes_per_launch": kern[dom]["fetch_bytes_corrected"] + kern[dom]["write_bytes"],
     "algorithmic_bytes_per_launch": K2_ALGO,
