@@ -211,6 +211,15 @@ int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int
 int tmjx_gemm_nt_silu_ln_ok(const float *A, int lda, const float *W, int ldw, int N);
 int tmjx_gemm_nt_silu_ln(const float *A, int lda, const float *W, int ldw, const float *bias, const float *gamma, const float *beta, float *Z, float *Y,
                          int ldc, float *stats, int M, int N, int K, float eps, void *stream);
+/* The input gradient of a layer whose INPUT is the output of a Dense -> SiLU -> LayerNorm block of width N = 256, with that block's LayerNorm +
+ * SiLU backward applied in the epilogue (tmjx_gemm_nn followed by tmjx_silu_ln_bwd in one launch): dz[M][256] = d loss / d z of the block,
+ * given dY[M][K] (gradient of this layer's output), W[K][256], and the block's saved z (without bias), bias, gamma, stats (mean, 1 / std).
+ * partial (>= tmjx_gemm_nn_ln_bwd_partial_floats(M, 256) floats) receives one row of [d gamma | d beta | d bias] column sums per 80-row
+ * workgroup: sum its rows (tmjx_colsum over (M + 79) / 80 rows of width 768). */
+int tmjx_gemm_nn_ln_bwd_ok(const float *dY, int ldy, const float *W, int ldw, int N);
+long long tmjx_gemm_nn_ln_bwd_partial_floats(int M, int N);
+int tmjx_gemm_nn_ln_bwd(const float *dY, int ldy, const float *W, int ldw, const float *z, const float *bias, const float *gamma, const float *stats,
+                        float *dz, float *partial, int M, int N, int K, void *stream);
 long long tmjx_gemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream);
 /* All weight (+ bias) gradients of one backward pass as ONE launch + one reduction launch: up to 16 independent problems of tmjx_gemm_dw,

@@ -160,3 +160,64 @@ def test_fused_dense_silu_layernorm_block(M, N, K, lda, monkeypatch):
         e_f, e_t = (a.double() - r).abs().max().item() / scale, (b.double() - r).abs().max().item() / scale
         print(f"{name}: fused {e_f:.2e}  two-launch {e_t:.2e} (rel. to max |ref|)")
         assert e_f <= max(3 * e_t, 2e-6), name
+
+
+@pytest.mark.parametrize("M,widths", [(20480, (470, 256, 256, 120)), (1000, (286, 256, 256, 76)), (163, (64, 256, 256, 256, 40))])
+def test_layernorm_backward_fused_into_the_next_input_gradient(M, widths, monkeypatch):
+    """tmjx_gemm_nn_ln_bwd: the LayerNorm + SiLU backward of a 256-wide block in the epilogue of its consumer's input-gradient GEMM (inside
+    `ln_bwd_links()`), against the unfused chain (tmjx_gemm_nn + tmjx_silu_ln_bwd) and float64 torch: every parameter gradient and dx."""
+    from track_mjx_amd.agent import networks as nw
+    g = torch.Generator(device=DEV).manual_seed(M + sum(widths))
+    blocks = []
+    for i, o in zip(widths[:-2], widths[1:-1]):
+        blk = nw._Block(i, o).to(DEV)
+        with torch.no_grad():
+            wpad = torch.zeros((o, (i + 3) // 4 * 4), device=DEV)
+            wpad[:, :i] = blk.dense.weight
+            blk.dense.weight.data = wpad[:, :i]
+            blk.dense.bias.copy_(torch.randn(o, generator=g, device=DEV) * 0.3)
+            blk.norm.weight.copy_(1 + 0.2 * torch.randn(o, generator=g, device=DEV))
+            blk.norm.bias.copy_(0.2 * torch.randn(o, generator=g, device=DEV))
+        blocks.append(blk)
+    head = nw._dense(widths[-2], widths[-1]).to(DEV)
+    with torch.no_grad():
+        head.bias.copy_(torch.randn(widths[-1], generator=g, device=DEV) * 0.1)
+    params = [p for b in blocks for p in (b.dense.weight, b.dense.bias, b.norm.weight, b.norm.bias)] + [head.weight, head.bias]
+    xbuf = torch.randn((M, (widths[0] + 3) // 4 * 4), generator=g, device=DEV)
+    cot = torch.randn((M, widths[-1]), generator=g, device=DEV)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("TMJX_NO_LN_BWD_FUSION", raising=False)
+        else:
+            monkeypatch.setenv("TMJX_NO_LN_BWD_FUSION", "1")
+        x = xbuf[:, :widths[0]].detach().requires_grad_(True)
+        with nw.ln_bwd_links():
+            h = x
+            for b in blocks:
+                h = b(h)
+            y = head(h)
+        return [t.detach() for t in torch.autograd.grad(y, [x] + params, cot)]
+
+    calls = []
+    orig = nw._dx_through_block
+    monkeypatch.setattr(nw, "_dx_through_block", lambda *a: (calls.append(1), orig(*a))[1])
+    got = run(True)
+    assert len(calls) == len(blocks), "every 256-wide block's backward must have gone through its consumer's epilogue"
+    two = run(False)
+    assert len(calls) == len(blocks)
+    x64 = xbuf[:, :widths[0]].double().detach().requires_grad_(True)
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    h = x64
+    for k in range(len(blocks)):
+        w, b, gm, be = p64[4 * k:4 * k + 4]
+        h = torch.nn.functional.layer_norm(torch.nn.functional.silu(h @ w.t() + b), (w.shape[0],), gm, be, 1e-6)
+    y64 = h @ p64[-2].t() + p64[-1]
+    ref = torch.autograd.grad(y64, [x64] + p64, cot.double())
+    worst = 0.0
+    for i, (a, b, r) in enumerate(zip(got, two, ref)):
+        scale = r.abs().max().item() + 1e-30
+        e_f, e_t = (a.double() - r).abs().max().item() / scale, (b.double() - r).abs().max().item() / scale
+        worst = max(worst, e_f)
+        assert e_f <= max(3 * e_t, 3e-6), (i, e_f, e_t)
+    print(f"M={M} widths={widths}: worst relative error of the fused chain {worst:.2e}")

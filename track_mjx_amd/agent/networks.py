@@ -207,6 +207,71 @@ class deferred_weight_grads:
         self.problems = []
 
 
+class _BlockLink:
+    """Hand-over between a Dense -> SiLU -> LayerNorm block and the ONE layer that consumes its output (inside `ln_bwd_links()`): the consumer's
+    backward applies the block's LayerNorm + SiLU backward in the epilogue of its own input-gradient GEMM (tmjx_gemm_nn_ln_bwd) and hands the
+    block d loss / d z instead of d loss / d y, plus the block's (d gamma, d beta, d bias)."""
+    __slots__ = ("y_ptr", "y_shape", "ctx", "dz_given", "grads")
+
+    def __init__(self):
+        self.y_ptr, self.y_shape, self.ctx, self.dz_given, self.grads = None, None, None, False, None
+
+
+class ln_bwd_links:
+    """`with ln_bwd_links():` around a forward pass whose blocks form chains (each block's output feeds exactly one dense layer, as in the
+    intention network's encoder and decoder): enables the fused LayerNorm-backward epilogue.  Outside it every block runs its own backward."""
+    active = False
+    last = None      # link of the most recent block's output
+
+    def __enter__(self):
+        self._prev = (ln_bwd_links.active, ln_bwd_links.last)
+        ln_bwd_links.active, ln_bwd_links.last = not os.environ.get("TMJX_NO_LN_BWD_FUSION"), None
+        return self
+
+    def __exit__(self, *a):
+        ln_bwd_links.active, ln_bwd_links.last = self._prev
+        return False
+
+    @staticmethod
+    def producer_of(x2):
+        """The link of the block whose output IS x2 (same storage, same shape), or None."""
+        l = ln_bwd_links.last
+        if ln_bwd_links.active and l is not None and l.y_ptr == x2.data_ptr() and l.y_shape == tuple(x2.shape) and x2.is_contiguous():
+            return l
+        return None
+
+
+def _dx_through_block(dy2, w, link):
+    """d loss / d z of the producing block from this layer's output gradient dy2 [M, N] and weight w [N, 256]: one launch."""
+    import ctypes as C
+    from .. import hip as _hip
+    L = _hip.lib()
+    x2, wp, z, b, gamma, stats = link.ctx.saved_tensors
+    M, H = z.shape
+    dz = torch.empty_like(z)
+    nblk = (M + 79) // 80
+    partial = torch.empty(int(L.tmjx_gemm_nn_ln_bwd_partial_floats(M, H)), dtype=torch.float32, device=z.device)
+    grads = torch.empty((3, H), dtype=torch.float32, device=z.device)
+    scratch = torch.empty(L.tmjx_colsum_scratch_floats(3 * H), dtype=torch.float32, device=z.device)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(z.device):
+        stream = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        _hip.check(L.tmjx_gemm_nn_ln_bwd(p(dy2), dy2.stride(0), p(w), w.stride(0), p(z), p(b), p(gamma), p(stats), p(dz), p(partial), M, H, dy2.shape[1], stream),
+                   "tmjx_gemm_nn_ln_bwd")
+        _hip.check(L.tmjx_colsum(p(partial), p(grads), p(scratch), nblk, 3 * H, stream), "tmjx_colsum")
+    link.dz_given, link.grads = True, grads
+    return dz
+
+
+def _fusable_dx(dy2, w, link, dx_cols) -> bool:
+    if link is None or dx_cols is not None or link.ctx is None:
+        return False
+    import ctypes as C
+    from .. import hip as _hip
+    z = link.ctx.saved_tensors[2]
+    return bool(z.shape[1] == w.shape[1] and _hip.lib().tmjx_gemm_nn_ln_bwd_ok(C.c_void_p(dy2.data_ptr()), dy2.stride(0), C.c_void_p(w.data_ptr()), w.stride(0), z.shape[1]))
+
+
 class _HipDenseFn(torch.autograd.Function):
     """y = x W^T (+ b) with all three contractions on the library's MFMA kernels: forward tmjx_gemm_nt, input gradient tmjx_gemm_nn,
     weight + bias gradient tmjx_gemm_dw.  `dx_cols`: the caller only needs the gradient of the first dx_cols input columns."""
@@ -217,13 +282,18 @@ class _HipDenseFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w)
         ctx.has_bias, ctx.dx_cols, ctx.x_shape = b is not None, dx_cols, x.shape
         ctx.params = (w, b)                    # the Parameter objects (their .grad = the flat-buffer views a deferred gradient lands in)
+        ctx.producer = ln_bwd_links.producer_of(x2)
+        ln_bwd_links.last = None
         return gemm_nt(x2, w, b).view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         dy2 = _rows2d(dy)
-        dx = gemm_nn(dy2, w, ctx.dx_cols).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[0] and _fusable_dx(dy2, w, ctx.producer, ctx.dx_cols):
+            dx = _dx_through_block(dy2, w, ctx.producer).view(ctx.x_shape)      # (d loss / d z of the producing block: its backward skips its own kernel)
+        else:
+            dx = gemm_nn(dy2, w, ctx.dx_cols).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         d = deferred_weight_grads.active
         got = d.try_add(dy2, x2, *ctx.params) if d is not None else None
         dw, db = got if got is not None else gemm_dw(dy2, x2, ctx.has_bias)
@@ -374,6 +444,12 @@ class _HipBlockFn(torch.autograd.Function):
                                                        float(eps), C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)), "tmjx_gemm_nt_silu_ln")
         ctx.save_for_backward(x2, w, z, b, gamma, stats)
         ctx.dx_cols, ctx.param = dx_cols, w
+        ctx.producer = ln_bwd_links.producer_of(x2)
+        ctx.link = None
+        if ln_bwd_links.active:
+            ctx.link = link = _BlockLink()
+            link.y_ptr, link.y_shape, link.ctx = y.data_ptr(), tuple(y.shape), ctx
+            ln_bwd_links.last = link
         return y
 
     @staticmethod
@@ -383,14 +459,22 @@ class _HipBlockFn(torch.autograd.Function):
         x2, w, z, b, gamma, stats = ctx.saved_tensors
         M, N = z.shape
         dy = dy.contiguous()
-        dz = torch.empty_like(z)
-        grads = torch.empty((3, N), dtype=torch.float32, device=z.device)
-        L = _hip.lib()
-        partial = torch.empty(L.tmjx_silu_ln_partial_floats(M, N), dtype=torch.float32, device=z.device)
-        with torch.cuda.device(z.device):
-            _hip.check(L.tmjx_silu_ln_bwd(*[C.c_void_p(t.data_ptr()) for t in (dy, z, b, gamma, stats, dz, grads, partial)], M, N,
-                                          C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)), "tmjx_silu_ln_bwd")
-        dx = gemm_nn(dz, w, ctx.dx_cols) if ctx.needs_input_grad[0] else None
+        if ctx.link is not None:
+            ctx.link.ctx = None                     # (break the ctx <-> link cycle)
+        if ctx.link is not None and ctx.link.dz_given:
+            dz, grads = dy, ctx.link.grads          # the consumer's input-gradient GEMM already applied this block's LayerNorm + SiLU backward
+        else:
+            dz = torch.empty_like(z)
+            grads = torch.empty((3, N), dtype=torch.float32, device=z.device)
+            L = _hip.lib()
+            partial = torch.empty(L.tmjx_silu_ln_partial_floats(M, N), dtype=torch.float32, device=z.device)
+            with torch.cuda.device(z.device):
+                _hip.check(L.tmjx_silu_ln_bwd(*[C.c_void_p(t.data_ptr()) for t in (dy, z, b, gamma, stats, dz, grads, partial)], M, N,
+                                              C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)), "tmjx_silu_ln_bwd")
+        if ctx.needs_input_grad[0] and _fusable_dx(dz, w, ctx.producer, ctx.dx_cols):
+            dx = _dx_through_block(dz, w, ctx.producer)
+        else:
+            dx = gemm_nn(dz, w, ctx.dx_cols) if ctx.needs_input_grad[0] else None
         d = deferred_weight_grads.active
         got = d.try_add(dz, x2, ctx.param, None) if d is not None else None
         dw = got[0] if got is not None else gemm_dw(dz, x2, False)[0]
@@ -485,8 +569,9 @@ class IntentionPolicy(nn.Module):
         """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar), or (logits, mean | logvar as
         one [.., 2*latents] tensor) with `return_fc2` (what the fused loss head consumes)."""
         traj = obs[..., :self.reference_obs_size]
-        h = self.encoder(traj)
-        fc2 = self.fc2(h)
+        with ln_bwd_links():       # encoder and decoder are chains: each block's output feeds exactly one dense layer
+            h = self.encoder(traj)
+            fc2 = self.fc2(h)
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
         if (not deterministic and fc2.is_cuda and fc2.dtype == torch.float32 and obs.dtype == torch.float32 and not torch.is_autocast_enabled()
                 and fc2.numel() >= 2 * self.latents * 1024):
@@ -496,7 +581,8 @@ class IntentionPolicy(nn.Module):
                 eps = torch.randn_like(mean)
             x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size)
             x = x.view(*lead, x.shape[-1])
-            logits = self.head(self.decoder(x))
+            with ln_bwd_links():
+                logits = self.head(self.decoder(x))
             if return_fc2:
                 return logits, fc2
             return logits, mean, logvar

@@ -72,7 +72,13 @@ __device__ __forceinline__ gf4 gemm_mask4(gf4 v, int mask) {
 // Fused forward epilogue of a Dense -> SiLU -> LayerNorm block (LN = true; the tile must span the whole row: N == 64 NIW, one column
 // block): z = A W^T goes to C as before (WITHOUT the bias: what k_silu_ln_bwd expects), y = LayerNorm(silu(z + bias)) to `y`, the row's
 // (mean, 1 / std) to `stats` — the arithmetic of k_silu_ln_fwd (two-pass variance), without its launch and its re-read of z.
-struct GemmLN { const float *gamma, *beta; float *y, *stats; float eps; };
+struct GemmLN {
+  const float *gamma, *beta; float *y, *stats; float eps;      // EPI 1 (forward);  EPI 2 reads gamma and stats
+  const float *z; float *partial;                              // EPI 2: the block's saved pre-activation z; per-workgroup column sums [3][BN]
+};
+// EPI 2 (input-gradient kernel, tile = whole rows, N == 256): the tile is d loss / d y of a Dense -> SiLU -> LayerNorm block (y its output);
+// the epilogue applies that block's LayerNorm + SiLU backward (the arithmetic of k_silu_ln_bwd) and stores d loss / d z instead, plus the
+// workgroup's column sums of (dy * ahat | dy | dz) = partial d gamma | d beta | d bias: the block's own backward launch disappears.
 // sum over the 16 lanes of a DPP row (all 16 lanes get it): quad xor 1, quad xor 2, half-row mirror, row mirror
 __device__ __forceinline__ float gemm_row16_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
@@ -83,7 +89,7 @@ __device__ __forceinline__ float gemm_row16_sum(float x) {
 }
 
 template <int NIW> struct GemmCfg { static constexpr int NWAVE = NIW >= 2 ? 8 : 4, THREADS = 64 * NWAVE, NI = 4 * NIW / NWAVE; };
-template <int NIW, bool BT, bool AVEC, bool WVEC, bool LN = false>
+template <int NIW, bool BT, bool AVEC, bool WVEC, int EPI = 0>
 __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
                                                   float *__restrict__ C, int ldc, int M, int N, int K, GemmLN ln = GemmLN{}) {
   constexpr int BN = 64 * NIW;
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
         for (int b = 0; b < NI; b++) {
           // BT: the weight fragment goes in as the FIRST operand, i.e. the tile comes out transposed: register r of lane (li, kq) is
           // C[16 a + li][16 b + 4 kq + r] — four consecutive columns of one row, stored as one dwordx4 (10 stores per wave instead of 40)
-          if constexpr (BT) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.b[b][e], F.a[a][e], acc[a][b], 0, 0, 0);
+          // (!BT with two interleaved tiles, see fread: likewise — the lane then holds EIGHT consecutive columns 8 kq .. 8 kq + 7 of a row)
+          if constexpr (BT || NI == 2) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.b[b][e], F.a[a][e], acc[a][b], 0, 0, 0);
           else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[a][e], F.b[b][e], acc[a][b], 0, 0, 0);
         }
   };
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #ifdef GEMM_PROF
   unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
+  constexpr bool LN = EPI == 1;
   if constexpr (LN) {
     // rows of the tile are whole rows of the layer (N == BN).  Lane (li, kq) of wave w holds, of the rows 16 a + li, the columns
     // nw + 16 b + 4 kq + r.  Row sums: over r and b in registers, over kq by two cross-lane adds, over the waves through LDS (the K loop's
@@ -385,20 +393,105 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     return;
   }
   // stored straight from the accumulators (routing the tile through LDS to store whole rows was tried and is 6 % SLOWER for these tiles)
-  if constexpr (!BT && NI == 2) {      // interleaved tile columns (see fread): lane holds columns n0 + nw + 2 li, + 1 of its rows
-    const int col = n0 + nw + 2 * li;
-    const bool pair = col + 1 < N && !(ldc & 1) && !((uintptr_t)C & 7);
+  if constexpr (EPI == 2) {
+    static_assert(!BT && NI == 2 && NIW == 4, "LayerNorm-backward epilogue: input-gradient kernel, 256-column tile");
+    constexpr int NW = GemmCfg<NIW>::NWAVE;
+    static_assert(2 * GEMM_BM * NW <= 2 * STAGE, "reduction scratch must fit the K loop's LDS");
+    float *red = gemm_lds;                                   // [80 rows][NW][2]
+    const int c0 = nw + 8 * kq;                              // the lane's eight columns (of rows 16 a + li)
+    float bv[8], gv[8];
+    {
+      const gf4 b0 = *reinterpret_cast<const gf4 *>(bias + c0), b1 = *reinterpret_cast<const gf4 *>(bias + c0 + 4);
+      const gf4 g0 = *reinterpret_cast<const gf4 *>(ln.gamma + c0), g1 = *reinterpret_cast<const gf4 *>(ln.gamma + c0 + 4);
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+      for (int j = 0; j < 4; j++) { bv[j] = b0[j]; bv[4 + j] = b1[j]; gv[j] = g0[j]; gv[4 + j] = g1[j]; }
+    }
+    float mean[5], rstd[5], m1[5], m2[5];      // (z is loaded twice, once per pass: keeping 40 more values live spilled registers)
+#define DY(a, j) acc[a][(j) & 1][(j) >> 1]      /* the tile entry of column c0 + j */
+    const float inv_n = 1.f / (float)BN;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = m0 + 16 * a + 4 * kq + r;
-        if (row < M) {
-          float *o = C + (long long)row * ldc + col;
-          if (pair) *reinterpret_cast<gf2 *>(o) = gf2{acc[a][0][r], acc[a][1][r]};
-          else { if (col < N) o[0] = acc[a][0][r]; if (col + 1 < N) o[1] = acc[a][1][r]; }
+    for (int a = 0; a < 5; a++) {
+      const int row = m0 + 16 * a + li;
+      const bool ok = row < M;
+      const long long rr = ok ? row : M - 1;
+      const gf4 z0 = *reinterpret_cast<const gf4 *>(ln.z + rr * ldc + c0), z1 = *reinterpret_cast<const gf4 *>(ln.z + rr * ldc + c0 + 4);
+      mean[a] = ln.stats[2 * rr]; rstd[a] = ln.stats[2 * rr + 1];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (!ok) DY(a, j) = 0.f;                            // (rows past M contribute nothing to the column sums)
+        const float v = (j < 4 ? z0[j] : z1[j - 4]) + bv[j];
+        const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
+        s1 += da; s2 += da * ah;
+      }
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      m1[a] = s1 + __shfl_xor(s1, 32); m2[a] = s2 + __shfl_xor(s2, 32);
+    }
+    __syncthreads();                   // every wave has read its last fragments
+    if (kq == 0) {
+#pragma unroll
+      for (int a = 0; a < 5; a++) *reinterpret_cast<gf2 *>(red + ((16 * a + li) * NW + wave) * 2) = gf2{m1[a], m2[a]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+      const gf4 *q = reinterpret_cast<const gf4 *>(red + (16 * a + li) * NW * 2);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < NW / 2; w4++) { const gf4 x = q[w4]; t1 += x.x + x.z; t2 += x.y + x.w; }
+      m1[a] = t1 * inv_n; m2[a] = t2 * inv_n;
+    }
+    float cg[8], cb[8], cz[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { cg[j] = 0.f; cb[j] = 0.f; cz[j] = 0.f; }
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+      const int row = m0 + 16 * a + li;
+      const long long rr = row < M ? row : M - 1;
+      const gf4 z0 = *reinterpret_cast<const gf4 *>(ln.z + rr * ldc + c0), z1 = *reinterpret_cast<const gf4 *>(ln.z + rr * ldc + c0 + 4);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float v = (j < 4 ? z0[j] : z1[j - 4]) + bv[j];
+        const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
+        const float dact = rstd[a] * (da - m1[a] - ah * m2[a]);
+        o[j] = dact * (sig * (1.f + v * (1.f - sig)));
+        cg[j] += DY(a, j) * ah; cb[j] += DY(a, j); cz[j] += row < M ? o[j] : 0.f;
+      }
+      if (row < M) {
+        float *dst = C + (long long)row * ldc + c0;
+        *reinterpret_cast<gf4 *>(dst) = gf4{o[0], o[1], o[2], o[3]}; *reinterpret_cast<gf4 *>(dst + 4) = gf4{o[4], o[5], o[6], o[7]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { cg[j] = gemm_row16_sum(cg[j]); cb[j] = gemm_row16_sum(cb[j]); cz[j] = gemm_row16_sum(cz[j]); }
+    if (li == 0) {
+      float *pp = ln.partial + (size_t)blockIdx.x * 3 * BN + c0;
+      *reinterpret_cast<gf4 *>(pp) = gf4{cg[0], cg[1], cg[2], cg[3]}; *reinterpret_cast<gf4 *>(pp + 4) = gf4{cg[4], cg[5], cg[6], cg[7]};
+      *reinterpret_cast<gf4 *>(pp + BN) = gf4{cb[0], cb[1], cb[2], cb[3]}; *reinterpret_cast<gf4 *>(pp + BN + 4) = gf4{cb[4], cb[5], cb[6], cb[7]};
+      *reinterpret_cast<gf4 *>(pp + 2 * BN) = gf4{cz[0], cz[1], cz[2], cz[3]}; *reinterpret_cast<gf4 *>(pp + 2 * BN + 4) = gf4{cz[4], cz[5], cz[6], cz[7]};
+    }
+#undef DY
+    return;
+  }
+  if constexpr (!BT && NI == 2) {
+    // interleaved tile columns (fread) + transposed tiles (mma): register r of tile b is C[16 a + li][nw + 8 kq + 2 r + b], i.e. the lane
+    // holds columns nw + 8 kq .. + 7 of the rows 16 a + li: two dwordx4 per row
+    const int col = n0 + nw + 8 * kq;
+    const bool vec = !(ldc & 3) && !((uintptr_t)C & 15) && col + 7 < N;
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+      const int row = m0 + 16 * a + li;
+      if (row < M) {
+        float *o = C + (long long)row * ldc + col;
+        const float v[8] = {acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1], acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
+        if (vec) { *reinterpret_cast<gf4 *>(o) = gf4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<gf4 *>(o + 4) = gf4{v[4], v[5], v[6], v[7]}; }
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) if (col + k < N) o[k] = v[k];
         }
       }
+    }
     return;
   }
   if constexpr (BT) {                  // transposed tiles (see mma): one dwordx4 per tile and lane where the row is 16-byte aligned

@@ -727,11 +727,11 @@ static int launch_gemm_ln(const float *A, int lda, const float *W, int ldw, cons
   constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + BN * GEMM_LDA);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act LN): ") + hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, true>), dim3((M + GEMM_BM - 1) / GEMM_BM, 1), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
+  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, 1>), dim3((M + GEMM_BM - 1) / GEMM_BM, 1), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
   return check_launch("k_gemm_act(LN)");
 }
 template <bool YVEC, bool XVEC>
@@ -759,11 +759,31 @@ int tmjx_gemm_nt_silu_ln(const float *A, int lda, const float *W, int ldw, const
   if (!A || !W || !bias || !gamma || !beta || !Z || !Y || !stats) return fail(TMJX_EINVAL, "null argument");
   if (M < 1 || K < 1 || lda < K || ldc < N || ldw < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
   if (!tmjx_gemm_nt_silu_ln_ok(A, lda, W, ldw, N)) return fail(TMJX_EINVAL, "tmjx_gemm_nt_silu_ln: N must be 64, 128 or 256 and the operands' rows 16-byte aligned");
-  GemmLN ln{gamma, beta, Y, stats, eps};
+  GemmLN ln{gamma, beta, Y, stats, eps, nullptr, nullptr};
   hipStream_t s = (hipStream_t)stream;
   if (N == 64) return launch_gemm_ln<1>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
   if (N == 128) return launch_gemm_ln<2>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
   return launch_gemm_ln<4>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+}
+int tmjx_gemm_nn_ln_bwd_ok(const float *dY, int ldy, const float *W, int ldw, int N) { return N == 256 && aligned16(dY, ldy) && aligned16(W, ldw); }
+long long tmjx_gemm_nn_ln_bwd_partial_floats(int M, int N) { return (long long)((M + GEMM_BM - 1) / GEMM_BM) * 3 * N; }
+int tmjx_gemm_nn_ln_bwd(const float *dY, int ldy, const float *W, int ldw, const float *z, const float *bias, const float *gamma, const float *stats,
+                        float *dz, float *partial, int M, int N, int K, void *stream) {
+  if (!dY || !W || !z || !bias || !gamma || !stats || !dz || !partial) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || K < 1 || ldy < K || ldw < N) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  if (!tmjx_gemm_nn_ln_bwd_ok(dY, ldy, W, ldw, N)) return fail(TMJX_EINVAL, "tmjx_gemm_nn_ln_bwd: N must be 256 and the operands' rows 16-byte aligned");
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + GEMM_BK * (256 + 4));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<4, false, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act LN bwd): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  GemmLN ln{gamma, nullptr, nullptr, const_cast<float *>(stats), 0.f, z, partial};
+  // (the kernel's contraction length is its "K" = the next layer's width; its "N" = this block's width = 256; z and dz are dense [M][256])
+  hipLaunchKernelGGL((k_gemm_act<4, false, true, true, 2>), dim3((M + GEMM_BM - 1) / GEMM_BM, 1), dim3(GemmCfg<4>::THREADS), lds, (hipStream_t)stream, dY, ldy, W, ldw, bias, dz, N,
+                     M, N, K, ln);
+  return check_launch("k_gemm_act(LN bwd)");
 }
 int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, void *stream) {
   return gemm_act<false>(A, lda, W, ldw, nullptr, C, ldc, M, N, K, stream);
