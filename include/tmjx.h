@@ -188,6 +188,12 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
 int tmjx_colsum_scratch_floats(int width);
 int tmjx_colsum(const float *src, float *out, float *scratch, int rows, int width, void *stream);
 
+/* Up to 16 independent column sums (out[width] = sum over `rows` rows of partial[rows][width]) in one launch: the per-workgroup
+ * (d gamma | d beta | d bias) partials of every LayerNorm block of a backward pass (tmjx_gemm_nn_ln_bwd), reduced once behind it.
+ * `problems` is a HOST array (copied into the launch). */
+typedef struct tmjx_colsum_problem_t { const float *partial; float *out; int32_t rows, width; } tmjx_colsum_problem_t;
+int tmjx_colsum_grouped(const tmjx_colsum_problem_t *problems, int n, void *stream);
+
 /* optax.chain(optax.clip_by_global_norm(max_norm), optax.adam(lr)) (track_mjx/agent/mlp_ppo/ppo.py:517-520) on FLAT fp32 device
  * buffers of n elements: param -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps) with the gradient scaled by max_norm / max(max_norm,
  * *grad_norm); `grad_norm` is a device scalar (the caller's ||grad||_2 of the averaged gradient), bias_correction{1,2} = 1 - beta^t. */

@@ -165,7 +165,7 @@ class deferred_weight_grads:
     active = None
 
     def __enter__(self):
-        self.problems, self.keep = [], []
+        self.problems, self.keep, self.colsums = [], [], []
         deferred_weight_grads.active = self
         return self
 
@@ -187,11 +187,18 @@ class deferred_weight_grads:
         return gw, gb
 
     def launch(self):
-        if not self.problems:
-            return
         import ctypes as C
         from .. import hip as _hip
         L = _hip.lib()
+        if self.colsums:      # the LayerNorm blocks' (d gamma | d beta | d bias) partials (networks._dx_through_block)
+            dev = self.colsums[0][0].device
+            arr = (_hip.ColsumProblem * len(self.colsums))(*[_hip.ColsumProblem(pt.data_ptr(), g.data_ptr(), nb, wd) for pt, g, nb, wd in self.colsums])
+            with torch.cuda.device(dev):
+                _hip.check(L.tmjx_colsum_grouped(arr, len(self.colsums), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_colsum_grouped")
+            self.keep += [t for c in self.colsums for t in c[:2]]
+            self.colsums = []
+        if not self.problems:
+            return
         dev = self.problems[0][0].device
         sizes = [int(L.tmjx_gemm_dw_scratch_floats(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _, _ in self.problems]
         scratch = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), dtype=torch.float32, device=dev)
@@ -203,7 +210,7 @@ class deferred_weight_grads:
             off += (sizes[i] + 3) // 4 * 4
         with torch.cuda.device(dev):
             _hip.check(L.tmjx_gemm_dw_grouped(arr, len(self.problems), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_gemm_dw_grouped")
-        self.keep = [scratch]
+        self.keep += [scratch]
         self.problems = []
 
 
@@ -252,13 +259,17 @@ def _dx_through_block(dy2, w, link):
     nblk = (M + 79) // 80
     partial = torch.empty(int(L.tmjx_gemm_nn_ln_bwd_partial_floats(M, H)), dtype=torch.float32, device=z.device)
     grads = torch.empty((3, H), dtype=torch.float32, device=z.device)
-    scratch = torch.empty(L.tmjx_colsum_scratch_floats(3 * H), dtype=torch.float32, device=z.device)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     with torch.cuda.device(z.device):
         stream = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
         _hip.check(L.tmjx_gemm_nn_ln_bwd(p(dy2), dy2.stride(0), p(w), w.stride(0), p(z), p(b), p(gamma), p(stats), p(dz), p(partial), M, H, dy2.shape[1], stream),
                    "tmjx_gemm_nn_ln_bwd")
-        _hip.check(L.tmjx_colsum(p(partial), p(grads), p(scratch), nblk, 3 * H, stream), "tmjx_colsum")
+        d = deferred_weight_grads.active
+        if d is not None and len(d.colsums) < 16:
+            d.colsums.append((partial, grads, nblk, 3 * H))      # reduced with the others in ONE launch behind the backward pass (launch())
+        else:
+            one = (_hip.ColsumProblem * 1)(_hip.ColsumProblem(partial.data_ptr(), grads.data_ptr(), nblk, 3 * H))
+            _hip.check(L.tmjx_colsum_grouped(one, 1, stream), "tmjx_colsum_grouped")
     link.dz_given, link.grads = True, grads
     return dz
 

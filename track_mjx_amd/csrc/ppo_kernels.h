@@ -697,6 +697,31 @@ __global__ __launch_bounds__(256) void k_colsum_rows(const float *__restrict__ s
 }
 
 
+// Several independent column-sum problems (per-workgroup partial rows -> one row) in ONE launch: the (d gamma | d beta | d bias) partials of
+// every LayerNorm block of a backward pass, reduced once behind it instead of by one launch per block inside its dependent chain.
+#define COLSUM_GROUP_MAX 16
+struct ColsumProblem { const float *partial; float *out; int nblk, width, blk_begin; };
+struct ColsumGroup { ColsumProblem p[COLSUM_GROUP_MAX]; int n; };
+__global__ __launch_bounds__(256) void k_colsum_grouped(const ColsumGroup G) {
+  __shared__ float lds[8][33];
+  int i = 0;
+  for (int j = 1; j < G.n; j++) if ((int)blockIdx.x >= G.p[j].blk_begin) i = j;       // uniform
+  const ColsumProblem &P = G.p[i];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, col = (blockIdx.x - P.blk_begin) * 32 + cx;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < P.width) {
+    int k = ry;
+    for (; k + 56 < P.nblk; k += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += P.partial[(size_t)(k + 8 * u) * P.width + col];
+    }
+    for (; k < P.nblk; k += 8) acc[0] += P.partial[(size_t)k * P.width + col];
+  }
+  lds[ry][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (ry == 0 && col < P.width) { float s = 0.f; for (int j = 0; j < 8; j++) s += lds[j][cx]; P.out[col] = s; }
+}
+
 // ---- K6: observation normaliser update (brax running_statistics.update, reference math track_mjx/agent/masked_running_statistics.py:161-214)
 // ONE pass over the roll-out observations [rows][W]: per column S1 = sum(x - mean_old), S2 = sum((x - mean_old)^2).  The reference's
 //   mean_update = S1 / count_new,  variance_update = sum((x - mean_old)(x - mean_new)) = S2 - mean_update * S1

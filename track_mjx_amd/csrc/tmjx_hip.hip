@@ -622,6 +622,20 @@ int tmjx_colsum(const float *src, float *out, float *scratch, int rows, int widt
   return check_launch("k_colsum_rows");
 }
 
+int tmjx_colsum_grouped(const tmjx_colsum_problem_t *q, int n, void *stream) {
+  if (!q || n < 1 || n > COLSUM_GROUP_MAX) return fail(TMJX_EINVAL, "tmjx_colsum_grouped: 1 .. 16 problems");
+  ColsumGroup G;
+  G.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; i++) {
+    if (!q[i].partial || !q[i].out || q[i].rows < 1 || q[i].width < 1) return fail(TMJX_EINVAL, "tmjx_colsum_grouped: bad problem");
+    G.p[i] = ColsumProblem{q[i].partial, q[i].out, q[i].rows, q[i].width, blocks};
+    blocks += (q[i].width + 31) / 32;
+  }
+  hipLaunchKernelGGL(k_colsum_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G);
+  return check_launch("k_colsum_grouped");
+}
+
 int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *grad_norm, long long n, float lr,
                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm) return fail(TMJX_EINVAL, "null argument");

@@ -31,7 +31,7 @@ class Layout(C.Structure):
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
-           "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
+           "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_colsum_grouped", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
 
@@ -40,6 +40,11 @@ class Minibatch(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in ("obs", "next_last", "raw_action", "log_prob", "reward", "discount", "truncation", "perm", "mean", "std", "obs_n", "next_n",
                                            "raw_action_g", "scalars_g", "eps", "noise", "state")] + [("seed", C.c_uint64)] +
                 [(k, C.c_int32) for k in ("T", "R", "B", "W", "A", "Z", "advance")])
+
+
+class ColsumProblem(C.Structure):
+    """tmjx_colsum_problem_t (include/tmjx.h)."""
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("width", C.c_int32)]
 
 
 class DwProblem(C.Structure):
@@ -124,6 +129,7 @@ def load(path: Path):
     sig.setdefault("tmjx_gemm_nt", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_gemm_nt_silu_ln_ok", [None, None])[0] = [fp, C.c_int, fp, C.c_int, C.c_int]
     sig.setdefault("tmjx_gemm_nt_silu_ln", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, fp, fp, fp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
+    sig.setdefault("tmjx_colsum_grouped", [None, None])[0] = [C.POINTER(ColsumProblem), C.c_int, vp]
     sig.setdefault("tmjx_gemm_nn_ln_bwd_ok", [None, None])[0] = [fp, C.c_int, fp, C.c_int, C.c_int]
     sig.setdefault("tmjx_gemm_nn_ln_bwd_partial_floats", [None, None])[0] = [C.c_int, C.c_int]
     sig.setdefault("tmjx_gemm_nn_ln_bwd_partial_floats", [None, None])[1] = C.c_longlong
