@@ -35,8 +35,8 @@ struct tmjx_model {
 #ifdef TMW_OLD_STRIDE
 #define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
 #else
-#define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz + (m)->h.nv) + 63) & ~63)
-#endif      // per env: the inertia matrix's copy | qfrc_smooth (wave_layout.h: lean)
+#define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
+#endif
 // record stride: state rows qpos .. qfrc_actuator, then the action, rounded up to 16 words
 #define WAVE_REC_STRIDE(m) ((((m)->h.s_prev_ctrl + (m)->h.nu) + 15) & ~15)
 // workspace words in front of the record: window partials (2 nu rows) + post partials (16 rows), each n_env wide

@@ -74,6 +74,7 @@ struct WCtx {
   // per-lane model constants of the J / J^T products, fetched once per launch (a global load in every call left its latency exposed):
   unsigned kmask[TMW_NL];     // lane = (subset, component) of tmw_jt_force: contact mask (slots 0..31) of the subset (valid if n_wsub * 6 <= 64)
   const float *action;        // [nu][n] action rows (direct mode, c.rs == 0) or null
+  float qfs0[TMW_NL], qfs1[TMW_NL];   // lean layout: qfrc_smooth of dof lane / lane + 64 (tmw_velocity_inertia -> solver, Euler)
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
 // solver statistics of the last substep, kept in the spare LDS word behind the centre of mass (registers are what this kernel has none
@@ -91,10 +92,11 @@ struct WCtx {
 // one-wavefront-per-env kernel moves full sectors instead of one 4-byte word per 32-byte sector
 #define WST(off, i) c.st[c.rs ? (size_t)c.e * (size_t)c.rs + (size_t)((off) + (i)) : (size_t)((off) + (i)) * (size_t)c.n + (size_t)c.e]
 
-// lean layout (K.lean, the rodent): the activation state stays in the env's global record, qfrc_smooth in the tail of the env's
-// inertia-matrix scratch, the contact frames share the floor's normal (wave_layout.h); the generic layout keeps all three in LDS
+// lean layout (K.lean, the rodent): the activation state stays in the env's global record, qfrc_smooth in two registers of the lane that
+// produces and consumes it (dof i = lane, lane + 64: every loop over the dofs uses that mapping), the contact frames share the floor's normal (wave_layout.h); the generic layout keeps all three in LDS
 #define TMW_ACT(a) (*(K.lean_act ? &WST(m.s_act, (a)) : &L[K.l_act + (a)]))
-#define TMW_QFS(i) (*(K.lean_qfs ? &c.mspill[K.nnz + (i)] : &L[K.l_qfrc_smooth + (i)]))
+#define TMW_QFS(i) (K.lean_qfs ? ((i) < 64 ? c.qfs0[TMW_LI] : c.qfs1[TMW_LI]) : L[K.l_qfrc_smooth + (i)])
+#define TMW_QFS_SET(i, v) do { if (!K.lean_qfs) L[K.l_qfrc_smooth + (i)] = (v); else if ((i) < 64) c.qfs0[TMW_LI] = (v); else c.qfs1[TMW_LI] = (v); } while (0)
 #define TMW_LIMSIGN(K) ((signed char *)(L + (K).l_lim_sign))      /* sign * (compact row + 1) of a violated limit, 0 otherwise */
 TM_DEV int tm_f2i(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
@@ -624,7 +626,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       WST(m.s_qfrc_actuator, i) = fa;
       float f = -m.dof_damping[i] * L[K.l_qvel + i] - bias + fa;
       if (m.dof_stiffness[i] != 0.f) f += -m.dof_stiffness[i] * (L[K.l_qpos + m.dof_qposadr[i]] - m.dof_qspring[i]);
-      TMW_QFS(i) = f;
+      TMW_QFS_SET(i, f);
     }
     // (act_dot = (clamp(ctrl) - act) / tau is formed in tmw_euler, where act is advanced: act does not change in between)
   }
@@ -1886,7 +1888,8 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
     // M is about to be factorised in place: keep a copy in global memory for Euler's factorisation of M + h D, and take the one
     // product with M the solver needs (M * warm start, tmw_solve_cg) now
     // (the warm start comes from the env's global record into the solver's iterate vector — region A is free here, l_Ma below is written
-    // by the product anyway; its load is in flight across the copy loop)
+    // by the product anyway; its load is in flight across the copy loop.  Keeping it in two registers across the substeps, like qfrc_smooth,
+    // was tried: 172 VGPRs, i.e. two instead of three waves per SIMD)
     const DModel &m = *c.mp;
     TMW_REG(float, w0); TMW_REG(float, w1);
     TMW_FOR { w0[TMW_LI] = WST(m.s_warm, lane); w1[TMW_LI] = lane + 64 < K.nv ? WST(m.s_warm, lane + 64) : 0.f; }
