@@ -170,12 +170,18 @@ int tmjx_latent_concat_bwd(const float *dx, const float *eps, const float *fc2, 
 /* Policy inference tails (ppo_networks.py:46-96, intention_network.py:78-88).
  * tmjx_latent_concat: x[i] = [ mean_i + eps_i * exp(logvar_i / 2) | obs_i[ref_w:] ], fc2 [n][2Z] = mean | logvar, eps [n][Z], obs
  *   addressed as obs[i * obs_s0 + c * obs_s1] (so the [obs][n_env] buffer of tmjx_step can be passed as is) and normalised with
- *   (. - mean[c]) / std[c] when mean != NULL, x [n][x_stride >= Z + obs_w - ref_w] (columns beyond are left alone).
+ *   (. - mean[c]) / std[c] when mean != NULL, x [n][x_stride >= Z + obs_w - ref_w] (columns beyond are written as zeros).
  * tmjx_sample_action: raw = loc + (softplus(raw_scale) + 0.001) * noise; action = tanh(raw) written as [A][n] (the layout
- *   tmjx_step takes); logp = NormalTanh log-prob of the sample; logits [n][2A], noise / raw [n][A], logp [n]. */
+ *   tmjx_step takes); logp = NormalTanh log-prob of the sample; logits [n][2A], noise / raw [n][A], logp [n].
+ * eps == NULL / noise == NULL: the N(0, 1) draws are made on the device, Philox4x32-10 streams 2 / 3 of (seed, draw counter rng_state[0]);
+ *   rng_state = device int64[2] {draw counter, 0}; tmjx_sample_action then advances the counter once all its workgroups are done, so one
+ *   inference = tmjx_latent_concat ... tmjx_sample_action on the same stream uses one counter value and a captured graph of it replays
+ *   with fresh noise and no host input. */
 int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
-                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, int x_stride, void *stream);
-int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, void *stream);
+                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, int x_stride, uint64_t seed, const int64_t *rng_state,
+                       void *stream);
+int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, uint64_t seed,
+                       int64_t *rng_state, void *stream);
 
 /* LDS-free dense layer (policy inference next to the physics kernel, which owns every CU's LDS):
  * C[M][N] = A W^T + bias (bias may be NULL); W [N][K] row-major; A[i][k] at A[i * sa_row + k * sa_k] with either sa_k == 1

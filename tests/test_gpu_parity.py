@@ -495,7 +495,7 @@ def test_fused_inference_tail_matches_torch_path():
     from track_mjx_amd.agent import ppo
     env, _, _ = make_env_and_oracle(num_envs=64, n_clips=4, wrappers=True)
     L = ppo.PPOLearner(env, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=5,
-                       batch_size=16, num_minibatches=4, num_updates_per_batch=1, seed=3, use_graph=False)
+                       batch_size=16, num_minibatches=4, num_updates_per_batch=1, seed=3, use_graph=False, act_rng="torch")
     st = env.reset(torch.Generator().manual_seed(0))
     state = L.gen.get_state()
     a_f, e_f = L.act(st.obs)
@@ -858,3 +858,68 @@ def test_philox_known_answers_and_self_advancing_minibatch():
         assert torch.equal(d1[k], d3[k]) and not torch.equal(d1[k], d2[k])
         assert abs(torch.corrcoef(torch.stack([d1[k].flatten(), d2[k].flatten()]))[0, 1].item()) < 5 / n ** 0.5
     assert abs(torch.corrcoef(torch.stack([d1["latent_eps"].flatten()[:100000], d1["entropy_noise"].flatten()[:100000]]))[0, 1].item()) < 0.02
+
+
+@pytest.mark.gpu
+def test_device_side_noise_of_the_acting_policy():
+    """act_rng="device": tmjx_latent_concat / tmjx_sample_action draw their N(0, 1) noise themselves (Philox streams 2 / 3 of the seed and a
+    device-side draw counter that tmjx_sample_action advances).  Checked: the standardised residuals of the latent sample and of the raw action
+    are N(0, 1) by their first four moments, one inference = one counter value, the same counter reproduces the draws, the next one does not,
+    and the learner's act() gives fresh actions on every call (eager and as a replayed graph)."""
+    import ctypes as C
+    from track_mjx_amd import hip
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator(device=dev).manual_seed(9)
+    n, Z, W, ref, A = 4096, 60, 696, 470, 38
+    fc2 = torch.randn((n, 2 * Z), generator=g, device=dev) * 0.5
+    obs = torch.randn((n, W), generator=g, device=dev)
+    logits = torch.randn((n, 2 * A), generator=g, device=dev)
+    state = torch.zeros(2, dtype=torch.long, device=dev)
+    state[0] = 5
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    wd = Z + W - ref
+
+    def concat():
+        x = torch.full((n, (wd + 3) // 4 * 4), float("nan"), device=dev)
+        hip.check(L.tmjx_latent_concat(p(fc2), None, p(obs), p(x), n, Z, W, ref, obs.stride(0), obs.stride(1), None, None, x.shape[1], 77, p(state), None), "concat")
+        return x
+
+    def sample():
+        raw, act, lp = torch.empty((n, A), device=dev), torch.empty((A, n), device=dev), torch.empty(n, device=dev)
+        hip.check(L.tmjx_sample_action(p(logits), None, p(raw), p(act), p(lp), n, A, 77, p(state), None), "sample")
+        return raw, act, lp
+
+    x1, x1b = concat(), concat()
+    assert state.tolist() == [5, 0] and torch.equal(x1, x1b)
+    assert torch.equal(x1[:, Z:wd], obs[:, ref:]) and not x1[:, wd:].any() and torch.isfinite(x1).all()       # copied columns, zeroed pad
+    r1, a1, lp1 = sample()
+    torch.cuda.synchronize()
+    assert state.tolist() == [6, 0]
+    x2 = concat()
+    r2, _, _ = sample()
+    assert state.tolist() == [7, 0] and not torch.equal(x1[:, :Z], x2[:, :Z]) and not torch.equal(r1, r2)
+    state[0] = 5
+    r1b, _, _ = sample()
+    assert torch.equal(r1, r1b)
+    eps = (x1[:, :Z] - fc2[:, :Z]) / torch.exp(0.5 * fc2[:, Z:])
+    scale = torch.nn.functional.softplus(logits[:, A:]) + 0.001
+    nz = (r1 - logits[:, :A]) / scale
+    for name, v in (("latent eps", eps), ("action noise", nz)):
+        xx = v.double().flatten()
+        k = xx.numel()
+        m, var = xx.mean().item(), xx.var().item()
+        skew, kurt = ((xx - m) ** 3).mean().item() / var ** 1.5, ((xx - m) ** 4).mean().item() / var ** 2
+        print(f"{name}: n {k} mean {m:+.4f} var {var:.4f} skew {skew:+.4f} kurt {kurt:.4f}")
+        assert abs(m) < 5 / k ** 0.5 and abs(var - 1) < 5 * (2 / k) ** 0.5 + 1e-3 and abs(skew) < 5 * (6 / k) ** 0.5 and abs(kurt - 3) < 5 * (24 / k) ** 0.5
+    assert torch.allclose(a1.t(), torch.tanh(r1), rtol=1e-5, atol=1e-6)
+    # through the learner: eager, then as a captured graph
+    from track_mjx_amd.agent import ppo
+    envs = [make_env_and_oracle(num_envs=64, n_clips=4, wrappers=True, seed=k)[0] for k in range(2)]
+    Ln = ppo.PPOLearner(envs, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=5,
+                        batch_size=32, num_minibatches=4, num_updates_per_batch=2, seed=3)
+    assert Ln.act_rng == "device"
+    st = envs[0].reset(torch.Generator().manual_seed(1))
+    acts = [Ln._act_graphed(st.obs, 0)[1]["raw_action"].clone() for _ in range(4)]       # capture happens on the first call
+    torch.cuda.synchronize()
+    assert all(not torch.equal(acts[i], acts[j]) for i in range(4) for j in range(i)), "every inference must draw fresh noise"

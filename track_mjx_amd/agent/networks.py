@@ -536,7 +536,7 @@ class _LatentConcatFn(torch.autograd.Function):
         x = torch.empty((n, (wd + 3) // 4 * 4), dtype=torch.float32, device=fc2.device)     # (the pad columns are never read: the GEMM masks k >= K)
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         with torch.cuda.device(fc2.device):
-            _hip.check(_hip.lib().tmjx_latent_concat(p(fc2), p(eps), p(obs), p(x), n, Z, W, ref, obs.stride(0), obs.stride(1), None, None, x.shape[1],
+            _hip.check(_hip.lib().tmjx_latent_concat(p(fc2), p(eps), p(obs), p(x), n, Z, W, ref, obs.stride(0), obs.stride(1), None, None, x.shape[1], 0, None,
                                                      C.c_void_p(torch.cuda.current_stream(fc2.device).cuda_stream)), "tmjx_latent_concat")
         ctx.save_for_backward(fc2, eps)
         return x[:, :wd]

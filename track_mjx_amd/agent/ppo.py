@@ -147,7 +147,7 @@ class PPOLearner:
                  clipping_epsilon: float = 0.2, unroll_length: int = 20, batch_size: int = 1024, num_minibatches: int = 16,
                  num_updates_per_batch: int = 4, normalize_observations: bool = True, kl_weight: float = 0.1,
                  seed: int = 0, group=None, matmul_dtype: torch.dtype | None = None, use_graph: bool = True, shuffle_rng: str = "torch",
-                 act_rng: str = "torch"):
+                 act_rng: str = "device"):
         # `env` may be a LIST of envs (equal halves of this rank's envs): their roll-outs are then pipelined on one HIP stream
         # each (collect()), so that the tail of one half's physics kernel, its reward / observation kernels and its policy
         # inference run next to the other half's physics kernel
@@ -208,9 +208,12 @@ class PPOLearner:
         # minibatch shuffle: "torch" = torch.randperm on the device (default, nothing leaves the GPU); "jax" = the reference's own draws from
         # the seed (jax_random.SgdKeys: key plumbing of ppo.py:443-451,303-307,324 + jax.random.permutation), computed on the host
         self.sgd_keys = None
-        self.act_rng = act_rng          # "jax" (needs shuffle_rng="jax"): the roll-outs' latent / action noise = the reference's draws too
-        if act_rng not in ("torch", "jax") or (act_rng == "jax" and shuffle_rng != "jax"):
-            raise ValueError("act_rng must be 'torch' or 'jax' (the latter together with shuffle_rng='jax')")
+        # acting noise: "device" (default) = Philox draws inside the inference kernels; "torch" = the learner's torch generators; "jax"
+        # (needs shuffle_rng="jax") = the reference's own draws from its key plumbing
+        self.act_rng = act_rng
+        self._act_rng: dict = {}
+        if act_rng not in ("device", "torch", "jax") or (act_rng == "jax" and shuffle_rng != "jax"):
+            raise ValueError("act_rng must be 'device', 'torch' or 'jax' (the latter together with shuffle_rng='jax')")
         if shuffle_rng == "jax":
             from ..jax_random import SgdKeys
             self.sgd_keys = SgdKeys(seed, process_id=0, device_index=self.rank, local_devices=self.world)
@@ -299,7 +302,16 @@ class PPOLearner:
                                               blk.dense.out_features, float(blk.norm.eps), stream), "tmjx_silu_ln_fwd")
                 return y
 
-            eps = torch.randn((n, Z), generator=gen, device=self.dev)
+            # act_rng "device": the two noise arrays are drawn inside tmjx_latent_concat / tmjx_sample_action from a per-generator Philox
+            # counter on the device (no torch generator in the inference graph, no normal_ launches); "torch": the learner's generator
+            device_rng = self.act_rng == "device"
+            if device_rng:
+                rs = self._act_rng.get(id(gen))
+                if rs is None:
+                    rs = self._act_rng[id(gen)] = (torch.zeros(2, dtype=torch.long, device=self.dev),
+                                                   (self._noise_seed ^ (0xD1B54A32D192ED03 * (len(self._act_rng) + 1))) & (2 ** 64 - 1), gen)
+                rng_state, rng_seed = rs[0], rs[1]
+            eps = None if device_rng else torch.randn((n, Z), generator=gen, device=self.dev)
             if lds_free:
                 h, first = None, True
                 for blk in pol.encoder:
@@ -309,9 +321,9 @@ class PPOLearner:
             else:
                 fc2 = pol.fc2(pol.encoder(x[..., :ref]))
             wdec = Z + W - ref
-            xdec = torch.zeros((n, (wdec + 3) // 4 * 4), **f32) if lds_free else torch.empty((n, wdec), **f32)
+            xdec = torch.empty((n, (wdec + 3) // 4 * 4 if lds_free else wdec), **f32)       # (the kernel zeroes the pad columns)
             _hip.check(L.tmjx_latent_concat(p(fc2), p(eps), p(src), p(xdec), n, Z, W, ref, src.stride(0), src.stride(1), None, None,
-                                            xdec.shape[1], stream), "tmjx_latent_concat")
+                                            xdec.shape[1], rng_seed if device_rng else 0, p(rng_state) if device_rng else None, stream), "tmjx_latent_concat")
             if lds_free:
                 h = xdec
                 for blk in pol.decoder:
@@ -319,11 +331,12 @@ class PPOLearner:
                 logits = linear(h, h.shape[1], 1, h.shape[1], pol.head)
             else:
                 logits = pol.head(pol.decoder(xdec))
-            noise = torch.randn((n, A), generator=gen, device=self.dev)
+            noise = None if device_rng else torch.randn((n, A), generator=gen, device=self.dev)
             raw = torch.empty((n, A), **f32)
             action_t = torch.empty((A, n), **f32)
             logp = torch.empty(n, **f32)
-            _hip.check(L.tmjx_sample_action(p(logits), p(noise), p(raw), p(action_t), p(logp), n, A, stream), "tmjx_sample_action")
+            _hip.check(L.tmjx_sample_action(p(logits), p(noise), p(raw), p(action_t), p(logp), n, A, rng_seed if device_rng else 0,
+                                            p(rng_state) if device_rng else None, stream), "tmjx_sample_action")
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
         return action_t.t(), {"raw_action": raw, "log_prob": logp, "logits": logits, "latent_mean": mean, "latent_logvar": logvar}
 
@@ -559,7 +572,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
           intention_latent_size: int = 60, progress_fn: Callable[[int, dict], None] = lambda *a: None,
           max_training_steps: int | None = None, eval_env=None, num_eval_envs: int = 128, deterministic_eval: bool = False,
           matmul_dtype: torch.dtype | None = None, group=None, checkpoint_path: str | None = None, restore_from: str | None = None,
-          shuffle_rng: str = "torch", act_rng: str = "torch", **unused):
+          shuffle_rng: str = "torch", act_rng: str = "device", **unused):
     """ppo.train(environment, num_timesteps, episode_length, ...) -> (make_policy, params, metrics)  (ppo.py:128-172,809).
 
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like

@@ -526,13 +526,21 @@ __global__ void k_philox_kat(const unsigned *ctr_key, unsigned *out) {
 // latent sample + decoder input in one pass:  x[i] = [ mean + eps * exp(logvar / 2)  |  obs[i][ref:] ]
 __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__ fc2, const float *__restrict__ eps, const float *__restrict__ obs,
                                                        float *__restrict__ x, int n, int Z, int obs_w, int ref_w, long long obs_s0, long long obs_s1,
-                                                       const float *__restrict__ mean, const float *__restrict__ stdv, int x_stride) {
+                                                       const float *__restrict__ mean, const float *__restrict__ stdv, int x_stride,
+                                                       unsigned long long seed, const long long *__restrict__ rng_state) {
+  // eps == nullptr: the latent noise is drawn here, Philox stream 2 of (seed, draw counter rng_state[0]) — the acting policy's graph then
+  // holds no torch generator (two state fills per replay) and no normal_ launch; the pad columns [W, x_stride) are written as zeros
   const int W = Z + obs_w - ref_w;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * W; i += (size_t)gridDim.x * 256) {
-    int c = (int)(i % W); size_t e = i / W;
-    float v;
-    if (c < Z) v = fc2[e * 2 * Z + c] + eps[e * Z + c] * expf(0.5f * fc2[e * 2 * Z + Z + c]);
-    else { int k = ref_w + c - Z; v = obs[(long long)e * obs_s0 + (long long)k * obs_s1]; if (mean) v = (v - mean[k]) / stdv[k]; }
+  const unsigned long long ctr = rng_state ? (unsigned long long)rng_state[0] : 0ull;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * x_stride; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % x_stride); size_t e = i / x_stride;
+    float v = 0.f;
+    if (c < Z) {
+      float ep;
+      if (eps) ep = eps[e * Z + c];
+      else { float v4[4]; const size_t idx = e * Z + c; tm_normal4(seed, ctr, 2u, (unsigned)(idx >> 2), v4); ep = v4[idx & 3]; }
+      v = fc2[e * 2 * Z + c] + ep * expf(0.5f * fc2[e * 2 * Z + Z + c]);
+    } else if (c < W) { int k = ref_w + c - Z; v = obs[(long long)e * obs_s0 + (long long)k * obs_s1]; if (mean) v = (v - mean[k]) / stdv[k]; }
     x[e * (size_t)x_stride + c] = v;
   }
 }
@@ -549,13 +557,20 @@ __global__ __launch_bounds__(256) void k_latent_concat_bwd(const float *__restri
 }
 // action sample, tanh post-processing and log-prob of the sample: one lane group of PPO_G per env
 __global__ __launch_bounds__(PPO_BLOCK) void k_sample_action(const float *__restrict__ logits, const float *__restrict__ noise, float *__restrict__ raw,
-                                                             float *__restrict__ action_t, float *__restrict__ logp, int n, int A) {
+                                                             float *__restrict__ action_t, float *__restrict__ logp, int n, int A,
+                                                             unsigned long long seed, long long *__restrict__ rng_state) {
+  // noise == nullptr: drawn here (Philox stream 3 of (seed, rng_state[0])); the workgroup that finishes last then advances the draw counter
+  // for the next inference (every workgroup has read it by then; ticket in rng_state[1])
   const int gid = blockIdx.x * PPO_BLOCK + threadIdx.x, e = gid / PPO_G, sub = gid % PPO_G;
+  const unsigned long long ctr = rng_state ? (unsigned long long)rng_state[0] : 0ull;
   float lp = 0.f;
   if (e < n) {
     const float *lg = logits + (size_t)e * 2 * A;
     for (int a = sub; a < A; a += PPO_G) {
-      float loc = lg[a], scale = ppo_softplus(lg[A + a]) + 0.001f, x = loc + scale * noise[(size_t)e * A + a], d = (x - loc) / scale;
+      float nz;
+      if (noise) nz = noise[(size_t)e * A + a];
+      else { float v4[4]; const size_t idx = (size_t)e * A + a; tm_normal4(seed, ctr, 3u, (unsigned)(idx >> 2), v4); nz = v4[idx & 3]; }
+      float loc = lg[a], scale = ppo_softplus(lg[A + a]) + 0.001f, x = loc + scale * nz, d = (x - loc) / scale;
       raw[(size_t)e * A + a] = x;
       action_t[(size_t)a * n + e] = tanhf(x);          // [A][n]: the env-minor layout tmjx_step takes
       lp += -0.5f * d * d - logf(scale) - 0.91893853320467274f - ppo_fldj(x);
@@ -563,6 +578,16 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_sample_action(const float *__rest
   }
   lp = ppo_group_sum(lp);
   if (e < n && sub == 0) logp[e] = lp;
+  if (rng_state) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long *st = (unsigned long long *)rng_state;
+      if (__hip_atomic_fetch_add(st + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull) {
+        __hip_atomic_store(st + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rng_state[0] += 1;
+      }
+    }
+  }
 }
 
 // ---- LDS-free dense layer for the policy inference that runs NEXT TO the physics kernel --------------------------------------

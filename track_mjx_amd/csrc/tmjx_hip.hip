@@ -647,12 +647,15 @@ int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_a
 }
 
 int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
-                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, int x_stride, void *stream) {
-  if (!fc2 || !eps || !obs || !x) return fail(TMJX_EINVAL, "null argument");
+                       int64_t obs_s0, int64_t obs_s1, const float *mean, const float *std, int x_stride, uint64_t seed, const int64_t *rng_state,
+                       void *stream) {
+  if (!fc2 || !obs || !x) return fail(TMJX_EINVAL, "null argument");
+  if (!eps && !rng_state) return fail(TMJX_EINVAL, "tmjx_latent_concat: eps == NULL needs rng_state");
   if (n < 1 || Z < 1 || ref_w < 0 || obs_w < ref_w || x_stride < Z + obs_w - ref_w) return fail(TMJX_EINVAL, "bad sizes");
-  size_t total = (size_t)n * (Z + obs_w - ref_w);
+  size_t total = (size_t)n * x_stride;
   int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1, mean, std, x_stride);
+  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1, mean, std, x_stride,
+                     (unsigned long long)seed, (const long long *)rng_state);
   return check_launch("k_latent_concat");
 }
 
@@ -665,10 +668,13 @@ int tmjx_latent_concat_bwd(const float *dx, const float *eps, const float *fc2, 
   return check_launch("k_latent_concat_bwd");
 }
 
-int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, void *stream) {
-  if (!logits || !noise || !raw || !action_t || !logp) return fail(TMJX_EINVAL, "null argument");
+int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, uint64_t seed,
+                       int64_t *rng_state, void *stream) {
+  if (!logits || !raw || !action_t || !logp) return fail(TMJX_EINVAL, "null argument");
+  if (!noise && !rng_state) return fail(TMJX_EINVAL, "tmjx_sample_action: noise == NULL needs rng_state");
   if (n < 1 || A < 1) return fail(TMJX_EINVAL, "bad sizes");
-  hipLaunchKernelGGL(k_sample_action, dim3((n * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK), dim3(PPO_BLOCK), 0, (hipStream_t)stream, logits, noise, raw, action_t, logp, n, A);
+  hipLaunchKernelGGL(k_sample_action, dim3((n * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK), dim3(PPO_BLOCK), 0, (hipStream_t)stream, logits, noise, raw, action_t, logp, n, A,
+                     (unsigned long long)seed, (long long *)(noise ? nullptr : rng_state));
   return check_launch("k_sample_action");
 }
 

@@ -119,9 +119,9 @@ def load(path: Path):
     sig.setdefault("tmjx_gather_minibatch", [None, None])[0] = [fp] * 14 + [C.c_int] * 5 + [vp]
     sig.setdefault("tmjx_minibatch_begin", [None, None])[0] = [C.POINTER(Minibatch), vp]
     sig.setdefault("tmjx_philox4x32_10", [None, None])[0] = [fp, fp, vp]
-    sig.setdefault("tmjx_latent_concat", [None, None])[0] = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, C.c_int, vp]
+    sig.setdefault("tmjx_latent_concat", [None, None])[0] = [fp] * 4 + [C.c_int] * 4 + [C.c_int64, C.c_int64, fp, fp, C.c_int, C.c_uint64, fp, vp]
     sig.setdefault("tmjx_latent_concat_bwd", [None, None])[0] = [fp] * 4 + [C.c_int] * 3 + [vp]
-    sig.setdefault("tmjx_sample_action", [None, None])[0] = [fp] * 5 + [C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_sample_action", [None, None])[0] = [fp] * 5 + [C.c_int, C.c_int, C.c_uint64, fp, vp]
     sig.setdefault("tmjx_linear_nolds", [None, None])[0] = [fp, C.c_int64, C.c_int64, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_colsum_scratch_floats", [None, None])[0] = [C.c_int]
     sig.setdefault("tmjx_colsum", [None, None])[0] = [fp, fp, fp, C.c_int, C.c_int, vp]
