@@ -478,7 +478,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     // interleaved tile columns (fread) + transposed tiles (mma): register r of tile b is C[16 a + li][nw + 8 kq + 2 r + b], i.e. the lane
     // holds columns nw + 8 kq .. + 7 of the rows 16 a + li: two dwordx4 per row
     const int col = n0 + nw + 8 * kq;
-    const bool vec = !(ldc & 3) && !((uintptr_t)C & 15) && col + 7 < N;
+    const bool vec = !(ldc & 3) && !((uintptr_t)C & 15) && col + 7 < N, vec2 = !(ldc & 1) && !((uintptr_t)C & 7);
 #pragma unroll
     for (int a = 0; a < 5; a++) {
       const int row = m0 + 16 * a + li;
@@ -486,7 +486,13 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
         float *o = C + (long long)row * ldc + col;
         const float v[8] = {acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1], acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
         if (vec) { *reinterpret_cast<gf4 *>(o) = gf4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<gf4 *>(o + 4) = gf4{v[4], v[5], v[6], v[7]}; }
-        else {
+        else if (vec2) {                 // rows 8-byte aligned only (an odd multiple of 2 floats wide, e.g. 470 or 286)
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            if (col + k + 1 < N) *reinterpret_cast<gf2 *>(o + k) = gf2{v[k], v[k + 1]};
+            else if (col + k < N) o[k] = v[k];
+          }
+        } else {
 #pragma unroll
           for (int k = 0; k < 8; k++) if (col + k < N) o[k] = v[k];
         }
