@@ -32,11 +32,7 @@ struct tmjx_model {
   mutable float *mspill = nullptr;
   mutable int mspill_envs = 0;
 };
-#ifdef TMW_OLD_STRIDE
 #define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
-#else
-#define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
-#endif
 // record stride: state rows qpos .. qfrc_actuator, then the action, rounded up to 16 words
 #define WAVE_REC_STRIDE(m) ((((m)->h.s_prev_ctrl + (m)->h.nu) + 15) & ~15)
 // workspace words in front of the record: window partials (2 nu rows) + post partials (16 rows), each n_env wide

@@ -17,16 +17,6 @@ struct WLayout {
   // aliased region B (position / velocity stage), same base as region A
   int l_scanA, l_scanB, l_jl_anchor, l_jl_axis, l_xipos, l_cinert, l_cfrc, l_dscanA, l_dscanB;
   int lds_floats;
-#ifndef TMW_LEAN_ACT
-#define TMW_LEAN_ACT 1
-#endif
-#ifndef TMW_LEAN_QFS
-#define TMW_LEAN_QFS 1
-#endif
-#ifndef TMW_LEAN_FRAME
-#define TMW_LEAN_FRAME 1
-#endif
-  int lean_act, lean_qfs, lean_frame;   // (experiment switches of the three lean pieces)
   int lean;     // 1: chain layout with the matrix spilled (m_spilled()): act, qfrc_smooth in global memory, shared contact normal
   int chains;   // 0: any tree (LDS-resident sparse factorisation); 1: the rodent's dof chains (register-resident, wave_physics.h)
 
@@ -37,9 +27,8 @@ struct WLayout {
         l_lim_sign(0), l_qfrc_smooth(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_hdamp(0), l_con_mu(0), l_con_grpb(0), l_rowmap(0), l_ccrow(0), l_dummy(0),
         l_alias0(0), l_LD(0), l_Dinv(0), l_efc_D(0), l_efc_aref(0), l_Jaref(0), l_jv(0), l_qacc_smooth(0), l_qacc(0), l_Ma(0),
         l_grad(0), l_Mgrad(0), l_search(0), l_mv(0), l_qfrc_constraint(0), l_tmp(0), l_scanA(0), l_scanB(0), l_jl_anchor(0),
-        l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0), lean_act(0), lean_qfs(0), lean_frame(0), lean(ch && 2 * nb * 8 <= nnz_ && nv_ * 7 <= nb * 8 && nu_ <= ng * 6), chains(ch) {
+        l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0), lean(ch && 2 * nb * 8 <= nnz_ && nv_ * 7 <= nb * 8 && nu_ <= ng * 6), chains(ch) {
     int l = 0;
-    lean_act = lean && TMW_LEAN_ACT; lean_qfs = lean && TMW_LEAN_QFS; lean_frame = lean && TMW_LEAN_FRAME;
     // NOT here (they were, 295 words): the warm start, ctrl, act_dot, qfrc_actuator and timestep * damping.  LDS is granted in 1280-byte
     // granules on gfx950 (tools/micro/lds_occupancy.hip): 16 284 bytes took 13 of the 128 granules of a CU, i.e. NINE resident envs, not the
     // ten that "16 KB x 10 = 160 KB" suggests; 15 104 bytes take 12 -> ten.  Those five are touched once or twice per substep: they live in
@@ -48,9 +37,9 @@ struct WLayout {
     // 128 -> ELEVEN envs: the activation state and qfrc_smooth live in global memory too (the env's record / the tail of its inertia-matrix
     // scratch; two and five accesses per substep), the contact frames share their first row (every contact is against the one static floor
     // plane: model_host.h checks it), the violated-limit table is bytes, the paw-group table one word per group.
-    l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += lean_act ? 0 : nu;
+    l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += lean ? 0 : nu;
     l_cdof = l; l += nv * 6; l_M = l; l += nnz; l_con_dist = l; l += ncon; l_con_off = l; l += ncon * 3;
-    l_con_frame = l; l += lean_frame ? 3 + ncon * 3 : ncon * 6; l_lim_sign = l; l += (nlim + 3) / 4; l_qfrc_smooth = l; l += lean_qfs ? 0 : nv;
+    l_con_frame = l; l += lean ? 3 + ncon * 3 : ncon * 6; l_lim_sign = l; l += (nlim + 3) / 4; l_qfrc_smooth = l; l += lean ? 0 : nv;
     l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_tdof = l; l += nv * 2;
     l_tgrp = l; l += (ngroup + 3) / 4;      // bytes: last dof of each paw group (-1 = none)
     l_con_mu = l; l += ncon;  // friction coefficient of every contact slot: a model constant the products with J / J^T need on every call

@@ -94,9 +94,9 @@ struct WCtx {
 
 // lean layout (K.lean, the rodent): the activation state stays in the env's global record, qfrc_smooth in two registers of the lane that
 // produces and consumes it (dof i = lane, lane + 64: every loop over the dofs uses that mapping), the contact frames share the floor's normal (wave_layout.h); the generic layout keeps all three in LDS
-#define TMW_ACT(a) (*(K.lean_act ? &WST(m.s_act, (a)) : &L[K.l_act + (a)]))
-#define TMW_QFS(i) (K.lean_qfs ? ((i) < 64 ? c.qfs0[TMW_LI] : c.qfs1[TMW_LI]) : L[K.l_qfrc_smooth + (i)])
-#define TMW_QFS_SET(i, v) do { if (!K.lean_qfs) L[K.l_qfrc_smooth + (i)] = (v); else if ((i) < 64) c.qfs0[TMW_LI] = (v); else c.qfs1[TMW_LI] = (v); } while (0)
+#define TMW_ACT(a) (*(K.lean ? &WST(m.s_act, (a)) : &L[K.l_act + (a)]))
+#define TMW_QFS(i) (K.lean ? ((i) < 64 ? c.qfs0[TMW_LI] : c.qfs1[TMW_LI]) : L[K.l_qfrc_smooth + (i)])
+#define TMW_QFS_SET(i, v) do { if (!K.lean) L[K.l_qfrc_smooth + (i)] = (v); else if ((i) < 64) c.qfs0[TMW_LI] = (v); else c.qfs1[TMW_LI] = (v); } while (0)
 #define TMW_LIMSIGN(K) ((signed char *)(L + (K).l_lim_sign))      /* sign * (compact row + 1) of a violated limit, 0 otherwise */
 TM_DEV int tm_f2i(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
@@ -179,7 +179,7 @@ TM_DEV int tmw_prefix(const int *flag, int *excl) {
 TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int i = lane; i < K.nq + K.nv + (K.lean_act ? 0 : K.nu); i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel (| act); the warm start stays in global memory
+    for (int i = lane; i < K.nq + K.nv + (K.lean ? 0 : K.nu); i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel (| act); the warm start stays in global memory
     for (int i = lane; i < 2 * K.nv; i += 64) {   // index table of the sparse rows (+ the dof's limit row / wrench subset in the top bytes)
       int dof = i >> 1, extra = (i & 1) ? m.dof_wsub[dof] + 1 : m.dof_limrow[dof] + 1;
       L[K.l_tdof + i] = tm_i2f(m.tdof[i] | (extra << 24));
@@ -213,7 +213,7 @@ TM_DEV int tmw_anc(int i, int q, int w1) {
 TM_DEV void tmw_store_state(WCtx &c, const WLayout &K, float time) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
-    for (int i = lane; i < K.nq + K.nv + (K.lean_act ? 0 : K.nu); i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];      // (warm start and qfrc_actuator are written where they arise)
+    for (int i = lane; i < K.nq + K.nv + (K.lean ? 0 : K.nu); i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];      // (warm start and qfrc_actuator are written where they arise)
     if (lane == 0) WST(m.s_time, 0) = time;
   }
   TMW_SYNC();
@@ -221,11 +221,11 @@ TM_DEV void tmw_store_state(WCtx &c, const WLayout &K, float time) {
 
 // contact frame rows n, b of slot cc: 6 words per slot, or (chain layout) the shared normal + 3 words per slot
 TM_DEV void tmw_put_con_frame(float *L, const WLayout &K, int cc, const float *fr) {
-  if (K.lean_frame) { if (cc == 0) for (int k = 0; k < 3; k++) L[K.l_con_frame + k] = fr[k]; for (int k = 0; k < 3; k++) L[K.l_con_frame + 3 + cc * 3 + k] = fr[3 + k]; }
+  if (K.lean) { if (cc == 0) for (int k = 0; k < 3; k++) L[K.l_con_frame + k] = fr[k]; for (int k = 0; k < 3; k++) L[K.l_con_frame + 3 + cc * 3 + k] = fr[3 + k]; }
   else for (int k = 0; k < 6; k++) L[K.l_con_frame + cc * 6 + k] = fr[k];
 }
 TM_DEV void tmw_get_con_frame(const float *L, const WLayout &K, int cc, float *fr) {
-  if (K.lean_frame) { for (int k = 0; k < 3; k++) { fr[k] = L[K.l_con_frame + k]; fr[3 + k] = L[K.l_con_frame + 3 + cc * 3 + k]; } }
+  if (K.lean) { for (int k = 0; k < 3; k++) { fr[k] = L[K.l_con_frame + k]; fr[3 + k] = L[K.l_con_frame + 3 + cc * 3 + k]; } }
   else for (int k = 0; k < 6; k++) fr[k] = L[K.l_con_frame + cc * 6 + k];
 }
 
@@ -599,7 +599,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
   // lean layout: the activation state lives in the env's global record, each value written and re-read by its OWN lane (tmw_euler) — a dof's
   // lane needs other lanes' values, and global memory gives no ordering between the lanes of a wave: stage it through the paw-velocity
   // buffer, which only the J products of the solver stage use (nu <= 6 ngroup: WLayout::lean)
-  if (K.lean_act) { TMW_FOR { for (int a = lane; a < K.nu; a += 64) L[K.l_sv + a] = WST(m.s_act, a); } }
+  if (K.lean) { TMW_FOR { for (int a = lane; a < K.nu; a += 64) L[K.l_sv + a] = WST(m.s_act, a); } }
   TMW_SYNC();
   TMW_TICK2(23);
   // M rows, bias, passive, actuation -> qfrc_smooth; act_dot
@@ -622,7 +622,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       float bias = 0.f;
       for (int k = 0; k < 6; k++) bias += cd[k] * fb[k];
       float fa = 0.f;
-      for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[(K.lean_act ? K.l_sv : K.l_act) + u]); }
+      for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[(K.lean ? K.l_sv : K.l_act) + u]); }
       WST(m.s_qfrc_actuator, i) = fa;
       float f = -m.dof_damping[i] * L[K.l_qvel + i] - bias + fa;
       if (m.dof_stiffness[i] != 0.f) f += -m.dof_stiffness[i] * (L[K.l_qpos + m.dof_qposadr[i]] - m.dof_qspring[i]);
