@@ -36,4 +36,5 @@ for it in range(steps):
         ep_end = 1.0 - L.buf["discount"].mean().item()
         print(f"step {it:3d}  env-steps {(it + 1) * L.env_steps_per_training_step / 1e6:6.1f} M  mean reward/step {r.mean().item():+.3f}  episode ends/step {ep_end:.3f}  "
               f"total {m['total_loss'].item():+.3f}  policy {m['policy_loss'].item():+.4f}  value {m['v_loss'].item():.4f}  kl {m['kl_latent_loss'].item():.4f}  "
-              f"entropy {m['entropy_loss'].item():+.4f}  finite {bool(torch.isfinite(r).all())}  {time.perf_counter() - t0:5.1f} s", flush=True)
+              f"entropy {m['entropy_loss'].item():+.4f}  finite {bool(torch.isfinite(r).all())}  {time.perf_counter() - t0:5.1f} s  "
+              f"mem {torch.cuda.memory_allocated() / 2 ** 20:.0f} MiB (peak {torch.cuda.max_memory_allocated() / 2 ** 20:.0f})", flush=True)
