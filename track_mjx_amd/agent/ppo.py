@@ -58,6 +58,7 @@ class FlatGrads:
         self.params = [p for p in params if p.requires_grad]
         self.segs, n = _flat_layout(self.params)
         self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        self._avg_ok = None
         for p, seg in zip(self.params, self.segs):
             p.grad = _flat_view(self.flat, seg, p)
 
@@ -81,8 +82,18 @@ class FlatGrads:
     def all_reduce_mean(self, group=None, force: bool = False):
         """`force`: issue the collective on a one-rank group too (identity) — lets a single-GPU box exercise the RCCL call path."""
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            if self._avg_ok is None:       # RCCL reduces with ncclAvg itself (no separate division launch); gloo (CPU tests) has no AVG
+                try:
+                    probe = torch.ones(1, dtype=self.flat.dtype, device=self.flat.device)
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+                    self._avg_ok = bool(probe.item() == 1.0)
+                except Exception:  # noqa: BLE001 — backend without AVG: sum, then divide
+                    self._avg_ok = False
+            if self._avg_ok:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(dist.get_world_size(group))
 
     def clip_by_global_norm(self, max_norm: float):
         norm = torch.linalg.vector_norm(self.flat)
