@@ -255,7 +255,7 @@ __global__ void k_gae(const float *__restrict__ trunc, const float *__restrict__
 extern "C" {
 
 const char *tmjx_last_error(void) { return g_err.c_str(); }
-const char *tmjx_version(void) { return "tmjx-hip 0.3 (gfx950, wave-per-env LDS physics)"; }
+const char *tmjx_version(void) { return "tmjx-hip 0.4 (gfx950, wave-per-env LDS physics)"; }
 
 int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
   if (!blob || !out) return fail(TMJX_EINVAL, "null argument");
