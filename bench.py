@@ -9,7 +9,11 @@ num_updates_per_batch*num_minibatches = 64 minibatch SGD updates with the gradie
 value = env steps collected by all ranks / wall time (the reference's own `training/sps`, ppo.py:427-431).
 Weak scaling: 4096 envs and 1024 minibatch rows per GPU; global batch_size = 1024*N.
 
-Usage: python bench.py [--gpus N --steps K --warmup W]   (N > 1: launched by torch.distributed.run, one rank per GPU)
+Usage: python bench.py [--gpus N --steps K --warmup W]
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...`: RANK / WORLD_SIZE are then in the environment) or bench.py does it itself: `python bench.py --gpus N` starts that
+command as a CHILD process before anything touches the GPU and relays rank 0's JSON line (track_mjx_amd/launch.py; the reference
+reaches all local devices from one process through jax.pmap, track_mjx/agent/mlp_ppo/ppo.py:409).
 """
 from __future__ import annotations
 
@@ -42,8 +46,9 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(blob, clip, seconds_budget: float = 15.0):
-    """The oracle (CPU restatement, kind "port") stepping the same kind of workload on the host cores."""
+def cpu_baseline(blob, clip, seconds_budget: float = 15.0, action_scale: float = 0.3):
+    """The oracle (CPU restatement, kind "port") stepping the same kind of workload on the host cores.  `action_scale`: actions are
+    clip(action_scale * N(0, 1), -1, 1) — 0.3 is the roll-out-only leg's regime (the cost of an env-step depends on it: DESIGN.md §7)."""
     import numpy as np
     from oracle.oracle import Oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -60,18 +65,59 @@ def cpu_baseline(blob, clip, seconds_budget: float = 15.0):
     rng = np.random.default_rng(0)
     for e in range(n):
         O.env_reset(envs, e, e % clip.position.shape[0], e % 44, rng.uniform(-1e-3, 1e-3, 74), rng.uniform(-1e-3, 1e-3, 73))
-    acts = np.clip(rng.normal(size=(n, 38)), -1, 1)
+    acts = np.clip(action_scale * rng.normal(size=(n, 38)), -1, 1)
     O.env_step_batch(envs, n, acts, cores)  # warm up threads
     t0, steps = time.time(), 0
     while time.time() - t0 < seconds_budget:
         O.env_step_batch(envs, n, acts, cores)
         steps += n
     dt = time.time() - t0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps // n} control steps (10 substeps each), OpenMP over envs, oracle/liboracle_f32.so"}
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port", "action_scale": action_scale,
+            "sample": f"{n} envs x {steps // n} control steps (10 substeps each), actions clip({action_scale} * N(0,1)), OpenMP over envs, oracle/liboracle_f32.so"}
 
 
-def main():
+def so_build_id() -> str:
+    """First 16 hex digits of the sha256 of the HIP library this run loads: ties the numbers read from profiles/*.json to a build."""
+    import hashlib
+    from track_mjx_amd import hip
+    try:
+        return hashlib.sha256(Path(hip.SO_PATH).read_bytes()).hexdigest()[:16]
+    except OSError:
+        return "missing"
+
+
+def mjx_cpu_probe() -> str:
+    """BASELINE.md §3.2 / SURVEY §8 d6: MJX on jax[cpu] is the baseline north_star names; it is timed only where it imports."""
+    try:
+        import jax  # noqa: F401
+        import mujoco.mjx  # noqa: F401
+        return "available (not timed: the reference env cannot travel to the GPU box)"
+    except Exception as e:  # noqa: BLE001
+        return f"unavailable ({type(e).__name__}: {e})"
+
+
+def dry_run_ranks(args) -> None:
+    """`--dry-run-ranks`: the launcher plumbing without a GPU — every rank joins a gloo group, all-reduces a one, rank 0 prints the
+    line's skeleton (tests/test_launch.py drives `bench.py --gpus 2 --dry-run-ranks` through the self-launch branch)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ranks_seen = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"metric": "dry-run-ranks", "n_gpus": world, "asked_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"ranks_seen": ranks_seen, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None, runner=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -83,7 +129,14 @@ def main():
                     "rocprofv3 kernel averages those of the timed training steps)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
                     help="BASELINE.json configs[1] (default, the headline line) / configs[3] / configs[4]; the others are extra measurements")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run-ranks", action="store_true", help="launcher check on CPU: gloo ranks, no GPU work (tests)")
+    args = ap.parse_args(argv)
+    from track_mjx_amd import launch
+    if launch.needs_spawn(args.gpus):
+        # `python bench.py --gpus N` as the driver types it: start the N ranks as a child process (nothing has touched the GPU yet)
+        return launch.spawn_ranks(args.gpus, [str(ROOT / "bench.py")], argv, runner=runner)
+    if args.dry_run_ranks:
+        return dry_run_ranks(args)
     bc = CONFIGS[args.config]
     if args.envs_per_gpu is None:
         args.envs_per_gpu = bc["envs_per_gpu"]
@@ -99,8 +152,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     # TMJX_COLLECTIVES_ALWAYS=1 under torch.distributed.run with ONE rank: RCCL is initialised and C1 / C2 / the timing reductions are
@@ -237,7 +289,8 @@ def main():
             "metric": "env-steps/sec (whole node), rodent task @ 4096 envs/GPU", "value": env_steps / elapsed,
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if bc["matmul_dtype"] is None else f"f32 (physics, reward, loss head, optimiser) + {bc['matmul_dtype']} MLP GEMM inputs with f32 accumulate",
+            "data": "synthetic", "so_build_id": so_build_id(), "mjx_cpu": mjx_cpu_probe(),
             "config": {"workload": f"rodent tracking PPO training step ({args.config}): {n_local} envs/GPU, {learner.env_steps_per_training_step // (n_local * learner.T * world)}x{learner.T}-step unrolls (10 physics substeps each) + {sgd_steps} minibatch updates, {bc['label']}",
                        "n_clips": bc["n_clips"], "mlp_gemm_inputs": bc["matmul_dtype"] or "f32",
                        "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
@@ -250,6 +303,8 @@ def main():
             # launch's average duration (HIP events on its launch stream; with --pipeline 2 the two groups' launches share the GPU)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
+                         "traffic_build_id": pmc.get("so_build_id") if pmc else None,
+                         "traffic_build_is_this_runs": bool(pmc and pmc.get("so_build_id") == so_build_id()),
                          "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (FETCH_SIZE doubled, the gfx950 correction), NOT collected by this run; bytes per launch scaled to this launch's env count",
                          "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env)",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * per_launch,
@@ -270,7 +325,9 @@ def main():
                               "flops_source": "profiles/oracle_flop_count.json: flop-counting build of the CPU oracle (dense MJX formulation: 1.03 Mflop per substep); the kernel's tree-sparse / matrix-free formulation executes fewer",
                               "valu_pipe_busy": sq.get("valu_pipe_busy") if sq else None, "lane_occupancy": sq.get("lane_occupancy") if sq else None,
                               "valu_insts_per_wave_substep": sq.get("SQ_INSTS_VALU_per_wave_substep") if sq else None,
-                              "counters_source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes, tools/sq_counters.sh), not collected by this run"},
+                              "counters_source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes, tools/sq_counters.sh), not collected by this run",
+                              "counters_build_id": sq.get("so_build_id") if sq else None,
+                              "counters_build_is_this_runs": bool(sq and sq.get("so_build_id") == so_build_id())},
             "roofline_mfma": {"bound": "mfma", "unit": "TFLOP/s", "peak": mfma_peak, "achieved": mfma_ach, "frac": mfma_ach / mfma_peak,
                               "what": f"{sgd_steps} minibatch SGD steps of {rows_mb} rows: GEMM flops (forward + d input + d weight, policy + value nets) / the whole SGD half's time incl. gathers, epilogues, loss head and optimiser (HIP events around update())",
                               "gemm_flops_per_minibatch_step": gemm_flops_step, "sgd_ms_per_minibatch_step": sgd_ms / sgd_steps,
@@ -278,7 +335,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(env._blob, env._reference_clips)
+                # same action regime as the roll-out-only leg (0.3 * N(0,1)); the full-scale regime of BASELINE config 1 beside it
+                out["cpu_baseline"] = cpu_baseline(env._blob, env._reference_clips, 12.0, 0.3)
+                out["cpu_baseline"]["full_scale_actions"] = cpu_baseline(env._blob, env._reference_clips, 6.0, 1.0)
+                out["cpu_baseline"]["mjx_cpu"] = out["mjx_cpu"]
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
@@ -288,4 +348,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -10,6 +10,9 @@ import sys
 from pathlib import Path
 
 src = Path(sys.argv[1])
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from buildid import checked_id  # noqa: E402
+BUILD = checked_id(src, "--force" in sys.argv)
 res = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA ... over tools/sgd_step.py --config <cfg> (eager launches); "
                "utilisation = MFMA busy cycles / (4 x CU busy cycles), summed per kernel family"}
 for cfg in ("cfg2", "cfg4"):
@@ -34,5 +37,6 @@ for cfg in ("cfg2", "cfg4"):
     out["library_gemm_kernels_in_timed_region"] = int(any(f.startswith("library") for f in agg))
     res[cfg] = out
 res["mfma_util"] = res.get("cfg2", {}).get("all_hand_written_gemm_kernels")
+res.update(BUILD)
 (Path(__file__).resolve().parents[1] / "profiles" / "mfma_counters.json").write_text(json.dumps(res, indent=1) + "\n")
 print(json.dumps(res, indent=1))

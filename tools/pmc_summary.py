@@ -10,6 +10,9 @@ import sys
 from pathlib import Path
 
 src = Path(sys.argv[1])
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from buildid import checked_id  # noqa: E402
+BUILD = checked_id(src, "--force" in sys.argv)
 ENVS = 4096
 K2_ALGO = 842 * 4 * ENVS
 step_kernels = ("void k_physics_wave", "k_rec_in", "k_rec_out", "k_window", "k_obs", "k_post_parts", "k_post", "k_autoreset")
@@ -39,5 +42,6 @@ res = {
     "algorithmic_bytes_per_launch": K2_ALGO,
     "hbm_bytes_per_launch_all_step_kernels": sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in kern.values()),
 }
+res.update(BUILD)
 (Path(__file__).resolve().parents[1] / "profiles" / "pmc_traffic.json").write_text(json.dumps(res, indent=1))
 print(json.dumps({k: res[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch_all_step_kernels")}))

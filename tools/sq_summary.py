@@ -14,7 +14,11 @@ import sys
 from pathlib import Path
 
 src = Path(sys.argv[1])
-envs_per_cu = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from buildid import checked_id  # noqa: E402
+BUILD = checked_id(src, "--force" in sys.argv)
+_pos = [a for a in sys.argv[2:] if not a.startswith("--")]
+envs_per_cu = float(_pos[0]) if _pos else 11.0
 ENVS, NSUB = 4096, 10
 tot = collections.defaultdict(list)
 for sub in ("a", "b"):
@@ -42,5 +46,6 @@ if c.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in c:
 if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
     res["wave_parked_fraction"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
     res["issue_stall_fraction"] = round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+res.update(BUILD)
 (Path(__file__).resolve().parents[1] / "profiles" / "sq_counters.json").write_text(json.dumps(res, indent=1) + "\n")
 print(json.dumps(res, indent=1))

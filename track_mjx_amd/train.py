@@ -3,7 +3,9 @@
 network sizes from the config and calls ppo.train.  hydra/wandb/orbax/rendering are out of scope (SURVEY.md §2);
 the derived quantities follow train.py:221-225 (episode_length) and :298-301 (num_evals, num_resets_per_eval).
 
-Multi-GPU: launch one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m track_mjx_amd.train`);
+Multi-GPU: one process per GPU.  `python -m track_mjx_amd.train num_gpus=N ...` starts its own N ranks as a child
+`python -m torch.distributed.run` (launch.py; the reference gets all local devices from one process via jax.pmap, ppo.py:409);
+started under a launcher (RANK / WORLD_SIZE in the environment) it is one of the ranks.
 `train_config.num_envs` is the GLOBAL env count as in the reference and is sharded across ranks.
 """
 from __future__ import annotations
@@ -55,12 +57,17 @@ def build_env(cfg: dict, num_envs_local: int, device, n_clips: int = 64, clip_se
     return env
 
 
-def main(argv=None) -> None:
+def main(argv=None, runner=None):
     argv = list(sys.argv[1:] if argv is None else argv)
+    full_argv = list(argv)
     cfg_path = None
     if argv and argv[0].endswith((".yaml", ".yml")):
         cfg_path = argv.pop(0)
     cfg = _config.load_config(cfg_path, argv)
+    from . import launch
+    num_gpus = int(cfg.get("num_gpus", 1))
+    if launch.needs_spawn(num_gpus):        # before anything touches the GPU: the ranks are a child process, never an exec
+        return launch.spawn_ranks(num_gpus, ["-m", "track_mjx_amd.train"], full_argv, runner=runner)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device(f"cuda:{local_rank}")
@@ -110,4 +117,4 @@ def main(argv=None) -> None:
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
