@@ -221,3 +221,40 @@ def test_layernorm_backward_fused_into_the_next_input_gradient(M, widths, monkey
         worst = max(worst, e_f)
         assert e_f <= max(3 * e_t, 3e-6), (i, e_f, e_t)
     print(f"M={M} widths={widths}: worst relative error of the fused chain {worst:.2e}")
+
+
+def test_weight_used_twice_under_deferred_weight_gradients():
+    """A layer applied to two inputs inside deferred_weight_grads(): autograd ADDS the two uses' gradients, so the view handed out for the
+    first use must hold that use's gradient by then (the recorded problem is launched on the spot, the second use gets a fresh tensor)."""
+    from track_mjx_amd.agent.networks import _dense, deferred_weight_grads
+    torch.manual_seed(0)
+    lin = _dense(256, 128).to(DEV)
+    lin.weight.grad, lin.bias.grad = torch.full_like(lin.weight, 3.0), torch.full_like(lin.bias, 3.0)     # stale contents of the gradient views
+    x1, x2 = torch.randn((2048, 256), device=DEV), torch.randn((2048, 256), device=DEV)
+    g1, g2 = torch.randn((2048, 128), device=DEV), torch.randn((2048, 128), device=DEV)
+    with deferred_weight_grads() as d:
+        gw, gb = torch.autograd.grad([lin(x1), lin(x2)], [lin.weight, lin.bias], [g1, g2])
+    d.launch()
+    torch.cuda.synchronize()
+    rw = g1.double().t() @ x1.double() + g2.double().t() @ x2.double()
+    rb = g1.double().sum(0) + g2.double().sum(0)
+    assert (gw.double() - rw).abs().max() <= 1e-5 * rw.abs().max(), float((gw.double() - rw).abs().max())
+    assert (gb.double() - rb).abs().max() <= 1e-5 * rb.abs().max()
+
+
+def test_second_backward_through_a_retained_fused_chain():
+    """retain_graph=True and a second backward through Dense->SiLU->LayerNorm blocks whose LayerNorm backward was fused into the consumer's
+    input-gradient GEMM the first time: the second pass (unfused: the link's context is gone) must give the same gradients."""
+    from track_mjx_amd.agent import networks as nw
+    torch.manual_seed(1)
+    blocks = [nw._Block(64, 256).to(DEV), nw._Block(256, 256).to(DEV)]
+    head = nw._dense(256, 40).to(DEV)
+    x = torch.randn((1200, 64), device=DEV, requires_grad=True)
+    with nw.ln_bwd_links():
+        y = head(blocks[1](blocks[0](x)))
+    cot = torch.randn_like(y)
+    params = [x] + [p for b in blocks for p in b.parameters()] + list(head.parameters())
+    first = torch.autograd.grad(y, params, cot, retain_graph=True)
+    second = torch.autograd.grad(y, params, cot)
+    for a, b in zip(first, second):
+        assert (a - b).abs().max() <= 2e-5 * (a.abs().max() + 1e-12), float((a - b).abs().max() / a.abs().max())

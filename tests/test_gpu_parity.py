@@ -323,6 +323,31 @@ def test_train_entrypoint_smoke():
 
 
 @pytest.mark.gpu
+def test_train_resume_continues_env_steps_iteration_and_noise_streams(tmp_path):
+    """restore_from= brings back the whole training state (checkpointing.load_training_state, track_mjx/agent/mlp_ppo/ppo.py:561-567): env_steps and
+    the iteration continue (new step directories, none overwritten), the device-side Philox counters do not restart at 0."""
+    import os
+    import numpy as np
+    from track_mjx_amd import train
+    base = ["train_setup.train_config.num_envs=256", "train_setup.train_config.batch_size=64", "train_setup.train_config.num_minibatches=4",
+            "train_setup.train_config.unroll_length=5", "train_setup.train_config.num_updates_per_batch=2", "network_config.encoder_layer_sizes=[64,64]",
+            "network_config.decoder_layer_sizes=[64,64]", "network_config.critic_layer_sizes=[64,64]", "train_setup.train_config.num_timesteps=6400",
+            "train_setup.eval_every=640", "train_setup.reset_every=640", "n_synthetic_clips=4", "train_setup.train_config.num_eval_envs=0"]
+    d = tmp_path / "ck"
+    train.main(base + [f"checkpoint_path={d}", "max_training_steps=2"])
+    first = sorted(int(x) for x in os.listdir(d))
+    assert first == [0, 1, 2], first
+    with np.load(d / "2" / "train_state.npz") as z:
+        steps2, draws2 = int(z["env_steps"]), int(z["rng/sgd_draw_counter"][0])
+        assert int(z["iteration"]) == 2 and steps2 == 2 * 64 * 4 * 5 and draws2 > 0 and int(z["rng/act_counters/0"][0]) > 0
+    train.main(base + [f"checkpoint_path={d}", f"restore_from={d}", "max_training_steps=1"])
+    assert sorted(int(x) for x in os.listdir(d)) == [0, 1, 2, 3]
+    with np.load(d / "3" / "train_state.npz") as z:
+        assert int(z["env_steps"]) == steps2 + 64 * 4 * 5 and int(z["iteration"]) == 3 and int(z["rng/sgd_draw_counter"][0]) > draws2
+        assert int(z["optimizer_state/count"]) == 3 * 2 * 4
+
+
+@pytest.mark.gpu
 def test_fused_ppo_loss_head_matches_torch_reference():
     """tmjx_ppo_loss (csrc/ppo_kernels.h) against the plain-torch restatement of losses.py:103-245: loss terms and the
     gradient of every network parameter (fp32 both; tolerance 2e-4 of the largest gradient entry)."""

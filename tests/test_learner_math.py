@@ -223,3 +223,54 @@ def test_flat_buffers_pad_odd_row_lengths_and_keep_pads_zero():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
     pad = opt.flat[:40].view(5, 8)[:, 7]
     assert (pad == 0).all() and (opt.exp_avg[:40].view(5, 8)[:, 7] == 0).all()
+
+
+def test_checkpoint_step_directory_is_atomic_named_like_the_reference_and_never_overwritten(tmp_path):
+    """save_step_dir / load_step_dir: <dir>/<it>/{policy.npz, train_state.npz, config/metadata} — the item names of the reference's
+    Composite save (checkpointing.py:280-306), optimiser moments as per-parameter trees in the parameters' own naming (independent of the
+    flat layout's pad rule), env_steps / iteration / noise-stream positions restored, an existing step refused, no temporary left behind."""
+    import json
+    import os
+    import numpy as np
+    import pytest
+    from tests.common import StubEnv, torch_gae
+    from track_mjx_amd.agent import checkpoint as ck
+    from track_mjx_amd.agent.ppo import PPOLearner
+
+    def make(seed):
+        ln = PPOLearner(StubEnv(4, 24, 16, 3), encoder_layers=(12,), decoder_layers=(10,), critic_layers=(8,), latents=4, unroll_length=3,
+                        batch_size=4, num_minibatches=2, num_updates_per_batch=1, learning_rate=1e-2, use_graph=False, seed=seed)
+        ln.gae_fn = torch_gae
+        return ln
+    a = make(3)
+    g = torch.Generator().manual_seed(0)
+    for k, v in a.buf.items():
+        v.copy_(torch.rand(v.shape, generator=g))
+    a.update()
+    a._mb_state[0] = 77                                     # the SGD step's Philox draw counter
+    a._act_rng_state(a.gens[0])[0][0] = 1234                # the acting stream's counter
+    d = tmp_path / "ckpt"
+    final = ck.save_step_dir(d, 2, a, config={"train_setup": {"seed": 3}}, env_steps=655360)
+    assert sorted(os.listdir(final)) == ["config", "policy.npz", "train_state.npz"] and os.listdir(d) == ["2"]
+    assert json.load(open(os.path.join(final, "config", "metadata")))["train_setup"]["seed"] == 3
+    with np.load(os.path.join(final, "policy.npz")) as z:
+        assert "0/mean" in z.files and "1/params/encoder/hidden_0/kernel" in z.files and z["1/params/encoder/hidden_0/kernel"].shape == (16, 12)
+    with np.load(os.path.join(final, "train_state.npz")) as z:
+        # un-padded per-parameter moments: the 16-wide first layer is stored [in, out] like its parameter
+        assert z["optimizer_state/mu/policy/params/encoder/hidden_0/kernel"].shape == (16, 12)
+        assert z["optimizer_state/nu/value/params/hidden_0/kernel"].shape == (24, 8) and int(z["env_steps"]) == 655360
+    with pytest.raises(FileExistsError):
+        ck.save_step_dir(d, 2, a)
+    assert ck.latest_step(d) == 2 and ck.latest_step(tmp_path / "nothing") is None
+    b = make(4)
+    extra = ck.restore(d, b)                                # the directory: its latest step
+    assert extra == {"config": {"train_setup": {"seed": 3}}, "env_steps": 655360, "iteration": 2}
+    assert torch.equal(a.opt.flat, b.opt.flat) and torch.equal(a.opt.exp_avg, b.opt.exp_avg) and torch.equal(a.opt.exp_avg_sq, b.opt.exp_avg_sq)
+    assert b.opt.t == a.opt.t and int(b._mb_state[0]) == 77 and int(b._act_rng_state(b.gens[0])[0][0]) == 1234
+    assert torch.equal(a.gens[0].get_state(), b.gens[0].get_state())
+    # .npz form: refuses to overwrite too, and carries the iteration
+    ck.save_npz(tmp_path / "x.npz", a, step=5, iteration=1)
+    with pytest.raises(FileExistsError):
+        ck.save_npz(tmp_path / "x.npz", a, step=5)
+    assert ck.restore(tmp_path / "x.npz", make(5))["iteration"] == 1
+    assert not [f for f in os.listdir(tmp_path) if f.startswith(".tmp")]

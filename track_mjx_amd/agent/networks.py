@@ -166,6 +166,7 @@ class deferred_weight_grads:
 
     def __enter__(self):
         self.problems, self.keep, self.colsums = [], [], []
+        self.seen: set = set()       # ids of the parameters whose gradient views have been handed to autograd in this block
         deferred_weight_grads.active = self
         return self
 
@@ -183,6 +184,15 @@ class deferred_weight_grads:
             return None
         if not (self._aligned(dy2) and self._aligned(x2) and gw.stride(1) == 1 and gw.shape == w.shape):
             return None
+        if id(w) in self.seen:
+            # the same weight a second time in one graph (a shared layer, a network applied to two inputs): autograd is about to ADD this
+            # use's gradient to the view it was handed for the first use — so that view must hold the first use's gradient by then.  Compute
+            # the recorded problem of this weight NOW (stream-ordered in front of autograd's add) and give this use a fresh tensor
+            mine = [q for q in self.problems if q[2].data_ptr() == gw.data_ptr()]
+            self.problems = [q for q in self.problems if q[2].data_ptr() != gw.data_ptr()]
+            self._launch_problems(mine)
+            return None
+        self.seen.add(id(w))
         self.problems.append((dy2, x2, gw, gb))
         return gw, gb
 
@@ -197,21 +207,27 @@ class deferred_weight_grads:
                 _hip.check(L.tmjx_colsum_grouped(arr, len(self.colsums), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_colsum_grouped")
             self.keep += [t for c in self.colsums for t in c[:2]]
             self.colsums = []
-        if not self.problems:
+        self._launch_problems(self.problems)
+        self.problems = []
+
+    def _launch_problems(self, problems):
+        import ctypes as C
+        from .. import hip as _hip
+        if not problems:
             return
-        dev = self.problems[0][0].device
-        sizes = [int(L.tmjx_gemm_dw_scratch_floats(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _, _ in self.problems]
+        L = _hip.lib()
+        dev = problems[0][0].device
+        sizes = [int(L.tmjx_gemm_dw_scratch_floats(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _, _ in problems]
         scratch = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), dtype=torch.float32, device=dev)
-        arr = (_hip.DwProblem * len(self.problems))()
+        arr = (_hip.DwProblem * len(problems))()
         off = 0
-        for i, (dy, x, gw, gb) in enumerate(self.problems):
+        for i, (dy, x, gw, gb) in enumerate(problems):
             arr[i] = _hip.DwProblem(dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
                                     scratch.data_ptr() + 4 * off, dy.stride(0), x.stride(0), gw.stride(0), dy.shape[0], dy.shape[1], x.shape[1])
             off += (sizes[i] + 3) // 4 * 4
         with torch.cuda.device(dev):
-            _hip.check(L.tmjx_gemm_dw_grouped(arr, len(self.problems), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_gemm_dw_grouped")
-        self.keep += [scratch]
-        self.problems = []
+            _hip.check(L.tmjx_gemm_dw_grouped(arr, len(problems), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_gemm_dw_grouped")
+        self.keep += [scratch] + [t for q in problems for t in q[:2]]
 
 
 class _BlockLink:
@@ -474,6 +490,9 @@ class _HipBlockFn(torch.autograd.Function):
             ctx.link.ctx = None                     # (break the ctx <-> link cycle)
         if ctx.link is not None and ctx.link.dz_given:
             dz, grads = dy, ctx.link.grads          # the consumer's input-gradient GEMM already applied this block's LayerNorm + SiLU backward
+            # consumed: a second backward through a retained graph finds link.ctx None, so its consumer sends a plain d loss / d y, which
+            # must then take the block's own backward below
+            ctx.link.dz_given, ctx.link.grads = False, None
         else:
             dz = torch.empty_like(z)
             grads = torch.empty((3, N), dtype=torch.float32, device=z.device)

@@ -231,6 +231,10 @@ class PPOLearner:
             self.perm_fn = lambda upd, rows: torch.from_numpy(self.sgd_keys.permutation(rows).astype("int64"))
         elif shuffle_rng != "torch":
             raise ValueError("shuffle_rng must be 'torch' or 'jax'")
+        # the roll-out generators' device-side Philox streams exist from the start, in group order (checkpoint.py saves / restores their
+        # counters in place: a captured inference graph keeps reading the same tensors); other generators (the evaluator's) join lazily
+        for gen in self.gens:
+            self._act_rng_state(gen)
         self.states = [None] * len(self.envs)
         self._streams = [torch.cuda.Stream(device=dev) for _ in self.envs] if (len(self.envs) > 1 and dev.type == "cuda") else None
 
@@ -317,10 +321,7 @@ class PPOLearner:
             # counter on the device (no torch generator in the inference graph, no normal_ launches); "torch": the learner's generator
             device_rng = self.act_rng == "device"
             if device_rng:
-                rs = self._act_rng.get(id(gen))
-                if rs is None:
-                    rs = self._act_rng[id(gen)] = (torch.zeros(2, dtype=torch.long, device=self.dev),
-                                                   (self._noise_seed ^ (0xD1B54A32D192ED03 * (len(self._act_rng) + 1))) & (2 ** 64 - 1), gen)
+                rs = self._act_rng_state(gen)
                 rng_state, rng_seed = rs[0], rs[1]
             eps = None if device_rng else torch.randn((n, Z), generator=gen, device=self.dev)
             if lds_free:
@@ -350,6 +351,14 @@ class PPOLearner:
                                             p(rng_state) if device_rng else None, stream), "tmjx_sample_action")
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
         return action_t.t(), {"raw_action": raw, "log_prob": logp, "logits": logits, "latent_mean": mean, "latent_logvar": logvar}
+
+    def _act_rng_state(self, gen):
+        """(device counter [2] int64, Philox key, generator) of the acting noise stream that belongs to a torch generator."""
+        rs = self._act_rng.get(id(gen))
+        if rs is None:
+            rs = self._act_rng[id(gen)] = (torch.zeros(2, dtype=torch.long, device=self.dev),
+                                           (self._noise_seed ^ (0xD1B54A32D192ED03 * (len(self._act_rng) + 1))) & (2 ** 64 - 1), gen)
+        return rs
 
     def _padded_weight(self, lin) -> torch.Tensor:
         K = lin.in_features
@@ -589,10 +598,14 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
     ppo.py:469-475 (wrappers.wrap with the default use_lstm=True wrapper semantics).
 
-    Checkpoints (reference: process 0 saves at step 0 and after every eval epoch, ppo.py:700-711,787-795): `checkpoint_path` = a
-    directory; rank 0 writes `PPONetwork_{env_steps}.npz` (agent/checkpoint.py: normaliser, policy, value, Adam moments, config JSON)
-    there.  `ckpt_mgr` may be any object with `.directory` (an orbax CheckpointManager has one) or a path; orbax itself is not in
-    this image.  `restore_from` = such a file: parameters and optimiser state are loaded before the first roll-out."""
+    Checkpoints (reference: process 0 saves step 0 and, after every eval epoch, step `it`: ppo.py:700-711,787-795): `checkpoint_path` = a
+    directory; rank 0 writes `<directory>/<it>/{policy.npz, train_state.npz, config/metadata}` there (agent/checkpoint.py:save_step_dir:
+    the reference's Composite item names; normaliser, policy, value, Adam state, env_steps, noise-stream positions, config JSON),
+    atomically, never over an existing step.  `ckpt_mgr` may be any object with `.directory` (an orbax CheckpointManager has one) or a
+    path; orbax itself is not in this image.  `restore_from` = a step directory, a checkpoint directory (its latest step) or a .npz of
+    save_npz: the whole training state comes back (checkpointing.load_training_state, ppo.py:561-567) — parameters, optimiser, env_steps,
+    noise streams — and the run continues at the iteration after the restored one (the reference leaves its iteration restart as a TODO,
+    ppo.py:670-677, and would then collide with the existing steps of the same directory)."""
     from ..environment import wrap
     # a list of environments = equal groups of this rank's envs whose roll-outs are pipelined on separate HIP streams (collect())
     env_list = [wrap(e, episode_length=int(episode_length), action_repeat=1) for e in (environment if isinstance(environment, (list, tuple)) else [environment])]
@@ -607,16 +620,15 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     from . import checkpoint as _ckpt
     if checkpoint_path is None and ckpt_mgr is not None:
         checkpoint_path = str(getattr(ckpt_mgr, "directory", ckpt_mgr))
+    restored = {"env_steps": None, "iteration": None}
     if restore_from is not None:
-        _ckpt.load_npz(restore_from, learner)
+        restored = _ckpt.restore(restore_from, learner)
+    start_it = int(restored.get("iteration") or 0)
 
-    def save_checkpoint(env_steps: int):
+    def save_checkpoint(it: int, env_steps: int):
         if checkpoint_path is None or learner.rank != 0:
             return None
-        os.makedirs(checkpoint_path, exist_ok=True)
-        path = os.path.join(checkpoint_path, f"PPONetwork_{env_steps}.npz")
-        _ckpt.save_npz(path, learner, config=config_dict, step=env_steps)
-        return path
+        return _ckpt.save_step_dir(checkpoint_path, it, learner, config=config_dict, env_steps=env_steps)
     env_step_per_training_step = learner.env_steps_per_training_step
     num_evals_after_init = max(num_evals - 1, 1)
     steps_per_epoch = int(math.ceil(num_timesteps / (num_evals_after_init * env_step_per_training_step * max(num_resets_per_eval, 1))))
@@ -635,9 +647,10 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
         evaluator = Evaluator(wrap(eval_env, episode_length=int(episode_length), action_repeat=1),
                               lambda obs: learner.act(obs, deterministic=deterministic_eval, gen=eval_gen), episode_length=int(episode_length), seed=seed + 7)
     metrics: dict = {}
-    total_steps, done_steps = 0, 0
-    save_checkpoint(0)                                    # ppo.py:700-711: the initial parameters
-    for it in range(1, num_evals_after_init + 1):
+    total_steps, done_steps = int(restored.get("env_steps") or 0), 0       # TrainingState.env_steps continues across a resume
+    if restore_from is None:
+        save_checkpoint(0, 0)                             # ppo.py:700-711: the initial parameters
+    for it in range(start_it + 1, num_evals_after_init + 1):
         for _ in range(max(num_resets_per_eval, 1)):
             t0 = time.time()
             acc: dict = {}
@@ -663,7 +676,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
             if evaluator is not None:
                 metrics = evaluator.run_evaluation(metrics)
             progress_fn(total_steps, metrics)
-        save_checkpoint(total_steps)                      # ppo.py:787-795: after every eval epoch, process 0
+        save_checkpoint(it, total_steps)                  # ppo.py:787-795: after every eval epoch, process 0, step = the iteration
         if max_training_steps is not None and done_steps >= max_training_steps:
             break
 
@@ -672,7 +685,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
         state dicts returned by train(), or a checkpoint file — loaded into the learner's networks IN PLACE first."""
         if params is not None:
             if isinstance(params, (str, os.PathLike)):
-                _ckpt.load_npz(params, learner, load_optimizer=False)
+                _ckpt.restore(params, learner, load_optimizer=False)
             else:
                 norm_sd, pol_sd = params[0], params[1]
                 with torch.no_grad():
