@@ -244,6 +244,30 @@ typedef struct tmjx_dw_problem_t {
 } tmjx_dw_problem_t;
 int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *problems, int n, void *stream);
 
+/* ---- bf16 GEMM-input mode (BASELINE config 5 "bf16 MLP on MFMA"; layers: track_mjx/agent/mlp_ppo/intention_network.py:14-142, sizes
+ * track_mjx/config/rodent-full-clips.yaml:50-57): operands bf16, accumulation and results fp32, v_mfma_f32_16x16x32_bf16 (csrc/gemm_bf16.h).
+ * Activations are either fp32 (converted when they are staged: no cast pass) or bf16 written by a producing kernel; weights come from bf16
+ * SHADOWS of the fp32 master parameters. */
+/* Shadows of up to 24 weight matrices src[N][K] (fp32, leading dimension ld_src) in ONE launch: dst[N][ld_dst] (ld_dst >= ceil64(K), zero
+ * beyond K: the forward operand) and / or dst_t[K][ld_dst_t] (ld_dst_t >= ceil64(N), zero beyond N: the input gradient's operand).  bf16 =
+ * round to nearest even of the fp32 value.  `items` is a HOST array (copied into the launch). */
+typedef struct tmjx_bf16_shadow_t {
+  const float *src;
+  uint16_t *dst, *dst_t;           /* either may be NULL */
+  int32_t N, K, ld_src, ld_dst, ld_dst_t;
+} tmjx_bf16_shadow_t;
+int tmjx_bf16_shadow(const tmjx_bf16_shadow_t *items, int n, void *stream);
+/* C[M][N] = A[M][K] . B[N][K]^T (+ bias[N]):  A fp32 (a_is_f32 = 1; lda % 4 == 0) or bf16 (lda % 8 == 0), B a bf16 shadow whose rows hold
+ * ceil64(K) elements (zero beyond K; ldb % 8 == 0); C fp32.  Forward pass: B = the weight's shadow; input gradient: A = dY, B = the
+ * transposed shadow (K and N exchange roles).  All base pointers 16-byte aligned. */
+int tmjx_bgemm_nt(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
+                  void *stream);
+/* dW[N][lddw] = dY[M][N]^T . X[M][K] and db[N] = column sums of dY (NULL: no bias gradient; sums are taken over the values AS STORED, in
+ * fp32) with bf16 operands (each of dY / X fp32 or bf16 in memory, rows 16-byte aligned); scratch >= tmjx_bgemm_dw_scratch_floats(M, N, K). */
+long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K);
+int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is_f32, int ldx, float *dW, int lddw, float *db, float *scratch,
+                  int M, int N, int K, void *stream);
+
 /* Observation normaliser update (brax running_statistics.update as called at track_mjx/agent/mlp_ppo/ppo.py:357-361; math:
  * track_mjx/agent/masked_running_statistics.py:161-214) in one pass over src [rows][W] (W % 4 == 0):
  *   tmjx_stats_sums:  sums[0..W) = sum_rows(x - mean), sums[W..2W) = sum_rows((x - mean)^2); scratch >= tmjx_stats_scratch_floats(W).

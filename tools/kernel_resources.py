@@ -17,8 +17,14 @@ def kernel_resources(so: Path) -> dict:
     with tempfile.TemporaryDirectory() as d:
         fat, co = Path(d) / "fat.bin", Path(d) / "k.co"
         subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(so), str(fat)], check=True)
-        subprocess.run([BUNDLER, "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-        notes = subprocess.run([READELF, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        # one offload bundle per translation unit, back to back in the section
+        blob, magic, notes = fat.read_bytes(), b"__CLANG_OFFLOAD_BUNDLE__", ""
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)] + [len(blob)]
+        for i in range(len(starts) - 1):
+            part = Path(d) / f"fat{i}.bin"
+            part.write_bytes(blob[starts[i]:starts[i + 1]])
+            subprocess.run([BUNDLER, "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+            notes += subprocess.run([READELF, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
     out = {}
     # one metadata map per kernel: fields in alphabetical order, .name before .private_segment_fixed_size .. .vgpr_count
     for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:

@@ -119,6 +119,71 @@ def gemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool):
     return dw, db
 
 
+# ---- bf16 GEMM-input mode on the library's own kernels (csrc/gemm_bf16.h) -------------------------------------------------------------
+def _ceil64(n: int) -> int:
+    return (int(n) + 63) // 64 * 64
+
+
+def _ld(x2: torch.Tensor) -> int:
+    """Leading dimension of a [rows, cols] operand for the bf16 kernels (a one-row tensor's stride is arbitrary: any aligned value >= cols)."""
+    return x2.stride(0) if x2.shape[0] > 1 else (x2.shape[1] + 7) // 8 * 8
+
+
+def bgemm_nt(x: torch.Tensor, wb: torch.Tensor, N: int, K: int, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """y[rows, N] = x[rows, K] wb[N, K]^T + bias on v_mfma_f32_16x16x32_bf16 (tmjx_bgemm_nt): x fp32 (converted to bf16 when it is staged) or
+    bf16; wb = a bf16 shadow [>= N rows][>= ceil64(K)], zero beyond K; fp32 result."""
+    x = _rows2d(x)
+    M = x.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _launch("tmjx_bgemm_nt", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(y), N, M, N, K)
+    return y
+
+
+def bgemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool, out: torch.Tensor | None = None, out_bias: torch.Tensor | None = None):
+    """(dw[N, K], db[N] or None) = (dy^T x, column sums of dy) with bf16 operands (tmjx_bgemm_dw: transposed LDS reads, row-range slabs + one
+    reduction launch); dy / x fp32 or bf16.  `out` / `out_bias`: destinations (e.g. flat-buffer gradient views; `out` may be row-padded)."""
+    from .. import hip as _hip
+    dy, x = _rows2d(dy), _rows2d(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device) if out is None else out
+    db = (torch.empty(N, dtype=torch.float32, device=dy.device) if out_bias is None else out_bias) if with_bias else None
+    scratch = torch.empty(int(_hip.lib().tmjx_bgemm_dw_scratch_floats(M, N, K)), dtype=torch.float32, device=dy.device)
+    _launch("tmjx_bgemm_dw", dy.device, _p(dy), int(dy.dtype == torch.float32), _ld(dy), _p(x), int(x.dtype == torch.float32), _ld(x),
+            _p(dw), dw.stride(0) if N > 1 else max(dw.stride(0), K), _p(db), _p(scratch), M, N, K)
+    return dw, db
+
+
+class Bf16Shadows:
+    """bf16 copies of the dense layers' weights: `w[lin]` = [N][ceil64 K] (forward operand), `wt[lin]` = [K][ceil64 N] (input-gradient operand),
+    zero padded, all refreshed by ONE launch (tmjx_bf16_shadow) — at the start of every SGD step, i.e. once per optimiser step."""
+
+    def __init__(self, linears, need_t=None):
+        from .. import hip as _hip
+        self.lins = list(linears)
+        need_t = set(self.lins if need_t is None else need_t)
+        dev = self.lins[0].weight.device
+        self.w, self.wt = {}, {}
+        items = []
+        for lin in self.lins:
+            N, K = lin.weight.shape
+            self.w[lin] = torch.zeros((N, _ceil64(K)), dtype=torch.bfloat16, device=dev)
+            if lin in need_t:
+                self.wt[lin] = torch.zeros((K, _ceil64(N)), dtype=torch.bfloat16, device=dev)
+            t = self.wt.get(lin)
+            items.append(_hip.Bf16Shadow(lin.weight.data_ptr(), self.w[lin].data_ptr(), t.data_ptr() if t is not None else None, N, K, lin.weight.stride(0),
+                                         self.w[lin].stride(0), t.stride(0) if t is not None else 0))
+        self._chunks = [(_hip.Bf16Shadow * len(items[i:i + 24]))(*items[i:i + 24]) for i in range(0, len(items), 24)]
+        self._ptrs = [lin.weight.data_ptr() for lin in self.lins]
+
+    def refresh(self) -> None:
+        if self._ptrs != [lin.weight.data_ptr() for lin in self.lins]:
+            raise RuntimeError("a parameter moved after its bf16 shadow was built (build the shadows after the flat optimiser re-seats the parameters)")
+        dev = self.lins[0].weight.device
+        for arr in self._chunks:
+            _launch("tmjx_bf16_shadow", dev, arr, len(arr))
+
+
 def _mm_nt(x, w):
     """x [m, k] @ w[n, k]^T -> fp32 [m, n] in the current GEMM-input dtype; also returns the operands as they went into the GEMM."""
     dt = gemm_inputs.dtype

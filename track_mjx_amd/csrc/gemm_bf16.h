@@ -1,0 +1,399 @@
+// csrc/gemm_bf16.h — the learner's dense contractions with bf16 operands / fp32 accumulation on v_mfma_f32_16x16x32_bf16 (BASELINE config 5:
+// "bf16 MLP on MFMA"; reference layers: flax nn.Dense in track_mjx/agent/mlp_ppo/intention_network.py:32-44,68-76, sizes
+// track_mjx/config/rodent-full-clips.yaml:50-57, brax value MLP ppo_networks.py:180-184).  Same shapes as csrc/gemm_kernels.h — a tall activation
+// matrix (40 960 rows in config 5) against small weight matrices — but the matrix pipe is 16 x faster here, so the kernels are built around
+// the memory system instead:
+//
+//   * NO cast pass.  Activations arrive as fp32 (converted to bf16 when the staged registers are written to LDS: v_cvt_pk_bf16_f32, round to
+//     nearest even = torch's .to(bfloat16)) or as bf16 written by the producing kernel's epilogue; weights come from bf16 SHADOWS of the fp32
+//     master parameters (k_bf16_shadow: [N][ceil64 K] and the transpose [K][ceil64 N], zero padded, refreshed once per optimiser step) and go
+//     global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write).
+//   * k_bgemm_nt: C[M][N] = A[M][K] . B[N][K]^T for both the forward pass (B = W shadow) and the input gradient (B = W^T shadow): every
+//     fragment is one ds_read_b128 from a [row][64] image whose 16-byte chunks are XOR-swizzled (chunk ^= (row >> 1) & 7: the 16 lanes of a
+//     ds_read_b128 group hit 16 distinct slots of the 256-byte bank row).  Workgroup tile 16 MI rows x 128 NI columns, 8 waves side by side
+//     along N; the weight fragment is the MFMA's FIRST operand, so a lane ends up with four consecutive columns of one row (vector stores).
+//   * k_bgemm_dw: dW[N][K] = dY[M][N]^T . X[M][K], the contraction runs over the rows.  Both operands are staged ROW-major as they lie in
+//     memory and read TRANSPOSED by ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major): no transposed copy
+//     of any activation exists anywhere.  Slabs over row ranges + csrc/gemm_kernels.h's k_dw_reduce, the bias gradient rides along.
+#pragma once
+
+typedef short bgs8 __attribute__((ext_vector_type(8)));
+typedef short bgs4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bgb8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bgb2 __attribute__((ext_vector_type(2)));
+typedef float bgf4 __attribute__((ext_vector_type(4)));
+typedef float bgf2 __attribute__((ext_vector_type(2)));
+typedef unsigned bgu4 __attribute__((ext_vector_type(4)));
+typedef unsigned bgu2 __attribute__((ext_vector_type(2)));
+typedef unsigned short bf16_t;
+
+#define BG_LDS(p) ((__attribute__((address_space(3))) void *)(p))
+#define BG_GLB(p) ((const __attribute__((address_space(1))) void *)(p))
+#define BG_BK 64
+
+// two floats -> two bf16 in one dword (lo in the low half), round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned bg_pack(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(bgf2{lo, hi}, bgb2)); }
+__device__ __forceinline__ bgu4 bg_pack8(bgf4 a, bgf4 b) { return bgu4{bg_pack(a.x, a.y), bg_pack(a.z, a.w), bg_pack(b.x, b.y), bg_pack(b.z, b.w)}; }
+__device__ __forceinline__ float bg_f32(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
+// byte offset of 16-byte chunk c (0 .. 7) of row r in a [rows][64 bf16] LDS image (128-byte rows, chunks XOR-swizzled)
+__device__ __forceinline__ int bg_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// ---- bf16 shadows of the weights: dst[n][k] (leading dimension ldd >= ceil64(K), zero beyond K) and dstT[k][n] (ldt >= ceil64(N), zero beyond N)
+#define BG_SHADOW_MAX 24
+struct BgShadowItem { const float *src; bf16_t *dst, *dstT; int N, K, lds_, ldd, ldt, blk_begin; };
+struct BgShadowTable { BgShadowItem it[BG_SHADOW_MAX]; int n; };
+// one workgroup (256 threads) per 32 x 32 tile of the padded [ceil64 N][ceil64 K] index space of one matrix
+__global__ __launch_bounds__(256) void k_bf16_shadow(const BgShadowTable T) {
+  __shared__ float tile[32][33];
+  int i = 0;
+  for (int j = 1; j < T.n; j++) if ((int)blockIdx.x >= T.it[j].blk_begin) i = j;
+  const BgShadowItem &q = T.it[i];
+  const int Np = (q.N + 63) & ~63, Kp = (q.K + 63) & ~63, tk = Kp / 32;
+  const int local = blockIdx.x - q.blk_begin, n0 = (local / tk) * 32, k0 = (local % tk) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + tx;
+    const float v = (n < q.N && k < q.K) ? q.src[(size_t)n * q.lds_ + k] : 0.f;
+    tile[r][tx] = v;
+    if (q.dst && n < q.N) q.dst[(size_t)n * q.ldd + k] = (bf16_t)(bg_pack(v, 0.f) & 0xffffu);
+  }
+  __syncthreads();
+  if (q.dstT) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int k = k0 + r, n = n0 + tx;
+      if (k < q.K) q.dstT[(size_t)k * q.ldt + n] = (bf16_t)(bg_pack(tile[tx][r], 0.f) & 0xffffu);
+    }
+  }
+}
+
+// ---- C = A . B^T ---------------------------------------------------------------------------------------------------------------------
+// Epilogues.  Register r of accumulator tile (a, b) of lane (li = lane & 15, kq = lane >> 4) of wave w is C[m0 + 16 a + li][n0 + 128 NI... see below]
+struct BgEpi {
+  const float *gamma, *beta;      // EPI 1 / 2: LayerNorm scale / shift of the block
+  float *stats;                   // EPI 1 writes (mean, 1 / std) per row, EPI 2 reads them
+  bf16_t *y16; int ldy16;         // EPI 1 / 3: the activation as bf16 (the next layer's operand);  EPI 2 / 4: d loss / d z as bf16
+  const float *z;                 // EPI 2 / 4: the block's saved pre-activation (fp32, leading dimension ldc)
+  float *partial;                 // EPI 2 / 4: per-workgroup column sums ([3][BN] resp. [1][BN])
+  float eps;
+};
+
+template <int MI, int NI> struct BgCfg {
+  static constexpr int BM = 16 * MI, BN = 128 * NI, A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
+};
+
+// EPI 0: C = acc (+ bias), fp32.   EPI 1: Dense -> SiLU -> LayerNorm forward (the tile spans whole rows: N == BN): z = acc to C (without the
+// bias: what the backward kernels expect), y = LayerNorm(silu(z + bias)) as bf16 to y16, (mean, 1 / std) to stats.
+template <int MI, int NI, int EPI, bool AF32>
+__global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, int lda, const bf16_t *__restrict__ B, int ldb, const float *__restrict__ bias,
+                                                  float *__restrict__ C, int ldc, int M, int N, int K, BgEpi epi) {
+  using Cfg = BgCfg<MI, NI>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
+  extern __shared__ __attribute__((aligned(16))) char bg_lds[];
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, nw = wave * 16 * NI;
+  const int nk = (K + BG_BK - 1) / BG_BK;
+
+  // ---- B: LDS-DMA.  One wave instruction moves 1 KiB = 8 rows of the image; wave w moves row groups w, w + 8, ...  The LDS side is
+  // lane-linear (lane i -> bytes 16 i .. 16 i + 15 of the group: row i >> 3, PHYSICAL chunk i & 7), so the swizzle goes on the source
+  // address: the lane fetches the LOGICAL chunk (i & 7) ^ swizzle(row).  Rows beyond N are clamped (their columns are never stored).
+  constexpr int B_INSTR = BN / 64;
+  const bf16_t *bsrc[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < B_INSTR; i++) {
+    const int row = 8 * (wave + 8 * i) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+    bsrc[i] = B + (size_t)min(n0 + row, N - 1) * ldb + 8 * c;
+  }
+  auto issue_b = [&](int stage, int k0) {
+#pragma unroll
+    for (int i = 0; i < B_INSTR; i++)
+      __builtin_amdgcn_global_load_lds(BG_GLB(bsrc[i] + k0), BG_LDS(bg_lds + stage * STAGE + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+
+  // ---- A: registers (fp32 -> bf16 at the LDS write, or bf16 as it is).  Chunk f = t + 512 p: row f >> 3, chunk f & 7.
+  constexpr int A_CH = BM * 8, A_FULL = A_CH / 512, A_REM_WAVES = (A_CH % 512) / 64, A_PASS = A_FULL + (A_REM_WAVES ? 1 : 0);
+  struct AStage { bgu4 v[A_PASS]; };
+  const char *arow[A_PASS];
+#pragma unroll
+  for (int p = 0; p < A_PASS; p++) {
+    const int f = t + 512 * p, r = min(f >> 3, BM - 1), c = f & 7;
+    arow[p] = (const char *)Av + ((size_t)min(m0 + r, M - 1) * lda + 8 * c) * (AF32 ? 4 : 2);
+  }
+  auto load_a = [&](AStage &R, int k0) {
+    const bool fast = k0 + BG_BK <= K;
+#pragma unroll
+    for (int p = 0; p < A_PASS; p++) {
+      if (p >= A_FULL && wave >= A_REM_WAVES) continue;           // (wave-uniform: the partly filled last pass)
+      const int c = (t + 512 * p) & 7;
+      if (fast) {
+        if (AF32) {
+          const bgf4 *q = reinterpret_cast<const bgf4 *>(arow[p] + (size_t)k0 * 4);
+          R.v[p] = bg_pack8(q[0], q[1]);
+        } else {
+          R.v[p] = *reinterpret_cast<const bgu4 *>(arow[p] + (size_t)k0 * 2);
+        }
+      } else {                                                      // the last, partial K tile: element by element, exact zeros beyond K
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int k = k0 + 8 * c + j;
+          e[j] = 0.f;
+          if (k < K) e[j] = AF32 ? reinterpret_cast<const float *>(arow[p])[k0 + j] : bg_f32(reinterpret_cast<const bf16_t *>(arow[p])[k0 + j]);
+        }
+        R.v[p] = bgu4{bg_pack(e[0], e[1]), bg_pack(e[2], e[3]), bg_pack(e[4], e[5]), bg_pack(e[6], e[7])};
+      }
+    }
+  };
+  auto write_a = [&](const AStage &R, int stage) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; p++) {
+      if (p >= A_FULL && wave >= A_REM_WAVES) continue;
+      const int f = t + 512 * p;
+      *reinterpret_cast<bgu4 *>(bg_lds + stage * STAGE + bg_off(f >> 3, f & 7)) = R.v[p];
+    }
+  };
+
+  bgf4 acc[MI][NI];
+#pragma unroll
+  for (int a = 0; a < MI; a++)
+#pragma unroll
+    for (int b = 0; b < NI; b++) acc[a][b] = bgf4{0.f, 0.f, 0.f, 0.f};
+  // fragment addresses: rows 16 a + li resp. nw + 16 b + li, so the swizzle term depends on li only
+  const int sw = (li >> 1) & 7, frow = li * 128;
+
+  AStage R;
+  issue_b(0, 0);
+  load_a(R, 0);
+  write_a(R, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1, knext = min(kt + 1, nk - 1) * BG_BK;      // (past the end: the last tile once more, into the stage nobody reads)
+    issue_b(cur ^ 1, knext);
+    load_a(R, knext);
+    const char *sa = bg_lds + cur * STAGE + frow, *sb = sa + A_BYTES + nw * 128;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int x = ((4 * s + kq) ^ sw) << 4;
+      bgs8 fa[MI], fb[NI];
+#pragma unroll
+      for (int a = 0; a < MI; a++) fa[a] = *reinterpret_cast<const bgs8 *>(sa + a * 2048 + x);
+#pragma unroll
+      for (int b = 0; b < NI; b++) fb[b] = *reinterpret_cast<const bgs8 *>(sb + b * 2048 + x);
+#pragma unroll
+      for (int a = 0; a < MI; a++)
+#pragma unroll
+        for (int b = 0; b < NI; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bgb8, fb[b]), __builtin_bit_cast(bgb8, fa[a]), acc[a][b], 0, 0, 0);
+    }
+    write_a(R, cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // register r of tile (a, b): C[m0 + 16 a + li][n0 + nw + 16 b + 4 kq + r] — four consecutive columns of one row
+  if constexpr (EPI == 0) {
+    const bool vec = !(ldc & 3) && !((uintptr_t)C & 15);
+#pragma unroll
+    for (int b = 0; b < NI; b++) {
+      const int col = n0 + nw + 16 * b + 4 * kq;
+      bgf4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) bv[r] = col + r < N ? bias[col + r] : 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < MI; a++) {
+        const int row = m0 + 16 * a + li;
+        if (row < M) {
+          float *o = C + (size_t)row * ldc + col;
+          const bgf4 v = acc[a][b] + bv;
+          if (vec && col + 3 < N) *reinterpret_cast<bgf4 *>(o) = v;
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (col + r < N) o[r] = v[r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- dW = dY^T X ----------------------------------------------------------------------------------------------------------------------
+// LDS image of a [rows][128 bf16] tile (256-byte rows) for transposed reads: byte offset of 16-byte chunk ch (0 .. 15) of row r; the XOR
+// makes the two 4-row blocks a 32-lane half reads (8 rows apart, same columns) land on disjoint banks
+__device__ __forceinline__ int bg_tr_off(int r, int ch) { return 256 * r + 16 * (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))); }
+
+#define BGDW_BT 128      // output tile 128 (n) x 128 (k)
+#define BGDW_BM 32       // rows of M per LDS stage = one MFMA k step
+#define BGDW_STAGE (2 * BGDW_BM * 256)
+// 4 waves, each 64 (n) x 64 (k) of the tile = 4 x 4 MFMA tiles.  YF32 / XF32: the operand is fp32 in memory (converted at the LDS write).
+template <bool YF32, bool XF32>
+__device__ __forceinline__ void bgemm_dw_tile(const void *__restrict__ dYv, int ldy, const void *__restrict__ Xv, int ldx, float *__restrict__ slabs,
+                                              int M, int N, int K, int with_bias, int rows_per_split, int ld_slab, int tile_n, int tile_k, int split) {
+  extern __shared__ __attribute__((aligned(16))) char bg_lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, i16 = lane & 15;
+  const int n0 = tile_n * BGDW_BT, k0 = tile_k * BGDW_BT;
+  const int r_begin = split * rows_per_split, r_end = min(M, r_begin + rows_per_split);
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  // staging: 32 rows x 16 chunks per operand = 512 chunks over 256 threads: chunk f = t + 256 p: row f >> 4, chunk f & 15
+  struct Stage { bgu4 y[2], x[2]; };
+  bgf4 colacc[2] = {bgf4{0.f, 0.f, 0.f, 0.f}, bgf4{0.f, 0.f, 0.f, 0.f}};         // sums over this thread's rows of its eight dY columns (bias gradient)
+  const int ch = t & 15;
+  // columns beyond the matrix are clamped to the last whole chunk (their products land in entries that are never stored); rows beyond
+  // r_end must be exact zeros (they are summed over): masked
+  const int ycol = min(n0 + 8 * ch, ((N + 7) & ~7) - 8), xcol = min(k0 + 8 * ch, ((K + 7) & ~7) - 8);
+  auto ld8 = [&](const void *base, int ld, int row, int col, int width, bool f32, bool ok, bgf4 *sum) -> bgu4 {
+    bgu4 out = {0u, 0u, 0u, 0u};
+    if (ok) {
+      if (col + 8 <= width) {
+        if (f32) {
+          const bgf4 *q = reinterpret_cast<const bgf4 *>(reinterpret_cast<const float *>(base) + (size_t)row * ld + col);
+          const bgf4 a = q[0], b = q[1];
+          if (sum) { sum[0] += a; sum[1] += b; }
+          out = bg_pack8(a, b);
+        } else {
+          out = *reinterpret_cast<const bgu4 *>(reinterpret_cast<const bf16_t *>(base) + (size_t)row * ld + col);
+          if (sum) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { sum[0][j] += bg_f32((bf16_t)(out[j >> 1] >> (16 * (j & 1)))); sum[1][j] += bg_f32((bf16_t)(out[2 + (j >> 1)] >> (16 * (j & 1)))); }
+          }
+        }
+      } else {                                    // the matrix' last, partial chunk of columns: element by element
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          e[j] = 0.f;
+          if (col + j < width) e[j] = f32 ? reinterpret_cast<const float *>(base)[(size_t)row * ld + col + j] : bg_f32(reinterpret_cast<const bf16_t *>(base)[(size_t)row * ld + col + j]);
+        }
+        if (sum) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { sum[0][j] += e[j]; sum[1][j] += e[4 + j]; }
+        }
+        out = bgu4{bg_pack(e[0], e[1]), bg_pack(e[2], e[3]), bg_pack(e[4], e[5]), bg_pack(e[6], e[7])};
+      }
+    }
+    return out;
+  };
+  auto gload = [&](Stage &R, int r0) {
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const int row = r0 + ((t + 256 * p) >> 4);
+      const bool ok = row < r_end;
+      R.y[p] = ld8(dYv, ldy, ok ? row : r_begin, ycol, N, YF32, ok, with_bias ? colacc : nullptr);
+      R.x[p] = ld8(Xv, ldx, ok ? row : r_begin, xcol, K, XF32, ok, nullptr);
+    }
+  };
+  auto swrite = [&](const Stage &R, int stage) {
+    char *sy = bg_lds + stage * BGDW_STAGE, *sx = sy + BGDW_BM * 256;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const int r = (t + 256 * p) >> 4;
+      *reinterpret_cast<bgu4 *>(sy + bg_tr_off(r, ch)) = R.y[p];
+      *reinterpret_cast<bgu4 *>(sx + bg_tr_off(r, ch)) = R.x[p];
+    }
+  };
+  // transposed reads: lane (group g, q = (lane & 15) >> 2, p = lane & 3) supplies the address of row 8 g (+ 4) + q, columns 16 tile + 4 p .. + 3;
+  // it receives, for column (lane & 15) of the block, the four rows.  Two reads = the eight k of the lane's MFMA operand.
+  const int q4 = i16 >> 2, p4 = i16 & 3;
+  auto tr_addr = [&](int row, int col16) { return bg_tr_off(row, 2 * col16 + (p4 >> 1)) + 8 * (p4 & 1); };
+  bgf4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = bgf4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int stage) {
+    const char *sy = bg_lds + stage * BGDW_STAGE, *sx = sy + BGDW_BM * 256;
+    bgs8 fy[4], fx[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      const bgs4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bgs4 *)BG_LDS(sy + tr_addr(8 * g + q4, wn / 16 + a)));
+      const bgs4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bgs4 *)BG_LDS(sy + tr_addr(8 * g + 4 + q4, wn / 16 + a)));
+      fy[a] = bgs8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const bgs4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bgs4 *)BG_LDS(sx + tr_addr(8 * g + q4, wk / 16 + b)));
+      const bgs4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bgs4 *)BG_LDS(sx + tr_addr(8 * g + 4 + q4, wk / 16 + b)));
+      fx[b] = bgs8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    }
+    // X fragment first: the tile comes out as D[k][n], i.e. a lane holds four consecutive k of one output row n (one dwordx4 per tile)
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bgb8, fx[b]), __builtin_bit_cast(bgb8, fy[a]), acc[a][b], 0, 0, 0);
+  };
+  const int nt = (r_end - r_begin + BGDW_BM - 1) / BGDW_BM;
+  if (nt > 0) {
+    Stage R;
+    gload(R, r_begin);
+    swrite(R, 0);
+    __syncthreads();
+    for (int it = 0; it < nt; it++) {
+      const int cur = it & 1;
+      gload(R, r_begin + (it + 1) * BGDW_BM);          // (past r_end: all rows masked -> zeros, written to the stage nobody reads)
+      compute(cur);
+      swrite(R, cur ^ 1);
+      __syncthreads();
+    }
+  }
+  float *out = slabs + (size_t)split * (size_t)N * ld_slab;
+  if (with_bias && tile_k == 0) {            // thread t holds dY columns n0 + 8 (t & 15) .. + 7 of the rows (t >> 4) + 16 j
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(bg_lds);            // [16][128]
+    *reinterpret_cast<bgf4 *>(red + (t >> 4) * BGDW_BT + 8 * ch) = colacc[0];
+    *reinterpret_cast<bgf4 *>(red + (t >> 4) * BGDW_BT + 8 * ch + 4) = colacc[1];
+    __syncthreads();
+    if (t < BGDW_BT) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) v += red[j * BGDW_BT + t];
+      // (a clamped column chunk repeats the matrix' last whole chunk: only columns inside the matrix are stored)
+      if (n0 + t < N && n0 + 8 * (t >> 3) == min(n0 + 8 * (t >> 3), ((N + 7) & ~7) - 8)) out[(size_t)(n0 + t) * ld_slab + K] = v;
+    }
+  }
+  // register r of tile (a, b): output row n0 + wn + 16 a + (lane & 15), columns k0 + wk + 16 b + 4 (lane >> 4) + r
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int row = n0 + wn + 16 * a + i16;
+    if (row < N) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int col = k0 + wk + 16 * b + 4 * g;
+        float *o = out + (size_t)row * ld_slab + col;
+        if (col + 3 < K) *reinterpret_cast<bgf4 *>(o) = acc[a][b];
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) if (col + r < K) o[r] = acc[a][b][r];
+        }
+      }
+    }
+  }
+}
+template <bool YF32, bool XF32>
+__global__ __launch_bounds__(256) void k_bgemm_dw(const void *__restrict__ dY, int ldy, const void *__restrict__ X, int ldx, float *__restrict__ slabs,
+                                                  int M, int N, int K, int with_bias, int rows_per_split, int ld_slab) {
+  bgemm_dw_tile<YF32, XF32>(dY, ldy, X, ldx, slabs, M, N, K, with_bias, rows_per_split, ld_slab, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// dW[n][k] = sum over the slabs; db[n] = the slabs' column K.  One lane per output element, eight loads in flight.
+__global__ __launch_bounds__(256) void k_bgemm_dw_reduce(const float *__restrict__ slabs, float *__restrict__ dW, float *__restrict__ db, int S, int N, int K,
+                                                         int with_bias, int ld_slab, int lddw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int Kx = K + (with_bias ? 1 : 0);
+  if (i >= (long long)N * Kx) return;
+  const int n = (int)(i / Kx), k = (int)(i % Kx);
+  const float *p = slabs + (size_t)n * ld_slab + k;
+  const size_t step = (size_t)N * ld_slab;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] += p[(size_t)(s + u) * step];
+  }
+  for (; s < S; s++) a[0] += p[(size_t)s * step];
+  const float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (k < K) dW[(size_t)n * lddw + k] = v; else db[n] = v;
+}

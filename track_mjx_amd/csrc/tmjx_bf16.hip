@@ -1,0 +1,112 @@
+// csrc/tmjx_bf16.hip — second translation unit of libtmjx_hip.so: the bf16-operand GEMM family (csrc/gemm_bf16.h) and its C-ABI entry points
+// (include/tmjx.h "bf16 GEMM-input mode").  Compiled next to tmjx_hip.hip (track_mjx_amd/hip.py:build) and linked into the same library.
+#include <hip/hip_runtime.h>
+
+#include <stdlib.h>
+
+#include <string>
+
+#include "../../include/tmjx.h"
+#include "gemm_bf16.h"
+
+extern "C" int tmjx_internal_fail(int code, const char *msg);       // tmjx_hip.hip: records the calling thread's error message
+static int fail(int code, const std::string &msg) { return tmjx_internal_fail(code, msg.c_str()); }
+static int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(TMJX_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+  return TMJX_OK;
+}
+
+template <int MI, int NI, int EPI, bool AF32>
+static int launch_bgemm(const void *A, int lda, const bf16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, const BgEpi &epi, hipStream_t s) {
+  using Cfg = BgCfg<MI, NI>;
+  static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_bgemm_nt<MI, NI, EPI, AF32>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_bgemm_nt): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid((M + Cfg::BM - 1) / Cfg::BM, (N + Cfg::BN - 1) / Cfg::BN);
+  hipLaunchKernelGGL((k_bgemm_nt<MI, NI, EPI, AF32>), grid, dim3(512), Cfg::LDS, s, A, lda, B, ldb, bias, C, ldc, M, N, K, epi);
+  return check_launch("k_bgemm_nt");
+}
+template <int EPI, bool AF32>
+static int bgemm_by_width(const void *A, int lda, const bf16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, const BgEpi &epi, hipStream_t s) {
+  if (N <= 128) return launch_bgemm<5, 1, EPI, AF32>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+  if (N <= 256) return launch_bgemm<5, 2, EPI, AF32>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+  return launch_bgemm<5, 4, EPI, AF32>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+}
+
+// rows of M per slab and number of slabs: about two workgroups (four waves each) per CU
+static void bdw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab) {
+  const int tiles = ((N + BGDW_BT - 1) / BGDW_BT) * ((K + BGDW_BT - 1) / BGDW_BT);
+  static const int target = getenv("TMJX_BDW_WGS") ? atoi(getenv("TMJX_BDW_WGS")) : 512;      // tuning knob
+  int want = (target + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  int rps = (((M + want - 1) / want) + BGDW_BM - 1) / BGDW_BM * BGDW_BM;
+  if (rps < BGDW_BM) rps = BGDW_BM;
+  *rows_per_split = rps;
+  *S = (M + rps - 1) / rps;
+  *ld_slab = ((K + BGDW_BT - 1) / BGDW_BT) * BGDW_BT + 4;
+}
+
+extern "C" {
+
+int tmjx_bf16_shadow(const tmjx_bf16_shadow_t *items, int n, void *stream) {
+  if (!items) return fail(TMJX_EINVAL, "null argument");
+  if (n < 1 || n > BG_SHADOW_MAX) return fail(TMJX_EINVAL, "1 .. 24 matrices per call");
+  BgShadowTable T;
+  T.n = n;
+  int blk = 0;
+  for (int i = 0; i < n; i++) {
+    const tmjx_bf16_shadow_t &q = items[i];
+    if (!q.src || (!q.dst && !q.dst_t)) return fail(TMJX_EINVAL, "null pointer in an item");
+    const int Np = (q.N + 63) & ~63, Kp = (q.K + 63) & ~63;
+    if (q.N < 1 || q.K < 1 || q.ld_src < q.K || (q.dst && q.ld_dst < Kp) || (q.dst_t && q.ld_dst_t < Np))
+      return fail(TMJX_EINVAL, "bad sizes: the shadows' leading dimensions must reach the next multiple of 64");
+    T.it[i] = BgShadowItem{q.src, q.dst, q.dst_t, q.N, q.K, q.ld_src, q.ld_dst, q.ld_dst_t, blk};
+    blk += (Np / 32) * (Kp / 32);
+  }
+  hipLaunchKernelGGL(k_bf16_shadow, dim3(blk), dim3(256), 0, (hipStream_t)stream, T);
+  return check_launch("k_bf16_shadow");
+}
+
+int tmjx_bgemm_nt(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, void *stream) {
+  if (!A || !B || !C) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1 || lda < K || ldc < N || ldb < ((K + 63) & ~63)) return fail(TMJX_EINVAL, "bad sizes / leading dimensions (ldb must reach ceil64(K))");
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 7) || (lda & (a_is_f32 ? 3 : 7))) return fail(TMJX_EINVAL, "tmjx_bgemm_nt: operand rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const BgEpi epi{};
+  if (a_is_f32) return bgemm_by_width<0, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+  return bgemm_by_width<0, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+}
+
+long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K) {
+  if (M < 1 || N < 1 || K < 1) return 0;
+  int rps, S, ld;
+  bdw_split(M, N, K, &rps, &S, &ld);
+  return (long long)S * N * ld;
+}
+
+int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is_f32, int ldx, float *dW, int lddw, float *db, float *scratch,
+                  int M, int N, int K, void *stream) {
+  if (!dY || !X || !dW || !scratch) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1 || ldy < N || ldx < K || lddw < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15) || (ldy & (y_is_f32 ? 3 : 7)) || (ldx & (x_is_f32 ? 3 : 7)))
+    return fail(TMJX_EINVAL, "tmjx_bgemm_dw: operand rows must be 16-byte aligned");
+  int rps, S, ld;
+  bdw_split(M, N, K, &rps, &S, &ld);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((N + BGDW_BT - 1) / BGDW_BT, (K + BGDW_BT - 1) / BGDW_BT, S);
+  const size_t lds = 2 * BGDW_STAGE;
+  const int wb = db ? 1 : 0;
+  if (y_is_f32 && x_is_f32) hipLaunchKernelGGL((k_bgemm_dw<true, true>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
+  else if (y_is_f32) hipLaunchKernelGGL((k_bgemm_dw<true, false>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
+  else if (x_is_f32) hipLaunchKernelGGL((k_bgemm_dw<false, true>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
+  else hipLaunchKernelGGL((k_bgemm_dw<false, false>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
+  const long long total = (long long)N * (K + wb);
+  hipLaunchKernelGGL(k_bgemm_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)scratch, dW, db, S, N, K, wb, ld, lddw);
+  return check_launch("k_bgemm_dw");
+}
+
+}  // extern "C"

@@ -42,6 +42,8 @@ static int launch_wave(const tmjx_model *m, float *state, const float *action, i
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// the library's other translation units (tmjx_bf16.hip) record their failures in the same per-thread message
+extern "C" int tmjx_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t e_ = (expr);                                                                             \

@@ -14,6 +14,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 SO_PATH = Path(os.environ.get("TMJX_SO", str(_PKG / "libtmjx_hip.so")))  # TMJX_SO: alternative build (profiling)
 CSRC = _PKG / "csrc"
+SOURCES = (CSRC / "tmjx_hip.hip", CSRC / "tmjx_bf16.hip")
 
 
 class TmjxError(RuntimeError):
@@ -32,6 +33,7 @@ EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
            "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_colsum_grouped", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
+           "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_scratch_floats",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
 
@@ -53,6 +55,12 @@ class DwProblem(C.Structure):
                 ("ldy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
 
 
+class Bf16Shadow(C.Structure):
+    """tmjx_bf16_shadow_t (include/tmjx.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("ld_src", C.c_int32),
+                ("ld_dst", C.c_int32), ("ld_dst_t", C.c_int32)]
+
+
 class PpoCfg(C.Structure):
     """tmjx_ppo_cfg_t (include/tmjx.h)."""
     _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("A", C.c_int32), ("Z", C.c_int32), ("reward_scaling", C.c_float),
@@ -68,13 +76,27 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
     # -fno-slp-vectorize: the SLP vectoriser packs the two dof slots of the row products into v_pk_* with more v_mov shuffles than
     # it saves (measured 1.8 % on the physics kernel); the explicitly packed FMAs of the chain kernels are not affected
     out = SO_PATH if out is None else Path(out)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-Wno-unused-value",
-           *[f"-D{d}" for d in defines], "-o", str(out), str(CSRC / "tmjx_hip.hip")]
+    # two translation units compiled side by side (each hipcc run is single-threaded per offload arch), then linked into ONE library
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-value", *[f"-D{d}" for d in defines]]
+    objs = [out.with_name(f"{out.stem}.{src.stem}.o") for src in SOURCES]
+
+    def compile_one(src, obj):
+        cmd = ["hipcc", *flags, "-c", "-o", str(obj), str(src)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise TmjxError(f"hipcc failed on {src.name}:\n" + res.stderr[-4000:])
+        if verbose:
+            print(" ".join(cmd))
+    with ThreadPoolExecutor(len(SOURCES)) as ex:
+        for f in [ex.submit(compile_one, s, o) for s, o in zip(SOURCES, objs)]:
+            f.result()
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o in objs]]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise TmjxError("hipcc failed:\n" + res.stderr[-4000:])
-    if verbose:
-        print(" ".join(cmd))
+        raise TmjxError("hipcc link failed:\n" + res.stderr[-4000:])
+    for o in objs:
+        o.unlink(missing_ok=True)
     return out
 
 
@@ -139,6 +161,11 @@ def load(path: Path):
     sig.setdefault("tmjx_gemm_dw_scratch_floats", [None, None])[1] = C.c_longlong
     sig.setdefault("tmjx_gemm_dw", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_gemm_dw_grouped", [None, None])[0] = [C.POINTER(DwProblem), C.c_int, vp]
+    sig.setdefault("tmjx_bf16_shadow", [None, None])[0] = [C.POINTER(Bf16Shadow), C.c_int, vp]
+    sig.setdefault("tmjx_bgemm_nt", [None, None])[0] = [fp, C.c_int, C.c_int, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_bgemm_dw_scratch_floats", [None, None])[0] = [C.c_int, C.c_int, C.c_int]
+    sig.setdefault("tmjx_bgemm_dw_scratch_floats", [None, None])[1] = C.c_longlong
+    sig.setdefault("tmjx_bgemm_dw", [None, None])[0] = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_set_wrappers", [None, None])[0] = [vp, C.c_int, C.c_int]
     sig.setdefault("tmjx_stats_scratch_floats", [None, None])[0] = [C.c_int]
     sig.setdefault("tmjx_stats_sums", [None, None])[0] = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]

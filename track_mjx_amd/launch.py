@@ -19,9 +19,10 @@ from typing import Callable, Sequence
 
 
 def needs_spawn(n_gpus: int, environ=None) -> bool:
-    """True when `n_gpus` > 1 ranks were asked for and this process is not already one of a launcher's ranks."""
+    """True when `n_gpus` > 1 ranks were asked for and this process is not already one of a launcher's ranks.  TMJX_FORCE_SPAWN=1 takes the
+    launcher path for one rank too (the self-launch + RCCL path on a single-GPU box)."""
     env = os.environ if environ is None else environ
-    return n_gpus > 1 and "RANK" not in env and "WORLD_SIZE" not in env
+    return (n_gpus > 1 or (n_gpus == 1 and bool(env.get("TMJX_FORCE_SPAWN")))) and "RANK" not in env and "WORLD_SIZE" not in env
 
 
 def free_port() -> int:
