@@ -12,8 +12,8 @@ The dense contractions run on the matrix cores through the library's own kernels
 fp32 in / fp32 accumulate v_mfma_f32_16x16x4_f32, 80-row tiles = one workgroup per CU at 20 480 rows, bias gradient fused into the
 weight-gradient kernel) — forward, input gradient and weight gradient alike, under autograd and in inference.  Everything is fp32 as
 in the reference unless `matmul_dtype=torch.bfloat16` is requested (BASELINE config 5): then the GEMM INPUTS are bf16
-(`gemm_inputs`, library bf16 GEMMs), accumulation, outputs and everything around the GEMMs stay fp32.  CPU tensors (host-logic
-tests) take plain torch ops.
+(`gemm_inputs` + `Bf16Shadows`: the library's own v_mfma_f32_16x16x32_bf16 kernels, csrc/gemm_bf16.h), accumulation, outputs and
+everything around the GEMMs stay fp32.  CPU tensors (host-logic tests) take plain torch ops.
 """
 from __future__ import annotations
 
@@ -41,25 +41,28 @@ def _lecun_normal_(w: torch.Tensor) -> None:
 
 
 class gemm_inputs:
-    """`with gemm_inputs(torch.bfloat16):` — the dense contractions of the networks take bf16 INPUTS with fp32 accumulation and
-    fp32 OUTPUTS (`torch.mm(..., out_dtype=float32)`: v_mfma_f32_*_bf16 through hipBLASLt); parameters, activations between the
-    layers, the fused epilogues, the loss head and the optimiser stay fp32 (BASELINE config 5).  No autocast: the cast of each
-    GEMM operand is explicit (one elementwise pass), everything around the GEMMs keeps its fused fp32 kernels.  None = fp32."""
+    """`with gemm_inputs(torch.bfloat16, shadows):` — the dense contractions of the networks take bf16 INPUTS with fp32 accumulation and
+    fp32 OUTPUTS on the library's own v_mfma_f32_16x16x32_bf16 kernels (csrc/gemm_bf16.h: activations converted when they are staged into
+    LDS, weights from the bf16 `shadows` of the fp32 master parameters — no cast pass, no library GEMM); parameters, the fused
+    epilogues, the loss head and the optimiser stay fp32 (BASELINE config 5).  No autocast.  None = fp32.  CPU tensors (host-logic tests)
+    take torch ops in fp32."""
     dtype = None
+    shadows = None          # Bf16Shadows of the networks' dense layers (CUDA: the library's own bf16 kernels take every contraction)
 
-    def __init__(self, dtype):
-        self.new = dtype
+    def __init__(self, dtype, shadows=None):
+        self.new = (dtype, shadows if dtype is not None else None)
 
     def __enter__(self):
-        self.old, gemm_inputs.dtype = gemm_inputs.dtype, self.new
+        self.old = (gemm_inputs.dtype, gemm_inputs.shadows)
+        gemm_inputs.dtype, gemm_inputs.shadows = self.new
 
     def __exit__(self, *a):
-        gemm_inputs.dtype = self.old
+        gemm_inputs.dtype, gemm_inputs.shadows = self.old
         return False
 
 
 def _hip_gemm_ok(*ts) -> bool:
-    """fp32 CUDA operands and no reduced-precision GEMM-input mode: the hand-written MFMA kernels take the contraction."""
+    """fp32 CUDA operands and no reduced-precision GEMM-input mode: the hand-written fp32 MFMA kernels take the contraction."""
     return gemm_inputs.dtype is None and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
 
 
@@ -129,13 +132,13 @@ def _ld(x2: torch.Tensor) -> int:
     return x2.stride(0) if x2.shape[0] > 1 else (x2.shape[1] + 7) // 8 * 8
 
 
-def bgemm_nt(x: torch.Tensor, wb: torch.Tensor, N: int, K: int, bias: torch.Tensor | None = None) -> torch.Tensor:
+def bgemm_nt(x: torch.Tensor, wb: torch.Tensor, N: int, K: int, bias: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """y[rows, N] = x[rows, K] wb[N, K]^T + bias on v_mfma_f32_16x16x32_bf16 (tmjx_bgemm_nt): x fp32 (converted to bf16 when it is staged) or
-    bf16; wb = a bf16 shadow [>= N rows][>= ceil64(K)], zero beyond K; fp32 result."""
+    bf16; wb = a bf16 shadow [>= N rows][>= ceil64(K)], zero beyond K; fp32 result.  `out`: a [rows, >= N] buffer whose first N columns are written."""
     x = _rows2d(x)
     M = x.shape[0]
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    _launch("tmjx_bgemm_nt", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(y), N, M, N, K)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device) if out is None else out
+    _launch("tmjx_bgemm_nt", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(y), max(y.stride(0), N), M, N, K)
     return y
 
 
@@ -184,15 +187,12 @@ class Bf16Shadows:
             _launch("tmjx_bf16_shadow", dev, arr, len(arr))
 
 
-def _mm_nt(x, w):
-    """x [m, k] @ w[n, k]^T -> fp32 [m, n] in the current GEMM-input dtype; also returns the operands as they went into the GEMM."""
-    dt = gemm_inputs.dtype
-    if _hip_gemm_ok(x, w):
-        return gemm_nt(x, w), x, w
-    if dt is None or not x.is_cuda:
-        return x @ w.t(), x, w
-    xb, wb = x.to(dt), w.to(dt)
-    return torch.mm(xb, wb.t(), out_dtype=torch.float32), xb, wb
+def _bf16_ok(x, lin) -> bool:
+    """The bf16 kernels take this layer: bf16 GEMM-input mode with shadows, CUDA fp32 activations with 16-byte aligned rows, an output wide
+    enough to have aligned gradient rows (the 1-wide value head stays on the fp32 kernels)."""
+    sh = gemm_inputs.shadows
+    return (gemm_inputs.dtype == torch.bfloat16 and sh is not None and lin in sh.w and x.is_cuda and x.dtype == torch.float32
+            and lin.out_features % 4 == 0)
 
 
 def _colsum(dy: torch.Tensor) -> torch.Tensor:
@@ -210,15 +210,6 @@ def _colsum(dy: torch.Tensor) -> torch.Tensor:
         _hip.check(L.tmjx_colsum(C.c_void_p(dy.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()), rows, width,
                                  C.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream)), "tmjx_colsum")
     return out
-
-
-def _splitk_dw(dy, x, s):
-    """dy^T x as SPLIT row slabs (one batched GEMM) + a sum; operands in their stored dtype, fp32 result (bf16 GEMM-input mode)."""
-    m = x.shape[0]
-    a, b = dy.view(s, m // s, dy.shape[1]).transpose(1, 2), x.view(s, m // s, x.shape[1])
-    if x.dtype != torch.float32 and x.dtype != torch.float64:
-        return torch.bmm(a, b, out_dtype=torch.float32).sum(0)
-    return torch.bmm(a, b).sum(0)
 
 
 class deferred_weight_grads:
@@ -392,42 +383,57 @@ class _HipDenseFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-class _SplitKLinearFn(torch.autograd.Function):
-    """bf16 GEMM-input mode (BASELINE config 5) only: y = x W^T + b with a weight gradient computed as a split-K batched library GEMM."""
-    SPLIT = 8
+class _BfDenseFn(torch.autograd.Function):
+    """bf16 GEMM-input mode (BASELINE config 5): y = x W^T (+ b) with all three contractions on the library's bf16 MFMA kernels — forward
+    tmjx_bgemm_nt against the weight's shadow, input gradient tmjx_bgemm_nt against the transposed shadow, weight + bias gradient
+    tmjx_bgemm_dw (transposed LDS reads).  x and dy stay fp32 in memory and are converted when they are staged: no cast pass."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        y, xs, ws = _mm_nt(x, w)
-        ctx.save_for_backward(xs, ws)          # the operands as they went into the GEMM (bf16 copies)
-        return y + b
+    def forward(ctx, x, w, b, lin, dx_cols):
+        x2 = _rows2d(x)
+        if x2.data_ptr() % 16 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        sh = gemm_inputs.shadows
+        ctx.save_for_backward(x2)
+        ctx.lin, ctx.sh, ctx.params, ctx.dx_cols, ctx.x_shape = lin, sh, (w, b), dx_cols, x.shape
+        N, K = w.shape
+        return bgemm_nt(x2, sh.w[lin], N, K, b).view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        s = _SplitKLinearFn.SPLIT
-        dys = dy if x.dtype == dy.dtype else dy.to(x.dtype)
-        if x.dtype == dy.dtype:
-            dx = dys @ w if ctx.needs_input_grad[0] else None
-        else:
-            dx = torch.mm(dys, w, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        return dx, _splitk_dw(dys, x, s).to(dy.dtype), _colsum(dy)
+        (x2,) = ctx.saved_tensors
+        w, b = ctx.params
+        N, K = w.shape
+        dy2 = _rows2d(dy)
+        if dy2.data_ptr() % 16 or dy2.stride(0) % 4:
+            dy2 = dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            cols = K if ctx.dx_cols is None else int(ctx.dx_cols)
+            dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy2.device)
+            bgemm_nt(dy2, ctx.sh.wt[ctx.lin], cols, N, out=dx)            # (only the first `cols` columns are computed)
+            dx = dx.view(ctx.x_shape)
+        # straight into the flat gradient buffer's (row-padded) views where the learner provides them
+        d = deferred_weight_grads.active
+        gw = w.grad if (d is not None and w.grad is not None and w.grad.shape == w.shape and w.grad.stride(1) == 1 and id(w) not in d.seen) else None
+        gb = b.grad if (b is not None and gw is not None and b.grad is not None) else None
+        if gw is not None:
+            d.seen.add(id(w))
+        dw, db = bgemm_dw(dy2, x2, b is not None, out=gw, out_bias=gb)
+        return dx, dw, db, None, None
 
 
 class _Dense(nn.Linear):
     def forward(self, x):
         rows = x.numel() // x.shape[-1]
-        if _hip_gemm_ok(x, self.weight):
+        if _bf16_ok(x, self):
+            if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+                return _BfDenseFn.apply(x, self.weight, self.bias, self, None)
+            return bgemm_nt(x, gemm_inputs.shadows.w[self], self.out_features, self.in_features, self.bias).view(*x.shape[:-1], self.out_features)
+        if x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32:      # fp32 mode, and the layers the bf16 kernels leave (1-wide head)
             if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
                 return _HipDenseFn.apply(x, self.weight, self.bias, None)
             return gemm_nt(x, self.weight, self.bias).view(*x.shape[:-1], self.out_features)
-        if torch.is_grad_enabled() and self.weight.requires_grad and rows >= 4096 and rows % _SplitKLinearFn.SPLIT == 0 and x.is_cuda:
-            y = _SplitKLinearFn.apply(x.reshape(rows, x.shape[-1]), self.weight, self.bias)
-            return y.view(*x.shape[:-1], self.out_features)
-        if gemm_inputs.dtype is not None and x.is_cuda:
-            y = _mm_nt(x.reshape(rows, x.shape[-1]), self.weight)[0] + self.bias
-            return y.view(*x.shape[:-1], self.out_features)
         return F.linear(x, self.weight, self.bias)
 
 
@@ -436,32 +442,6 @@ def _dense(i: int, o: int, init=_lecun_uniform_) -> nn.Linear:
     init(lin.weight)
     nn.init.zeros_(lin.bias)
     return lin
-
-
-class _SplitKMatmulFn(torch.autograd.Function):
-    """bf16 GEMM-input mode only: z = x W^T (no bias) with the split-K weight gradient of _SplitKLinearFn."""
-
-    @staticmethod
-    def forward(ctx, x, w):
-        z, xs, ws = _mm_nt(x, w)
-        ctx.save_for_backward(xs, ws)
-        return z
-
-    @staticmethod
-    def backward(ctx, dz):
-        x, w = ctx.saved_tensors
-        m, s = x.shape[0], _SplitKLinearFn.SPLIT
-        dz = dz.contiguous()
-        low = x.dtype != dz.dtype
-        dzs = dz.to(x.dtype) if low else dz
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.mm(dzs, w, out_dtype=torch.float32) if low else dzs @ w
-        if m % s == 0 and m >= 4096:
-            dw = _splitk_dw(dzs, x, s)
-        else:
-            dw = torch.mm(dzs.t(), x, out_dtype=torch.float32) if low else dzs.t() @ x
-        return dx, dw.to(dz.dtype)
 
 
 class _SiluLayerNormFn(torch.autograd.Function):
@@ -592,12 +572,15 @@ class _Block(nn.Module):
             if torch.is_grad_enabled() and _block_fusable(x2, self.dense.weight):
                 y = _HipBlockFn.apply(x2, self.dense.weight, self.dense.bias, self.norm.weight, self.norm.bias, self.norm.eps, self.dx_cols)
                 return y.view(*x.shape[:-1], self.dense.out_features)
-            if not torch.is_grad_enabled():
-                z = _mm_nt(x2, self.dense.weight)[0]
-            elif _hip_gemm_ok(x2, self.dense.weight):
-                z = _HipDenseFn.apply(x2, self.dense.weight, None, self.dx_cols)     # (the bias lives in the fused epilogue below)
+            if _bf16_ok(x2, self.dense):
+                if torch.is_grad_enabled():
+                    z = _BfDenseFn.apply(x2, self.dense.weight, None, self.dense, self.dx_cols)     # (the bias lives in the fused epilogue below)
+                else:
+                    z = bgemm_nt(x2, gemm_inputs.shadows.w[self.dense], self.dense.out_features, self.dense.in_features)
+            elif not torch.is_grad_enabled():
+                z = gemm_nt(x2, self.dense.weight)
             else:
-                z = _SplitKMatmulFn.apply(x2, self.dense.weight)
+                z = _HipDenseFn.apply(x2, self.dense.weight, None, self.dx_cols)     # (the bias lives in the fused epilogue below)
             y = _SiluLayerNormFn.apply(z, self.dense.bias, self.norm.weight, self.norm.bias, self.norm.eps)
             return y.view(*x.shape[:-1], self.dense.out_features)
         return self.norm(F.silu(self.dense(x)))

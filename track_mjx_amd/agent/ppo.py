@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import losses as _losses
-from .networks import IntentionPolicy, NormalTanh, RunningStatistics, ValueNet, deferred_weight_grads, gemm_inputs
+from .networks import Bf16Shadows, IntentionPolicy, NormalTanh, RunningStatistics, ValueNet, deferred_weight_grads, gemm_inputs
 
 
 import contextlib
@@ -203,6 +203,13 @@ class PPOLearner:
                     "discount": torch.empty((T, rows), **f32), "truncation": torch.empty((T, rows), **f32),
                     "next_observation_last": torch.empty((rows, obs), **f32)}
         self.matmul_dtype = matmul_dtype
+        # bf16 GEMM-input mode (BASELINE config 5): bf16 shadows of every dense layer's weight (built AFTER FlatAdam re-seated the parameters
+        # in the flat buffer), refreshed at the start of every SGD step; the first layers need no transposed shadow (no input gradient)
+        self.shadows = None
+        if matmul_dtype == torch.bfloat16 and dev.type == "cuda":
+            lins = [m for net in (self.policy, self.value) for m in net.modules() if isinstance(m, torch.nn.Linear) and m.out_features % 4 == 0]
+            first = {self.policy.encoder[0].dense, next(m for m in self.value.net if isinstance(m, torch.nn.Linear))}
+            self.shadows = Bf16Shadows(lins, need_t=[m for m in lins if m not in first])
         self._sgd_side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and os.environ.get("TMJX_SGD_TWO_STREAMS", "1") != "0") else None
         if self._sgd_side is not None and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)    # intentional: the value net's gradients arrive from the side stream
@@ -256,20 +263,19 @@ class PPOLearner:
         gen = self.gen if gen is None else gen
         if draws is not None:
             x = self.normalizer.normalize(obs) if self.normalize_observations else obs
-            with gemm_inputs(self.matmul_dtype):
-                logits, mean, logvar = self.policy(x, eps=draws[0], deterministic=False)
+            logits, mean, logvar = self.policy(x, eps=draws[0], deterministic=False)
             logits = logits.float()
             raw = NormalTanh.sample_no_postprocessing(logits, draws[1])
             return NormalTanh.postprocess(raw), {"raw_action": raw, "log_prob": NormalTanh.log_prob(logits, raw), "logits": logits,
                                                  "latent_mean": mean, "latent_logvar": logvar}
-        if (not deterministic and self.dev.type == "cuda" and self.matmul_dtype is None and obs.dim() == 2 and obs.dtype == torch.float32):
+        # (the acting policy runs on the fp32 LDS-free kernels in either GEMM-input mode: next to the physics kernel the matrix pipe is idle)
+        if (not deterministic and self.dev.type == "cuda" and obs.dim() == 2 and obs.dtype == torch.float32):
             if self.lds_free and obs.shape[0] % 4 == 0 and obs.stride(0) == 1:     # K-major float4 loads need 4 | n_env
                 return self._act_fused(None, obs_raw=obs, gen=gen)
             return self._act_fused(self.normalizer.normalize(obs) if self.normalize_observations else obs, gen=gen)
         x = self.normalizer.normalize(obs) if self.normalize_observations else obs
-        with gemm_inputs(self.matmul_dtype):
-            eps = torch.randn((x.shape[0], self.policy.latents), generator=gen, device=self.dev)
-            logits, mean, logvar = self.policy(x, eps=eps, deterministic=deterministic)
+        eps = torch.randn((x.shape[0], self.policy.latents), generator=gen, device=self.dev)
+        logits, mean, logvar = self.policy(x, eps=eps, deterministic=deterministic)
         logits = logits.float()
         if deterministic:
             return NormalTanh.mode(logits), {"latent_mean": mean, "latent_logvar": logvar}
@@ -476,7 +482,9 @@ class PPOLearner:
             data = _losses.gather_minibatch(self.buf, idx, self.normalizer)      # all seven leaves in one launch
         else:
             data = {k: (self.buf[k].index_select(1, idx) if k != "next_observation_last" else self.buf[k].index_select(0, idx)) for k in self.buf}
-        with gemm_inputs(self.matmul_dtype):
+        if self.shadows is not None:
+            self.shadows.refresh()          # one launch: the optimiser step behind the previous replay changed the master weights
+        with gemm_inputs(self.matmul_dtype, self.shadows):
             if self.dev.type == "cuda":
                 # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
                 m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,

@@ -113,46 +113,57 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
       __builtin_amdgcn_global_load_lds(BG_GLB(bsrc[i] + k0), BG_LDS(bg_lds + stage * STAGE + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
   };
 
-  // ---- A: registers (fp32 -> bf16 at the LDS write, or bf16 as it is).  Chunk f = t + 512 p: row f >> 3, chunk f & 7.
-  constexpr int A_CH = BM * 8, A_FULL = A_CH / 512, A_REM_WAVES = (A_CH % 512) / 64, A_PASS = A_FULL + (A_REM_WAVES ? 1 : 0);
+  // ---- A: registers (fp32 -> bf16 at the LDS write, or bf16 as it is), in units of 16 BYTES OF MEMORY so that a wave instruction reads
+  // whole contiguous row segments (a lane reading 32 bytes = two dwordx4 with a 32-byte lane stride half-uses every cache line per
+  // instruction: the vector cache's fill rate, ~29 B/clk/CU, is what bounds these kernels).  fp32: unit = 4 elements -> 8 bytes of LDS;
+  // bf16: unit = 8 elements -> 16 bytes.  Unit f = t + 512 p: row f / UPR, unit f % UPR of the row.
+  constexpr int UPR = AF32 ? 16 : 8, EPU = 64 / UPR;                  // units per 64-element row of the tile, elements per unit
+  constexpr int A_UNITS = BM * UPR, A_FULL = A_UNITS / 512, A_REM_WAVES = (A_UNITS % 512) / 64, A_PASS = A_FULL + (A_REM_WAVES ? 1 : 0);
+  static_assert(A_UNITS % 64 == 0, "whole waves");
   struct AStage { bgu4 v[A_PASS]; };
   const char *arow[A_PASS];
 #pragma unroll
   for (int p = 0; p < A_PASS; p++) {
-    const int f = t + 512 * p, r = min(f >> 3, BM - 1), c = f & 7;
-    arow[p] = (const char *)Av + ((size_t)min(m0 + r, M - 1) * lda + 8 * c) * (AF32 ? 4 : 2);
+    const int f = t + 512 * p, r = min(f / UPR, BM - 1), u = f % UPR;
+    arow[p] = (const char *)Av + ((size_t)min(m0 + r, M - 1) * lda + EPU * u) * (AF32 ? 4 : 2);
   }
   auto load_a = [&](AStage &R, int k0) {
     const bool fast = k0 + BG_BK <= K;
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
       if (p >= A_FULL && wave >= A_REM_WAVES) continue;           // (wave-uniform: the partly filled last pass)
-      const int c = (t + 512 * p) & 7;
-      if (fast) {
+      const int k = k0 + EPU * ((t + 512 * p) % UPR);             // first element of the unit
+      // the last, partial K tile: a unit that starts inside the row's allocation (lda) is loaded whole — lda is a multiple of the unit —
+      // and its elements beyond K are zeroed below; units beyond lda are not loaded at all
+      bgu4 raw = {0u, 0u, 0u, 0u};
+      if (fast || k < lda) raw = *reinterpret_cast<const bgu4 *>(arow[p] + (size_t)k0 * (AF32 ? 4 : 2));
+      if (!fast) {
         if (AF32) {
-          const bgf4 *q = reinterpret_cast<const bgf4 *>(arow[p] + (size_t)k0 * 4);
-          R.v[p] = bg_pack8(q[0], q[1]);
-        } else {
-          R.v[p] = *reinterpret_cast<const bgu4 *>(arow[p] + (size_t)k0 * 2);
-        }
-      } else {                                                      // the last, partial K tile: element by element, exact zeros beyond K
-        float e[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int k = k0 + 8 * c + j;
-          e[j] = 0.f;
-          if (k < K) e[j] = AF32 ? reinterpret_cast<const float *>(arow[p])[k0 + j] : bg_f32(reinterpret_cast<const bf16_t *>(arow[p])[k0 + j]);
+          for (int j = 0; j < 4; j++) if (k + j >= K) raw[j] = 0u;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (k + 2 * j >= K) raw[j] = 0u;
+            else if (k + 2 * j + 1 >= K) raw[j] &= 0xffffu;
+          }
         }
-        R.v[p] = bgu4{bg_pack(e[0], e[1]), bg_pack(e[2], e[3]), bg_pack(e[4], e[5]), bg_pack(e[6], e[7])};
       }
+      R.v[p] = raw;
     }
   };
   auto write_a = [&](const AStage &R, int stage) {
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
       if (p >= A_FULL && wave >= A_REM_WAVES) continue;
-      const int f = t + 512 * p;
-      *reinterpret_cast<bgu4 *>(bg_lds + stage * STAGE + bg_off(f >> 3, f & 7)) = R.v[p];
+      const int f = t + 512 * p, r = f / UPR, u = f % UPR;
+      char *dst = bg_lds + stage * STAGE;
+      if (AF32) {
+        const bgf4 v = __builtin_bit_cast(bgf4, R.v[p]);
+        *reinterpret_cast<bgu2 *>(dst + bg_off(r, u >> 1) + 8 * (u & 1)) = bgu2{bg_pack(v.x, v.y), bg_pack(v.z, v.w)};
+      } else {
+        *reinterpret_cast<bgu4 *>(dst + bg_off(r, u)) = R.v[p];
+      }
     }
   };
 
@@ -238,61 +249,75 @@ __device__ __forceinline__ void bgemm_dw_tile(const void *__restrict__ dYv, int 
   const int n0 = tile_n * BGDW_BT, k0 = tile_k * BGDW_BT;
   const int r_begin = split * rows_per_split, r_end = min(M, r_begin + rows_per_split);
   const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
-  // staging: 32 rows x 16 chunks per operand = 512 chunks over 256 threads: chunk f = t + 256 p: row f >> 4, chunk f & 15
-  struct Stage { bgu4 y[2], x[2]; };
-  bgf4 colacc[2] = {bgf4{0.f, 0.f, 0.f, 0.f}, bgf4{0.f, 0.f, 0.f, 0.f}};         // sums over this thread's rows of its eight dY columns (bias gradient)
-  const int ch = t & 15;
-  // columns beyond the matrix are clamped to the last whole chunk (their products land in entries that are never stored); rows beyond
-  // r_end must be exact zeros (they are summed over): masked
-  const int ycol = min(n0 + 8 * ch, ((N + 7) & ~7) - 8), xcol = min(k0 + 8 * ch, ((K + 7) & ~7) - 8);
-  auto ld8 = [&](const void *base, int ld, int row, int col, int width, bool f32, bool ok, bgf4 *sum) -> bgu4 {
-    bgu4 out = {0u, 0u, 0u, 0u};
-    if (ok) {
-      if (col + 8 <= width) {
+  // staging in units of 16 bytes of memory (whole contiguous row segments per wave instruction, see k_bgemm_nt): fp32 operand: unit = 4
+  // columns -> 8 bytes of LDS, 32 units per row, 4 passes of 256 threads per 32-row stage; bf16: unit = 8 columns -> 16 bytes, 16 per row, 2 passes.
+  // Columns beyond the matrix: a unit that starts inside the row's allocation (ld) is loaded whole and masked to zero beyond the width; rows
+  // beyond r_end must be exact zeros (they are summed over): not loaded.
+  constexpr int YU = YF32 ? 32 : 16, XU = XF32 ? 32 : 16, YP = YU / 8, XP = XU / 8, YE = 128 / YU, XE = 128 / XU;
+  struct Stage { bgu4 y[YP], x[XP]; };
+  bgf4 colacc[YF32 ? 1 : 2];               // sums over this thread's rows of its dY columns (bias gradient): 4 resp. 8 columns
+  colacc[0] = bgf4{0.f, 0.f, 0.f, 0.f};
+  if (!YF32) colacc[1] = bgf4{0.f, 0.f, 0.f, 0.f};
+  const int yu = t % YU, xu = t % XU;       // (256 % YU == 0: the unit of a thread is the same in every pass)
+  auto ldu = [&](const void *base, int ld, int row, int col, int width, bool f32, bool ok) -> bgu4 {
+    bgu4 raw = {0u, 0u, 0u, 0u};
+    if (ok && col < ld) {
+      raw = f32 ? *reinterpret_cast<const bgu4 *>(reinterpret_cast<const float *>(base) + (size_t)row * ld + col)
+                : *reinterpret_cast<const bgu4 *>(reinterpret_cast<const bf16_t *>(base) + (size_t)row * ld + col);
+      if (col + (f32 ? 4 : 8) > width) {
         if (f32) {
-          const bgf4 *q = reinterpret_cast<const bgf4 *>(reinterpret_cast<const float *>(base) + (size_t)row * ld + col);
-          const bgf4 a = q[0], b = q[1];
-          if (sum) { sum[0] += a; sum[1] += b; }
-          out = bg_pack8(a, b);
-        } else {
-          out = *reinterpret_cast<const bgu4 *>(reinterpret_cast<const bf16_t *>(base) + (size_t)row * ld + col);
-          if (sum) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) { sum[0][j] += bg_f32((bf16_t)(out[j >> 1] >> (16 * (j & 1)))); sum[1][j] += bg_f32((bf16_t)(out[2 + (j >> 1)] >> (16 * (j & 1)))); }
+          for (int j = 0; j < 4; j++) if (col + j >= width) raw[j] = 0u;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (col + 2 * j >= width) raw[j] = 0u;
+            else if (col + 2 * j + 1 >= width) raw[j] &= 0xffffu;
           }
         }
-      } else {                                    // the matrix' last, partial chunk of columns: element by element
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          e[j] = 0.f;
-          if (col + j < width) e[j] = f32 ? reinterpret_cast<const float *>(base)[(size_t)row * ld + col + j] : bg_f32(reinterpret_cast<const bf16_t *>(base)[(size_t)row * ld + col + j]);
-        }
-        if (sum) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) { sum[0][j] += e[j]; sum[1][j] += e[4 + j]; }
-        }
-        out = bgu4{bg_pack(e[0], e[1]), bg_pack(e[2], e[3]), bg_pack(e[4], e[5]), bg_pack(e[6], e[7])};
       }
     }
-    return out;
+    return raw;
   };
   auto gload = [&](Stage &R, int r0) {
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-      const int row = r0 + ((t + 256 * p) >> 4);
-      const bool ok = row < r_end;
-      R.y[p] = ld8(dYv, ldy, ok ? row : r_begin, ycol, N, YF32, ok, with_bias ? colacc : nullptr);
-      R.x[p] = ld8(Xv, ldx, ok ? row : r_begin, xcol, K, XF32, ok, nullptr);
+    for (int p = 0; p < YP; p++) {
+      const int row = r0 + (t + 256 * p) / YU;
+      R.y[p] = ldu(dYv, ldy, min(row, M - 1), n0 + YE * yu, N, YF32, row < r_end);
+    }
+#pragma unroll
+    for (int p = 0; p < XP; p++) {
+      const int row = r0 + (t + 256 * p) / XU;
+      R.x[p] = ldu(Xv, ldx, min(row, M - 1), k0 + XE * xu, K, XF32, row < r_end);
     }
   };
   auto swrite = [&](const Stage &R, int stage) {
     char *sy = bg_lds + stage * BGDW_STAGE, *sx = sy + BGDW_BM * 256;
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-      const int r = (t + 256 * p) >> 4;
-      *reinterpret_cast<bgu4 *>(sy + bg_tr_off(r, ch)) = R.y[p];
-      *reinterpret_cast<bgu4 *>(sx + bg_tr_off(r, ch)) = R.x[p];
+    for (int p = 0; p < YP; p++) {
+      const int r = (t + 256 * p) / YU;
+      if (YF32) {
+        const bgf4 v = __builtin_bit_cast(bgf4, R.y[p]);
+        colacc[0] += v;
+        *reinterpret_cast<bgu2 *>(sy + bg_tr_off(r, yu >> 1) + 8 * (yu & 1)) = bgu2{bg_pack(v.x, v.y), bg_pack(v.z, v.w)};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          colacc[0][j] += bg_f32((bf16_t)(R.y[p][j >> 1] >> (16 * (j & 1))));
+          colacc[YF32 ? 0 : 1][j] += bg_f32((bf16_t)(R.y[p][2 + (j >> 1)] >> (16 * (j & 1))));
+        }
+        *reinterpret_cast<bgu4 *>(sy + bg_tr_off(r, yu)) = R.y[p];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < XP; p++) {
+      const int r = (t + 256 * p) / XU;
+      if (XF32) {
+        const bgf4 v = __builtin_bit_cast(bgf4, R.x[p]);
+        *reinterpret_cast<bgu2 *>(sx + bg_tr_off(r, xu >> 1) + 8 * (xu & 1)) = bgu2{bg_pack(v.x, v.y), bg_pack(v.z, v.w)};
+      } else {
+        *reinterpret_cast<bgu4 *>(sx + bg_tr_off(r, xu)) = R.x[p];
+      }
     }
   };
   // transposed reads: lane (group g, q = (lane & 15) >> 2, p = lane & 3) supplies the address of row 8 g (+ 4) + q, columns 16 tile + 4 p .. + 3;
@@ -341,18 +366,17 @@ __device__ __forceinline__ void bgemm_dw_tile(const void *__restrict__ dYv, int 
     }
   }
   float *out = slabs + (size_t)split * (size_t)N * ld_slab;
-  if (with_bias && tile_k == 0) {            // thread t holds dY columns n0 + 8 (t & 15) .. + 7 of the rows (t >> 4) + 16 j
+  if (with_bias && tile_k == 0) {            // thread t holds the sums of dY columns n0 + YE yu .. of the rows t / YU + (256 / YU) j
     __syncthreads();
-    float *red = reinterpret_cast<float *>(bg_lds);            // [16][128]
-    *reinterpret_cast<bgf4 *>(red + (t >> 4) * BGDW_BT + 8 * ch) = colacc[0];
-    *reinterpret_cast<bgf4 *>(red + (t >> 4) * BGDW_BT + 8 * ch + 4) = colacc[1];
+    float *red = reinterpret_cast<float *>(bg_lds);            // [256 / YU][128]
+    *reinterpret_cast<bgf4 *>(red + (t / YU) * BGDW_BT + YE * yu) = colacc[0];
+    if (!YF32) *reinterpret_cast<bgf4 *>(red + (t / YU) * BGDW_BT + YE * yu + 4) = colacc[YF32 ? 0 : 1];
     __syncthreads();
     if (t < BGDW_BT) {
       float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < 16; j++) v += red[j * BGDW_BT + t];
-      // (a clamped column chunk repeats the matrix' last whole chunk: only columns inside the matrix are stored)
-      if (n0 + t < N && n0 + 8 * (t >> 3) == min(n0 + 8 * (t >> 3), ((N + 7) & ~7) - 8)) out[(size_t)(n0 + t) * ld_slab + K] = v;
+      for (int j = 0; j < 256 / YU; j++) v += red[j * BGDW_BT + t];
+      if (n0 + t < N) out[(size_t)(n0 + t) * ld_slab + K] = v;
     }
   }
   // register r of tile (a, b): output row n0 + wn + 16 a + (lane & 15), columns k0 + wk + 16 b + 4 (lane >> 4) + r
@@ -373,10 +397,15 @@ __device__ __forceinline__ void bgemm_dw_tile(const void *__restrict__ dYv, int 
     }
   }
 }
+// 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so all tiles of one row slab — which re-read the
+// same rows of dY and X — are given ids of ONE residue class mod 8: id = 8 q + xcd -> slab (q / tiles) 8 + xcd, tile q % tiles.
 template <bool YF32, bool XF32>
 __global__ __launch_bounds__(256) void k_bgemm_dw(const void *__restrict__ dY, int ldy, const void *__restrict__ X, int ldx, float *__restrict__ slabs,
-                                                  int M, int N, int K, int with_bias, int rows_per_split, int ld_slab) {
-  bgemm_dw_tile<YF32, XF32>(dY, ldy, X, ldx, slabs, M, N, K, with_bias, rows_per_split, ld_slab, blockIdx.x, blockIdx.y, blockIdx.z);
+                                                  int M, int N, int K, int with_bias, int rows_per_split, int ld_slab, int tiles_n, int tiles_k, int S) {
+  const int tiles = tiles_n * tiles_k, xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int split = (q / tiles) * 8 + xcd, tl = q % tiles;
+  if (split >= S) return;
+  bgemm_dw_tile<YF32, XF32>(dY, ldy, X, ldx, slabs, M, N, K, with_bias, rows_per_split, ld_slab, tl / tiles_k, tl % tiles_k, split);
 }
 // dW[n][k] = sum over the slabs; db[n] = the slabs' column K.  One lane per output element, eight loads in flight.
 __global__ __launch_bounds__(256) void k_bgemm_dw_reduce(const float *__restrict__ slabs, float *__restrict__ dW, float *__restrict__ db, int S, int N, int K,

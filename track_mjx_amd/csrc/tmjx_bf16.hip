@@ -97,13 +97,14 @@ int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is
   int rps, S, ld;
   bdw_split(M, N, K, &rps, &S, &ld);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((N + BGDW_BT - 1) / BGDW_BT, (K + BGDW_BT - 1) / BGDW_BT, S);
+  const int tn = (N + BGDW_BT - 1) / BGDW_BT, tk = (K + BGDW_BT - 1) / BGDW_BT;
+  dim3 grid((unsigned)(tn * tk * ((S + 7) / 8) * 8));
   const size_t lds = 2 * BGDW_STAGE;
   const int wb = db ? 1 : 0;
-  if (y_is_f32 && x_is_f32) hipLaunchKernelGGL((k_bgemm_dw<true, true>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
-  else if (y_is_f32) hipLaunchKernelGGL((k_bgemm_dw<true, false>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
-  else if (x_is_f32) hipLaunchKernelGGL((k_bgemm_dw<false, true>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
-  else hipLaunchKernelGGL((k_bgemm_dw<false, false>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld);
+  if (y_is_f32 && x_is_f32) hipLaunchKernelGGL((k_bgemm_dw<true, true>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld, tn, tk, S);
+  else if (y_is_f32) hipLaunchKernelGGL((k_bgemm_dw<true, false>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld, tn, tk, S);
+  else if (x_is_f32) hipLaunchKernelGGL((k_bgemm_dw<false, true>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld, tn, tk, S);
+  else hipLaunchKernelGGL((k_bgemm_dw<false, false>), grid, dim3(256), lds, s, dY, ldy, X, ldx, scratch, M, N, K, wb, rps, ld, tn, tk, S);
   const long long total = (long long)N * (K + wb);
   hipLaunchKernelGGL(k_bgemm_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)scratch, dW, db, S, N, K, wb, ld, lddw);
   return check_launch("k_bgemm_dw");

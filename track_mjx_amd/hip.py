@@ -76,16 +76,44 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
     # -fno-slp-vectorize: the SLP vectoriser packs the two dof slots of the row products into v_pk_* with more v_mov shuffles than
     # it saves (measured 1.8 % on the physics kernel); the explicitly packed FMAs of the chain kernels are not affected
     out = SO_PATH if out is None else Path(out)
-    # two translation units compiled side by side (each hipcc run is single-threaded per offload arch), then linked into ONE library
+    # two translation units compiled side by side (each hipcc run is single-threaded per offload arch), then linked into ONE library.
+    # Objects are cached next to the library, keyed by a hash of the flags and of the source with every header it includes (recursively):
+    # editing one kernel family recompiles one unit
+    import hashlib
+    import re
     from concurrent.futures import ThreadPoolExecutor
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-value", *[f"-D{d}" for d in defines]]
-    objs = [out.with_name(f"{out.stem}.{src.stem}.o") for src in SOURCES]
+
+    def closure(path: Path, seen: dict) -> dict:
+        if path in seen or not path.exists():
+            return seen
+        text = path.read_text()
+        seen[path] = text
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, re.M):
+            closure((path.parent / inc).resolve(), seen)
+        return seen
+
+    cache = out.parent / ".build"
+    cache.mkdir(exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        h = hashlib.sha256(" ".join(flags).encode())
+        for pth, text in sorted(closure(src.resolve(), {}).items()):
+            h.update(str(pth.name).encode()); h.update(text.encode())
+        objs.append(cache / f"{src.stem}.{h.hexdigest()[:16]}.o")
 
     def compile_one(src, obj):
-        cmd = ["hipcc", *flags, "-c", "-o", str(obj), str(src)]
+        if obj.exists():
+            return
+        for stale in cache.glob(f"{src.stem}.*.o"):
+            if len(list(cache.glob(f"{src.stem}.*.o"))) > 6:
+                stale.unlink(missing_ok=True)
+        tmp = obj.with_suffix(f".tmp{os.getpid()}.o")
+        cmd = ["hipcc", *flags, "-c", "-o", str(tmp), str(src)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise TmjxError(f"hipcc failed on {src.name}:\n" + res.stderr[-4000:])
+        tmp.replace(obj)
         if verbose:
             print(" ".join(cmd))
     with ThreadPoolExecutor(len(SOURCES)) as ex:
@@ -95,8 +123,6 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise TmjxError("hipcc link failed:\n" + res.stderr[-4000:])
-    for o in objs:
-        o.unlink(missing_ok=True)
     return out
 
 
