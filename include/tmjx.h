@@ -262,6 +262,28 @@ int tmjx_bf16_shadow(const tmjx_bf16_shadow_t *items, int n, void *stream);
  * transposed shadow (K and N exchange roles).  All base pointers 16-byte aligned. */
 int tmjx_bgemm_nt(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
                   void *stream);
+/* The same GEMM with a block epilogue on the accumulators (the hidden activations then exist in memory only as bf16, the operand format of
+ * the next GEMM; z = the pre-activation WITHOUT the bias stays fp32 for the backward pass).  Row tiles are 80 rows high.
+ *   tmjx_bgemm_ln_fwd   Dense -> SiLU -> LayerNorm forward (intention_network.py:32-44,68-76), N = 128, 256 or 512 (tmjx_bgemm_row_tile_ok):
+ *                       Z[M][ldz] = A B^T;  Y16 = LayerNorm(silu(Z + bias)) * gamma + beta as bf16;  stats[M][2] = (mean, 1 / std).
+ *   tmjx_bgemm_ln_bwd   A = dY[M][K] = gradient of the CONSUMER layer's output, Bt = the consumer's transposed shadow (N = the block's width):
+ *                       the tile A Bt^T is d loss / d y of the block; stores dZ16[M][lddz] = d loss / d z of the block (its LayerNorm + SiLU
+ *                       backward from z, bias, gamma, stats) as bf16 and partial[(M + 79) / 80][3][N] = the row tiles' column sums
+ *                       (d gamma | d beta | d bias): reduce them with tmjx_colsum_grouped (rows = (M + 79) / 80, width = 3 N).
+ *   tmjx_bgemm_silu_fwd Dense -> SiLU forward (brax value MLP, ppo_networks.py:180-184), any N: Z = A B^T, Y16 (or Yf, fp32) = silu(Z + bias).
+ *   tmjx_bgemm_silu_bwd its backward in the consumer's input-gradient GEMM: dZ16 = (A Bt^T) silu'(z + bias), partial[(M + 79) / 80][N] = column sums
+ *                       of dZ (d bias).
+ * tmjx_bgemm_partial_floats(M, N, sums): floats of `partial` for sums = 3 (ln) or 1 (silu). */
+int tmjx_bgemm_row_tile_ok(int N);
+long long tmjx_bgemm_partial_floats(int M, int N, int sums);
+int tmjx_bgemm_ln_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, const float *gamma, const float *beta, float *Z, int ldz,
+                      uint16_t *Y16, int ldy16, float *stats, int M, int N, int K, float eps, void *stream);
+int tmjx_bgemm_ln_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const float *z, int ldz, const float *bias, const float *gamma,
+                      const float *stats, uint16_t *dZ16, int lddz, float *partial, int M, int N, int K, void *stream);
+int tmjx_bgemm_silu_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *Z, int ldz, uint16_t *Y16, int ldy16,
+                        float *Yf, int ldyf, int M, int N, int K, void *stream);
+int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz,
+                        float *partial, int M, int N, int K, void *stream);
 /* dW[N][lddw] = dY[M][N]^T . X[M][K] and db[N] = column sums of dY (NULL: no bias gradient; sums are taken over the values AS STORED, in
  * fp32) with bf16 operands (each of dY / X fp32 or bf16 in memory, rows 16-byte aligned); scratch >= tmjx_bgemm_dw_scratch_floats(M, N, K). */
 long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K);

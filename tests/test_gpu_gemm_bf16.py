@@ -101,3 +101,96 @@ def test_bgemm_dw(M, N, K, ldx, bias, y_bf16, x_bf16):
         assert ((db.double() - src.sum(0)).abs() <= src.abs().sum(0) * EPS * (M ** 0.5 + 4) * 2 + 1e-30).all()
     else:
         assert db is None
+
+
+def _ln_ref(z64, b64, g64, be64, eps):
+    a = torch.nn.functional.silu(z64 + b64)
+    return torch.nn.functional.layer_norm(a, (z64.shape[1],), g64, be64, eps), a
+
+
+@pytest.mark.parametrize("a_bf16", [False, True])
+@pytest.mark.parametrize("M,N,K,lda", [(40960, 512, 512, 512), (20480, 256, 470, 696), (1000, 128, 286, 288), (77, 512, 100, 104), (4096, 256, 256, 256)])
+def test_bgemm_ln_forward_epilogue(M, N, K, lda, a_bf16):
+    """tmjx_bgemm_ln_fwd: z against the float64 product of the bf16-rounded operands, y (bf16) and the row statistics against LayerNorm(silu(z + b))
+    evaluated in float64 ON THE KERNEL'S OWN z (so what is tested is the epilogue, to one bf16 rounding)."""
+    from track_mjx_amd.agent.networks import Bf16Shadows, _Block, bgemm_ln_fwd
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    blk = _Block(K, N).to(DEV)
+    with torch.no_grad():
+        blk.dense.bias.copy_(torch.randn(N, generator=g, device=DEV) * 0.3)
+        blk.norm.weight.copy_(1 + 0.2 * torch.randn(N, generator=g, device=DEV))
+        blk.norm.bias.copy_(0.2 * torch.randn(N, generator=g, device=DEV))
+    sh = Bf16Shadows([blk.dense]); sh.refresh()
+    buf = torch.randn((M, lda), generator=g, device=DEV)
+    x = (buf.to(torch.bfloat16) if a_bf16 else buf)[:, :K]
+    z, y, stats = bgemm_ln_fwd(x, sh.w[blk.dense], N, K, blk.dense.bias, blk.norm.weight, blk.norm.bias, 1e-6)
+    torch.cuda.synchronize()
+    a64, w64 = _bf(x).double(), _bf(blk.dense.weight.detach()).double()
+    ref = a64 @ w64.t()
+    bound = (a64.abs() @ w64.abs().t()) * EPS * (K ** 0.5 + 4) * 2 + 1e-30
+    assert ((z.double() - ref).abs() <= bound).all()
+    yr, a = _ln_ref(z.double(), blk.dense.bias.detach().double(), blk.norm.weight.detach().double(), blk.norm.bias.detach().double(), 1e-6)
+    assert y.dtype == torch.bfloat16 and ((y.double() - yr).abs() <= 2.0 ** -8 * yr.abs() + 2e-5).all(), float((y.double() - yr).abs().max())
+    mean, var = a.mean(1), a.var(1, unbiased=False)
+    assert (stats[:, 0].double() - mean).abs().max() < 1e-5 and ((stats[:, 1].double() - (var + 1e-6).rsqrt()).abs() <= 1e-5 * (var + 1e-6).rsqrt()).all()
+
+
+@pytest.mark.parametrize("dy_bf16", [False, True])
+@pytest.mark.parametrize("M,N,K,ldy", [(40960, 512, 512, 512), (20480, 256, 120, 120), (3000, 512, 76, 80), (77, 128, 40, 40), (4096, 256, 256, 256)])
+def test_bgemm_ln_backward_epilogue(M, N, K, ldy, dy_bf16):
+    """tmjx_bgemm_ln_bwd: d loss / d z of a Dense -> SiLU -> LayerNorm block from the gradient dY of its consumer's output (the consumer's input-gradient
+    GEMM + the block's LayerNorm / SiLU backward in the epilogue) and the (d gamma | d beta | d bias) column sums, against float64 autograd through
+    LayerNorm(silu(z + b)) fed with the float64 product of the bf16-rounded operands."""
+    from track_mjx_amd.agent.networks import Bf16Shadows, _dense, bgemm_ln_bwd
+    g = torch.Generator(device=DEV).manual_seed(M + N + 7 * K)
+    cons = _dense(N, K).to(DEV)                       # the consumer layer: N (the block's width) -> K
+    sh = Bf16Shadows([cons]); sh.refresh()
+    z = torch.randn((M, N), generator=g, device=DEV)
+    b = torch.randn(N, generator=g, device=DEV) * 0.3
+    gam = 1 + 0.2 * torch.randn(N, generator=g, device=DEV)
+    a = torch.nn.functional.silu(z + b)
+    stats = torch.stack([a.mean(1), (a.var(1, unbiased=False) + 1e-6).rsqrt()], 1).contiguous()
+    buf = torch.randn((M, ldy), generator=g, device=DEV)
+    dy = (buf.to(torch.bfloat16) if dy_bf16 else buf)[:, :K]
+    dz, partial = bgemm_ln_bwd(dy, sh.wt[cons], N, K, z, b, gam, stats)
+    torch.cuda.synchronize()
+    gy = _bf(dy).double() @ _bf(cons.weight.detach()).double()                  # d loss / d y of the block, exact operands
+    z64 = z.double().requires_grad_(True)
+    b64, g64 = b.double().requires_grad_(True), gam.double().requires_grad_(True)
+    be64 = torch.zeros(N, dtype=torch.float64, device=DEV, requires_grad=True)
+    yr, _ = _ln_ref(z64, b64, g64, be64, 1e-6)
+    rz, rb, rg, rbe = torch.autograd.grad(yr, [z64, b64, g64, be64], gy)
+    scale = rz.abs().max()
+    assert dz.dtype == torch.bfloat16 and ((dz.double() - rz).abs() <= 2.0 ** -8 * rz.abs() + 3e-5 * scale).all(), float(((dz.double() - rz).abs() / scale).max())
+    sums = partial.double().sum(0)
+    for got, ref in ((sums[0], rg), (sums[1], rbe), (sums[2], rb)):
+        assert (got - ref).abs().max() <= 2e-4 * ref.abs().max() + 1e-6, float((got - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,lda,yf32", [(40960, 512, 696, 696, False), (4096, 256, 512, 512, True), (1000, 120, 100, 104, False), (77, 40, 33, 40, False)])
+def test_bgemm_silu_forward_and_backward_epilogues(M, N, K, lda, yf32):
+    """tmjx_bgemm_silu_fwd / _bwd (brax value MLP: Dense -> SiLU): z, y = silu(z + b) (bf16 or fp32), and dz = (dY Wc) silu'(z + b) with its column sums."""
+    from track_mjx_amd.agent.networks import Bf16Shadows, _dense, bgemm_silu_bwd, bgemm_silu_fwd
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    lin, cons = _dense(K, N).to(DEV), _dense(N, 64).to(DEV)
+    with torch.no_grad():
+        lin.bias.copy_(torch.randn(N, generator=g, device=DEV) * 0.3)
+    sh = Bf16Shadows([lin, cons]); sh.refresh()
+    x = torch.randn((M, lda), generator=g, device=DEV)[:, :K]
+    z, y = bgemm_silu_fwd(x, sh.w[lin], N, K, lin.bias, y_f32=yf32)
+    torch.cuda.synchronize()
+    a64, w64 = _bf(x).double(), _bf(lin.weight.detach()).double()
+    ref = a64 @ w64.t()
+    assert ((z.double() - ref).abs() <= (a64.abs() @ w64.abs().t()) * EPS * (K ** 0.5 + 4) * 2 + 1e-30).all()
+    yr = torch.nn.functional.silu(z.double() + lin.bias.detach().double())
+    tol = 1e-6 if yf32 else 2.0 ** -8
+    assert y.dtype == (torch.float32 if yf32 else torch.bfloat16) and ((y.double() - yr).abs() <= tol * yr.abs() + 1e-6).all()
+    dy = torch.randn((M, 64), generator=g, device=DEV)
+    dz, partial = bgemm_silu_bwd(dy, sh.wt[cons], N, 64, z, lin.bias)
+    torch.cuda.synchronize()
+    gy = _bf(dy).double() @ _bf(cons.weight.detach()).double()
+    v = z.double() + lin.bias.detach().double()
+    sig = torch.sigmoid(v)
+    rz = gy * (sig * (1 + v * (1 - sig)))
+    assert ((dz.double() - rz).abs() <= 2.0 ** -8 * rz.abs() + 3e-5 * rz.abs().max()).all()
+    assert (partial.double().sum(0) - rz.sum(0)).abs().max() <= 2e-3 * rz.sum(0).abs().max() + 1e-4

@@ -157,6 +157,59 @@ def bgemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool, out: torch.Tens
     return dw, db
 
 
+def bgemm_ln_fwd(x, wb, N: int, K: int, bias, gamma, beta, eps: float):
+    """Dense -> SiLU -> LayerNorm forward in one launch (tmjx_bgemm_ln_fwd; N = 128 / 256 / 512): returns (z fp32 [rows, N] without the bias,
+    y bf16 [rows, N], stats fp32 [rows, 2] = (mean, 1 / std))."""
+    x = _rows2d(x)
+    M = x.shape[0]
+    z = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    _launch("tmjx_bgemm_ln_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(gamma), _p(beta), _p(z), N, _p(y), N,
+            _p(stats), M, N, K, float(eps))
+    return z, y, stats
+
+
+def bgemm_ln_bwd(dy, wtb, N: int, K: int, z, bias, gamma, stats):
+    """The input gradient of a block's CONSUMER (dy [rows, K] = gradient of the consumer's output, wtb = the consumer's transposed shadow) with the
+    block's LayerNorm + SiLU backward in the epilogue (tmjx_bgemm_ln_bwd): returns (dz bf16 [rows, N] = d loss / d z of the block, partial =
+    per-row-tile column sums [tiles, 3, N])."""
+    from .. import hip as _hip
+    dy = _rows2d(dy)
+    M = dy.shape[0]
+    dz = torch.empty((M, N), dtype=torch.bfloat16, device=dy.device)
+    partial = torch.empty(int(_hip.lib().tmjx_bgemm_partial_floats(M, N, 3)), dtype=torch.float32, device=dy.device)
+    _launch("tmjx_bgemm_ln_bwd", dy.device, _p(dy), int(dy.dtype == torch.float32), _ld(dy), _p(wtb), wtb.stride(0), _p(z), z.stride(0), _p(bias), _p(gamma), _p(stats),
+            _p(dz), N, _p(partial), M, N, K)
+    return dz, partial.view(-1, 3, N)
+
+
+def bgemm_silu_fwd(x, wb, N: int, K: int, bias, y_f32: bool = False):
+    """Dense -> SiLU forward in one launch (tmjx_bgemm_silu_fwd): (z fp32 without the bias, y = silu(z + bias) as bf16 — or fp32 with y_f32)."""
+    x = _rows2d(x)
+    M = x.shape[0]
+    z = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    ld = (N + 3) // 4 * 4
+    y = torch.empty((M, ld), dtype=torch.float32 if y_f32 else torch.bfloat16, device=x.device)
+    _launch("tmjx_bgemm_silu_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(z), N,
+            None if y_f32 else _p(y), ld, _p(y) if y_f32 else None, ld, M, N, K)
+    return z, y[:, :N]
+
+
+def bgemm_silu_bwd(dy, wtb, N: int, K: int, z, bias):
+    """The consumer's input-gradient GEMM with the Dense -> SiLU block's backward in the epilogue (tmjx_bgemm_silu_bwd): (dz bf16 [rows, N], partial
+    [tiles, N] = column sums of dz per row tile)."""
+    from .. import hip as _hip
+    dy = _rows2d(dy)
+    M = dy.shape[0]
+    ld = (N + 3) // 4 * 4
+    dz = torch.empty((M, ld), dtype=torch.bfloat16, device=dy.device)
+    partial = torch.empty(int(_hip.lib().tmjx_bgemm_partial_floats(M, N, 1)), dtype=torch.float32, device=dy.device)
+    _launch("tmjx_bgemm_silu_bwd", dy.device, _p(dy), int(dy.dtype == torch.float32), _ld(dy), _p(wtb), wtb.stride(0), _p(z), z.stride(0), _p(bias), _p(dz), ld,
+            _p(partial), M, N, K)
+    return dz[:, :N], partial.view(-1, N)
+
+
 class Bf16Shadows:
     """bf16 copies of the dense layers' weights: `w[lin]` = [N][ceil64 K] (forward operand), `wt[lin]` = [K][ceil64 N] (input-gradient operand),
     zero padded, all refreshed by ONE launch (tmjx_bf16_shadow) — at the start of every SGD step, i.e. once per optimiser step."""

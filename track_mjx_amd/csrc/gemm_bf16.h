@@ -75,17 +75,33 @@ struct BgEpi {
   const float *gamma, *beta;      // EPI 1 / 2: LayerNorm scale / shift of the block
   float *stats;                   // EPI 1 writes (mean, 1 / std) per row, EPI 2 reads them
   bf16_t *y16; int ldy16;         // EPI 1 / 3: the activation as bf16 (the next layer's operand);  EPI 2 / 4: d loss / d z as bf16
-  const float *z;                 // EPI 2 / 4: the block's saved pre-activation (fp32, leading dimension ldc)
-  float *partial;                 // EPI 2 / 4: per-workgroup column sums ([3][BN] resp. [1][BN])
+  float *yf; int ldyf;            // EPI 3: the activation as fp32 instead (the consumer is an fp32 kernel)
+  const float *z; int ldz;        // EPI 2 / 4: the block's saved pre-activation (fp32, without the bias)
+  float *partial;                 // EPI 2 / 4: per-row-tile column sums: [gridDim.x][3][N] (d gamma | d beta | d bias) resp. [gridDim.x][N] (d bias)
   float eps;
 };
+// sum over the 16 lanes of a DPP row (all 16 lanes get it): quad xor 1, quad xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float bg_row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+  return x;
+}
 
 template <int MI, int NI> struct BgCfg {
   static constexpr int BM = 16 * MI, BN = 128 * NI, A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
 };
 
-// EPI 0: C = acc (+ bias), fp32.   EPI 1: Dense -> SiLU -> LayerNorm forward (the tile spans whole rows: N == BN): z = acc to C (without the
-// bias: what the backward kernels expect), y = LayerNorm(silu(z + bias)) as bf16 to y16, (mean, 1 / std) to stats.
+// EPI 0: C = acc (+ bias), fp32.
+// EPI 1: Dense -> SiLU -> LayerNorm forward (the tile spans whole rows: N == BN): z = acc to C (without the bias: what the backward kernels
+//        expect), y = LayerNorm(silu(z + bias)) as bf16 to y16, (mean, 1 / std) to stats.
+// EPI 2: the tile is d loss / d y of a Dense -> SiLU -> LayerNorm block (whole rows, N == BN = the block's width; this GEMM is the input
+//        gradient of the block's consumer): that block's LayerNorm + SiLU backward (the arithmetic of k_silu_ln_bwd) applied on the
+//        accumulators, d loss / d z stored as bf16 (the operand of the block's own input- and weight-gradient GEMMs) + the row tile's column
+//        sums (dy ahat | dy | dz).  C is not written.
+// EPI 3: Dense -> SiLU forward (brax value MLP): z = acc to C, y = silu(z + bias) as bf16 (or fp32).   EPI 4: its backward on the tile
+//        d loss / d y: dz = dy silu'(z + bias) as bf16 + column sums of dz.
 template <int MI, int NI, int EPI, bool AF32>
 __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, int lda, const bf16_t *__restrict__ B, int ldb, const float *__restrict__ bias,
                                                   float *__restrict__ C, int ldc, int M, int N, int K, BgEpi epi) {
@@ -204,6 +220,12 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  // (an opaque copy of the lane's row / column origin: otherwise the epilogue's MI NI 64-bit store / load addresses are computed in front of the
+  // K loop and stay live through it)
+  int li_e = li, kq_e = kq;
+  asm volatile("" : "+v"(li_e), "+v"(kq_e));
+#define li li_e
+#define kq kq_e
   // register r of tile (a, b): C[m0 + 16 a + li][n0 + nw + 16 b + 4 kq + r] — four consecutive columns of one row
   if constexpr (EPI == 0) {
     const bool vec = !(ldc & 3) && !((uintptr_t)C & 15);
@@ -230,6 +252,217 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
       }
     }
   }
+  // cross-wave exchange of per-row partial sums through LDS (the K loop's stages are dead: its last trip ended with a barrier)
+  constexpr int NW = 8;
+  if constexpr (EPI == 1) {
+    // whole rows: N == BN, n0 == 0.  Row sums: over r and b in registers, over kq by two cross-lane adds, over the waves through LDS.
+    float *red1 = reinterpret_cast<float *>(bg_lds), *red2 = red1 + BM * NW;
+    bgf4 bv[NI], gv[NI], bev[NI];
+#pragma unroll
+    for (int b = 0; b < NI; b++) {
+      const int col = nw + 16 * b + 4 * kq;
+      bv[b] = *reinterpret_cast<const bgf4 *>(bias + col); gv[b] = *reinterpret_cast<const bgf4 *>(epi.gamma + col); bev[b] = *reinterpret_cast<const bgf4 *>(epi.beta + col);
+    }
+    float stat[MI];
+#pragma unroll
+    for (int a = 0; a < MI; a++) {
+      const int row = m0 + 16 * a + li;
+      float p = 0.f;
+#pragma unroll
+      for (int b = 0; b < NI; b++) {
+        if (row < M) *reinterpret_cast<bgf4 *>(C + (size_t)row * ldc + nw + 16 * b + 4 * kq) = acc[a][b];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
+      }
+      p += __shfl_xor(p, 16);
+      stat[a] = p + __shfl_xor(p, 32);
+    }
+    auto exchange = [&](float *red) {  // stat[a] <- sum over the waves
+      if (kq == 0) {
+#pragma unroll
+        for (int a = 0; a < MI; a++) red[(16 * a + li) * NW + wave] = stat[a];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < MI; a++) {
+        const bgf4 *q = reinterpret_cast<const bgf4 *>(red + (16 * a + li) * NW);
+        const bgf4 v0 = q[0], v1 = q[1];
+        stat[a] = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
+      }
+    };
+    exchange(red1);
+    const float inv_n = 1.f / (float)BN;
+    float mean[MI];
+#pragma unroll
+    for (int a = 0; a < MI; a++) {
+      mean[a] = stat[a] * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int b = 0; b < NI; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { acc[a][b][r] -= mean[a]; q += acc[a][b][r] * acc[a][b][r]; }      // centred from here on
+      q += __shfl_xor(q, 16);
+      stat[a] = q + __shfl_xor(q, 32);
+    }
+    exchange(red2);
+#pragma unroll
+    for (int a = 0; a < MI; a++) {
+      const int row = m0 + 16 * a + li;
+      const float rstd = rsqrtf(stat[a] * inv_n + epi.eps);
+      if (row < M) {
+#pragma unroll
+        for (int b = 0; b < NI; b++) {
+          const bgf4 y = acc[a][b] * rstd * gv[b] + bev[b];
+          *reinterpret_cast<bgu2 *>(epi.y16 + (size_t)row * epi.ldy16 + nw + 16 * b + 4 * kq) = bgu2{bg_pack(y.x, y.y), bg_pack(y.z, y.w)};
+        }
+        if (wave == 0 && kq == 0) { epi.stats[2 * (size_t)row] = mean[a]; epi.stats[2 * (size_t)row + 1] = rstd; }
+      }
+    }
+  }
+  if constexpr (EPI == 2) {
+    float *red = reinterpret_cast<float *>(bg_lds);                  // [BM rows][NW][2]
+    // (bias / gamma of a column block are re-loaded where they are used — L1 hits — instead of 8 NI registers held through both passes)
+    const float inv_n = 1.f / (float)BN;
+    float m1[MI], m2[MI];                            // (mean / rstd of a row are re-loaded in the second pass)        // (z is loaded twice, once per pass: keeping it live costs MI NI 4 registers)
+#pragma unroll
+    for (int a = 0; a < MI; a++) {
+      const int row = m0 + 16 * a + li;
+      const bool ok = row < M;
+      const size_t rr = ok ? row : M - 1;
+      const float mean_a = epi.stats[2 * rr], rstd_a = epi.stats[2 * rr + 1];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int b = 0; b < NI; b++) {
+        const int col = nw + 16 * b + 4 * kq;
+        const bgf4 z4 = *reinterpret_cast<const bgf4 *>(epi.z + rr * epi.ldz + col);
+        const bgf4 bv4 = *reinterpret_cast<const bgf4 *>(bias + col), gv4 = *reinterpret_cast<const bgf4 *>(epi.gamma + col);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (!ok) acc[a][b][r] = 0.f;                  // (rows past M: clamped duplicates of the last row — nothing of them may reach the column sums)
+          const float v = z4[r] + bv4[r];
+          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean_a) * rstd_a, da = acc[a][b][r] * gv4[r];
+          s1 += da; s2 += da * ah;
+        }
+      }
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      m1[a] = s1 + __shfl_xor(s1, 32); m2[a] = s2 + __shfl_xor(s2, 32);
+      asm volatile("" ::: "memory");            // one row tile's z at a time: hoisting all MI NI loads spills (77 registers at NI = 4)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kq == 0) {
+#pragma unroll
+      for (int a = 0; a < MI; a++) *reinterpret_cast<bgf2 *>(red + ((16 * a + li) * NW + wave) * 2) = bgf2{m1[a], m2[a]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < MI; a++) {
+      const bgf4 *q = reinterpret_cast<const bgf4 *>(red + (16 * a + li) * NW * 2);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < NW / 2; w4++) { const bgf4 x = q[w4]; t1 += x.x + x.z; t2 += x.y + x.w; }
+      m1[a] = t1 * inv_n; m2[a] = t2 * inv_n;
+    }
+    // second pass column block by column block: the three column sums of ONE block are live at a time (all NI of them cost 12 NI registers).
+    // z is RE-LOADED through an opaque pointer: otherwise the loads (and the sigmoid / ahat values computed from them) of the first pass are
+    // kept live across the exchange for the second one — MI NI 12 registers, spilled at NI = 4
+    const float *z2 = epi.z;
+    asm volatile("" : "+s"(z2));
+    float *pp = epi.partial + (size_t)blockIdx.x * 3 * BN;
+#pragma unroll
+    for (int b = 0; b < NI; b++) {
+      bgf4 cg = {0.f, 0.f, 0.f, 0.f}, cb = cg, cz = cg;
+      const int col = nw + 16 * b + 4 * kq;
+      const bgf4 bv4 = *reinterpret_cast<const bgf4 *>(bias + col), gv4 = *reinterpret_cast<const bgf4 *>(epi.gamma + col);
+#pragma unroll
+      for (int a = 0; a < MI; a++) {
+        const int row = m0 + 16 * a + li;
+        const bool ok = row < M;
+        const size_t rr = ok ? row : M - 1;
+        const bgf4 z4 = *reinterpret_cast<const bgf4 *>(z2 + rr * epi.ldz + col);
+        const float mean_a = epi.stats[2 * rr], rstd_a = epi.stats[2 * rr + 1];
+        bgf4 o;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float v = z4[r] + bv4[r], dy = acc[a][b][r];
+          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean_a) * rstd_a, da = dy * gv4[r];
+          const float dact = rstd_a * (da - m1[a] - ah * m2[a]);
+          o[r] = ok ? dact * (sig * (1.f + v * (1.f - sig))) : 0.f;
+          cg[r] += dy * ah; cb[r] += dy; cz[r] += o[r];
+        }
+        if (ok) *reinterpret_cast<bgu2 *>(epi.y16 + (size_t)row * epi.ldy16 + col) = bgu2{bg_pack(o.x, o.y), bg_pack(o.z, o.w)};
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) { cg[r] = bg_row16_sum(cg[r]); cb[r] = bg_row16_sum(cb[r]); cz[r] = bg_row16_sum(cz[r]); }
+      if (li == 0) { *reinterpret_cast<bgf4 *>(pp + col) = cg; *reinterpret_cast<bgf4 *>(pp + BN + col) = cb; *reinterpret_cast<bgf4 *>(pp + 2 * BN + col) = cz; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (EPI == 3 || EPI == 4) {
+    // element-wise on the tile (any N: columns beyond N are computed on clamped weight rows and never stored)
+    const bool vec = EPI == 3 ? (!(ldc & 3) && !((uintptr_t)C & 15)) : true;
+#pragma unroll
+    for (int b = 0; b < NI; b++) {
+      const int col = n0 + nw + 16 * b + 4 * kq;
+      bgf4 bv;
+#pragma unroll
+      for (int r = 0; r < 4; r++) bv[r] = col + r < N ? bias[col + r] : 0.f;
+      bgf4 cz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < MI; a++) {
+        const int row = m0 + 16 * a + li;
+        const bool ok = row < M;
+        bgf4 o;
+        if constexpr (EPI == 3) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[r]; o[r] = v / (1.f + expf(-v)); }
+          if (ok) {
+            float *zo = C + (size_t)row * ldc + col;
+            if (vec && col + 3 < N) *reinterpret_cast<bgf4 *>(zo) = acc[a][b];
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; r++) if (col + r < N) zo[r] = acc[a][b][r];
+            }
+          }
+        } else {
+          const size_t rr = ok ? row : M - 1;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float zz = col + r < N ? epi.z[rr * epi.ldz + col + r] : 0.f;
+            const float v = zz + bv[r], sig = 1.f / (1.f + expf(-v));
+            o[r] = ok ? acc[a][b][r] * (sig * (1.f + v * (1.f - sig))) : 0.f;
+            cz[r] += o[r];
+          }
+        }
+        if (ok) {
+          if (EPI == 3 && epi.yf) {
+            float *yo = epi.yf + (size_t)row * epi.ldyf + col;
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (col + r < N) yo[r] = o[r];
+          } else {
+            bf16_t *yo = epi.y16 + (size_t)row * epi.ldy16 + col;
+            if (col + 3 < N) *reinterpret_cast<bgu2 *>(yo) = bgu2{bg_pack(o.x, o.y), bg_pack(o.z, o.w)};
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; r++) if (col + r < N) yo[r] = (bf16_t)(bg_pack(o[r], 0.f) & 0xffffu);
+            }
+          }
+        }
+      }
+      if constexpr (EPI == 4) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) cz[r] = bg_row16_sum(cz[r]);
+        if (li == 0) {
+          float *pp = epi.partial + (size_t)blockIdx.x * N + col;
+#pragma unroll
+          for (int r = 0; r < 4; r++) if (col + r < N) pp[r] = cz[r];
+        }
+      }
+    }
+  }
+#undef li
+#undef kq
 }
 
 // ---- dW = dY^T X ----------------------------------------------------------------------------------------------------------------------
@@ -255,9 +488,9 @@ __device__ __forceinline__ void bgemm_dw_tile(const void *__restrict__ dYv, int 
   // beyond r_end must be exact zeros (they are summed over): not loaded.
   constexpr int YU = YF32 ? 32 : 16, XU = XF32 ? 32 : 16, YP = YU / 8, XP = XU / 8, YE = 128 / YU, XE = 128 / XU;
   struct Stage { bgu4 y[YP], x[XP]; };
-  bgf4 colacc[YF32 ? 1 : 2];               // sums over this thread's rows of its dY columns (bias gradient): 4 resp. 8 columns
+  bgf4 colacc[2];                          // sums over this thread's rows of its dY columns (bias gradient): 4 resp. 8 columns
   colacc[0] = bgf4{0.f, 0.f, 0.f, 0.f};
-  if (!YF32) colacc[1] = bgf4{0.f, 0.f, 0.f, 0.f};
+  colacc[1] = bgf4{0.f, 0.f, 0.f, 0.f};
   const int yu = t % YU, xu = t % XU;       // (256 % YU == 0: the unit of a thread is the same in every pass)
   auto ldu = [&](const void *base, int ld, int row, int col, int width, bool f32, bool ok) -> bgu4 {
     bgu4 raw = {0u, 0u, 0u, 0u};
@@ -304,7 +537,7 @@ __device__ __forceinline__ void bgemm_dw_tile(const void *__restrict__ dYv, int 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           colacc[0][j] += bg_f32((bf16_t)(R.y[p][j >> 1] >> (16 * (j & 1))));
-          colacc[YF32 ? 0 : 1][j] += bg_f32((bf16_t)(R.y[p][2 + (j >> 1)] >> (16 * (j & 1))));
+          colacc[1][j] += bg_f32((bf16_t)(R.y[p][2 + (j >> 1)] >> (16 * (j & 1))));
         }
         *reinterpret_cast<bgu4 *>(sy + bg_tr_off(r, yu)) = R.y[p];
       }
@@ -370,7 +603,7 @@ __device__ __forceinline__ void bgemm_dw_tile(const void *__restrict__ dYv, int 
     __syncthreads();
     float *red = reinterpret_cast<float *>(bg_lds);            // [256 / YU][128]
     *reinterpret_cast<bgf4 *>(red + (t / YU) * BGDW_BT + YE * yu) = colacc[0];
-    if (!YF32) *reinterpret_cast<bgf4 *>(red + (t / YU) * BGDW_BT + YE * yu + 4) = colacc[YF32 ? 0 : 1];
+    if (!YF32) *reinterpret_cast<bgf4 *>(red + (t / YU) * BGDW_BT + YE * yu + 4) = colacc[1];
     __syncthreads();
     if (t < BGDW_BT) {
       float v = 0.f;

@@ -50,6 +50,21 @@ static void bdw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_
   *ld_slab = ((K + BGDW_BT - 1) / BGDW_BT) * BGDW_BT + 4;
 }
 
+// ---- fused block epilogues (whole-row tiles: the layer is exactly one tile wide)
+static bool row_tile_width(int N) { return N == 128 || N == 256 || N == 512; }
+template <int EPI>
+static int bgemm_epi(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, const BgEpi &epi, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (a_is_f32) return bgemm_by_width<EPI, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+  return bgemm_by_width<EPI, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+}
+static int check_operands(const char *what, const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, int M, int N, int K) {
+  if (!A || !B) return fail(TMJX_EINVAL, std::string(what) + ": null argument");
+  if (M < 1 || N < 1 || K < 1 || lda < K || ldb < ((K + 63) & ~63)) return fail(TMJX_EINVAL, std::string(what) + ": bad sizes / leading dimensions (ldb must reach ceil64(K))");
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 7) || (lda & (a_is_f32 ? 3 : 7))) return fail(TMJX_EINVAL, std::string(what) + ": operand rows must be 16-byte aligned");
+  return TMJX_OK;
+}
+
 extern "C" {
 
 int tmjx_bf16_shadow(const tmjx_bf16_shadow_t *items, int n, void *stream) {
@@ -79,6 +94,51 @@ int tmjx_bgemm_nt(const void *A, int a_is_f32, int lda, const uint16_t *B, int l
   const BgEpi epi{};
   if (a_is_f32) return bgemm_by_width<0, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
   return bgemm_by_width<0, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+}
+
+int tmjx_bgemm_row_tile_ok(int N) { return row_tile_width(N) ? 1 : 0; }
+long long tmjx_bgemm_partial_floats(int M, int N, int sums) { return (M < 1 || N < 1) ? 0 : (long long)((M + 79) / 80) * sums * N; }
+
+int tmjx_bgemm_ln_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, const float *gamma, const float *beta, float *Z, int ldz,
+                      uint16_t *Y16, int ldy16, float *stats, int M, int N, int K, float eps, void *stream) {
+  if (int rc = check_operands("tmjx_bgemm_ln_fwd", A, a_is_f32, lda, B, ldb, M, N, K)) return rc;
+  if (!bias || !gamma || !beta || !Z || !Y16 || !stats) return fail(TMJX_EINVAL, "tmjx_bgemm_ln_fwd: null argument");
+  if (!row_tile_width(N) || ldz < N || ldy16 < N || (ldz & 3) || (ldy16 & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)Y16 & 7))
+    return fail(TMJX_EINVAL, "tmjx_bgemm_ln_fwd: N must be 128, 256 or 512 and the outputs' rows aligned");
+  BgEpi e{};
+  e.gamma = gamma; e.beta = beta; e.stats = stats; e.y16 = Y16; e.ldy16 = ldy16; e.eps = eps;
+  return bgemm_epi<1>(A, a_is_f32, lda, B, ldb, bias, Z, ldz, M, N, K, e, stream);
+}
+
+int tmjx_bgemm_ln_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const float *z, int ldz, const float *bias, const float *gamma,
+                      const float *stats, uint16_t *dZ16, int lddz, float *partial, int M, int N, int K, void *stream) {
+  if (int rc = check_operands("tmjx_bgemm_ln_bwd", dY, dy_is_f32, ldy, Bt, ldb, M, N, K)) return rc;
+  if (!z || !bias || !gamma || !stats || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bgemm_ln_bwd: null argument");
+  if (!row_tile_width(N) || ldz < N || lddz < N || (ldz & 3) || (lddz & 3) || ((uintptr_t)z & 15) || ((uintptr_t)dZ16 & 7))
+    return fail(TMJX_EINVAL, "tmjx_bgemm_ln_bwd: N must be 128, 256 or 512 and z / dZ rows aligned");
+  BgEpi e{};
+  e.gamma = gamma; e.stats = const_cast<float *>(stats); e.y16 = dZ16; e.ldy16 = lddz; e.z = z; e.ldz = ldz; e.partial = partial;
+  return bgemm_epi<2>(dY, dy_is_f32, ldy, Bt, ldb, bias, nullptr, N, M, N, K, e, stream);
+}
+
+int tmjx_bgemm_silu_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *Z, int ldz, uint16_t *Y16, int ldy16,
+                        float *Yf, int ldyf, int M, int N, int K, void *stream) {
+  if (int rc = check_operands("tmjx_bgemm_silu_fwd", A, a_is_f32, lda, B, ldb, M, N, K)) return rc;
+  if (!bias || !Z || (!Y16 && !Yf)) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_fwd: null argument");
+  if (ldz < N || (Y16 && (ldy16 < N || (ldy16 & 3) || ((uintptr_t)Y16 & 7))) || (Yf && ldyf < N)) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_fwd: bad output leading dimensions / alignment");
+  BgEpi e{};
+  e.y16 = Y16; e.ldy16 = ldy16; e.yf = Yf; e.ldyf = ldyf;
+  return bgemm_epi<3>(A, a_is_f32, lda, B, ldb, bias, Z, ldz, M, N, K, e, stream);
+}
+
+int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz,
+                        float *partial, int M, int N, int K, void *stream) {
+  if (int rc = check_operands("tmjx_bgemm_silu_bwd", dY, dy_is_f32, ldy, Bt, ldb, M, N, K)) return rc;
+  if (!z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: null argument");
+  if (ldz < N || lddz < N || (lddz & 3) || ((uintptr_t)dZ16 & 7)) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: bad leading dimensions / alignment");
+  BgEpi e{};
+  e.y16 = dZ16; e.ldy16 = lddz; e.z = z; e.ldz = ldz; e.partial = partial;
+  return bgemm_epi<4>(dY, dy_is_f32, ldy, Bt, ldb, bias, nullptr, N, M, N, K, e, stream);
 }
 
 long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K) {
