@@ -189,7 +189,7 @@ def bgemm_silu_fwd(x, wb, N: int, K: int, bias, y_f32: bool = False):
     x = _rows2d(x)
     M = x.shape[0]
     z = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    ld = (N + 3) // 4 * 4
+    ld = (N + 7) // 8 * 8
     y = torch.empty((M, ld), dtype=torch.float32 if y_f32 else torch.bfloat16, device=x.device)
     _launch("tmjx_bgemm_silu_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(z), N,
             None if y_f32 else _p(y), ld, _p(y) if y_f32 else None, ld, M, N, K)
@@ -202,7 +202,7 @@ def bgemm_silu_bwd(dy, wtb, N: int, K: int, z, bias):
     from .. import hip as _hip
     dy = _rows2d(dy)
     M = dy.shape[0]
-    ld = (N + 3) // 4 * 4
+    ld = (N + 7) // 8 * 8
     dz = torch.empty((M, ld), dtype=torch.bfloat16, device=dy.device)
     partial = torch.empty(int(_hip.lib().tmjx_bgemm_partial_floats(M, N, 1)), dtype=torch.float32, device=dy.device)
     _launch("tmjx_bgemm_silu_bwd", dy.device, _p(dy), int(dy.dtype == torch.float32), _ld(dy), _p(wtb), wtb.stride(0), _p(z), z.stride(0), _p(bias), _p(dz), ld,
@@ -337,6 +337,163 @@ class deferred_weight_grads:
         with torch.cuda.device(dev):
             _hip.check(L.tmjx_gemm_dw_grouped(arr, len(problems), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_gemm_dw_grouped")
         self.keep += [scratch] + [t for q in problems for t in q[:2]]
+
+
+# ---- a whole MLP chain as ONE autograd function (bf16 GEMM-input mode) -------------------------------------------------------------------
+class _Layer:
+    """One layer of a chain: kind "ln" (Dense -> SiLU -> LayerNorm block), "silu" (Dense -> SiLU, brax value MLP) or "dense" (un-activated)."""
+    __slots__ = ("kind", "lin", "norm", "fused")
+
+    def __init__(self, kind, lin, norm=None):
+        from .. import hip as _hip
+        self.kind, self.lin, self.norm = kind, lin, norm
+        # whole-row epilogues need the layer to be one tile wide; Dense -> SiLU epilogues are element-wise (any width)
+        self.fused = kind == "silu" or (kind == "ln" and bool(_hip.lib().tmjx_bgemm_row_tile_ok(lin.out_features)))
+
+    def params(self):
+        return [self.lin.weight, self.lin.bias] + ([self.norm.weight, self.norm.bias] if self.kind == "ln" else [])
+
+
+class _BfChainFn(torch.autograd.Function):
+    """y = chain(x) for a sequence of layers with every contraction on the bf16 kernels (csrc/gemm_bf16.h) and every block epilogue fused:
+    forward one launch per layer (tmjx_bgemm_ln_fwd / _silu_fwd / _nt), the hidden activations exist only as bf16 (the next GEMM's operand),
+    the pre-activations z stay fp32 for the backward pass; backward per layer ONE launch for the input gradient with the PRODUCING block's
+    LayerNorm / SiLU backward in its epilogue (tmjx_bgemm_ln_bwd / _silu_bwd: d loss / d z as bf16 + column-sum partials) and one for the
+    weight gradient (tmjx_bgemm_dw, transposed LDS reads), written straight into the flat gradient buffer's views where the learner provides
+    them; all column-sum partials are reduced by one grouped launch at the end.  Layers that are not one tile wide (the 1024-wide first
+    encoder block) take the unfused kernels (tmjx_bgemm_nt + tmjx_silu_ln_fwd / _bwd, fp32 activations).  `last_y_f32`: the chain ends with
+    a block whose output goes to an fp32 kernel (the value net's last hidden layer in front of the 1-wide head)."""
+
+    @staticmethod
+    def forward(ctx, x, layers, sh, dx_cols, last_y_f32, *params):
+        import ctypes as C
+        from .. import hip as _hip
+        x2 = _rows2d(x)
+        if x2.data_ptr() % 16 or x2.stride(0) % (4 if x2.dtype == torch.float32 else 8):
+            x2 = x2.contiguous()
+        saved, h = [], x2
+        for i, L in enumerate(layers):
+            lin = L.lin
+            N, K = lin.weight.shape
+            last = i == len(layers) - 1
+            if L.kind == "dense":
+                y = bgemm_nt(h, sh.w[lin], N, K, lin.bias)
+                saved.append((h, None, None))
+            elif L.kind == "silu":
+                z, y = bgemm_silu_fwd(h, sh.w[lin], N, K, lin.bias, y_f32=last and last_y_f32)
+                saved.append((h, z, None))
+            elif L.fused:
+                z, y, stats = bgemm_ln_fwd(h, sh.w[lin], N, K, lin.bias, L.norm.weight, L.norm.bias, L.norm.eps)
+                saved.append((h, z, stats))
+            else:
+                z = bgemm_nt(h, sh.w[lin], N, K)
+                y = torch.empty_like(z)
+                stats = torch.empty((z.shape[0], 2), dtype=torch.float32, device=z.device)
+                _launch("tmjx_silu_ln_fwd", z.device, _p(z), _p(lin.bias), _p(L.norm.weight), _p(L.norm.bias), _p(y), _p(stats), z.shape[0], N, float(L.norm.eps))
+                saved.append((h, z, stats))
+            h = y
+        ctx.layers, ctx.sh, ctx.dx_cols, ctx.saved, ctx.x_shape = layers, sh, dx_cols, saved, x.shape
+        return h.view(*x.shape[:-1], h.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .. import hip as _hip
+        layers, sh, saved = ctx.layers, ctx.sh, ctx.saved
+        Lh = _hip.lib()
+        d = deferred_weight_grads.active
+        g = _rows2d(dout)
+        if g.data_ptr() % 16 or g.stride(0) % 4:
+            g = g.contiguous()
+        M = g.shape[0]
+        g_is_dz = layers[-1].kind == "dense"
+        grads = {}                 # id(param) -> gradient tensor
+        colsums = []               # (partial, out, rows, width): reduced by one grouped launch
+
+        def dest(p):               # the flat-buffer view to write a weight gradient into, if the learner provides one
+            if d is not None and p.grad is not None and p.grad.shape == p.shape and p.grad.stride(-1) == 1 and id(p) not in d.seen:
+                d.seen.add(id(p))
+                return p.grad
+            return None
+
+        def block_sums(L, partial):
+            N = L.lin.out_features
+            if L.kind == "ln":
+                out = torch.empty((3, N), dtype=torch.float32, device=partial.device)
+                colsums.append((partial, out, partial.shape[0], 3 * N))
+                grads[id(L.norm.weight)], grads[id(L.norm.bias)], grads[id(L.lin.bias)] = out[0], out[1], out[2]
+            else:
+                out = torch.empty(N, dtype=torch.float32, device=partial.device)
+                colsums.append((partial, out, partial.shape[0], N))
+                grads[id(L.lin.bias)] = out
+
+        dx = None
+        for i in range(len(layers) - 1, -1, -1):
+            L = layers[i]
+            lin = L.lin
+            N, K = lin.weight.shape
+            h, z, stats = saved[i]
+            if not g_is_dz:        # g = d loss / d y of this block: its own (unfused) backward
+                if L.kind == "ln":
+                    gy = g if g.dtype == torch.float32 and g.is_contiguous() else g.float().contiguous()
+                    dz = torch.empty_like(z)
+                    g3 = torch.empty((3, N), dtype=torch.float32, device=z.device)
+                    partial = torch.empty(int(Lh.tmjx_silu_ln_partial_floats(M, N)), dtype=torch.float32, device=z.device)
+                    _launch("tmjx_silu_ln_bwd", z.device, _p(gy), _p(z), _p(lin.bias), _p(L.norm.weight), _p(stats), _p(dz), _p(g3), _p(partial), M, N)
+                    grads[id(L.norm.weight)], grads[id(L.norm.bias)], grads[id(lin.bias)] = g3[0], g3[1], g3[2]
+                    g = dz
+                else:
+                    gy = g if g.dtype == torch.float32 else g.float()
+                    ld = (N + 7) // 8 * 8
+                    dz = torch.empty((M, ld), dtype=torch.bfloat16, device=z.device)
+                    partial = torch.empty(int(Lh.tmjx_bgemm_partial_floats(M, N, 1)), dtype=torch.float32, device=z.device)
+                    _launch("tmjx_bf_silu_bwd", z.device, _p(gy), gy.stride(0), _p(z), z.stride(0), _p(lin.bias), _p(dz), ld, _p(partial), M, N)
+                    block_sums(L, partial.view(-1, N))
+                    g = dz[:, :N]
+            # g = d loss / d z of layer i
+            with_bias = L.kind == "dense"
+            dw, db = bgemm_dw(g, h, with_bias, out=dest(lin.weight), out_bias=dest(lin.bias) if with_bias else None)
+            grads[id(lin.weight)] = dw
+            if with_bias:
+                grads[id(lin.bias)] = db
+            if i > 0:
+                P = layers[i - 1]
+                Np = P.lin.out_features
+                ph, pz, pstats = saved[i - 1]
+                if P.fused and P.kind == "ln":
+                    g, partial = bgemm_ln_bwd(g, sh.wt[lin], Np, N, pz, P.lin.bias, P.norm.weight, pstats)
+                    block_sums(P, partial)
+                    g_is_dz = True
+                elif P.fused:
+                    g, partial = bgemm_silu_bwd(g, sh.wt[lin], Np, N, pz, P.lin.bias)
+                    block_sums(P, partial)
+                    g_is_dz = True
+                else:
+                    g = bgemm_nt(g, sh.wt[lin], Np, N)
+                    g_is_dz = False
+            elif ctx.needs_input_grad[0]:
+                cols = K if ctx.dx_cols is None else int(ctx.dx_cols)
+                dx = torch.empty((M, K), dtype=torch.float32, device=g.device)
+                bgemm_nt(g, sh.wt[lin], cols, N, out=dx)
+                dx = dx.view(ctx.x_shape)
+        if colsums:
+            arr = (_hip.ColsumProblem * len(colsums))(*[_hip.ColsumProblem(pt.data_ptr(), o.data_ptr(), nb, wd) for pt, o, nb, wd in colsums])
+            _launch("tmjx_colsum_grouped", colsums[0][0].device, arr, len(colsums))
+            ctx._keep = colsums
+        out = []
+        for L in layers:
+            out += [grads.get(id(p)) for p in L.params()]
+        return (dx, None, None, None, None, *out)
+
+
+def bf16_chain(x, layers, dx_cols=None, last_y_f32=False):
+    params = [p for L in layers for p in L.params()]
+    return _BfChainFn.apply(x, layers, gemm_inputs.shadows, dx_cols, last_y_f32, *params)
+
+
+def _bf16_chain_ok(x) -> bool:
+    sh = gemm_inputs.shadows
+    return gemm_inputs.dtype == torch.bfloat16 and sh is not None and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not os.environ.get("TMJX_NO_BF16_CHAIN")
+
 
 
 class _BlockLink:
@@ -700,9 +857,16 @@ class IntentionPolicy(nn.Module):
         """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar), or (logits, mean | logvar as
         one [.., 2*latents] tensor) with `return_fc2` (what the fused loss head consumes)."""
         traj = obs[..., :self.reference_obs_size]
-        with ln_bwd_links():       # encoder and decoder are chains: each block's output feeds exactly one dense layer
-            h = self.encoder(traj)
-            fc2 = self.fc2(h)
+        chains = _bf16_chain_ok(obs) and all(m.out_features % 4 == 0 for m in (self.fc2, self.head))
+        if chains:                 # bf16 GEMM-input mode: the encoder (+ fc2) as ONE autograd function (fused epilogues, bf16 hidden activations)
+            if getattr(self, "_enc_chain", None) is None:
+                self._enc_chain = [_Layer("ln", b.dense, b.norm) for b in self.encoder] + [_Layer("dense", self.fc2)]
+                self._dec_chain = [_Layer("ln", b.dense, b.norm) for b in self.decoder] + [_Layer("dense", self.head)]
+            fc2 = bf16_chain(traj, self._enc_chain)
+        else:
+            with ln_bwd_links():       # encoder and decoder are chains: each block's output feeds exactly one dense layer
+                h = self.encoder(traj)
+                fc2 = self.fc2(h)
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
         if (not deterministic and fc2.is_cuda and fc2.dtype == torch.float32 and obs.dtype == torch.float32 and not torch.is_autocast_enabled()
                 and fc2.numel() >= 2 * self.latents * 1024):
@@ -712,8 +876,11 @@ class IntentionPolicy(nn.Module):
                 eps = torch.randn_like(mean)
             x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size)
             x = x.view(*lead, x.shape[-1])
-            with ln_bwd_links():
-                logits = self.head(self.decoder(x))
+            if chains:
+                logits = bf16_chain(x, self._dec_chain, dx_cols=self.latents)
+            else:
+                with ln_bwd_links():
+                    logits = self.head(self.decoder(x))
             if return_fc2:
                 return logits, fc2
             return logits, mean, logvar
@@ -724,7 +891,7 @@ class IntentionPolicy(nn.Module):
                 eps = torch.randn_like(mean)
             z = mean + eps * torch.exp(0.5 * logvar)
         x = torch.cat([z, obs[..., self.reference_obs_size:]], dim=-1)
-        logits = self.head(self.decoder(x))
+        logits = bf16_chain(x, self._dec_chain) if chains else self.head(self.decoder(x))
         if return_fc2:
             return logits, fc2
         return logits, mean, logvar
@@ -742,6 +909,13 @@ class ValueNet(nn.Module):
         self.net = nn.Sequential(*layers)
 
     def forward(self, obs):
+        if _bf16_chain_ok(obs) and len(self.net) > 1:
+            # bf16 GEMM-input mode: the hidden layers as one chain (Dense -> SiLU epilogues), the 1-wide head on the fp32 kernels
+            if getattr(self, "_chain", None) is None:
+                dense = [m for m in self.net if isinstance(m, nn.Linear)]
+                self._chain = [_Layer("silu", m) for m in dense[:-1]]
+            h = bf16_chain(obs, self._chain, last_y_f32=True)
+            return self.net[-1](h).squeeze(-1)
         return self.net(obs).squeeze(-1)
 
 

@@ -427,10 +427,15 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
           }
         } else {
           const size_t rr = ok ? row : M - 1;
+          bgf4 z4 = {0.f, 0.f, 0.f, 0.f};
+          if (!(epi.ldz & 3) && col + 3 < N) z4 = *reinterpret_cast<const bgf4 *>(epi.z + rr * epi.ldz + col);       // (z's base is 16-byte aligned: checked by the entry point)
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (col + r < N) z4[r] = epi.z[rr * epi.ldz + col + r];
+          }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float zz = col + r < N ? epi.z[rr * epi.ldz + col + r] : 0.f;
-            const float v = zz + bv[r], sig = 1.f / (1.f + expf(-v));
+            const float v = z4[r] + bv[r], sig = 1.f / (1.f + expf(-v));
             o[r] = ok ? acc[a][b][r] * (sig * (1.f + v * (1.f - sig))) : 0.f;
             cz[r] += o[r];
           }
@@ -463,6 +468,25 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
   }
 #undef li
 #undef kq
+}
+
+// Unfused backward of a Dense -> SiLU block whose output gradient does not come out of a bf16 GEMM (the value net's last hidden layer: its
+// consumer is the 1-wide head on the fp32 kernels): dz = dy silu'(z + bias) as bf16 + per-80-row-tile column sums.  One workgroup per row tile,
+// a thread per column (coalesced rows).
+__global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ dy, int ldy, const float *__restrict__ z, int ldz, const float *__restrict__ bias,
+                                                     bf16_t *__restrict__ dz, int lddz, float *__restrict__ partial, int M, int N) {
+  const int r0 = blockIdx.x * 80, r1 = min(M, r0 + 80);
+  for (int c = threadIdx.x; c < N; c += 256) {
+    const float b = bias[c];
+    float sum = 0.f;
+    for (int r = r0; r < r1; r++) {
+      const float v = z[(size_t)r * ldz + c] + b, sig = 1.f / (1.f + expf(-v));
+      const float o = dy[(size_t)r * ldy + c] * (sig * (1.f + v * (1.f - sig)));
+      dz[(size_t)r * lddz + c] = (bf16_t)(bg_pack(o, 0.f) & 0xffffu);
+      sum += o;
+    }
+    partial[(size_t)blockIdx.x * N + c] = sum;
+  }
 }
 
 // ---- dW = dY^T X ----------------------------------------------------------------------------------------------------------------------

@@ -135,10 +135,17 @@ int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *
                         float *partial, int M, int N, int K, void *stream) {
   if (int rc = check_operands("tmjx_bgemm_silu_bwd", dY, dy_is_f32, ldy, Bt, ldb, M, N, K)) return rc;
   if (!z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: null argument");
-  if (ldz < N || lddz < N || (lddz & 3) || ((uintptr_t)dZ16 & 7)) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: bad leading dimensions / alignment");
+  if (ldz < N || lddz < N || (lddz & 3) || ((uintptr_t)dZ16 & 7) || ((uintptr_t)z & 15)) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: bad leading dimensions / alignment");
   BgEpi e{};
   e.y16 = dZ16; e.ldy16 = lddz; e.z = z; e.ldz = ldz; e.partial = partial;
   return bgemm_epi<4>(dY, dy_is_f32, ldy, Bt, ldb, bias, nullptr, N, M, N, K, e, stream);
+}
+
+int tmjx_bf_silu_bwd(const float *dY, int ldy, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream) {
+  if (!dY || !z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd: null argument");
+  if (M < 1 || N < 1 || ldy < N || ldz < N || lddz < N) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd: bad sizes / leading dimensions");
+  hipLaunchKernelGGL(k_bf_silu_bwd, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, z, ldz, bias, dZ16, lddz, partial, M, N);
+  return check_launch("k_bf_silu_bwd");
 }
 
 long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K) {
