@@ -172,7 +172,8 @@ def main(argv=None, runner=None):
     from track_mjx_amd.walker import Rodent
     table = _clips.make_synthetic_clips(Rodent(**cfg["walker_config"]).model, bc["n_clips"], n_frames=cfg["reference_config"]["clip_length"],
                                         mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"])
-    envs = [wrap(build_env(cfg, n_local // ngrp, device, reference_clip=table), episode_length=195) for _ in range(ngrp)]
+    envs = [wrap(build_env(cfg, n_local // ngrp, device, reference_clip=table), episode_length=195)]
+    envs += [wrap(build_env(cfg, n_local // ngrp, device, reference_clip=table, share_clips_with=envs[0]), episode_length=195) for _ in range(1, ngrp)]      # one clip upload per rank
     env = envs[0]
     nc = cfg["network_config"]
     learner = ppo.PPOLearner(envs if ngrp > 1 else env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"],

@@ -293,6 +293,23 @@ long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is_f32, int ldx, float *dW, int lddw, float *db, float *scratch,
                   int M, int N, int K, void *stream);
 
+/* The stores of one env-group step into the roll-out buffers in one launch (the Transition of brax acting.actor_step, as the learner of
+ * track_mjx/agent/mlp_ppo/ppo.py:330-348 collects it): obs [W][n] (env-minor) -> up to two row-major [n][W] destinations; raw [n][A],
+ * logp [n], reward [n], trunc [n] copied; discount_dst = 1 - done.  Any destination may be NULL (skipped).  No LDS. */
+typedef struct tmjx_rollout_store_t {
+  const float *obs; float *obs_dst0, *obs_dst1;
+  const float *raw; float *raw_dst;
+  const float *logp; float *logp_dst;
+  const float *reward; float *reward_dst;
+  const float *done; float *discount_dst;
+  const float *trunc; float *trunc_dst;
+  int32_t n, W, A;
+} tmjx_rollout_store_t;
+int tmjx_rollout_store(const tmjx_rollout_store_t *s, void *stream);
+/* `m` reads `owner`'s resident clip table instead of holding a copy of its own (the env groups of one rank: one upload per rank).  `owner`
+ * must outlive every launch of `m`. */
+int tmjx_clips_share(tmjx_model *m, const tmjx_model *owner);
+
 /* Observation normaliser update (brax running_statistics.update as called at track_mjx/agent/mlp_ppo/ppo.py:357-361; math:
  * track_mjx/agent/masked_running_statistics.py:161-214) in one pass over src [rows][W] (W % 4 == 0):
  *   tmjx_stats_sums:  sums[0..W) = sum_rows(x - mean), sums[W..2W) = sum_rows((x - mean)^2); scratch >= tmjx_stats_scratch_floats(W).

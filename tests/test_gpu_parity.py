@@ -579,6 +579,65 @@ def test_pipelined_rollout_two_env_groups():
 
 
 @pytest.mark.gpu
+def test_rollout_store_kernel_and_multi_unroll_buffer_rows():
+    """tmjx_rollout_store (one launch per env-group step instead of seven copies) against the torch ops it replaces, and — through a
+    learner with TWO unrolls per training step — that row 0 of the second unroll equals next_observation_last of the first, every
+    observation row t + 1 is the env's observation after step t, and the env groups share ONE resident clip table."""
+    import ctypes as C
+    from track_mjx_amd import hip
+    from track_mjx_amd.agent import ppo
+    g = torch.Generator(device=DEV).manual_seed(0)
+    n, W, A = 200, 696, 38
+    obs = torch.randn((W, n), generator=g, device=DEV)
+    raw, logp = torch.randn((n, A), generator=g, device=DEV), torch.randn(n, generator=g, device=DEV)
+    rew, done, tr = torch.randn(n, generator=g, device=DEV), (torch.rand(n, generator=g, device=DEV) < 0.3).float(), (torch.rand(n, generator=g, device=DEV) < 0.1).float()
+    d0, d1 = torch.zeros((n, W), device=DEV), torch.zeros((n, W), device=DEV)
+    o = [torch.zeros((n, A), device=DEV)] + [torch.zeros(n, device=DEV) for _ in range(4)]
+    p = lambda t: t.data_ptr()  # noqa: E731
+    q = hip.RolloutStore(p(obs), p(d0), p(d1), p(raw), p(o[0]), p(logp), p(o[1]), p(rew), p(o[2]), p(done), p(o[3]), p(tr), p(o[4]), n, W, A)
+    hip.check(hip.lib().tmjx_rollout_store(C.byref(q), None), "tmjx_rollout_store")
+    torch.cuda.synchronize()
+    assert torch.equal(d0, obs.t()) and torch.equal(d1, obs.t()) and torch.equal(o[0], raw) and torch.equal(o[1], logp)
+    assert torch.equal(o[2], rew) and torch.equal(o[3], 1 - done) and torch.equal(o[4], tr)
+    q = hip.RolloutStore(None, None, None, None, None, None, None, p(rew), p(o[1]), None, None, None, None, n, 0, 0)      # every destination is optional
+    hip.check(hip.lib().tmjx_rollout_store(C.byref(q), None), "tmjx_rollout_store")
+    torch.cuda.synchronize()
+    assert torch.equal(o[1], rew)
+    # two env groups sharing one clip table, two unrolls per training step
+    e0 = make_env_and_oracle(num_envs=32, n_clips=4, wrappers=True, seed=0)[0]
+    from track_mjx_amd.environment import MultiClipTracking, RewardConfig, wrap
+    from tests.common import default_walker
+    w, cfg = default_walker()
+    e1 = wrap(MultiClipTracking(e0._reference_clips, w, RewardConfig(**cfg["env_config"]["reward_weights"]), **cfg["env_config"]["env_args"],
+                                **cfg["reference_config"], num_envs=32, device=DEV, share_clips_with=e0), episode_length=195)
+    L = ppo.PPOLearner([e0, e1], encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=4,
+                       batch_size=32, num_minibatches=4, num_updates_per_batch=1, seed=3)
+    assert L.unrolls == 2 and L.n_local == 64
+    seen = []
+    orig = L._store_transition
+
+    def spy(env, st, extra, d0_, d1_, t, sl):
+        seen.append((t, sl.start, st.obs.clone(), st.reward.clone(), st.done.clone(), extra["raw_action"].clone()))
+        orig(env, st, extra, d0_, d1_, t, sl)
+    L._store_transition = spy
+    for k, e in enumerate([e0, e1]):
+        L.states[k] = e.reset(torch.Generator().manual_seed(20 + k), torch.arange(32, dtype=torch.int32) % 4)
+    L.collect()
+    torch.cuda.synchronize()
+    b = L.buf
+    assert torch.equal(b["observation"][0, 64:128], b["next_observation_last"][0:64])      # unroll 1 starts where unroll 0 ended
+    for t, start, ob, rw, dn, ra in seen:
+        sl = slice(start, start + 32)
+        assert torch.equal(b["reward"][t, sl], rw) and torch.equal(b["discount"][t, sl], 1 - dn) and torch.equal(b["raw_action"][t, sl], ra)
+        nxt = b["observation"][t + 1, sl] if t + 1 < 4 else b["next_observation_last"][sl]
+        assert torch.equal(nxt, ob)
+    assert len(seen) == 2 * 4 * 2
+    out = L.update(0)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())
+
+
+@pytest.mark.gpu
 def test_bf16_gemm_inputs_match_fp32_gradients():
     """BASELINE config 5: MLP GEMMs with bf16 inputs / fp32 accumulation (autocast around the networks, parameters, loss head,
     optimizer in fp32).  On the same roll-out buffer and parameters the loss and the flat gradient must agree with the fp32

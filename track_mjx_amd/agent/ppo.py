@@ -366,6 +366,20 @@ class PPOLearner:
                                            (self._noise_seed ^ (0xD1B54A32D192ED03 * (len(self._act_rng) + 1))) & (2 ** 64 - 1), gen)
         return rs
 
+    def _store_transition(self, env, st, extra, obs_dst0, obs_dst1, t: int, sl: slice) -> None:
+        import ctypes as C
+        from .. import hip as _hip
+        raw, logp = extra["raw_action"], extra["log_prob"]
+        if not (raw.is_contiguous() and logp.is_contiguous() and st.obs.stride(0) == 1 and st.obs.stride(1) == st.obs.shape[0]):
+            raise RuntimeError("roll-out store: unexpected layout of the policy outputs / the env's observation buffer")
+        p = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
+        b = self.buf
+        q = _hip.RolloutStore(p(st.obs), p(obs_dst0), p(obs_dst1), p(raw), p(b["raw_action"][t, sl]), p(logp), p(b["log_prob"][t, sl]),
+                              p(st.reward), p(b["reward"][t, sl]), p(st.done), p(b["discount"][t, sl]), p(st.info["truncation"]), p(b["truncation"][t, sl]),
+                              st.obs.shape[0], st.obs.shape[1], raw.shape[1])
+        with torch.cuda.device(self.dev):
+            _hip.check(_hip.lib().tmjx_rollout_store(C.byref(q), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)), "tmjx_rollout_store")
+
     def _padded_weight(self, lin) -> torch.Tensor:
         K = lin.in_features
         if K % 4 == 0:
@@ -444,22 +458,20 @@ class PPOLearner:
                     sl = slice(u * n_local + offs[g], u * n_local + offs[g + 1])
                     with torch.cuda.stream(self._streams[g]) if self._streams else _nullctx():
                         st = self.states[g]
-                        self.buf["observation"][t, sl] = st.obs
+                        if u == 0 and t == 0:
+                            self.buf["observation"][0, sl] = st.obs          # (every later row is written by the step that produces it)
                         if jax_noise:
                             action, extra = self.act(st.obs, draws=(eps_all[offs[g]:offs[g + 1]], noise_all[offs[g]:offs[g + 1]]))
                         else:
                             action, extra = self._act_graphed(st.obs, g)
-                        self.buf["raw_action"][t, sl] = extra["raw_action"]     # before env.step: the graph's outputs are re-used next step
-                        self.buf["log_prob"][t, sl] = extra["log_prob"]
                         st = env.step(st, action)
-                        self.buf["reward"][t, sl] = st.reward
-                        self.buf["discount"][t, sl] = 1.0 - st.done
-                        self.buf["truncation"][t, sl] = st.info["truncation"]
+                        # ONE launch stores this step's transition: the new observation (transposed into row t + 1 — or, at the end of an
+                        # unroll, into next_observation_last and row 0 of the next unroll), raw action / log-prob of the acting policy
+                        # (the inference graph's outputs are overwritten only by the next replay), reward, discount = 1 - done, truncation
+                        nxt = self.buf["observation"][t + 1, sl] if t + 1 < T else self.buf["next_observation_last"][sl]
+                        nxt1 = self.buf["observation"][0, slice(sl.start + n_local, sl.stop + n_local)] if (t + 1 == T and u + 1 < self.unrolls) else None
+                        self._store_transition(env, st, extra, nxt, nxt1, t, sl)
                         self.states[g] = st
-            for g in range(len(self.envs)):
-                sl = slice(u * n_local + offs[g], u * n_local + offs[g + 1])
-                with torch.cuda.stream(self._streams[g]) if self._streams else _nullctx():
-                    self.buf["next_observation_last"][sl] = self.states[g].obs
         if self._streams:
             for sg in self._streams:
                 cur.wait_stream(sg)

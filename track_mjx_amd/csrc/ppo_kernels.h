@@ -800,3 +800,53 @@ __global__ void k_stats_finalize(const float *__restrict__ sums, float n_added, 
   // written by a second tiny launch (k_stats_count) — stream order makes it safe
 }
 __global__ void k_stats_count(float *count, float n_added) { *count += n_added; }
+
+// ---- roll-out buffer stores of one env-group step in ONE launch (agent/ppo.py: collect; brax acting.actor_step builds the Transition the
+// same way, track_mjx/agent/mlp_ppo/ppo.py:330-348): the env's observation [W][n] (env-minor, what the kernels and the LDS-free inference
+// read) transposed into the row-major roll-out buffer [n][W] (up to two destinations: row t + 1 of this unroll, or the unroll's
+// next_observation_last and row 0 of the next unroll), raw action / log-prob of the acting policy, reward, discount = 1 - done, truncation.
+// Seven torch copy launches per group step before (about 700 runtime copy kernels per training step).  No LDS (the other env group's
+// physics kernel owns it): one lane per env x 16 observation rows, coalesced on the env-minor side, 64 contiguous bytes per lane on the other.
+struct RolloutStore {
+  const float *obs; float *obs_dst0, *obs_dst1;
+  const float *raw; float *raw_dst;
+  const float *logp; float *logp_dst;
+  const float *reward; float *reward_dst;
+  const float *done; float *discount_dst;
+  const float *trunc; float *trunc_dst;
+  int n, W, A;
+};
+__global__ __launch_bounds__(64) void k_rollout_store(const RolloutStore s) {
+  const int e = blockIdx.x * 64 + threadIdx.x, ny = gridDim.y - 1;
+  if ((int)blockIdx.y < ny) {
+    if (e >= s.n || !s.obs) return;
+    const int k0 = blockIdx.y * 16;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = k0 + j < s.W ? s.obs[(size_t)(k0 + j) * s.n + e] : 0.f;
+    float *d[2] = {s.obs_dst0, s.obs_dst1};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (!d[q]) continue;
+      float *o = d[q] + (size_t)e * s.W + k0;
+      if (!(s.W & 3) && k0 + 16 <= s.W) {
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4 *>(o + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) if (k0 + j < s.W) o[j] = v[j];
+      }
+    }
+    return;
+  }
+  if (e < s.n) {
+    if (s.logp_dst) s.logp_dst[e] = s.logp[e];
+    if (s.reward_dst) s.reward_dst[e] = s.reward[e];
+    if (s.discount_dst) s.discount_dst[e] = 1.f - s.done[e];
+    if (s.trunc_dst) s.trunc_dst[e] = s.trunc[e];
+  }
+  if (s.raw_dst) {
+    const int total = s.n * s.A, nth = gridDim.x * 64;
+    for (int i = e; i < total; i += nth) s.raw_dst[i] = s.raw[i];
+  }
+}

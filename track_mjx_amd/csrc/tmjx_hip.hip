@@ -31,6 +31,7 @@ struct tmjx_model {
   // piece of mutable per-handle scratch: a handle serves one stream at a time (include/tmjx.h)
   mutable float *mspill = nullptr;
   mutable int mspill_envs = 0;
+  bool clips_owned = true;   // false: the clip table belongs to another handle of the same device (tmjx_clips_share)
 };
 #define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
 // record stride: state rows qpos .. qfrc_actuator, then the action, rounded up to 16 words
@@ -291,7 +292,7 @@ int tmjx_model_create(const void *blob, size_t nbytes, tmjx_model **out) {
 
 void tmjx_model_destroy(tmjx_model *m) {
   if (!m) return;
-  for (int i = 0; i < 5; i++) if (m->clips[i]) hipFree(m->clips[i]);
+  for (int i = 0; i < 5; i++) if (m->clips[i] && m->clips_owned) hipFree(m->clips[i]);
   if (m->d) hipFree(m->d);
   if (m->mspill) hipFree(m->mspill);
   delete m;
@@ -331,13 +332,36 @@ int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quatern
   size_t widths[5] = {3, 4, (size_t)(m->h.nq - 7), (size_t)(m->h.nbody - 1) * 3, 3};
   const float *src[5] = {position, quaternion, joints, body_positions, angular_velocity};
   for (int i = 0; i < 5; i++) {
-    if (m->clips[i]) { hipFree(m->clips[i]); m->clips[i] = nullptr; }
+    if (m->clips[i] && m->clips_owned) hipFree(m->clips[i]);
+    m->clips[i] = nullptr;
+  }
+  m->clips_owned = true;
+  for (int i = 0; i < 5; i++) {
     HIP_TRY(hipMalloc((void **)&m->clips[i], cf * widths[i] * sizeof(float)));
     HIP_TRY(hipMemcpy(m->clips[i], src[i], cf * widths[i] * sizeof(float), hipMemcpyHostToDevice));
   }
   m->h.clip_pos = m->clips[0]; m->h.clip_quat = m->clips[1]; m->h.clip_joints = m->clips[2];
   m->h.clip_bodypos = m->clips[3]; m->h.clip_angvel = m->clips[4];
   m->h.n_clips = n_clips; m->h.n_frames_clip = n_frames;
+  HIP_TRY(hipMemcpy(m->d, &m->h, sizeof(DModel), hipMemcpyHostToDevice));
+  return TMJX_OK;
+}
+
+// The env groups of one rank (pipelined roll-outs: one handle each) read ONE resident clip table: `m` takes over `owner`'s device
+// arrays (631 MB at 1024 clips) without owning them.  `owner` must outlive `m`'s launches and be of the same model dimensions.
+int tmjx_clips_share(tmjx_model *m, const tmjx_model *owner) {
+  if (!m || !owner) return fail(TMJX_EINVAL, "null argument");
+  if (m == owner) return TMJX_OK;
+  if (!owner->clips[0]) return fail(TMJX_EINVAL, "the owner has no clip table");
+  if (m->h.nq != owner->h.nq || m->h.nbody != owner->h.nbody || m->h.traj_length > owner->h.n_frames_clip) return fail(TMJX_EINVAL, "handles of different models cannot share a clip table");
+  for (int i = 0; i < 5; i++) {
+    if (m->clips[i] && m->clips_owned) hipFree(m->clips[i]);
+    m->clips[i] = owner->clips[i];
+  }
+  m->clips_owned = false;
+  m->h.clip_pos = m->clips[0]; m->h.clip_quat = m->clips[1]; m->h.clip_joints = m->clips[2];
+  m->h.clip_bodypos = m->clips[3]; m->h.clip_angvel = m->clips[4];
+  m->h.n_clips = owner->h.n_clips; m->h.n_frames_clip = owner->h.n_frames_clip;
   HIP_TRY(hipMemcpy(m->d, &m->h, sizeof(DModel), hipMemcpyHostToDevice));
   return TMJX_OK;
 }
@@ -872,6 +896,19 @@ int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
   hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(wg), dim3(512), lds, s, G);
   hipLaunchKernelGGL(k_dw_reduce_grouped, dim3(red), dim3(256), 0, s, G);
   return check_launch("k_gemm_dw_grouped");
+}
+
+int tmjx_rollout_store(const tmjx_rollout_store_t *q, void *stream) {
+  if (!q) return fail(TMJX_EINVAL, "null argument");
+  if (q->n < 1 || q->W < 0 || q->A < 0) return fail(TMJX_EINVAL, "bad sizes");
+  if ((q->obs_dst0 || q->obs_dst1) && (!q->obs || q->W < 1)) return fail(TMJX_EINVAL, "observation destination without a source");
+  if ((q->raw_dst && !q->raw) || (q->logp_dst && !q->logp) || (q->reward_dst && !q->reward) || (q->discount_dst && !q->done) || (q->trunc_dst && !q->trunc))
+    return fail(TMJX_EINVAL, "destination without a source");
+  RolloutStore s{q->obs, q->obs_dst0, q->obs_dst1, q->raw, q->raw_dst, q->logp, q->logp_dst, q->reward, q->reward_dst, q->done, q->discount_dst,
+                 q->trunc, q->trunc_dst, q->n, q->W, q->A};
+  const int ny = (q->obs_dst0 || q->obs_dst1) ? (q->W + 15) / 16 : 0;
+  hipLaunchKernelGGL(k_rollout_store, dim3((q->n + 63) / 64, ny + 1), dim3(64), 0, (hipStream_t)stream, s);
+  return check_launch("k_rollout_store");
 }
 
 int tmjx_stats_scratch_floats(int W) { return STATS_SLABS * 2 * W; }

@@ -86,7 +86,7 @@ class MultiClipTracking:
                  physics_steps_per_control_step: int, reset_noise_scale: float, solver: str = "cg", iterations: int = 4,
                  ls_iterations: int = 4, mj_model_timestep: float = 0.002, mocap_hz: int = 50, clip_length: int = 250,
                  random_init_range: int = 50, traj_length: int = 5, *, num_envs: int = 1, device: str | torch.device = "cuda",
-                 episode_length: int | None = None, auto_reset: bool = False, **kwargs: Any):
+                 episode_length: int | None = None, auto_reset: bool = False, share_clips_with: "MultiClipTracking | None" = None, **kwargs: Any):
         if solver.lower() != "cg":
             raise NotImplementedError("only the CG solver is built (every shipped reference config uses solver: cg)")
         self.walker = walker
@@ -106,6 +106,8 @@ class MultiClipTracking:
         self._physics_events = None   # list => step() records (start, end) HIP events around the physics kernel
         self._episode_length = int(episode_length) if episode_length is not None else (1 << 30)
         self._auto_reset = bool(auto_reset)
+        # the env groups of one rank read ONE resident clip table (tmjx_clips_share): this env uses `share_clips_with`'s device arrays
+        self._clip_owner = share_clips_with
         self._create_handle()
         self._alloc()
 
@@ -123,7 +125,9 @@ class MultiClipTracking:
             _hip.check(self._L.tmjx_model_create(blob, len(blob), C.byref(self._handle)), "tmjx_model_create")
             self.layout = _hip.Layout()
             _hip.check(self._L.tmjx_layout(self._handle, C.byref(self.layout)), "tmjx_layout")
-            if self._reference_clips is not None:
+            if self._clip_owner is not None:
+                _hip.check(self._L.tmjx_clips_share(self._handle, self._clip_owner._handle), "tmjx_clips_share")
+            elif self._reference_clips is not None:
                 c = self._reference_clips
                 arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in
                         (c.position, c.quaternion, c.joints, c.body_positions, c.angular_velocity)]

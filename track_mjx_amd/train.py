@@ -46,14 +46,15 @@ def load_clip_sets(cfg: dict, n_synthetic_clips: int = 64, clip_seed: int = 0):
     return all_clips, None
 
 
-def build_env(cfg: dict, num_envs_local: int, device, n_clips: int = 64, clip_seed: int = 0, reference_clip=None):
-    """`reference_clip`: a clip table built earlier (env groups of one rank share it); None = generate the synthetic table."""
+def build_env(cfg: dict, num_envs_local: int, device, n_clips: int = 64, clip_seed: int = 0, reference_clip=None, share_clips_with=None):
+    """`reference_clip`: a clip table built earlier (env groups of one rank share it); None = generate the synthetic table.
+    `share_clips_with`: an env of this rank built from the same table: its resident device copy is used instead of a second upload."""
     walker = Rodent(**cfg["walker_config"])
     reward_config = RewardConfig(**cfg["env_config"]["reward_weights"])
     if reference_clip is None:
         reference_clip = load_clip_sets(cfg, n_clips, clip_seed)[0]
     env = MultiClipTracking(reference_clip, walker, reward_config, **cfg["env_config"]["env_args"], **cfg["reference_config"],
-                            num_envs=num_envs_local, device=device)
+                            num_envs=num_envs_local, device=device, share_clips_with=share_clips_with)
     return env
 
 
@@ -81,7 +82,8 @@ def main(argv=None, runner=None):
     if ngrp < 1 or (hi - lo) % ngrp:
         ngrp = 1
     train_clips, test_clips = load_clip_sets(cfg, int(cfg.get("n_synthetic_clips", 64)))
-    envs = [build_env(cfg, (hi - lo) // ngrp, device, reference_clip=train_clips) for _ in range(ngrp)]
+    envs = [build_env(cfg, (hi - lo) // ngrp, device, reference_clip=train_clips)]
+    envs += [build_env(cfg, (hi - lo) // ngrp, device, reference_clip=train_clips, share_clips_with=envs[0]) for _ in range(1, ngrp)]      # one clip upload per rank
     env = envs[0]
     rc, ts = cfg["reference_config"], cfg["train_setup"]
     # train.py:221-225
