@@ -54,7 +54,7 @@ def test_substep_worst_env_and_solver_integers(scale):
     qpos, qvel = _init_states(cl, n, rng)
     d32 = [O32.new_data(qpos[e], qvel[e]) for e in range(n)]
     d64 = [O64.new_data(qpos[e], qvel[e]) for e in range(n)]
-    err = {k: {"gpu": [], "f32": []} for k in ("qpos", "qvel")}
+    err = {k: {"gpu": [], "f32": [], "gpu_vs_f32": []} for k in ("qpos", "qvel")}
     n_in_mismatch = n_final_mismatch = n_rows = 0
     niter_eq64 = niter_between = ls_between = ls_loose = total = contact_substeps = 0
     ls_sum = np.zeros(3)
@@ -71,8 +71,10 @@ def test_substep_worst_env_and_solver_integers(scale):
             O32.step(d32[e], a[e]); O64.step(d64[e], a[e])
         ref = _oracle_states(O64, d64, ("qpos", "qvel")); r32 = _oracle_states(O32, d32, ("qpos", "qvel"))
         for k in ("qpos", "qvel"):
-            err[k]["gpu"].append(rel_err(env.rows(k).cpu().numpy(), ref[k], axis=0))
+            got = env.rows(k).cpu().numpy()
+            err[k]["gpu"].append(rel_err(got, ref[k], axis=0))
             err[k]["f32"].append(rel_err(r32[k], ref[k], axis=0))
+            err[k]["gpu_vs_f32"].append(rel_err(got, r32[k], axis=0))          # MJX runs in float32: the north_star comparison, directly
         # ---- integer paths of the solver, per env
         ss = env.rows("solver_stats").cpu().numpy()
         n64 = np.array([O64.get(d, "solver_niter")[0] for d in d64]); n32 = np.array([O32.get(d, "solver_niter")[0] for d in d32])
@@ -95,20 +97,32 @@ def test_substep_worst_env_and_solver_integers(scale):
         contact_substeps += int((in_ref[67:].any(0)).sum())
     assert contact_substeps > 0.2 * total, "the trajectory must spend time in contact"
     assert n_in_mismatch == 0, "rows entering the solver (violated limits, penetrating contacts) are a bit-exact integer path"
-    g = {k: np.stack(err[k]["gpu"]) for k in err}; f = {k: np.stack(err[k]["f32"]) for k in err}
+    g = {k: np.stack(err[k]["gpu"]) for k in err}; f = {k: np.stack(err[k]["f32"]) for k in err}; gf = {k: np.stack(err[k]["gpu_vs_f32"]) for k in err}
     print(f"\n[scale {scale}] {total} env-substeps, {contact_substeps} with active contacts")
     for k in ("qpos", "qvel"):
         print(f"  {k}: HIP worst env {g[k].max():.3e} (float32 oracle {f[k].max():.3e}); 99th pct {np.quantile(g[k], .99):.3e} ({np.quantile(f[k], .99):.3e}); "
               f"median {np.median(g[k]):.3e} ({np.median(f[k]):.3e})")
+        print(f"  {k}: HIP against the FLOAT32 oracle directly: median {np.median(gf[k]):.3e}, 99th pct {np.quantile(gf[k], .99):.3e}, worst {gf[k].max():.3e}; "
+              f"fraction of env-substeps within 1e-5 of the float64 oracle: HIP {np.mean(g[k] <= 1e-5):.4f}, float32 oracle {np.mean(f[k] <= 1e-5):.4f}; "
+              f"within 1e-5 of the float32 oracle: HIP {np.mean(gf[k] <= 1e-5):.4f}")
     print(f"  solver_niter == float64 oracle on {niter_eq64}/{total}, within [float32, float64] oracle counts on {niter_between}/{total}; "
           f"ls_total within the oracles' range +-2 on {ls_between}/{total}, +-(1 + niter) on {ls_loose}/{total}, mean per solve HIP {ls_sum[0] / total:.2f} / "
           f"float32 oracle {ls_sum[1] / total:.2f} / float64 oracle {ls_sum[2] / total:.2f}; final active-row bitmap differs in {n_final_mismatch}/{n_rows} rows")
+    # floors on the fraction of env-substeps inside the 1e-5 contract (measured round 3, 64 envs x 40 substeps through contact: qpos 1.000 / 0.990 /
+    # 0.943, qvel 0.906 / 0.795 / 0.629 at the three action scales; the float32 restatement of MJX's dense path itself reaches 0.931 / 0.840 / 0.739
+    # for qvel: no float32 implementation keeps every env-substep of this model inside 1e-5 of a float64 run)
+    floor_qvel = {0.03: 0.88, 0.3: 0.76, 1.0: 0.59}[scale]
     for k in ("qpos", "qvel"):
         # the contract (BASELINE north_star: 1e-5 rel) holds for the typical env; the WORST env is bounded against what MJX's own
-        # formulation reaches in float32 (dense restatement, same inputs): 5 CG iterations do not converge, rounding is amplified
-        assert np.median(g[k]) <= 1e-5 if scale <= 0.3 else np.median(g[k]) <= 3e-5, (k, np.median(g[k]))
-        assert g[k].max() <= 8 * f[k].max() + 1e-5, (k, g[k].max(), f[k].max())
-        assert np.quantile(g[k], 0.99) <= 6 * np.quantile(f[k], 0.99) + 1e-5, (k, np.quantile(g[k], 0.99), np.quantile(f[k], 0.99))
+        # formulation reaches in float32 (dense restatement, same inputs): 5 CG iterations do not converge, rounding is amplified.
+        # The typical env sits 2.5 - 3 x above the float32 dense restatement: the price of the fill-free leaf -> root elimination order
+        # (tests/diagnostics/ldl_vs_cholesky.py: 4.4 x for a plain float32 L^T D L against dense Cholesky on the same matrices)
+        assert np.median(g[k]) <= 1e-5, (k, np.median(g[k]))
+        assert np.median(g[k]) <= 4 * np.median(f[k]) + 1e-7, (k, np.median(g[k]), np.median(f[k]))
+        assert g[k].max() <= 2 * f[k].max() + 1e-5, (k, g[k].max(), f[k].max())
+        assert np.quantile(g[k], 0.99) <= 3 * np.quantile(f[k], 0.99) + 1e-5, (k, np.quantile(g[k], 0.99), np.quantile(f[k], 0.99))
+        assert np.mean(g[k] <= 1e-5) >= (0.92 if k == "qpos" else floor_qvel), (k, np.mean(g[k] <= 1e-5))
+        assert np.mean(g[k] <= 1e-5) >= np.mean(f[k] <= 1e-5) - 0.12, (k, np.mean(g[k] <= 1e-5), np.mean(f[k] <= 1e-5))
     assert niter_between >= 0.97 * total and niter_eq64 >= 0.8 * total
     # the line search stops when no candidate tightens the bracket any more — a comparison of derivatives that differ by rounding noise
     # near the minimum, so the count is not reproducible across precisions or formulations (the two oracles differ from each other as
