@@ -115,6 +115,7 @@ typedef struct {
   int32_t T, B, A, Z;
   float reward_scaling, discounting, gae_lambda, clip_eps, entropy_cost, kl_weight;
   int32_t normalize_advantage;
+  int32_t accumulate;              /* 1: out[0..7] += this call's values (a running sum over the minibatch steps of an update), 0: out = values */
 } tmjx_ppo_cfg_t;
 int tmjx_ppo_scratch_floats(int T, int B);
 int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *raw_action, const float *behaviour_logp,
@@ -188,6 +189,11 @@ int tmjx_sample_action(const float *logits, const float *noise, float *raw, floa
  * (row-major activations) or sa_row == 1 (the [obs][n_env] buffer; M % 4 == 0 and 16-byte aligned columns required). */
 int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
                       void *stream);
+/* The same with the operand normalised while it is loaded: C = ((A - mean[k]) * inv_std[k]) W^T + bias (mean, inv_std: [K] device vectors) — the
+ * acting policy's first layer reading the env's RAW observation buffer (brax running_statistics.normalize, track_mjx/agent/mlp_ppo/ppo_networks.py:46-60).
+ * Matrix-core variant only: K % 4 == 0, 16-byte aligned operands. */
+int tmjx_linear_nolds_norm(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
+                           const float *mean, const float *inv_std, void *stream);
 
 /* out[width] = column sums of the row-major src[rows][width] (the bias gradient dy.sum(0) of a dense layer: flax nn.Dense's bias in
  * track_mjx/agent/mlp_ppo/intention_network.py:32-44 and brax's value MLP); `scratch`: tmjx_colsum_scratch_floats(width) floats. */
@@ -205,6 +211,12 @@ int tmjx_colsum_grouped(const tmjx_colsum_problem_t *problems, int n, void *stre
  * *grad_norm); `grad_norm` is a device scalar (the caller's ||grad||_2 of the averaged gradient), bias_correction{1,2} = 1 - beta^t. */
 int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *grad_norm, long long n, float lr,
                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream);
+/* The same step with the global norm computed by the library itself: tmjx_adam_norm_floats() per-workgroup sums of squares (fixed
+ * summation order: bit-identical on every rank for the same averaged gradient) into norm_scratch, added up inside the Adam kernel;
+ * norm_out (may be NULL) receives ||grad||_2.  grad 16-byte aligned. */
+int tmjx_adam_norm_floats(void);
+int tmjx_adam_clip_norm(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *norm_scratch, float *norm_out, long long n, float lr,
+                        float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream);
 
 /* Dense layers of the learner on the matrix cores, fp32 in / fp32 accumulate (flax nn.Dense of the intention network,
  * track_mjx/agent/mlp_ppo/intention_network.py:32-44,68-76, and brax's value MLP, ppo_networks.py:180-184; the gradients are those of
@@ -232,6 +244,13 @@ int tmjx_gemm_nn_ln_bwd_ok(const float *dY, int ldy, const float *W, int ldw, in
 long long tmjx_gemm_nn_ln_bwd_partial_floats(int M, int N);
 int tmjx_gemm_nn_ln_bwd(const float *dY, int ldy, const float *W, int ldw, const float *z, const float *bias, const float *gamma, const float *stats,
                         float *dz, float *partial, int M, int N, int K, void *stream);
+/* Dense -> SiLU (brax value MLP, track_mjx/agent/mlp_ppo/ppo_networks.py:180-184: swish activations, no LayerNorm).  tmjx_gemm_nt_silu: Z[M][ldc] = A W^T
+ * (WITHOUT the bias) and Y = silu(Z + bias) in one launch (operand rows 16-byte aligned: tmjx_gemm_nt_silu_ok); tmjx_silu_fwd: the activation alone;
+ * tmjx_silu_bwd: dz = dy silu'(z + bias), dense [rows][N] arrays. */
+int tmjx_gemm_nt_silu_ok(const float *A, int lda, const float *W, int ldw);
+int tmjx_gemm_nt_silu(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, float *Y, int ldc, int M, int N, int K, void *stream);
+int tmjx_silu_fwd(const float *z, const float *bias, float *y, long long rows, int N, void *stream);
+int tmjx_silu_bwd(const float *dy, const float *z, const float *bias, float *dz, long long rows, int N, void *stream);
 long long tmjx_gemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream);
 /* All weight (+ bias) gradients of one backward pass as ONE launch + one reduction launch: up to 16 independent problems of tmjx_gemm_dw,

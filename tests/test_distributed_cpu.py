@@ -91,10 +91,12 @@ def _perm(rank):
     return lambda upd, rows: torch.randperm(rows, generator=torch.Generator().manual_seed(1000 + 10 * rank + upd))
 
 
-def _make_learner(world_batch):
+def _make_learner(world_batch, groups=1):
     from tests.common import StubEnv, torch_gae
     from track_mjx_amd.agent.ppo import PPOLearner
-    ln = PPOLearner(StubEnv(_NLOC, _OBS, _REF, _NU), **_NETS, unroll_length=_T, batch_size=world_batch, num_minibatches=2, num_updates_per_batch=2,
+    # `groups` env groups per rank (rollout_groups of train.py / bench.py --pipeline): the rank's envs as a LIST of equal parts
+    envs = StubEnv(_NLOC, _OBS, _REF, _NU) if groups == 1 else [StubEnv(_NLOC // groups, _OBS, _REF, _NU) for _ in range(groups)]
+    ln = PPOLearner(envs, **_NETS, unroll_length=_T, batch_size=world_batch, num_minibatches=2, num_updates_per_batch=2,
                     learning_rate=1e-2, use_graph=False, seed=3)
     ln.gae_fn = torch_gae
     return ln
@@ -112,11 +114,11 @@ def _seeded(ln, rank):
     ln._minibatch_grads = f
 
 
-def _learner_worker(rank, world, port, q):
+def _learner_worker(rank, world, port, q, groups=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ln = _make_learner(4 * world)                 # global batch_size; every rank takes batch_size / world rows of each minibatch
-    assert ln.world == 2 and ln.local_batch == 4 and ln.unrolls == 2
+    ln = _make_learner(4 * world, groups)         # global batch_size; every rank takes batch_size / world rows of each minibatch
+    assert ln.world == 2 and ln.local_batch == 4 and ln.unrolls == 2 and ln.n_local == _NLOC and len(ln.envs) == groups
     for k, v in _shard_data(rank).items():
         ln.buf[k].copy_(v)
     ln.perm_fn = _perm(rank)
@@ -128,11 +130,17 @@ def _learner_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_learner_update_matches_manual_gradient_average():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_two_rank_learner_update_matches_manual_gradient_average(groups):
+    """groups = 2: two ranks x two env groups per rank (the layout of the 8-GPU bench: rollout_groups = 2 on every rank) — the roll-out buffer rows
+    of a rank are its groups' slices side by side, the update must not depend on how the rank's envs are grouped."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + 37 * groups
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q, groups)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict()

@@ -258,3 +258,30 @@ def test_second_backward_through_a_retained_fused_chain():
     second = torch.autograd.grad(y, params, cot)
     for a, b in zip(first, second):
         assert (a - b).abs().max() <= 2e-5 * (a.abs().max() + 1e-12), float((a - b).abs().max() / a.abs().max())
+
+
+@pytest.mark.parametrize("M,widths", [(20480, (696, 256, 256, 1)), (2048, (696, 512, 512, 256, 1)), (333, (40, 24, 8, 1))])
+def test_value_net_silu_layers_without_torch_elementwise_kernels(M, widths):
+    """brax value MLP (Dense -> SiLU ... Dense(1), track_mjx/agent/mlp_ppo/ppo_networks.py:180-184) on the GPU: forward one launch per hidden layer
+    (tmjx_gemm_nt_silu), backward tmjx_silu_bwd + the MFMA input / weight gradient kernels; value and all gradients against float64 torch."""
+    from track_mjx_amd.agent.networks import ValueNet
+    torch.manual_seed(M)
+    net = ValueNet(widths[0], widths[1:-1]).to(DEV)
+    with torch.no_grad():
+        for m in net.net:
+            if isinstance(m, torch.nn.Linear):
+                m.bias.copy_(0.3 * torch.randn_like(m.bias))
+    x = torch.randn((M, widths[0]), device=DEV)
+    v = net(x)
+    cot = torch.randn_like(v)
+    params = list(net.parameters())
+    grads = torch.autograd.grad(v, params, cot)
+    ref = torch.nn.Sequential(*[torch.nn.Linear(m.in_features, m.out_features) if isinstance(m, torch.nn.Linear) else torch.nn.SiLU() for m in net.net]).double().to(DEV)
+    ref.load_state_dict({k: t.double() for k, t in net.net.state_dict().items()})
+    vr = ref(x.double()).squeeze(-1)
+    gr = torch.autograd.grad(vr, list(ref.parameters()), cot.double())
+    assert (v.double() - vr).abs().max() <= 2e-5 * vr.abs().max() + 1e-6
+    for a, b in zip(grads, gr):
+        assert (a.double() - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, float((a.double() - b).abs().max() / b.abs().max())
+    with torch.no_grad():
+        assert torch.allclose(net(x), v, rtol=0, atol=0)          # the inference path runs the same kernels

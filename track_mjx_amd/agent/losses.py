@@ -109,7 +109,7 @@ class _FusedLossHead(torch.autograd.Function):
         scratch = torch.empty(L.tmjx_ppo_scratch_floats(T, B), dtype=torch.float32, device=dev)
         out = torch.empty(8, dtype=torch.float32, device=dev)
         c = _hip.PpoCfg(T, B, raw_action.shape[-1], fc2.shape[-1] // 2, cfg["reward_scaling"], cfg["discounting"], cfg["gae_lambda"],
-                        cfg["clipping_epsilon"], cfg["entropy_cost"], cfg["kl_weight"], int(cfg["normalize_advantage"]))
+                        cfg["clipping_epsilon"], cfg["entropy_cost"], cfg["kl_weight"], int(cfg["normalize_advantage"]), 0)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             ptr = [C.c_void_p(a.data_ptr()) for a in args + [dlogits, dbaseline, dfc2, scratch, out]]
@@ -126,7 +126,7 @@ class _FusedLossHead(torch.autograd.Function):
 
 def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
                               discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
-                              clipping_epsilon: float = 0.3, normalize_advantage: bool = True, side_stream=None):
+                              clipping_epsilon: float = 0.3, normalize_advantage: bool = True, side_stream=None, acc_out: torch.Tensor | None = None):
     """The learner's form of compute_ppo_loss_fused: network outputs with autograd, then tmjx_ppo_loss OUTSIDE autograd; returns
     (metrics, outputs, output_grads) so that the caller runs ONE torch.autograd.grad(outputs, params, grad_outputs=output_grads) —
     no autograd node for the loss head, no `grad * 1.0` passes over the three gradient arrays, no clone of the scalar."""
@@ -159,9 +159,10 @@ def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_
         dlogits, dbaseline, dfc2 = torch.empty_like(args[0]), torch.empty_like(args[4]), torch.empty_like(args[9])
         L = _hip.lib()
         scratch = torch.empty(L.tmjx_ppo_scratch_floats(T, B), dtype=torch.float32, device=dev)
-        out = torch.empty(8, dtype=torch.float32, device=dev)
+        # `acc_out`: the caller's running sums of the eight loss scalars (the kernel ADDS to them: no add launch per minibatch step)
+        out = torch.empty(8, dtype=torch.float32, device=dev) if acc_out is None else acc_out
         c = _hip.PpoCfg(T, B, data["raw_action"].shape[-1], fc2.shape[-1] // 2, reward_scaling, discounting, gae_lambda, clipping_epsilon,
-                        entropy_cost, kl_weight, int(normalize_advantage))
+                        entropy_cost, kl_weight, int(normalize_advantage), int(acc_out is not None))
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             ptr = [C.c_void_p(a.data_ptr()) for a in args + [dlogits, dbaseline, dfc2, scratch, out]]

@@ -593,6 +593,44 @@ class _HipDenseFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _HipSiluDenseFn(torch.autograd.Function):
+    """y = silu(x W^T + b) (a hidden layer of brax's value MLP, ppo_networks.py:180-184), fp32: forward ONE launch (tmjx_gemm_nt_silu: the activation
+    on the accumulators of the MFMA tile; z without the bias is kept for the backward pass), backward dz = dy silu'(z + b) (tmjx_silu_bwd), then the
+    input gradient (tmjx_gemm_nn) and the weight + bias gradient (deferred into the grouped launch, or tmjx_gemm_dw) — no torch element-wise kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        import ctypes as C
+        from .. import hip as _hip
+        x2 = _rows2d(x)
+        M, K = x2.shape
+        N = w.shape[0]
+        z = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+        y = torch.empty_like(z)
+        L = _hip.lib()
+        if L.tmjx_gemm_nt_silu_ok(_p(x2), x2.stride(0), _p(w), w.stride(0)):
+            _launch("tmjx_gemm_nt_silu", x2.device, _p(x2), x2.stride(0), _p(w), w.stride(0), _p(b), _p(z), _p(y), N, M, N, K)
+        else:
+            _launch("tmjx_gemm_nt", x2.device, _p(x2), x2.stride(0), _p(w), w.stride(0), None, _p(z), N, M, N, K)
+            _launch("tmjx_silu_fwd", x2.device, _p(z), _p(b), _p(y), M, N)
+        ctx.save_for_backward(x2, w, z, b)
+        ctx.params, ctx.x_shape = (w, b), x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, z, b = ctx.saved_tensors
+        M, N = z.shape
+        dy2 = _rows2d(dy).contiguous()
+        dz = torch.empty_like(z)
+        _launch("tmjx_silu_bwd", z.device, _p(dy2), _p(z), _p(b), _p(dz), M, N)
+        dx = gemm_nn(dz, w).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        d = deferred_weight_grads.active
+        got = d.try_add(dz, x2, *ctx.params) if d is not None else None
+        dw, db = got if got is not None else gemm_dw(dz, x2, True)
+        return dx, dw, db
+
+
 class _BfDenseFn(torch.autograd.Function):
     """bf16 GEMM-input mode (BASELINE config 5): y = x W^T (+ b) with all three contractions on the library's bf16 MFMA kernels — forward
     tmjx_bgemm_nt against the weight's shadow, input gradient tmjx_bgemm_nt against the transposed shadow, weight + bias gradient
@@ -897,6 +935,12 @@ class IntentionPolicy(nn.Module):
         return logits, mean, logvar
 
 
+class _NoCtx:
+    """Stand-in for an autograd context when a Function's forward is run outside autograd (inference)."""
+    def save_for_backward(self, *a):
+        pass
+
+
 class ValueNet(nn.Module):
     """brax make_value_network: MLP(hidden..., 1), swish activations, lecun_uniform, output squeezed."""
 
@@ -916,6 +960,16 @@ class ValueNet(nn.Module):
                 self._chain = [_Layer("silu", m) for m in dense[:-1]]
             h = bf16_chain(obs, self._chain, last_y_f32=True)
             return self.net[-1](h).squeeze(-1)
+        if obs.is_cuda and obs.dtype == torch.float32 and gemm_inputs.dtype is None:
+            # fp32 on the GPU: every hidden layer is ONE launch forward (GEMM + SiLU epilogue), no torch element-wise kernel in either direction
+            h = obs
+            dense = [m for m in self.net if isinstance(m, nn.Linear)]
+            for lin in dense[:-1]:
+                if torch.is_grad_enabled() and (lin.weight.requires_grad or h.requires_grad):
+                    h = _HipSiluDenseFn.apply(h, lin.weight, lin.bias)
+                else:
+                    h = _HipSiluDenseFn.forward(_NoCtx(), h, lin.weight, lin.bias)
+            return dense[-1](h).squeeze(-1)
         return self.net(obs).squeeze(-1)
 
 

@@ -125,15 +125,21 @@ class FlatAdam:
         self.t += 1
         b1, b2 = self.betas
         bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        norm = torch.linalg.vector_norm(g)
         if g.is_cuda:
+            # the global norm is part of the step: per-workgroup sums of squares (one launch, fixed order: bit-identical on every rank) that the
+            # Adam kernel adds up itself — no library reduction kernel (tmjx_adam_clip_norm)
             import ctypes as C
             from .. import hip as _hip
+            if getattr(self, "_norm_scratch", None) is None:
+                self._norm_scratch = torch.empty(int(_hip.lib().tmjx_adam_norm_floats()), dtype=torch.float32, device=g.device)
+                self._norm = torch.zeros((), dtype=torch.float32, device=g.device)
+            norm = self._norm
             with torch.cuda.device(g.device):
-                _hip.check(_hip.lib().tmjx_adam_clip(*[C.c_void_p(t.data_ptr()) for t in (self.flat, g, self.exp_avg, self.exp_avg_sq, norm)],
-                                                     g.numel(), self.lr, b1, b2, self.eps, bc1, bc2, self.max_norm,
-                                                     C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "tmjx_adam_clip")
+                _hip.check(_hip.lib().tmjx_adam_clip_norm(*[C.c_void_p(t.data_ptr()) for t in (self.flat, g, self.exp_avg, self.exp_avg_sq, self._norm_scratch, norm)],
+                                                          g.numel(), self.lr, b1, b2, self.eps, bc1, bc2, self.max_norm,
+                                                          C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "tmjx_adam_clip_norm")
         else:
+            norm = torch.linalg.vector_norm(g)
             gs = g * (self.max_norm / torch.clamp(norm, min=self.max_norm))
             self.exp_avg.mul_(b1).add_(gs, alpha=1 - b1)
             self.exp_avg_sq.mul_(b2).addcmul_(gs, gs, value=1 - b2)
@@ -297,8 +303,16 @@ class PPOLearner:
         pol, L = self.policy, _hip.lib()
         Z, A, ref = pol.latents, pol.action_size, pol.reference_obs_size
         lds_free = self.lds_free and obs_raw is not None
-        if lds_free:     # element-wise normalisation keeps the [obs][n_env] memory layout of the env's buffer (and uses no LDS)
-            x = self.normalizer.normalize(obs_raw) if self.normalize_observations else obs_raw
+        # LDS-free path: the observation is read RAW from the env's [obs][n_env] buffer — the normalisation (obs - mean) / std is applied while the
+        # first encoder layer loads its operand (tmjx_linear_nolds_norm; 1 / std refreshed once per collect(): _refresh_padded_weights) and by
+        # tmjx_latent_concat for the proprioceptive part: no element-wise launch in front of the inference.  (Folding it into the layer's
+        # weights instead — W / std, b - (W / std) mean — was tried and is NOT safe: a near-constant observation column has std = 1e-6, and
+        # x W / std - mean W / std then cancels catastrophically: 0.24 absolute error on the logits in the unit test)
+        fold = lds_free and self.normalize_observations
+        if fold and getattr(self, "_fold", None) is None:
+            self._refresh_padded_weights()
+        if lds_free:
+            x = obs_raw
         src = x
         n, W = src.shape
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -315,11 +329,18 @@ class PPOLearner:
                                                n, lin.out_features, w.shape[1], stream), "tmjx_linear_nolds")
                 return out
 
-            def block(a, sa_row, sa_k, K, blk):
-                z = linear(a, sa_row, sa_k, K, blk.dense, bias=False)
+            def block(a, sa_row, sa_k, K, blk, folded=False):
+                if folded:      # the operand is normalised while it is loaded (mean / inv_std padded with 0 / 0 to the weight's padded K)
+                    w = self._padded_weight(blk.dense)
+                    z = torch.empty((n, blk.dense.out_features), **f32)
+                    _hip.check(L.tmjx_linear_nolds_norm(p(a), sa_row, sa_k, p(w), None, p(z), n, blk.dense.out_features, w.shape[1],
+                                                        p(self._fold[0]), p(self._fold[1]), stream), "tmjx_linear_nolds_norm")
+                    bias_v = blk.dense.bias
+                else:
+                    z, bias_v = linear(a, sa_row, sa_k, K, blk.dense, bias=False), blk.dense.bias
                 y = torch.empty_like(z)
                 stats = torch.empty((n, 2), **f32)
-                _hip.check(L.tmjx_silu_ln_fwd(p(z), p(blk.dense.bias), p(blk.norm.weight), p(blk.norm.bias), p(y), p(stats), n,
+                _hip.check(L.tmjx_silu_ln_fwd(p(z), p(bias_v), p(blk.norm.weight), p(blk.norm.bias), p(y), p(stats), n,
                                               blk.dense.out_features, float(blk.norm.eps), stream), "tmjx_silu_ln_fwd")
                 return y
 
@@ -333,14 +354,15 @@ class PPOLearner:
             if lds_free:
                 h, first = None, True
                 for blk in pol.encoder:
-                    h = block(src, src.stride(0), src.stride(1), ref, blk) if first else block(h, h.shape[1], 1, h.shape[1], blk)
+                    h = block(src, src.stride(0), src.stride(1), ref, blk, folded=fold) if first else block(h, h.shape[1], 1, h.shape[1], blk)
                     first = False
                 fc2 = linear(h, h.shape[1], 1, h.shape[1], pol.fc2)
             else:
                 fc2 = pol.fc2(pol.encoder(x[..., :ref]))
             wdec = Z + W - ref
             xdec = torch.empty((n, (wdec + 3) // 4 * 4 if lds_free else wdec), **f32)       # (the kernel zeroes the pad columns)
-            _hip.check(L.tmjx_latent_concat(p(fc2), p(eps), p(src), p(xdec), n, Z, W, ref, src.stride(0), src.stride(1), None, None,
+            _hip.check(L.tmjx_latent_concat(p(fc2), p(eps), p(src), p(xdec), n, Z, W, ref, src.stride(0), src.stride(1),
+                                            p(self.normalizer.mean) if fold else None, p(self.normalizer.std) if fold else None,
                                             xdec.shape[1], rng_seed if device_rng else 0, p(rng_state) if device_rng else None, stream), "tmjx_latent_concat")
             if lds_free:
                 h = xdec
@@ -394,6 +416,16 @@ class PPOLearner:
     def _refresh_padded_weights(self) -> None:
         for lin, buf in self._wpad.items():
             buf[:, :lin.in_features].copy_(lin.weight.detach())
+        # mean and 1 / std of the reference part of the observation for tmjx_linear_nolds_norm (padded to the first layer's padded K: the pad
+        # columns of the weight are zero); persistent buffers (the inference graphs hold their addresses), rewritten in place
+        if self.lds_free and self.normalize_observations:
+            K = self.policy.encoder[0].dense.in_features
+            Kp = (K + 3) // 4 * 4
+            with torch.no_grad():
+                if getattr(self, "_fold", None) is None:
+                    self._fold = (torch.zeros(Kp, dtype=torch.float32, device=self.dev), torch.zeros(Kp, dtype=torch.float32, device=self.dev))
+                self._fold[0][:K].copy_(self.normalizer.mean[:K])
+                torch.reciprocal(self.normalizer.std[:K], out=self._fold[1][:K])
 
     def _act_graphed(self, obs: torch.Tensor, g: int = 0):
         """act() replayed as one hipGraph per env group.  Valid while `obs` is the group's persistent observation buffer (same
@@ -500,7 +532,7 @@ class PPOLearner:
             if self.dev.type == "cuda":
                 # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
                 m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,
-                                                                         side_stream=self._sgd_side, **self.hp)
+                                                                         side_stream=self._sgd_side, acc_out=self._acc8 if idx is None else None, **self.hp)
                 with deferred_weight_grads() as dwg:
                     grads = torch.autograd.grad(outs, self.grads.params, grad_outputs=gouts)
                 if self._sgd_side is not None:
@@ -509,8 +541,7 @@ class PPOLearner:
                 self._dwg = dwg          # (keeps the slab scratch alive until the next step)
                 self.grads.assign(grads)
                 if idx is None:
-                    self._acc8.add_(out8)                # (reordered to METRIC_KEYS once per update())
-                    return self._acc8
+                    return self._acc8                    # (the loss kernel added this step's scalars; reordered to METRIC_KEYS once per update())
                 return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
             loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp,
                                                **({"gae_fn": self.gae_fn} if self.gae_fn is not None else {}))

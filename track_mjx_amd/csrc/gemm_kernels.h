@@ -518,6 +518,18 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
         if (row < M) {
           float *o = C + (long long)row * ldc + col;
           const gf4 v = acc[a][b] + bv;
+          if constexpr (EPI == 3) {
+            // Dense -> SiLU (brax value MLP, ppo_networks.py:180-184): z = acc WITHOUT the bias to C (what tmjx_silu_bwd expects), y = silu(z + bias) to ln.y
+            float *yo = ln.y + (long long)row * ldc + col;
+            gf4 y;
+#pragma unroll
+            for (int r = 0; r < 4; r++) y[r] = v[r] / (1.f + expf(-v[r]));
+            if (vec && col + 3 < N) { *reinterpret_cast<gf4 *>(o) = acc[a][b]; *reinterpret_cast<gf4 *>(yo) = y; }
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; r++) if (col + r < N) { o[r] = acc[a][b][r]; yo[r] = y[r]; }
+            }
+          } else
           if (vec && col + 3 < N) *reinterpret_cast<gf4 *>(o) = v;
           else {
 #pragma unroll

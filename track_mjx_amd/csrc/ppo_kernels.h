@@ -16,6 +16,7 @@ struct PpoCfg {
   int T, B, A, Z;
   float reward_scaling, discounting, gae_lambda, clip_eps, entropy_cost, kl_weight;
   int normalize_advantage;
+  int accumulate;
 };
 
 #define PPO_BLOCK 256
@@ -225,7 +226,9 @@ __global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk) {
   ppo_block_sum<1>(acc, lds);
   if (threadIdx.x == 0) {
     float policy = -acc[0] / (float)N, v = scal[2], entl = -c.entropy_cost * scal[3], kl = scal[4];
-    out[0] = policy + v + entl + kl; out[1] = policy; out[2] = v; out[3] = entl; out[4] = kl; out[5] = scal[0]; out[6] = scal[1]; out[7] = scal[3];
+    const float o[8] = {policy + v + entl + kl, policy, v, entl, kl, scal[0], scal[1], scal[3]};
+    // accumulate: `out` is a running sum over the minibatch steps of an update (the learner's metric accumulator: no add launch per step)
+    for (int i = 0; i < 8; i++) out[i] = c.accumulate ? out[i] + o[i] : o[i];
   }
 }
 
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partia
 // is idle there while the vector ALU is what the physics kernel is bound by; and a one-wave workgroup fits any free wave slot.
 template <bool A_KMAJOR>
 __global__ __launch_bounds__(64) void k_linear_nolds_mfma(const float *__restrict__ A, long long sa_row, long long sa_k, const float *__restrict__ W,
-                                                          const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K) {
+                                                          const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
+                                                          const float *__restrict__ mean = nullptr, const float *__restrict__ inv_std = nullptr) {
+  // mean / inv_std (optional, [K]): the operand is (A - mean) * inv_std — the observation normaliser applied while the raw observation is
+  // loaded (the first layer of the LDS-free inference: no element-wise launch in front of it)
   typedef float __attribute__((ext_vector_type(4))) f4;
   const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
@@ -355,6 +361,10 @@ __global__ __launch_bounds__(64) void k_linear_nolds_mfma(const float *__restric
         v.z = A[(long long)(kc + 2) * sa_k + ar[t]]; v.w = A[(long long)(kc + 3) * sa_k + ar[t]];
       } else {
         v = *reinterpret_cast<const float4 *>(A + (long long)ar[t] * sa_row + kc);
+      }
+      if (mean) {
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + kc), is = *reinterpret_cast<const float4 *>(inv_std + kc);
+        v = float4{(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
       }
       f.a[t] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
       float4 w = *reinterpret_cast<const float4 *>(W + (size_t)wc[t] * K + kc);
@@ -684,10 +694,38 @@ __global__ __launch_bounds__(128) void k_linear_nolds(const float *__restrict__ 
 // ---- optimiser: optax.chain(clip_by_global_norm(max_norm), adam(lr)) (reference: agent/mlp_ppo/ppo.py:517-520) over FLAT fp32 buffers
 // (parameters, gradients and the two moments as one contiguous array each): one launch instead of the norm-dependent scale kernels,
 // the multi-tensor scale and the multi-tensor Adam.  `grad_norm` is the device scalar ||g||_2 of the (already averaged) gradient.
+// sum of squares of the flat gradient as ADAM_NORM_PARTS per-workgroup partials (float4 loads, fixed summation order: every rank of a data-
+// parallel run gets the same bits from the same all-reduced gradient); k_adam_clip adds them up itself — the global norm costs no launch of
+// its own beyond this one and no library reduction kernel
+#define ADAM_NORM_PARTS 256
+__global__ __launch_bounds__(256) void k_grad_sumsq(const float *__restrict__ g, long long n, float *__restrict__ partial) {
+  __shared__ float lds[4];
+  const long long n4 = n >> 2;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)ADAM_NORM_PARTS * 256) {
+    const float4 v = reinterpret_cast<const float4 *>(g)[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = g[(n4 << 2) + threadIdx.x]; s += t * t; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+// NORM_PARTS: grad_norm points at ADAM_NORM_PARTS partial sums of squares (k_grad_sumsq) instead of the norm itself; norm_out (optional) receives the norm
+template <bool NORM_PARTS>
 __global__ __launch_bounds__(256) void k_adam_clip(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                                                    const float *__restrict__ grad_norm, long long n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2, float max_norm) {
-  const float nrm = grad_norm[0];
+                                                   float bc1, float bc2, float max_norm, float *__restrict__ norm_out) {
+  float nrm;
+  if (NORM_PARTS) {       // every workgroup adds the same 256 numbers in the same order
+    __shared__ float lds[4];
+    float s = wave_sum(grad_norm[threadIdx.x]);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    nrm = sqrtf((lds[0] + lds[1]) + (lds[2] + lds[3]));
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = nrm;
+  } else nrm = grad_norm[0];
   const float scale = max_norm / fmaxf(max_norm, nrm);               // g if ||g|| < max_norm else g / ||g|| * max_norm
   const float step = lr / bc1, rs = 1.f / sqrtf(bc2);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -800,6 +838,36 @@ __global__ void k_stats_finalize(const float *__restrict__ sums, float n_added, 
   // written by a second tiny launch (k_stats_count) — stream order makes it safe
 }
 __global__ void k_stats_count(float *count, float n_added) { *count += n_added; }
+
+// ---- Dense -> SiLU (brax value MLP: swish, no LayerNorm) element-wise halves: y = silu(z + bias) for layers the fused GEMM epilogue
+// (tmjx_gemm_nt_silu) does not take, and dz = dy silu'(z + bias) — the operand of the layer's input- and weight-gradient GEMMs
+// (the bias gradient = column sums of dz rides along in the weight-gradient kernel).  float4 per lane where the width allows.
+__global__ __launch_bounds__(256) void k_silu_fwd_f32(const float *__restrict__ z, const float *__restrict__ bias, float *__restrict__ y, long long total, int N) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
+  if (!(N & 3)) {
+    const float4 zv = *reinterpret_cast<const float4 *>(z + i), bv = *reinterpret_cast<const float4 *>(bias + (int)(i % N));
+    float v[4] = {zv.x + bv.x, zv.y + bv.y, zv.z + bv.z, zv.w + bv.w};
+    *reinterpret_cast<float4 *>(y + i) = make_float4(v[0] / (1.f + expf(-v[0])), v[1] / (1.f + expf(-v[1])), v[2] / (1.f + expf(-v[2])), v[3] / (1.f + expf(-v[3])));
+  } else {
+    for (long long j = i; j < i + 4 && j < total; j++) { const float v = z[j] + bias[(int)(j % N)]; y[j] = v / (1.f + expf(-v)); }
+  }
+}
+__global__ __launch_bounds__(256) void k_silu_bwd_f32(const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ bias, float *__restrict__ dz,
+                                                      long long total, int N) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
+  if (!(N & 3)) {
+    const float4 zv = *reinterpret_cast<const float4 *>(z + i), bv = *reinterpret_cast<const float4 *>(bias + (int)(i % N)), dv = *reinterpret_cast<const float4 *>(dy + i);
+    const float v[4] = {zv.x + bv.x, zv.y + bv.y, zv.z + bv.z, zv.w + bv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const float sig = 1.f / (1.f + expf(-v[k])); o[k] = d[k] * (sig * (1.f + v[k] * (1.f - sig))); }
+    *reinterpret_cast<float4 *>(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    for (long long j = i; j < i + 4 && j < total; j++) { const float v = z[j] + bias[(int)(j % N)], sig = 1.f / (1.f + expf(-v)); dz[j] = dy[j] * (sig * (1.f + v * (1.f - sig))); }
+  }
+}
 
 // ---- roll-out buffer stores of one env-group step in ONE launch (agent/ppo.py: collect; brax acting.actor_step builds the Transition the
 // same way, track_mjx/agent/mlp_ppo/ppo.py:330-348): the env's observation [W][n] (env-minor, what the kernels and the LDS-free inference

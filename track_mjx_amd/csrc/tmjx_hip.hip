@@ -549,7 +549,7 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
       !fc2 || !dlogits || !dbaseline || !dfc2 || !scratch || !out) return fail(TMJX_EINVAL, "null argument");
   if (cfg->T < 1 || cfg->B < 1 || cfg->A < 1 || cfg->Z < 1) return fail(TMJX_EINVAL, "bad T / B / A / Z");
   PpoCfg c{cfg->T, cfg->B, cfg->A, cfg->Z, cfg->reward_scaling, cfg->discounting, cfg->gae_lambda, cfg->clip_eps, cfg->entropy_cost,
-           cfg->kl_weight, cfg->normalize_advantage};
+           cfg->kl_weight, cfg->normalize_advantage, cfg->accumulate};
   const int N = c.T * c.B, nblk = (N * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_ppo_a, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, noise, fc2, scratch, nblk);
@@ -663,9 +663,22 @@ int tmjx_adam_clip(float *param, const float *grad, float *exp_avg, float *exp_a
   if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm) return fail(TMJX_EINVAL, "null argument");
   if (n < 1 || !(bias_correction1 > 0.f) || !(bias_correction2 > 0.f) || !(max_norm > 0.f)) return fail(TMJX_EINVAL, "bad n / bias corrections / max_norm");
   int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_adam_clip, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, grad_norm, n, lr, beta1, beta2, eps,
-                     bias_correction1, bias_correction2, max_norm);
+  hipLaunchKernelGGL(k_adam_clip<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, grad_norm, n, lr, beta1, beta2, eps,
+                     bias_correction1, bias_correction2, max_norm, (float *)nullptr);
   return check_launch("k_adam_clip");
+}
+int tmjx_adam_norm_floats(void) { return ADAM_NORM_PARTS; }
+int tmjx_adam_clip_norm(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *norm_scratch, float *norm_out, long long n, float lr,
+                        float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, float max_norm, void *stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !norm_scratch) return fail(TMJX_EINVAL, "null argument");
+  if (n < 1 || !(bias_correction1 > 0.f) || !(bias_correction2 > 0.f) || !(max_norm > 0.f)) return fail(TMJX_EINVAL, "bad n / bias corrections / max_norm");
+  if ((uintptr_t)grad & 15) return fail(TMJX_EINVAL, "tmjx_adam_clip_norm: the gradient buffer must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_grad_sumsq, dim3(ADAM_NORM_PARTS), dim3(256), 0, s, grad, n, norm_scratch);
+  int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_adam_clip<true>, dim3(grid), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, (const float *)norm_scratch, n, lr, beta1, beta2, eps,
+                     bias_correction1, bias_correction2, max_norm, norm_out);
+  return check_launch("k_adam_clip(norm)");
 }
 
 int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, float *x, int n, int Z, int obs_w, int ref_w,
@@ -700,6 +713,22 @@ int tmjx_sample_action(const float *logits, const float *noise, float *raw, floa
   return check_launch("k_sample_action");
 }
 
+// The same with the operand normalised on the fly: (A - mean[k]) * inv_std[k] (the acting policy's first layer reading the RAW observation).
+// Only the matrix-core variant: K % 4 == 0, 16-byte aligned W / mean / inv_std, A row-major with aligned rows or K-major.
+int tmjx_linear_nolds_norm(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
+                           const float *mean, const float *inv_std, void *stream) {
+  if (!A || !W || !C || !mean || !inv_std) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1) return fail(TMJX_EINVAL, "bad sizes");
+  const bool kmajor = sa_row == 1 && sa_k != 1;
+  if (!kmajor && sa_k != 1) return fail(TMJX_EINVAL, "A must be row-major (sa_k == 1) or K-major (sa_row == 1)");
+  if ((K & 3) || ((uintptr_t)W & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)inv_std & 15) || (!kmajor && ((sa_row & 3) || ((uintptr_t)A & 15))))
+    return fail(TMJX_EINVAL, "tmjx_linear_nolds_norm: K % 4 == 0 and 16-byte aligned operands");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g2((M + 31) / 32, (N + 31) / 32);
+  if (kmajor) hipLaunchKernelGGL((k_linear_nolds_mfma<true>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K, mean, inv_std);
+  else hipLaunchKernelGGL((k_linear_nolds_mfma<false>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K, mean, inv_std);
+  return check_launch("k_linear_nolds_mfma(norm)");
+}
 int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
                       void *stream) {
   if (!A || !W || !C) return fail(TMJX_EINVAL, "null argument");
@@ -714,8 +743,8 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
   hipStream_t s = (hipStream_t)stream;
   if (V == 4 && !getenv("TMJX_NOLDS_VALU")) {      // matrix-core variant: float4 operands along K
     dim3 g2((M + 31) / 32, (N + 31) / 32);
-    if (kmajor) hipLaunchKernelGGL((k_linear_nolds_mfma<true>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K);
-    else hipLaunchKernelGGL((k_linear_nolds_mfma<false>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K);
+    if (kmajor) hipLaunchKernelGGL((k_linear_nolds_mfma<true>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K, (const float *)nullptr, (const float *)nullptr);
+    else hipLaunchKernelGGL((k_linear_nolds_mfma<false>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K, (const float *)nullptr, (const float *)nullptr);
     return check_launch("k_linear_nolds_mfma");
   }
   dim3 grid((M + 63) / 64, (N + 31) / 32), block(128);
@@ -789,6 +818,20 @@ static int launch_gemm_dw(const float *dY, int ldy, const float *X, int ldx, flo
   hipLaunchKernelGGL((k_gemm_dw<YVEC, XVEC>), grid, dim3(512), lds, s, dY, ldy, X, ldx, scratch, M, N, K, with_bias, rps, ld);
   return TMJX_OK;
 }
+template <int NIW>
+static int launch_gemm_silu(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, float *Y, int ldc, int M, int N, int K, hipStream_t s) {
+  constexpr int BN = 64 * NIW;
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + BN * GEMM_LDA);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act SiLU): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  GemmLN ln{nullptr, nullptr, Y, nullptr, 0.f, nullptr, nullptr};
+  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, 3>), dim3((M + GEMM_BM - 1) / GEMM_BM, (N + BN - 1) / BN), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
+  return check_launch("k_gemm_act(SiLU)");
+}
 extern "C" {
 int tmjx_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, void *stream) {
   return gemm_act<true>(A, lda, W, ldw, bias, C, ldc, M, N, K, stream);
@@ -806,6 +849,31 @@ int tmjx_gemm_nt_silu_ln(const float *A, int lda, const float *W, int ldw, const
   if (N == 64) return launch_gemm_ln<1>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
   if (N == 128) return launch_gemm_ln<2>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
   return launch_gemm_ln<4>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+}
+// Dense -> SiLU forward in one launch (k_gemm_act<.., EPI = 3>): Z = A W^T (without the bias), Y = silu(Z + bias); any N, 16-byte aligned operand rows
+int tmjx_gemm_nt_silu_ok(const float *A, int lda, const float *W, int ldw) { return aligned16(A, lda) && aligned16(W, ldw); }
+int tmjx_gemm_nt_silu(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, float *Y, int ldc, int M, int N, int K, void *stream) {
+  if (!A || !W || !bias || !Z || !Y) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1 || lda < K || ldc < N || ldw < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  if (!tmjx_gemm_nt_silu_ok(A, lda, W, ldw)) return fail(TMJX_EINVAL, "tmjx_gemm_nt_silu: the operands' rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 64) return launch_gemm_silu<1>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+  if (N <= 128) return launch_gemm_silu<2>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+  return launch_gemm_silu<4>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+}
+int tmjx_silu_fwd(const float *z, const float *bias, float *y, long long rows, int N, void *stream) {
+  if (!z || !bias || !y) return fail(TMJX_EINVAL, "null argument");
+  if (rows < 1 || N < 1) return fail(TMJX_EINVAL, "bad sizes");
+  const long long total = rows * N;
+  hipLaunchKernelGGL(k_silu_fwd_f32, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, z, bias, y, total, N);
+  return check_launch("k_silu_fwd_f32");
+}
+int tmjx_silu_bwd(const float *dy, const float *z, const float *bias, float *dz, long long rows, int N, void *stream) {
+  if (!dy || !z || !bias || !dz) return fail(TMJX_EINVAL, "null argument");
+  if (rows < 1 || N < 1) return fail(TMJX_EINVAL, "bad sizes");
+  const long long total = rows * N;
+  hipLaunchKernelGGL(k_silu_bwd_f32, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dy, z, bias, dz, total, N);
+  return check_launch("k_silu_bwd_f32");
 }
 int tmjx_gemm_nn_ln_bwd_ok(const float *dY, int ldy, const float *W, int ldw, int N) { return N == 256 && aligned16(dY, ldy) && aligned16(W, ldw); }
 long long tmjx_gemm_nn_ln_bwd_partial_floats(int M, int N) { return (long long)((M + GEMM_BM - 1) / GEMM_BM) * 3 * N; }

@@ -31,9 +31,9 @@ class Layout(C.Structure):
 
 EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss",
-           "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_adam_clip", "tmjx_colsum_scratch_floats", "tmjx_colsum",
+           "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_linear_nolds_norm", "tmjx_adam_clip", "tmjx_adam_clip_norm", "tmjx_adam_norm_floats", "tmjx_colsum_scratch_floats", "tmjx_colsum",
            "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_colsum_grouped", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
-           "tmjx_rollout_store", "tmjx_clips_share", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bgemm_partial_floats",
+           "tmjx_rollout_store", "tmjx_clips_share", "tmjx_gemm_nt_silu", "tmjx_gemm_nt_silu_ok", "tmjx_silu_fwd", "tmjx_silu_bwd", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bgemm_partial_floats",
            "tmjx_bgemm_ln_fwd", "tmjx_bgemm_ln_bwd", "tmjx_bgemm_silu_fwd", "tmjx_bgemm_silu_bwd", "tmjx_bf_silu_bwd",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
@@ -72,7 +72,7 @@ class PpoCfg(C.Structure):
     """tmjx_ppo_cfg_t (include/tmjx.h)."""
     _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("A", C.c_int32), ("Z", C.c_int32), ("reward_scaling", C.c_float),
                 ("discounting", C.c_float), ("gae_lambda", C.c_float), ("clip_eps", C.c_float), ("entropy_cost", C.c_float),
-                ("kl_weight", C.c_float), ("normalize_advantage", C.c_int32)]
+                ("kl_weight", C.c_float), ("normalize_advantage", C.c_int32), ("accumulate", C.c_int32)]
 
 _lib = None
 
@@ -178,9 +178,11 @@ def load(path: Path):
     sig.setdefault("tmjx_latent_concat_bwd", [None, None])[0] = [fp] * 4 + [C.c_int] * 3 + [vp]
     sig.setdefault("tmjx_sample_action", [None, None])[0] = [fp] * 5 + [C.c_int, C.c_int, C.c_uint64, fp, vp]
     sig.setdefault("tmjx_linear_nolds", [None, None])[0] = [fp, C.c_int64, C.c_int64, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_linear_nolds_norm", [None, None])[0] = [fp, C.c_int64, C.c_int64, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, vp]
     sig.setdefault("tmjx_colsum_scratch_floats", [None, None])[0] = [C.c_int]
     sig.setdefault("tmjx_colsum", [None, None])[0] = [fp, fp, fp, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_adam_clip", [None, None])[0] = [fp] * 5 + [C.c_longlong] + [C.c_float] * 7 + [vp]
+    sig.setdefault("tmjx_adam_clip_norm", [None, None])[0] = [fp] * 6 + [C.c_longlong] + [C.c_float] * 7 + [vp]
     sig.setdefault("tmjx_gemm_nt", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_gemm_nt_silu_ln_ok", [None, None])[0] = [fp, C.c_int, fp, C.c_int, C.c_int]
     sig.setdefault("tmjx_gemm_nt_silu_ln", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, fp, fp, fp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
@@ -194,6 +196,10 @@ def load(path: Path):
     sig.setdefault("tmjx_gemm_dw_scratch_floats", [None, None])[1] = C.c_longlong
     sig.setdefault("tmjx_gemm_dw", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_gemm_dw_grouped", [None, None])[0] = [C.POINTER(DwProblem), C.c_int, vp]
+    sig.setdefault("tmjx_gemm_nt_silu_ok", [None, None])[0] = [fp, C.c_int, fp, C.c_int]
+    sig.setdefault("tmjx_gemm_nt_silu", [None, None])[0] = [fp, C.c_int, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_silu_fwd", [None, None])[0] = [fp, fp, fp, C.c_longlong, C.c_int, vp]
+    sig.setdefault("tmjx_silu_bwd", [None, None])[0] = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]
     sig.setdefault("tmjx_rollout_store", [None, None])[0] = [C.POINTER(RolloutStore), vp]
     sig.setdefault("tmjx_clips_share", [None, None])[0] = [vp, vp]
     sig.setdefault("tmjx_bf16_shadow", [None, None])[0] = [C.POINTER(Bf16Shadow), C.c_int, vp]
