@@ -15,14 +15,16 @@ from buildid import checked_id  # noqa: E402
 BUILD = checked_id(src, "--force" in sys.argv)
 res = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA ... over tools/sgd_step.py --config <cfg> (eager launches); "
                "utilisation = MFMA busy cycles / (4 x CU busy cycles), summed per kernel family"}
-for cfg in ("cfg2", "cfg4"):
+for cfg in ("cfg2", "cfg4", "cfg5"):
     fs = glob.glob(str(src / cfg / "*" / "*_counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"]
-        fam = "k_gemm_act (forward / input gradient)" if "k_gemm_act" in k else "k_gemm_dw (weight gradient)" if "k_gemm_dw" in k else ("library GEMM" if k.startswith("Cijk") else None)
+        fam = ("k_gemm_act (forward / input gradient)" if "k_gemm_act" in k else "k_gemm_dw (weight gradient)" if "k_gemm_dw" in k else
+               "k_bgemm_nt (bf16 forward / input gradient, fused epilogues)" if "k_bgemm_nt" in k else "k_bgemm_dw (bf16 weight gradient)" if "k_bgemm_dw<" in k else
+               ("library GEMM" if k.startswith("Cijk") else None))
         if fam:
             agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
     out, tot = {}, collections.defaultdict(float)
