@@ -90,7 +90,9 @@ __device__ __forceinline__ float bg_row16_sum(float x) {
 }
 
 template <int MI, int NI> struct BgCfg {
-  static constexpr int BM = 16 * MI, BN = 128 * NI, A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
+  // LDS: a ring of THREE A stages (the activation tile comes from HBM: fetched two K tiles ahead) in front of a ring of TWO B stages (the
+  // weight tile comes from L2: one tile ahead): 3 x 10 KiB + 2 x 64 KiB = 158 KiB at the widest tile
+  static constexpr int BM = 16 * MI, BN = 128 * NI, A_BYTES = BM * 128, B_BYTES = BN * 128, B_BASE = 3 * A_BYTES, LDS = 3 * A_BYTES + 2 * B_BYTES;
 };
 
 // EPI 0: C = acc (+ bias), fp32.
@@ -102,16 +104,24 @@ template <int MI, int NI> struct BgCfg {
 //        sums (dy ahat | dy | dz).  C is not written.
 // EPI 3: Dense -> SiLU forward (brax value MLP): z = acc to C, y = silu(z + bias) as bf16 (or fp32).   EPI 4: its backward on the tile
 //        d loss / d y: dz = dy silu'(z + bias) as bf16 + column sums of dz.
-template <int MI, int NI, int EPI, bool AF32>
+// DMA_A (bf16 A, K a multiple of 64): the activation tile goes global -> LDS by LDS-DMA as well, two tiles ahead, and the K loop waits with a
+// COUNTED vmcnt that leaves those DMAs in flight across the barrier (raw s_barrier: __syncthreads() would drain them).  Otherwise A is staged
+// through registers one tile ahead (fp32 A: converted at the LDS write; ragged K: masked).
+template <int MI, int NI, int EPI, bool AF32, bool DMA_A = false>
 __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, int lda, const bf16_t *__restrict__ B, int ldb, const float *__restrict__ bias,
                                                   float *__restrict__ C, int ldc, int M, int N, int K, BgEpi epi) {
   using Cfg = BgCfg<MI, NI>;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, A_BYTES = Cfg::A_BYTES, B_BYTES = Cfg::B_BYTES, B_BASE = Cfg::B_BASE;
+  static_assert(!(DMA_A && AF32), "LDS-DMA cannot convert");
   extern __shared__ __attribute__((aligned(16))) char bg_lds[];
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, nw = wave * 16 * NI;
   const int nk = (K + BG_BK - 1) / BG_BK;
+  // tuning aid (EPI 0 with a `partial` buffer: tools/bf16_stamps.py): s_memtime stamps of wave 0 around prologue / K loop / stores
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  const bool stamp = EPI == 0 && epi.partial != nullptr;
+  if (stamp) ts0 = __builtin_amdgcn_s_memtime();
 
   // ---- B: LDS-DMA.  One wave instruction moves 1 KiB = 8 rows of the image; wave w moves row groups w, w + 8, ...  The LDS side is
   // lane-linear (lane i -> bytes 16 i .. 16 i + 15 of the group: row i >> 3, PHYSICAL chunk i & 7), so the swizzle goes on the source
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
   auto issue_b = [&](int stage, int k0) {
 #pragma unroll
     for (int i = 0; i < B_INSTR; i++)
-      __builtin_amdgcn_global_load_lds(BG_GLB(bsrc[i] + k0), BG_LDS(bg_lds + stage * STAGE + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(BG_GLB(bsrc[i] + k0), BG_LDS(bg_lds + B_BASE + stage * B_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
   };
 
   // ---- A: registers (fp32 -> bf16 at the LDS write, or bf16 as it is), in units of 16 BYTES OF MEMORY so that a wave instruction reads
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
     for (int p = 0; p < A_PASS; p++) {
       if (p >= A_FULL && wave >= A_REM_WAVES) continue;
       const int f = t + 512 * p, r = f / UPR, u = f % UPR;
-      char *dst = bg_lds + stage * STAGE;
+      char *dst = bg_lds + stage * A_BYTES;
       if (AF32) {
         const bgf4 v = __builtin_bit_cast(bgf4, R.v[p]);
         *reinterpret_cast<bgu2 *>(dst + bg_off(r, u >> 1) + 8 * (u & 1)) = bgu2{bg_pack(v.x, v.y), bg_pack(v.z, v.w)};
@@ -191,17 +201,8 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
   // fragment addresses: rows 16 a + li resp. nw + 16 b + li, so the swizzle term depends on li only
   const int sw = (li >> 1) & 7, frow = li * 128;
 
-  AStage R;
-  issue_b(0, 0);
-  load_a(R, 0);
-  write_a(R, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    const int cur = kt & 1, knext = min(kt + 1, nk - 1) * BG_BK;      // (past the end: the last tile once more, into the stage nobody reads)
-    issue_b(cur ^ 1, knext);
-    load_a(R, knext);
-    const char *sa = bg_lds + cur * STAGE + frow, *sb = sa + A_BYTES + nw * 128;
+  auto compute = [&](int a_stage, int b_stage) {
+    const char *sa = bg_lds + a_stage * A_BYTES + frow, *sb = bg_lds + B_BASE + b_stage * B_BYTES + nw * 128 + frow;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       const int x = ((4 * s + kq) ^ sw) << 4;
@@ -216,10 +217,65 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
         for (int b = 0; b < NI; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bgb8, fb[b]), __builtin_bit_cast(bgb8, fa[a]), acc[a][b], 0, 0, 0);
     }
-    write_a(R, cur ^ 1);
+  };
+  if constexpr (DMA_A) {
+    // A by LDS-DMA: BM / 8 wave instructions per tile (8 rows each); wave w issues instruction w, and w + 8 if that exists — so waves
+    // below A_EXTRA have two in flight per tile, the others one (the counted wait below is per wave)
+    constexpr int A_INSTR = BM / 8, A_EXTRA = A_INSTR > 8 ? A_INSTR - 8 : 0;
+    static_assert(A_INSTR <= 16 && A_INSTR >= 8, "one or two A instructions per wave and tile");
+    const bf16_t *asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = 8 * (wave + 8 * i) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+      asrc[i] = reinterpret_cast<const bf16_t *>(Av) + (size_t)min(m0 + min(row, BM - 1), M - 1) * lda + 8 * c;
+    }
+    auto issue_a = [&](int stage, int k0) {
+      __builtin_amdgcn_global_load_lds(BG_GLB(asrc[0] + k0), BG_LDS(bg_lds + stage * A_BYTES + wave * 1024), 16, 0, 0);
+      if (wave < A_EXTRA) __builtin_amdgcn_global_load_lds(BG_GLB(asrc[1] + k0), BG_LDS(bg_lds + stage * A_BYTES + (wave + 8) * 1024), 16, 0, 0);
+    };
+    // wait until only this wave's youngest A tile is still in flight, then the workgroup barrier WITHOUT draining it
+    auto wait_keep_a = [&]() {
+      if (wave < A_EXTRA) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    issue_b(0, 0);
+    issue_a(0, 0);
+    issue_a(1, min(1, nk - 1) * BG_BK);
+    wait_keep_a();
+    if (stamp) ts1 = __builtin_amdgcn_s_memtime();
+    int sa3 = 0;                                   // kt % 3
+    for (int kt = 0; kt < nk; kt++) {
+      // issue order matters: the B tile first, the A tile (which stays in flight across the barrier) last
+      issue_b((kt + 1) & 1, min(kt + 1, nk - 1) * BG_BK);
+      const int sa_next2 = sa3 == 0 ? 2 : sa3 - 1;                    // (kt + 2) % 3
+      issue_a(sa_next2, min(kt + 2, nk - 1) * BG_BK);
+      compute(sa3, kt & 1);
+      wait_keep_a();
+      sa3 = sa3 == 2 ? 0 : sa3 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the (unused) tiles fetched past the end must have landed before the epilogue reuses LDS
+    __syncthreads();
+  } else {
+    AStage R;
+    issue_b(0, 0);
+    load_a(R, 0);
+    write_a(R, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (stamp) ts1 = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < nk; kt++) {
+      const int cur = kt & 1, knext = min(kt + 1, nk - 1) * BG_BK;      // (past the end: the last tile once more, into the stage nobody reads)
+      issue_b(cur ^ 1, knext);
+      load_a(R, knext);
+      compute(cur, cur);
+      write_a(R, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
+  if (stamp) ts2 = __builtin_amdgcn_s_memtime();
   // (an opaque copy of the lane's row / column origin: otherwise the epilogue's MI NI 64-bit store / load addresses are computed in front of the
   // K loop and stay live through it)
   int li_e = li, kq_e = kq;
@@ -250,6 +306,12 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
           }
         }
       }
+    }
+    if (stamp && t == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the stores have been accepted by the memory system)
+      const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      float *o = epi.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+      o[0] = (float)(ts0 & 0xffffffu); o[1] = (float)(ts1 - ts0); o[2] = (float)(ts2 - ts1); o[3] = (float)(ts3 - ts2);
     }
   }
   // cross-wave exchange of per-row partial sums through LDS (the K loop's stages are dead: its last trip ended with a barrier)

@@ -17,18 +17,27 @@ static int check_launch(const char *what) {
   return TMJX_OK;
 }
 
-template <int MI, int NI, int EPI, bool AF32>
-static int launch_bgemm(const void *A, int lda, const bf16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, const BgEpi &epi, hipStream_t s) {
+template <int MI, int NI, int EPI, bool AF32, bool DMA_A>
+static int launch_bgemm2(const void *A, int lda, const bf16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, const BgEpi &epi, hipStream_t s) {
   using Cfg = BgCfg<MI, NI>;
   static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_bgemm_nt<MI, NI, EPI, AF32>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipError_t e = hipFuncSetAttribute((const void *)k_bgemm_nt<MI, NI, EPI, AF32, DMA_A>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_bgemm_nt): ") + hipGetErrorString(e));
     attr_set = true;
   }
   dim3 grid((M + Cfg::BM - 1) / Cfg::BM, (N + Cfg::BN - 1) / Cfg::BN);
-  hipLaunchKernelGGL((k_bgemm_nt<MI, NI, EPI, AF32>), grid, dim3(512), Cfg::LDS, s, A, lda, B, ldb, bias, C, ldc, M, N, K, epi);
+  hipLaunchKernelGGL((k_bgemm_nt<MI, NI, EPI, AF32, DMA_A>), grid, dim3(512), Cfg::LDS, s, A, lda, B, ldb, bias, C, ldc, M, N, K, epi);
   return check_launch("k_bgemm_nt");
+}
+template <int MI, int NI, int EPI, bool AF32>
+static int launch_bgemm(const void *A, int lda, const bf16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, const BgEpi &epi, hipStream_t s) {
+  // bf16 activations with a contraction length that is a whole number of K tiles: A by LDS-DMA, two tiles ahead (TMJX_BG_NO_DMA_A=1: A/B switch)
+  static const bool no_dma = getenv("TMJX_BG_NO_DMA_A") != nullptr;
+  if constexpr (!AF32) {
+    if (!(K % BG_BK) && !no_dma) return launch_bgemm2<MI, NI, EPI, false, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+  }
+  return launch_bgemm2<MI, NI, EPI, AF32, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
 }
 template <int EPI, bool AF32>
 static int bgemm_by_width(const void *A, int lda, const bf16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K, const BgEpi &epi, hipStream_t s) {
@@ -91,7 +100,11 @@ int tmjx_bgemm_nt(const void *A, int a_is_f32, int lda, const uint16_t *B, int l
   if (M < 1 || N < 1 || K < 1 || lda < K || ldc < N || ldb < ((K + 63) & ~63)) return fail(TMJX_EINVAL, "bad sizes / leading dimensions (ldb must reach ceil64(K))");
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 7) || (lda & (a_is_f32 ? 3 : 7))) return fail(TMJX_EINVAL, "tmjx_bgemm_nt: operand rows must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const BgEpi epi{};
+  BgEpi epi{};
+  static float *stamps = nullptr;          // TMJX_BG_STAMPS=<device pointer, hex>: per-workgroup s_memtime stamps (tools/bf16_stamps.py)
+  static bool checked = false;
+  if (!checked) { const char *e = getenv("TMJX_BG_STAMPS"); if (e) stamps = (float *)(uintptr_t)strtoull(e, nullptr, 16); checked = true; }
+  epi.partial = stamps;
   if (a_is_f32) return bgemm_by_width<0, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
   return bgemm_by_width<0, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
 }
