@@ -96,6 +96,28 @@ def mjx_cpu_probe() -> str:
         return f"unavailable ({type(e).__name__}: {e})"
 
 
+def other_configs(timeout_s: float = 150.0) -> dict:
+    """Short runs of `bench.py --config cfg4 / cfg5` as child processes; the fields of their lines that matter."""
+    import subprocess
+    res = {}
+    for cfg in ("cfg4", "cfg5"):
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-rollout-only"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                res[cfg] = {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
+                continue
+            o = json.loads(line[-1])
+            c = o["config"]
+            res[cfg] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "dtype": o["dtype"], "workload": c["workload"],
+                        "rollout_ms_per_step": c["rollout_ms_per_step"], "sgd_ms_per_minibatch_step": c["sgd_ms_per_minibatch_step"], "steps": o["steps"],
+                        "mlp_gemm_inputs": c["mlp_gemm_inputs"], "roofline_mfma_frac": o["roofline_mfma"]["frac"]}
+        except Exception as e:  # noqa: BLE001 — a report beside the headline, never a reason to lose it
+            res[cfg] = {"error": f"{type(e).__name__}: {e}"}
+    return res
+
+
 def dry_run_ranks(args) -> None:
     """`--dry-run-ranks`: the launcher plumbing without a GPU — every rank joins a gloo group, all-reduces a one, rank 0 prints the
     line's skeleton (tests/test_launch.py drives `bench.py --gpus 2 --dry-run-ranks` through the self-launch branch)."""
@@ -130,6 +152,7 @@ def main(argv=None, runner=None):
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
                     help="BASELINE.json configs[1] (default, the headline line) / configs[3] / configs[4]; the others are extra measurements")
     ap.add_argument("--dry-run-ranks", action="store_true", help="launcher check on CPU: gloo ranks, no GPU work (tests)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short cfg4 / cfg5 measurements the default N = 1 line carries under config.other_configs")
     args = ap.parse_args(argv)
     from track_mjx_amd import launch
     if launch.needs_spawn(args.gpus):
@@ -342,6 +365,10 @@ def main(argv=None, runner=None):
                 out["cpu_baseline"]["mjx_cpu"] = out["mjx_cpu"]
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        # BASELINE configs[3] / configs[4] beside the headline line (driver-visible: the default run is the only one the driver makes): each as a
+        # CHILD process of this script after the timed region (own process: its failure or time-out cannot touch the headline), 2 timed steps
+        if world == 1 and args.config == "cfg2" and not args.no_other_configs and not args.no_cpu_baseline:
+            out["config"]["other_configs"] = other_configs()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

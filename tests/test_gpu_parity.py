@@ -697,6 +697,46 @@ def test_full_size_networks_training_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_baseline_configs_4_and_5_at_full_size(cfg):
+    """BASELINE configs[3] / configs[4] as bench.py builds them, at FULL size, one training step each through the product path: config 4 =
+    rodent-mc-intention nets (rodent-full-clips.yaml:50-57) at 4096 envs in two pipelined groups, fp32; config 5 = 8192 envs, a 1024-clip table
+    (per-env clip gather), the same nets with bf16 GEMM inputs on the repo's own kernels.  Finite losses, moved parameters, and for config 5 no
+    library GEMM: the bf16 shadows exist and every hidden activation of the chains is bf16."""
+    import bench
+    from track_mjx_amd import clips as _clips, config as _config
+    from track_mjx_amd.agent import ppo
+    from track_mjx_amd.environment import wrap
+    from track_mjx_amd.train import build_env
+    from track_mjx_amd.walker import Rodent
+    bc = bench.CONFIGS[cfg]
+    c = _config.default_config()
+    c["network_config"].update(**bc["nets"])
+    tc, nc = c["train_setup"]["train_config"], c["network_config"]
+    n = bc["envs_per_gpu"]
+    table = _clips.make_synthetic_clips(Rodent(**c["walker_config"]).model, bc["n_clips"], n_frames=c["reference_config"]["clip_length"], mocap_hz=c["env_config"]["env_args"]["mocap_hz"])
+    e0 = wrap(build_env(c, n // 2, DEV, reference_clip=table), episode_length=195)
+    envs = [e0, wrap(build_env(c, n // 2, DEV, reference_clip=table, share_clips_with=e0), episode_length=195)]
+    L = ppo.PPOLearner(envs, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"], critic_layers=nc["critic_layer_sizes"],
+                       latents=nc["intention_size"], unroll_length=tc["unroll_length"], batch_size=tc["batch_size"] * n // 4096, num_minibatches=tc["num_minibatches"],
+                       num_updates_per_batch=1, kl_weight=nc["kl_weight"], seed=0, matmul_dtype=torch.bfloat16 if bc["matmul_dtype"] == "bf16" else None)
+    assert L.n_params() == 4_294_853 and L.local_batch * L.T == (20480 if cfg == "cfg4" else 40960)
+    g = torch.Generator().manual_seed(1)
+    for k, e in enumerate(envs):
+        idx = torch.randint(0, bc["n_clips"], (n // 2,), generator=g, dtype=torch.int32)
+        L.states[k] = e.reset(g, idx)
+        assert int(e.istate_buf[e.layout.i_clip_idx].max()) < bc["n_clips"]
+    before = L.opt.flat.clone()
+    out = L.training_step(0)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in out.values()), out
+    assert float((L.opt.flat - before).abs().max()) > 0
+    if cfg == "cfg5":
+        assert L.shadows is not None and all(w.dtype == torch.bfloat16 for w in L.shadows.w.values())
+        assert int(envs[0].istate_buf[envs[0].layout.i_clip_idx].max()) > 64          # the 1024-clip table is really indexed
+
+
+@pytest.mark.gpu
 def test_reset_from_jax_key_draws():
     """reset(key) with a jax PRNG key: clip index, start frame and noise are the threefry draws of the reference's reset
     (bit-exact integers; the state equals the reference frame + that noise)."""
