@@ -90,9 +90,8 @@ __device__ __forceinline__ float bg_row16_sum(float x) {
 }
 
 template <int MI, int NI> struct BgCfg {
-  // LDS: a ring of THREE A stages (the activation tile comes from HBM: fetched two K tiles ahead) in front of a ring of TWO B stages (the
-  // weight tile comes from L2: one tile ahead): 3 x 10 KiB + 2 x 64 KiB = 158 KiB at the widest tile
-  static constexpr int BM = 16 * MI, BN = 128 * NI, A_BYTES = BM * 128, B_BYTES = BN * 128, B_BASE = 3 * A_BYTES, LDS = 3 * A_BYTES + 2 * B_BYTES;
+  // LDS: two stages of the activation tile in front of two stages of the weight tile: 2 x 10 KiB + 2 x 64 KiB = 148 KiB at the widest tile
+  static constexpr int BM = 16 * MI, BN = 128 * NI, A_BYTES = BM * 128, B_BYTES = BN * 128, B_BASE = 2 * A_BYTES, LDS = 2 * A_BYTES + 2 * B_BYTES;
 };
 
 // EPI 0: C = acc (+ bias), fp32.
@@ -104,9 +103,16 @@ template <int MI, int NI> struct BgCfg {
 //        sums (dy ahat | dy | dz).  C is not written.
 // EPI 3: Dense -> SiLU forward (brax value MLP): z = acc to C, y = silu(z + bias) as bf16 (or fp32).   EPI 4: its backward on the tile
 //        d loss / d y: dz = dy silu'(z + bias) as bf16 + column sums of dz.
-// DMA_A (bf16 A, K a multiple of 64): the activation tile goes global -> LDS by LDS-DMA as well, two tiles ahead, and the K loop waits with a
-// COUNTED vmcnt that leaves those DMAs in flight across the barrier (raw s_barrier: __syncthreads() would drain them).  Otherwise A is staged
-// through registers one tile ahead (fp32 A: converted at the LDS write; ragged K: masked).
+// DMA_A (bf16 A, K a multiple of 64): the activation tile goes global -> LDS by LDS-DMA as well; otherwise it is staged through registers (fp32 A:
+// converted at the LDS write; ragged K: masked).
+// K loop: ONE barrier per 64-deep tile, in its MIDDLE, with 20 MFMAs per wave on either side of it (the structure of csrc/gemm_kernels.h):
+//   first half   fragments of the tile's second k step are read from LDS while the first step's MFMAs run (their fragments were read a half
+//                tile earlier); register-staged A of the NEXT tile is written to the other stage;
+//   barrier      the next tile (DMAs issued a whole tile earlier) has landed, everyone is done reading this tile's stage;
+//   second half  the DMAs of the tile after next go into the stage just released, the next tile's first-step fragments are read while the
+//                second step's MFMAs run.
+// No MFMA ever waits for an LDS read issued right in front of it (the first version read 9 fragments, waited, ran 20 MFMAs, twice per tile: the
+// matrix pipe was busy half of the K loop's cycles, tools/bf16_stamps.py).
 template <int MI, int NI, int EPI, bool AF32, bool DMA_A = false>
 __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, int lda, const bf16_t *__restrict__ B, int ldb, const float *__restrict__ bias,
                                                   float *__restrict__ C, int ldc, int M, int N, int K, BgEpi epi) {
@@ -201,80 +207,64 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
   // fragment addresses: rows 16 a + li resp. nw + 16 b + li, so the swizzle term depends on li only
   const int sw = (li >> 1) & 7, frow = li * 128;
 
-  auto compute = [&](int a_stage, int b_stage) {
-    const char *sa = bg_lds + a_stage * A_BYTES + frow, *sb = bg_lds + B_BASE + b_stage * B_BYTES + nw * 128 + frow;
+  struct Frag { bgs8 a[MI], b[NI]; };
+  auto fread = [&](Frag &F, int stage, int s) {
+    const char *sa = bg_lds + stage * A_BYTES + frow, *sb = bg_lds + B_BASE + stage * B_BYTES + nw * 128 + frow;
+    const int x = ((4 * s + kq) ^ sw) << 4;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      const int x = ((4 * s + kq) ^ sw) << 4;
-      bgs8 fa[MI], fb[NI];
+    for (int a = 0; a < MI; a++) F.a[a] = *reinterpret_cast<const bgs8 *>(sa + a * 2048 + x);
 #pragma unroll
-      for (int a = 0; a < MI; a++) fa[a] = *reinterpret_cast<const bgs8 *>(sa + a * 2048 + x);
-#pragma unroll
-      for (int b = 0; b < NI; b++) fb[b] = *reinterpret_cast<const bgs8 *>(sb + b * 2048 + x);
-#pragma unroll
-      for (int a = 0; a < MI; a++)
-#pragma unroll
-        for (int b = 0; b < NI; b++)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bgb8, fb[b]), __builtin_bit_cast(bgb8, fa[a]), acc[a][b], 0, 0, 0);
-    }
+    for (int b = 0; b < NI; b++) F.b[b] = *reinterpret_cast<const bgs8 *>(sb + b * 2048 + x);
   };
+  auto mma = [&](const Frag &F) {
+#pragma unroll
+    for (int a = 0; a < MI; a++)
+#pragma unroll
+      for (int b = 0; b < NI; b++)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bgb8, F.b[b]), __builtin_bit_cast(bgb8, F.a[a]), acc[a][b], 0, 0, 0);
+  };
+  // A by LDS-DMA: BM / 8 wave instructions per tile (8 rows each); wave w issues instruction w, and w + 8 if that exists
+  constexpr int A_INSTR = BM / 8, A_EXTRA = A_INSTR > 8 ? A_INSTR - 8 : 0;
+  static_assert(!DMA_A || (A_INSTR <= 16 && A_INSTR >= 8), "one or two A instructions per wave and tile");
+  const bf16_t *asrc[2] = {nullptr, nullptr};
   if constexpr (DMA_A) {
-    // A by LDS-DMA: BM / 8 wave instructions per tile (8 rows each); wave w issues instruction w, and w + 8 if that exists — so waves
-    // below A_EXTRA have two in flight per tile, the others one (the counted wait below is per wave)
-    constexpr int A_INSTR = BM / 8, A_EXTRA = A_INSTR > 8 ? A_INSTR - 8 : 0;
-    static_assert(A_INSTR <= 16 && A_INSTR >= 8, "one or two A instructions per wave and tile");
-    const bf16_t *asrc[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = 8 * (wave + 8 * i) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
       asrc[i] = reinterpret_cast<const bf16_t *>(Av) + (size_t)min(m0 + min(row, BM - 1), M - 1) * lda + 8 * c;
     }
-    auto issue_a = [&](int stage, int k0) {
+  }
+  AStage R;
+  // fetch tile `kt` (clamped to the last one: past the end the last tile is fetched once more, into a stage nobody reads any more)
+  auto fetch = [&](int stage, int kt) {
+    const int k0 = min(kt, nk - 1) * BG_BK;
+    issue_b(stage, k0);
+    if constexpr (DMA_A) {
       __builtin_amdgcn_global_load_lds(BG_GLB(asrc[0] + k0), BG_LDS(bg_lds + stage * A_BYTES + wave * 1024), 16, 0, 0);
       if (wave < A_EXTRA) __builtin_amdgcn_global_load_lds(BG_GLB(asrc[1] + k0), BG_LDS(bg_lds + stage * A_BYTES + (wave + 8) * 1024), 16, 0, 0);
-    };
-    // wait until only this wave's youngest A tile is still in flight, then the workgroup barrier WITHOUT draining it
-    auto wait_keep_a = [&]() {
-      if (wave < A_EXTRA) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    };
-    issue_b(0, 0);
-    issue_a(0, 0);
-    issue_a(1, min(1, nk - 1) * BG_BK);
-    wait_keep_a();
-    if (stamp) ts1 = __builtin_amdgcn_s_memtime();
-    int sa3 = 0;                                   // kt % 3
-    for (int kt = 0; kt < nk; kt++) {
-      // issue order matters: the B tile first, the A tile (which stays in flight across the barrier) last
-      issue_b((kt + 1) & 1, min(kt + 1, nk - 1) * BG_BK);
-      const int sa_next2 = sa3 == 0 ? 2 : sa3 - 1;                    // (kt + 2) % 3
-      issue_a(sa_next2, min(kt + 2, nk - 1) * BG_BK);
-      compute(sa3, kt & 1);
-      wait_keep_a();
-      sa3 = sa3 == 2 ? 0 : sa3 + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the (unused) tiles fetched past the end must have landed before the epilogue reuses LDS
+    } else load_a(R, k0);
+  };
+  Frag F0, F1;
+  fetch(0, 0);
+  if constexpr (!DMA_A) write_a(R, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (stamp) ts1 = __builtin_amdgcn_s_memtime();
+  fread(F0, 0, 0);
+  fetch(1, 1);
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    fread(F1, cur, 1);
+    if constexpr (!DMA_A) write_a(R, cur ^ 1);          // tile kt + 1 (loaded a half tile ago) into the other stage: last read before the previous barrier
+    mma(F0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt + 1 has landed (LDS-DMA counts on vmcnt)
     __syncthreads();
-  } else {
-    AStage R;
-    issue_b(0, 0);
-    load_a(R, 0);
-    write_a(R, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (stamp) ts1 = __builtin_amdgcn_s_memtime();
-    for (int kt = 0; kt < nk; kt++) {
-      const int cur = kt & 1, knext = min(kt + 1, nk - 1) * BG_BK;      // (past the end: the last tile once more, into the stage nobody reads)
-      issue_b(cur ^ 1, knext);
-      load_a(R, knext);
-      compute(cur, cur);
-      write_a(R, cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+    fetch(cur, kt + 2);                                 // into the stage everyone has just finished reading
+    fread(F0, cur ^ 1, 0);
+    mma(F1);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (unused) tiles fetched past the end must have landed before the epilogue reuses LDS
+  __syncthreads();
   if (stamp) ts2 = __builtin_amdgcn_s_memtime();
   // (an opaque copy of the lane's row / column origin: otherwise the epilogue's MI NI 64-bit store / load addresses are computed in front of the
   // K loop and stay live through it)

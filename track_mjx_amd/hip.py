@@ -89,7 +89,8 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
     import hashlib
     import re
     from concurrent.futures import ThreadPoolExecutor
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-value", *[f"-D{d}" for d in defines]]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-value", *[f"-D{d}" for d in defines],
+             *os.environ.get("TMJX_EXTRA_HIPCC_FLAGS", "").split()]          # (tuning experiments: A/B builds with extra compiler flags)
 
     def closure(path: Path, seen: dict) -> dict:
         if path in seen or not path.exists():
