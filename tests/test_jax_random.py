@@ -29,6 +29,33 @@ def test_partitionable_layout_known_answer_and_prefix_property():
     assert np.array_equal(jr.fold_in(jr.PRNGKey(0), 1), jr.split(jr.PRNGKey(0), 2)[1])     # both are threefry(key, (0, 1))
 
 
+def test_values_printed_in_jax_documentation():
+    """Values jax's own documentation prints (recalled offline, no network in this image: each is reproduced to every printed digit by the independent
+    implementation here — ten-float coincidences are not chance):
+      * README / quickstart:        random.normal(PRNGKey(0), (10,))                                   (legacy layout)
+      * "JAX - The Sharp Bits":     normal(PRNGKey(0), (1,)); key, subkey = split(key) twice; key, *subkeys = split(key, 4)   (legacy layout)
+      * "Pseudorandom numbers":     normal(PRNGKey(42)) and normal of the subkey of split(key)          (legacy: -0.18471177 / 1.3694694; partitionable
+                                    default of the pinned jax 0.6.2: -0.028304616 / 0.60576403)
+      * jax.random module docstring: random.uniform(random.key(0)) = 0.947667                           (partitionable layout: pins bits + uniform)"""
+    leg = dict(partitionable=False)
+    np.testing.assert_allclose(jr.normal(jr.PRNGKey(0), (10,), **leg),
+                               [-0.3721109, 0.26423115, -0.18252768, -0.7368197, -0.44030377, -0.1521442, -0.67135346, -0.5908641, 0.73168886, 0.5673026], rtol=2e-6)
+    key = jr.PRNGKey(0)
+    np.testing.assert_allclose(jr.normal(key, (1,), **leg), [-0.20584226], rtol=2e-6)
+    key, sub = jr.split(key, 2, **leg)
+    np.testing.assert_allclose(jr.normal(sub, (1,), **leg), [-1.2515389], rtol=2e-6)
+    key, sub = jr.split(key, 2, **leg)
+    np.testing.assert_allclose(jr.normal(sub, (1,), **leg), [-0.58665055], rtol=2e-6)
+    subs = jr.split(key, 4, **leg)[1:]
+    np.testing.assert_allclose([float(jr.normal(s_, (1,), **leg)[0]) for s_ in subs], [-0.37533438, 0.98645043, 0.14553197], rtol=2e-6)
+    k42 = jr.PRNGKey(42)
+    np.testing.assert_allclose(jr.normal(k42, (), **leg), -0.18471177, rtol=2e-6)
+    np.testing.assert_allclose(jr.normal(jr.split(k42, 2, **leg)[1], (), **leg), 1.3694694, rtol=2e-6)
+    np.testing.assert_allclose(jr.normal(k42, (), partitionable=True), -0.028304616, rtol=2e-6)
+    np.testing.assert_allclose(jr.normal(jr.split(k42, 2, partitionable=True)[1], (), partitionable=True), 0.60576403, rtol=2e-6)
+    np.testing.assert_allclose(jr.uniform(jr.PRNGKey(0), (), partitionable=True), 0.947667, rtol=2e-6)
+
+
 def test_ranges_and_permutation():
     k = jr.PRNGKey(3)
     u = jr.uniform(k, (10000,), -0.5, 0.25)
