@@ -1644,6 +1644,18 @@ TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num) {
   TMW_TICK2(17);
   return gn;
 }
+// A value rounded to float32 where it stands: the compiler may not fuse the product behind it into a following add.  The line search
+// needs this for the derivative  d0 = 2 alpha q2 + q1:  at the Newton point alpha = -q1 / (2 q2) the ROUNDED product cancels q1 exactly
+// about half of the time, d0 == 0 is a fixed point of the bracket update and the search stops (MJX's behaviour, and the oracle's);
+// fused (hipcc contracts a * b + c by default) d0 is the exact, almost never zero, rounding residual of the division and the search keeps
+// refining a converged bracket: +28 % line-search iterations for the same result (tests/diagnostics/ls_iterations.py).
+#if defined(TMW_FUSED_D0)      // the diagnostic's "before" arm
+TM_DEV float tmw_round(float p) { return p; }
+#elif defined(TM_HOST_EMU)
+TM_DEV float tmw_round(float p) { volatile float q = p; return q; }
+#else
+TM_DEV float tmw_round(float p) { asm volatile("" : "+v"(p)); return p; }
+#endif
 struct TmwLS { float alpha, cost, d0, d1; };
 // The constraint rows of a line search live in registers: per row e = lane + 64 s the three quadratic coefficients
 // t0 = D ja^2 / 2, t1 = D ja jv, t2 = D jv^2 / 2 and (ja, jv) for the activity test ja + alpha jv < 0.
@@ -1682,7 +1694,7 @@ TM_DEV void tmw_ls_points16(WCtx &c, const TmwLSRows &R, const float *a, float g
     float r0 = g0 + s0[p], r1 = g1 + s1[p], r2 = g2 + s2[p], al = a[p];
     out[p].alpha = al;
     out[p].cost = al * al * r2 + al * r1 + r0;
-    out[p].d0 = 2.f * al * r2 + r1;
+    out[p].d0 = tmw_round(2.f * al * r2) + r1;
     out[p].d1 = 2.f * r2 + (r2 == 0.f ? TM_MINVAL : 0.f);
   }
 }
@@ -1716,7 +1728,7 @@ TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const f
     float q0 = g0 + qq[3 * p], q1 = g1 + qq[3 * p + 1], q2 = g2 + qq[3 * p + 2], al = a[p];
     out[p].alpha = al;
     out[p].cost = al * al * q2 + al * q1 + q0;
-    out[p].d0 = 2.f * al * q2 + q1;
+    out[p].d0 = tmw_round(2.f * al * q2) + q1;
     out[p].d1 = 2.f * q2 + (q2 == 0.f ? TM_MINVAL : 0.f);
   }
 }
@@ -1732,6 +1744,17 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
   al[0] = p0.alpha - p0.d0 * tmw_rcp(p0.d1);     // d1 = 2 q2 > 0: hardware reciprocal + one Newton step instead of the IEEE division sequence
   tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
   TmwLS lo0 = pt[0];
+#ifndef TMW_LS_NO_SHORTCUT
+  // d0 == 0 EXACTLY at the Newton point — the usual outcome when no row changes sides on the way (tmw_round).  What the loop below then
+  // does is determined: its first iteration moves both ends of the bracket onto this point (whatever the midpoint evaluates to), the
+  // second finds nothing to swap.  Those six evaluations are skipped; the step returned and the iteration count reported are the loop's.
+  if (lo0.d0 == 0.f) {
+    const bool done0 = (p0.d0 < 0.f && p0.d0 > -gtol) || (p0.d0 > 0.f && p0.d0 < gtol);
+    const int cnt = done0 ? 0 : (p0.d0 == 0.f ? 1 : 2);
+    TMW_STATS(K) += (float)(cnt < m.ls_iterations ? cnt : m.ls_iterations);
+    return lo0.cost < p0.cost ? lo0.alpha : 0.f;
+  }
+#endif
   bool lesser = lo0.d0 < p0.d0;
   TmwLS hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
   bool swap = true;
@@ -1739,6 +1762,10 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
   for (; it < m.ls_iterations; it++) {
     bool done = !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
     if (done) break;
+#ifndef TMW_LS_NO_SHORTCUT
+    // the bracket has collapsed onto a point with d0 == 0: all three candidates of this iteration ARE that point, nothing swaps
+    if (lo.alpha == hi.alpha && lo.d0 == 0.f && hi.d0 == 0.f) { it++; break; }
+#endif
     al[0] = lo.alpha - lo.d0 * tmw_rcp(lo.d1); al[1] = hi.alpha - hi.d0 * tmw_rcp(hi.d1); al[2] = 0.5f * (lo.alpha + hi.alpha);
     tmw_ls_points<3, WIDTH>(c, K, R, al, g0, g1, g2, pt);
     TmwLS lo_next = pt[0], hi_next = pt[1], mid = pt[2];
