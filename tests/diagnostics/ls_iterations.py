@@ -9,6 +9,10 @@ Measured (0.3 N(0,1) actions, 16 envs x 30 substeps): 6.79 / 8.70 / 6.73 iterati
 qvel median error unchanged (1.9e-6).  The fused derivative is the exact rounding residual of the Newton division — never zero — so a
 converged bracket keeps "improving" by noise; rounded on its own the product cancels exactly and the search stops, as MJX's does.
 
+The "full loop" arm also switches off the kernel's two result-preserving shortcuts (-DTMW_LS_NO_SHORTCUT: evaluations the bracket update
+provably ignores once d0 == 0; -DTMW_CG_NO_EARLY_EXIT: the gradient / search-direction update of a CG pass that is known to be the last);
+the script asserts that the shipped arm reproduces its state, warm start and solver statistics bit for bit.
+
 usage: python tests/diagnostics/ls_iterations.py [scale] [envs] [substeps]
 """
 import subprocess
@@ -53,8 +57,8 @@ blob = default_blob(w, cfg)
 clip = _clips.make_synthetic_clips(w.model, 4, seed=0)
 variants = {"no contraction anywhere": emu_variant("nofma", ["-ffp-contract=off"]),
             "contracted, d0 fused too (before)": emu_variant("fma", ["-mfma", "-ffp-contract=fast", "-DTMW_FUSED_D0"]),
-            "contracted, d0 unfused, full loop": emu_variant("fma_d0", ["-mfma", "-ffp-contract=fast", "-DTMW_LS_NO_SHORTCUT"]),
-            "same + d0 == 0 shortcuts (shipped)": emu_variant("fma_d0s", ["-mfma", "-ffp-contract=fast"])}
+            "contracted, d0 unfused, full loop": emu_variant("fma_d0", ["-mfma", "-ffp-contract=fast", "-DTMW_LS_NO_SHORTCUT", "-DTMW_CG_NO_EARLY_EXIT"]),
+            "same + exact shortcuts (shipped)": emu_variant("fma_d0s", ["-mfma", "-ffp-contract=fast"])}
 E = {k: EmuAt(so, blob, n) for k, so in variants.items()}
 O32 = make_oracle(blob, clip, "f32"); O64 = make_oracle(blob, clip, "f64")
 rng = np.random.default_rng(1)
@@ -79,7 +83,7 @@ for sub in range(nsub):
         em.physics_wave(a.T.astype(np.float32).copy(), 1, True, dump=True)
         ss = em.rows("solver_stats")
         ni[k] += ss[0].sum(); ls[k] += ss[1].sum()
-    full, short = E["contracted, d0 unfused, full loop"], E["same + d0 == 0 shortcuts (shipped)"]
+    full, short = E["contracted, d0 unfused, full loop"], E["same + exact shortcuts (shipped)"]
     assert all(np.array_equal(full.rows(k), short.rows(k)) for k in ("qpos", "qvel", "qacc_warmstart", "solver_stats")), "the shortcuts must not change a bit"
     for e in range(n):
         O32.step(d32[e], a[e]); O64.step(d64[e], a[e])

@@ -1620,12 +1620,13 @@ TM_DEV void tmw_solve_down(WCtx &c, const WLayout &K, int x, int out) {
   TMW_SYNC();
 }
 // qfrc_constraint = J^T f at the current Jaref;  w = ut - D^-1 N^T qfrc_constraint;  returns gn = w.D w (= grad.M^-1 grad) and,
-// through `num`, w.D (w - w_prev) with w_prev = l_tmp (Polak-Ribiere numerator)
-TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num) {
+// through `num`, w.D (w - w_prev) with w_prev = l_tmp (Polak-Ribiere numerator); `improvement < last_if`: qfrc_constraint only, returns -1
+TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num, float improvement = 0.f, float last_if = -INFINITY) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
   tmw_jt_force(c, K, K.l_qfrc_constraint);
   TMW_TICK2(16);
+  if (improvement < last_if) return -1.f;      // the solve's last pass (tmw_solve_cg): qfrc_constraint only
   tmw_solve_up(c, K, K.l_qfrc_constraint, K.l_Mgrad);
   TMW_TICK2(26);
   TMW_REG(float, pa); TMW_REG(float, pb);
@@ -1887,10 +1888,21 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     prev_cost = cost;
     cost = cost_new;
     float den = gn;
-    gn = tmw_update_gradient(c, K, num);
-    float beta = fmaxf(0.f, num / fmaxf(TM_MINVAL, den));
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_mv + i] = -L[K.l_Mgrad + i] + beta * L[K.l_mv + i]; }
-    TMW_SYNC();
+    // `last_if`: the loop is about to end — the iteration cap, or the improvement test of its next pass, which needs nothing but the two
+    // costs at hand (in float32 a converged solve ends by that test: the gradient test sits below the rounding noise of gn).  The new
+    // gradient's D^-1 N^T half, its norms and the next search direction would never be read; only qfrc_constraint is (Euler's right-hand
+    // side).  tmw_update_gradient then returns -1 after J^T f (decided there, so that no flag lives across that product).
+#ifndef TMW_CG_NO_EARLY_EXIT
+    const float last_if = it + 1 >= m.iterations ? INFINITY : m.tolerance;     // ends if  (prev_cost - cost) / scale < last_if: the loop's own test
+#else
+    const float last_if = -INFINITY;
+#endif
+    gn = tmw_update_gradient(c, K, num, (prev_cost - cost) / scale, last_if);
+    if (gn >= 0.f) {
+      float beta = fmaxf(0.f, num / fmaxf(TM_MINVAL, den));
+      TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_mv + i] = -L[K.l_Mgrad + i] + beta * L[K.l_mv + i]; }
+      TMW_SYNC();
+    }
     TMW_TICK(8);
   }
   TMW_STATS(K) += 64.f * (float)it;
