@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict
   c.dump = ws_dump;
 #endif
 #ifdef TMW_PROFILE
-  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)(blockIdx.x + e0) * 32; c.tlast = __builtin_amdgcn_s_memtime(); }
+  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)(blockIdx.x + e0) * 40; c.tlast = __builtin_amdgcn_s_memtime(); }
 #endif
   constexpr WLayout ks(TMW_RODENT_DIMS, 1);
   const WLayout kd = STATIC ? ks : WLayout(mp->nbody, mp->njnt, mp->nq, mp->nv, mp->nu, mp->ncon, mp->nlim, mp->nnz, mp->ngroup,

@@ -83,9 +83,11 @@ struct WCtx {
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
 #define TMW_TICK(idx) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (c.prof && c.lane == 0) c.prof[idx] += t_ - c.tlast; c.tlast = t_; } while (0)
 #define TMW_TICK2(idx) TMW_TICK(idx)
+#define TMW_COUNT(idx, v) do { if (c.prof && c.lane == 0) c.prof[idx] += (v); } while (0)
 #else
 #define TMW_TICK(idx) do { } while (0)
 #define TMW_TICK2(idx) do { } while (0)
+#define TMW_COUNT(idx, v) do { } while (0)
 #endif
 // state word (row off + i) of this env: the C-ABI layout [row][n_env], or — when the launch goes through the env-major physics
 // record (c.rs = record stride; tmjx_hip.hip: k_rec_in / k_rec_out) — word (off + i) of this env's contiguous record, so that the
@@ -106,6 +108,9 @@ TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
 TM_DEV float tmw_sum(const float *v) { float s = 0.f; for (int i = 0; i < 64; i++) s += v[i]; return s; }
 TM_DEV float tmw_readlane(const float *v, int src) { return v[src]; }
 #else
+// (all steps with FULL row / bank masks: only the last lane of the reduced span is read afterwards, whose value does not depend on what the
+// other lanes accumulate, and only then does the compiler fold the move into one `v_add_f32_dpp` — with the textbook partial masks each
+// step was v_mov_b32_dpp + v_add_f32 + a re-zeroing v_mov)
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 TM_DEV float tmw_dpp_add(float v) {
   int moved = __builtin_amdgcn_update_dpp(0, tm_f2i(v), CTRL, ROW_MASK, BANK_MASK, false);
@@ -128,10 +133,10 @@ TM_DEV float tmw_sum_dpp(const float *vp) {
   float v = vp[0];
   v = tmw_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
   v = tmw_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
-  v = tmw_dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4
-  v = tmw_dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8
-  v = tmw_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15
-  v = tmw_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31
+  v = tmw_dpp_add<0x114, 0xf, 0xf>(v);  // row_shr:4
+  v = tmw_dpp_add<0x118, 0xf, 0xf>(v);  // row_shr:8
+  v = tmw_dpp_add<0x142, 0xf, 0xf>(v);  // row_bcast:15
+  v = tmw_dpp_add<0x143, 0xf, 0xf>(v);  // row_bcast:31
   return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 63));  // the builtin is typed int: pass the BITS, not the value
 }
 TM_DEV float tmw_readlane_dpp(const float *v, int src) { return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v[0]), src)); }
@@ -145,12 +150,12 @@ template <int WIDTH> TM_DEV float tmw_sum_w(const float *vp) {
   float v = vp[0];
   v = tmw_dpp_add<0x111, 0xf, 0xf>(v);
   v = tmw_dpp_add<0x112, 0xf, 0xf>(v);
-  v = tmw_dpp_add<0x114, 0xf, 0xe>(v);
-  v = tmw_dpp_add<0x118, 0xf, 0xc>(v);
+  v = tmw_dpp_add<0x114, 0xf, 0xf>(v);
+  v = tmw_dpp_add<0x118, 0xf, 0xf>(v);
   if (WIDTH <= 16) return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 15));
-  v = tmw_dpp_add<0x142, 0xa, 0xf>(v);
+  v = tmw_dpp_add<0x142, 0xf, 0xf>(v);
   if (WIDTH <= 32) return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 31));
-  v = tmw_dpp_add<0x143, 0xc, 0xf>(v);
+  v = tmw_dpp_add<0x143, 0xf, 0xf>(v);
   return tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 63));
 }
 #endif
@@ -1670,10 +1675,31 @@ template <int NROW> TM_DEV void tmw_rowsum16(const float *vp, float *out) {
   float v = vp[0];
   v = tmw_dpp_add<0x111, 0xf, 0xf>(v);
   v = tmw_dpp_add<0x112, 0xf, 0xf>(v);
-  v = tmw_dpp_add<0x114, 0xf, 0xe>(v);
-  v = tmw_dpp_add<0x118, 0xf, 0xc>(v);
+  v = tmw_dpp_add<0x114, 0xf, 0xf>(v);
+  v = tmw_dpp_add<0x118, 0xf, 0xf>(v);
 #pragma unroll
   for (int r = 0; r < NROW; r++) out[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 16 * r + 15));
+}
+#endif
+// three row sums side by side, written step-interleaved: a DPP operand needs two wait states after the instruction that wrote it, and the
+// three independent chains fill each other's slots (one after the other they were 8 s_nop per evaluation)
+#ifdef TM_HOST_EMU
+template <int NROW> TM_DEV void tmw_rowsum16x3(const float *a, const float *b, const float *d, float *oa, float *ob, float *od) {
+  tmw_rowsum16<NROW>(a, oa); tmw_rowsum16<NROW>(b, ob); tmw_rowsum16<NROW>(d, od);
+}
+#else
+template <int NROW> TM_DEV void tmw_rowsum16x3(const float *a, const float *b, const float *d, float *oa, float *ob, float *od) {
+  float x = a[0], y = b[0], z = d[0];
+  x = tmw_dpp_add<0x111, 0xf, 0xf>(x); y = tmw_dpp_add<0x111, 0xf, 0xf>(y); z = tmw_dpp_add<0x111, 0xf, 0xf>(z);
+  x = tmw_dpp_add<0x112, 0xf, 0xf>(x); y = tmw_dpp_add<0x112, 0xf, 0xf>(y); z = tmw_dpp_add<0x112, 0xf, 0xf>(z);
+  x = tmw_dpp_add<0x114, 0xf, 0xf>(x); y = tmw_dpp_add<0x114, 0xf, 0xf>(y); z = tmw_dpp_add<0x114, 0xf, 0xf>(z);
+  x = tmw_dpp_add<0x118, 0xf, 0xf>(x); y = tmw_dpp_add<0x118, 0xf, 0xf>(y); z = tmw_dpp_add<0x118, 0xf, 0xf>(z);
+#pragma unroll
+  for (int r = 0; r < NROW; r++) {
+    oa[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(x), 16 * r + 15));
+    ob[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(y), 16 * r + 15));
+    od[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(z), 16 * r + 15));
+  }
 }
 #endif
 // At most 16 active rows (the usual case): the rows are replicated in lanes 0-15, 16-31 and 32-47 (tmw_linesearch) and the three
@@ -1689,7 +1715,7 @@ TM_DEV void tmw_ls_points16(WCtx &c, const TmwLSRows &R, const float *a, float g
     q0[TMW_LI] = act ? R.t0[TMW_LI][0] : 0.f; q1[TMW_LI] = act ? R.t1[TMW_LI][0] : 0.f; q2[TMW_LI] = act ? R.t2[TMW_LI][0] : 0.f;
   }
   float s0[NP], s1[NP], s2[NP];
-  tmw_rowsum16<NP>(q0, s0); tmw_rowsum16<NP>(q1, s1); tmw_rowsum16<NP>(q2, s2);
+  tmw_rowsum16x3<NP>(q0, q1, q2, s0, s1, s2);
 #pragma unroll
   for (int p = 0; p < NP; p++) {
     float r0 = g0 + s0[p], r1 = g1 + s1[p], r2 = g2 + s2[p], al = a[p];
@@ -1745,6 +1771,7 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
   al[0] = p0.alpha - p0.d0 * tmw_rcp(p0.d1);     // d1 = 2 q2 > 0: hardware reciprocal + one Newton step instead of the IEEE division sequence
   tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
   TmwLS lo0 = pt[0];
+  TMW_TICK2(35);
 #ifndef TMW_LS_NO_SHORTCUT
   // d0 == 0 EXACTLY at the Newton point — the usual outcome when no row changes sides on the way (tmw_round).  What the loop below then
   // does is determined: its first iteration moves both ends of the bracket onto this point (whatever the midpoint evaluates to), the
@@ -1753,6 +1780,7 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
     const bool done0 = (p0.d0 < 0.f && p0.d0 > -gtol) || (p0.d0 > 0.f && p0.d0 < gtol);
     const int cnt = done0 ? 0 : (p0.d0 == 0.f ? 1 : 2);
     TMW_STATS(K) += (float)(cnt < m.ls_iterations ? cnt : m.ls_iterations);
+    TMW_COUNT(38, 1000);
     return lo0.cost < p0.cost ? lo0.alpha : 0.f;
   }
 #endif
@@ -1781,6 +1809,7 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
     swap = s1 || s2 || s3 || s4;
   }
   TMW_STATS(K) += (float)it;
+  TMW_COUNT(37, 1000 * it);
   bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
   return improved ? alpha : 0.f;
@@ -1791,7 +1820,9 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
   tmw_solve_down(c, K, K.l_mv, K.l_search);            // search_q = N s
+  TMW_TICK2(32);
   tmw_jmul(c, K, K.l_search, K.l_jv);
+  TMW_TICK2(33);
   // |search_q|^2, s.D ut (= search.Ma - search.qfrc_smooth) and s.D s (= search.M search) in one pass, three reductions side by side
   TMW_REG(float, p0); TMW_REG(float, p1); TMW_REG(float, p2);
   TMW_FOR {
@@ -1805,6 +1836,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   float smag = sqrtf(tmw_sum(p0)) * scale;
   float gtol = m.tolerance * m.ls_tolerance * smag;
   float g0 = gauss, g1 = tmw_sum(p1), g2 = 0.5f * tmw_sum(p2);
+  TMW_TICK2(34);
   TmwLSRows R;
   const bool w16 = c.nact <= 16;
   TMW_FOR {
@@ -1883,6 +1915,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     }
     float cost_new = tmw_linesearch(c, K, gauss);
     TMW_TICK(7);
+    TMW_COUNT(36, 1000);
     TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_Mgrad + i]; }
     TMW_SYNC();
     prev_cost = cost;
