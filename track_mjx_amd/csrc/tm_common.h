@@ -103,8 +103,8 @@ TM_DEV void tm_make_frame(const float *a_in, float *fr) {
   tm_cross(c, a, b);
   for (int k = 0; k < 3; k++) { fr[k] = a[k]; fr[3 + k] = b[k]; fr[6 + k] = c[k]; }
 }
-TM_DEV void tm_kbi(const DModel &m, const float *solref, const float *solimp, float pos, float &k, float &b, float &imp) {
-  float timeconst = fmaxf(solref[0], 2.f * m.timestep), dampratio = solref[1];
+TM_DEV void tm_kbi(float timestep, const float *solref, const float *solimp, float pos, float &k, float &b, float &imp) {
+  float timeconst = fmaxf(solref[0], 2.f * timestep), dampratio = solref[1];
   float dmin = fminf(fmaxf(solimp[0], TM_MINIMP), TM_MAXIMP), dmax = fminf(fmaxf(solimp[1], TM_MINIMP), TM_MAXIMP);
   float width = fmaxf(TM_MINVAL, solimp[2]), mid = fminf(fmaxf(solimp[3], TM_MINIMP), TM_MAXIMP), power = fmaxf(1.f, solimp[4]);
   k = 1.f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
@@ -127,4 +127,7 @@ TM_DEV void tm_kbi(const DModel &m, const float *solref, const float *solimp, fl
   im = fminf(fmaxf(im, dmin), dmax);
   if (x > 1.f) im = dmax;
   imp = im;
+}
+TM_DEV void tm_kbi(const DModel &m, const float *solref, const float *solimp, float pos, float &k, float &b, float &imp) {
+  tm_kbi(m.timestep, solref, solimp, pos, k, b, imp);
 }

@@ -179,11 +179,13 @@ __global__ __launch_bounds__(64) void k_rec_out(const DModel *__restrict__ mp, f
 
 // K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
 // STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
+// __launch_bounds__(64, 3): three waves per SIMD are what 11 envs per CU need, i.e. at most 168 VGPRs — as a bound the compiler
+// keeps, not a number a later edit silently exceeds (168 -> 173 registers means two waves per SIMD; tests/test_abi.py pins it too).
 template <bool STATIC>
-__global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
+__global__ __launch_bounds__(64, 3) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
                                                      int do_euler, float *ws_dump, int n, int e0, int rs, float *spill, int spill_stride) {
   extern __shared__ float tmw_lds[];
-  WCtx c{mp, tmw_lds, st, n, (int)blockIdx.x + e0, (int)threadIdx.x, nullptr, 0ull, nullptr};
+  WCtx c{(TmwModel *)mp, tmw_lds, st, n, (int)blockIdx.x + e0, (int)threadIdx.x, nullptr, 0ull, nullptr};
   c.rs = rs;
   c.mspill = spill ? spill + 64 + (size_t)(blockIdx.x + e0) * (size_t)spill_stride : nullptr;
   c.action = action;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(64, 2) void k_physics_wave(const DModel *__restrict
   for (int f = 0; f < nsub; f++) {
     // fresh, opaque copies of the lane id and the model pointer per substep: LICM otherwise hoists every lane-derived LDS /
     // global address of the substep body (cheap adds) out of this loop, and the register allocator then SPILLS them
-    { int l = threadIdx.x; asm volatile("" : "+v"(l)); c.lane = l; const DModel *q = mp; asm volatile("" : "+s"(q)); c.mp = q; }
+    { int l = threadIdx.x; asm volatile("" : "+v"(l)); c.lane = l; TmwModel *q = (TmwModel *)mp; asm volatile("" : "+s"(q)); c.mp = q; }
     tmw_forward(c, K, f == nsub - 1);
     if (do_euler) time = tmw_euler(c, K, time);
   }

@@ -59,8 +59,19 @@
 #endif
 #define TMW_DS 7   // floats per dof-scan entry: 6-vector + ancestor pointer
 
+// The model is immutable for the whole launch.  Through a plain pointer the compiler cannot know that (the kernel stores to global memory),
+// so every model scalar — iteration caps, tolerances, counts — became a VECTOR load with a `s_waitcnt vmcnt(0)` in the middle of the solver
+// (214 vector loads, 1.7 scalar loads per wave-substep in profiles/sq_counters.json).  The constant address space says "never written":
+// uniform reads become s_load (scalar cache), per-lane table reads invariant global loads that may move above stores.
+#ifdef TM_HOST_EMU
+typedef const DModel TmwModel;
+#else
+typedef const __attribute__((address_space(4))) DModel TmwModel;
+#endif
+// a small model array as a local (the vector helpers of tm_common.h take plain pointers)
+#define TMW_LOCAL(name, n, src) float name[n]; { _Pragma("unroll") for (int k_ = 0; k_ < (n); k_++) name[k_] = (src)[k_]; }
 struct WCtx {
-  const DModel *mp;
+  TmwModel *mp;
   float *L;          // LDS
   float *st;         // global float state [rows][n]
   int n, e;
@@ -182,7 +193,7 @@ TM_DEV int tmw_prefix(const int *flag, int *excl) {
 
 // ------------------------------------------------------------------------------------------ state in / out
 TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     for (int i = lane; i < K.nq + K.nv + (K.lean ? 0 : K.nu); i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel (| act); the warm start stays in global memory
     for (int i = lane; i < 2 * K.nv; i += 64) {   // index table of the sparse rows (+ the dof's limit row / wrench subset in the top bytes)
@@ -216,7 +227,7 @@ TM_DEV int tmw_anc(int i, int q, int w1) {
   return q <= r ? i - q : ((w1 >> 8) & 0xff) + r - q;
 }
 TM_DEV void tmw_store_state(WCtx &c, const WLayout &K, float time) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     for (int i = lane; i < K.nq + K.nv + (K.lean ? 0 : K.nu); i += 64) WST(m.s_qpos, i) = L[K.l_qpos + i];      // (warm start and qfrc_actuator are written where they arise)
     if (lane == 0) WST(m.s_time, 0) = time;
@@ -237,7 +248,7 @@ TM_DEV void tmw_get_con_frame(const float *L, const WLayout &K, int cc, float *f
 // ------------------------------------------------------------------------------------------ fwd_position
 // kinematics by pointer jumping; com; collision; cdof; cinert.  `emit`: also write xpos / torso xmat to global.
 TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   // (1) local transform of every body relative to its parent (absolute for the free-joint body)
   TMW_FOR {
     for (int b = lane; b < K.nbody; b += 64) {
@@ -253,15 +264,15 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
           for (int k = 0; k < 3; k++) { L[K.l_jl_anchor + j * 3 + k] = t[k]; L[K.l_jl_axis + j * 3 + k] = (k == 2) ? 1.f : 0.f; }
         } else {
           float r[3], an[3], ax[3], ql[4], q2[4];
-          tm_rotate(r, m.jnt_pos[j], q);
+          { TMW_LOCAL(jp_, 3, m.jnt_pos[j]); tm_rotate(r, jp_, q); }
           for (int k = 0; k < 3; k++) an[k] = t[k] + r[k];
-          tm_rotate(ax, m.jnt_axis[j], q);
+          { TMW_LOCAL(ja_, 3, m.jnt_axis[j]); tm_rotate(ax, ja_, q); }
           float ang = (L[K.l_qpos + qa] - m.qpos0[qa]) * 0.5f, sn, cs;
           sincosf(ang, &sn, &cs);      // one shared range reduction
           ql[0] = cs; ql[1] = m.jnt_axis[j][0] * sn; ql[2] = m.jnt_axis[j][1] * sn; ql[3] = m.jnt_axis[j][2] * sn;
           tm_quat_mul(q2, q, ql);
           for (int k = 0; k < 4; k++) q[k] = q2[k];
-          tm_rotate(r, m.jnt_pos[j], q);
+          { TMW_LOCAL(jp_, 3, m.jnt_pos[j]); tm_rotate(r, jp_, q); }
           for (int k = 0; k < 3; k++) { t[k] = an[k] - r[k]; L[K.l_jl_anchor + j * 3 + k] = an[k]; L[K.l_jl_axis + j * 3 + k] = ax[k]; }
         }
       }
@@ -304,7 +315,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
     for (int b = lane; b < K.nbody; b += 64) {
       const float *s = L + K.l_scanA + b * 8;
       float r[3];
-      tm_rotate(r, m.body_ipos[b], s + 3);
+      { TMW_LOCAL(ip_, 3, m.body_ipos[b]); tm_rotate(r, ip_, s + 3); }
       float x0 = s[0] + r[0], x1 = s[1] + r[1], x2 = s[2] + r[2];
       L[K.l_xipos + b * 3] = x0; L[K.l_xipos + b * 3 + 1] = x1; L[K.l_xipos + b * 3 + 2] = x2;
       if (m.body_moving[b]) { float mb = m.body_mass[b]; a0 += x0 * mb; a1 += x1 * mb; a2 += x2 * mb; }
@@ -324,14 +335,14 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
       int b1 = m.con_body1[cc], b2 = m.con_body2[cc];
       const float *s1p = L + K.l_scanA + b1 * 8, *s2p = L + K.l_scanA + b2 * 8;
       float t[3], pp[3], pq[4], pm[9], gp[3], gq[4], gm[9];
-      tm_rotate(t, m.con_g1_pos[cc], s1p + 3);
+      { TMW_LOCAL(gp_, 3, m.con_g1_pos[cc]); tm_rotate(t, gp_, s1p + 3); }
       for (int k = 0; k < 3; k++) pp[k] = s1p[k] + t[k];
-      tm_quat_mul(pq, s1p + 3, m.con_g1_quat[cc]); tm_quat_to_mat(pm, pq);
-      tm_rotate(t, m.con_g2_pos[cc], s2p + 3);
+      { TMW_LOCAL(gq_, 4, m.con_g1_quat[cc]); tm_quat_mul(pq, s1p + 3, gq_); } tm_quat_to_mat(pm, pq);
+      { TMW_LOCAL(gp_, 3, m.con_g2_pos[cc]); tm_rotate(t, gp_, s2p + 3); }
       for (int k = 0; k < 3; k++) gp[k] = s2p[k] + t[k];
-      tm_quat_mul(gq, s2p + 3, m.con_g2_quat[cc]); tm_quat_to_mat(gm, gq);
+      { TMW_LOCAL(gq_, 4, m.con_g2_quat[cc]); tm_quat_mul(gq, s2p + 3, gq_); } tm_quat_to_mat(gm, gq);
       float nrm[3] = {pm[2], pm[5], pm[8]}, fr[9], pos[3], dist;
-      const float *size = m.con_g2_size[cc];
+      TMW_LOCAL(size, 3, m.con_g2_size[cc]);
       if (m.con_type[cc] == 3) {
         float axis[3] = {gm[2], gm[5], gm[8]}, bb[3], na = tm_dot3(nrm, axis), cr[3];
         for (int k = 0; k < 3; k++) bb[k] = axis[k] - nrm[k] * na;
@@ -402,11 +413,11 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
       else {
         const float *s = L + K.l_scanA + b * 8;
         float q[4], X[9], off[3];
-        tm_quat_mul(q, s + 3, m.body_iquat[b]);
+        { TMW_LOCAL(iq_, 4, m.body_iquat[b]); tm_quat_mul(q, s + 3, iq_); }
         tm_quat_to_mat(X, q);
         float mass = m.body_mass[b];
         for (int k = 0; k < 3; k++) off[k] = L[K.l_xipos + b * 3 + k] - com[k];
-        const float *in = m.body_inertia[b];
+        TMW_LOCAL(in, 3, m.body_inertia[b]);
         float oo = tm_dot3(off, off);
         ci[0] = X[0] * in[0] * X[0] + X[1] * in[1] * X[1] + X[2] * in[2] * X[2] + (oo - off[0] * off[0]) * mass;
         ci[1] = X[3] * in[0] * X[3] + X[4] * in[1] * X[4] + X[5] * in[2] * X[5] + (oo - off[1] * off[1]) * mass;
@@ -462,7 +473,7 @@ TM_DEV void tmw_chain_scan(WCtx &c, const WLayout &K, int base) {
 // ------------------------------------------------------------------------------------------ fwd_velocity + smooth forces
 // com_vel / rne prefixes by pointer jumping over dofs, body forces, up-sweep (crb, cfrc), M, qfrc_smooth, act_dot
 TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   int R = K.nround_dof + (K.nround_dof & 1);
   // inclusive prefix P_i = sum over ancestors-or-self of cdof * qvel
   TMW_FOR {
@@ -647,7 +658,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
 // `rhs` >= 0: an LDS vector eliminated alongside (x <- L^-T x, the leaf -> root sweep of mj_solveLD), so that one more
 // root -> leaf pass (tmw_subst_down) completes (M + hD)^-1 rhs without inverting L.
 TM_DEV void tmw_factor(WCtx &c, const WLayout &K, float hdamp, int rhs = -1) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     for (int i = lane; i < K.nnz; i += 64) L[K.l_LD + i] = L[K.l_M + i];
   }
@@ -841,7 +852,7 @@ TM_DEV void tmw_rank1_rows(tmw_f2 (*T)[TMW_NL], const int CNT, const int BASE, c
 // EULER = false: plain M (no damping term, no right-hand side)
 template <int FIRST, int N, int D0, bool EULER>
 TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float hdamp, int rhs) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_M + tmw_chain_madr(FIRST);
   TMW_REG(float, hd);   // hdamp * damping of the chain dof whose DIAGONAL sits in this lane (depth = lane): from LDS (l_hdamp = timestep *
                         // damping; a global load of the model constant here cost one exposed memory latency per chain)
@@ -1327,7 +1338,7 @@ TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
 // J v in two stages (no barrier inside a stage, so a caller can put independent work next to it):
 //   stage 1: spatial velocity of each paw body -> l_sv;   stage 2 (after a barrier): one lane per active row
 TM_DEV void tmw_jmul_stage1(WCtx &c, const WLayout &K, int v) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     if (lane < K.ngroup * 6) {  // spatial velocity of each paw body, one lane per (group, component)
       int g = lane / 6, k = lane - g * 6, ld = ((const signed char *)(L + K.l_tgrp))[g];
@@ -1342,7 +1353,7 @@ TM_DEV void tmw_jmul_stage1(WCtx &c, const WLayout &K, int v) {
   }
 }
 TM_DEV void tmw_jmul_stage2(WCtx &c, const WLayout &K, int v, int out) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   // one lane per ACTIVE row (compact row space): a violated limit is one-hot, a pyramid edge of an active contact is
   // n.vel +- mu t.vel of the paw body's point velocity
   TMW_FOR {
@@ -1376,7 +1387,7 @@ TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
 }
 // out = J^T f where f_r = active ? -D_r Jaref_r : 0 is formed on the fly (efc_force is never stored)
 TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     for (int cc = lane; cc < K.ncon; cc += 64) {
       float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1467,7 +1478,7 @@ TM_DEV void tmw_mul_m_jmul(WCtx &c, const WLayout &K, int x, int y, int out) {
 // numbered consecutively in the original order (limits, then contacts); l_rowmap maps back, lim_sign / l_ccrow map forward.
 // Typical counts (a few limits + 2..8 contacts) fit ONE 64-row slot instead of three.
 TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_REG(int, f0); TMW_REG(int, f1); TMW_REG(int, fc); TMW_REG(int, x0); TMW_REG(int, x1); TMW_REG(int, xc);
   TMW_REG(float, s0); TMW_REG(float, s1); TMW_REG(int, d0); TMW_REG(int, d1);
   TMW_FOR {
@@ -1506,20 +1517,22 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
     for (int kr = lane; kr < c.nact; kr += 64) {
       int r = rm[kr];
       float k, b, imp, pos, iw;
-      const float *solref, *solimp;      // ONE impedance evaluation for limit and contact rows (both kinds share a wave)
+      float solref[2], solimp[5];        // ONE impedance evaluation for limit and contact rows (both kinds share a wave)
       if (kr < c.nla) {
         int j = m.dof_jntid[r & 0x7f];
         float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
         pos = fminf(dmin, dmax) - m.jnt_margin[j];
-        solref = m.jnt_solref[j]; solimp = m.jnt_solimp[j];
+        for (int t = 0; t < 2; t++) solref[t] = m.jnt_solref[j][t];
+        for (int t = 0; t < 5; t++) solimp[t] = m.jnt_solimp[j][t];
         iw = m.dof_invweight0[m.jnt_dofadr[j]];
       } else {
         int cc = (r - K.nlim) >> 2;
         pos = L[K.l_con_dist + cc];
-        solref = m.con_solref[cc]; solimp = m.con_solimp[cc];
+        for (int t = 0; t < 2; t++) solref[t] = m.con_solref[cc][t];
+        for (int t = 0; t < 5; t++) solimp[t] = m.con_solimp[cc][t];
         iw = m.con_invweight[cc];
       }
-      tm_kbi(m, solref, solimp, pos, k, b, imp);
+      tm_kbi(m.timestep, solref, solimp, pos, k, b, imp);
       float Rr = fmaxf(iw * (1.f - imp) / imp, TM_MINVAL);
       L[K.l_efc_D + kr] = 1.f / Rr;
       L[K.l_efc_aref + kr] = -b * L[K.l_jv + kr] - k * imp * pos;
@@ -1534,14 +1547,14 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
           int j = m.lim_jnt[r];
           float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
           pos = fminf(dmin, dmax) - m.jnt_margin[j];
-          tm_kbi(m, m.jnt_solref[j], m.jnt_solimp[j], pos, k, b, imp);
+          { TMW_LOCAL(sr_, 2, m.jnt_solref[j]); TMW_LOCAL(si_, 5, m.jnt_solimp[j]); tm_kbi(m.timestep, sr_, si_, pos, k, b, imp); }
           iw = m.dof_invweight0[m.jnt_dofadr[j]];
           float sv = (float)TMW_LIMSIGN(K)[r];
           if (sv != 0.f) kr = (int)fabsf(sv) - 1;
         } else {
           int cc = (r - K.nlim) >> 2;
           pos = L[K.l_con_dist + cc];
-          tm_kbi(m, m.con_solref[cc], m.con_solimp[cc], pos, k, b, imp);
+          { TMW_LOCAL(sr_, 2, m.con_solref[cc]); TMW_LOCAL(si_, 5, m.con_solimp[cc]); tm_kbi(m.timestep, sr_, si_, pos, k, b, imp); }
           iw = m.con_invweight[cc];
           if (TMW_CCROW(K)[cc] != 255) kr = TMW_CCROW(K)[cc] + ((r - K.nlim) & 3);
         }
@@ -1556,7 +1569,7 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
 
 // ------------------------------------------------------------------------------------------ CG solver
 TM_DEV float tmw_dot(WCtx &c, const WLayout &K, int a, int b) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, p);
   TMW_FOR { float s = 0.f; for (int i = lane; i < K.nv; i += 64) s += L[a + i] * L[b + i]; p[TMW_LI] = s; }
   return tmw_sum(p);
@@ -1566,7 +1579,7 @@ TM_DEV float tmw_dot(WCtx &c, const WLayout &K, int a, int b) {
 // well) and M q is not needed by the caller (tmw_solve_cg) — no product with M
 // `have_ma`: l_Ma already holds M q (chain layout: taken before M was factorised in place) — J q only, Gauss term from l_Ma
 TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool jonly = false, bool have_ma = false) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
   if (jonly || have_ma) tmw_jmul(c, K, q, K.l_Jaref);
   else tmw_mul_m_jmul(c, K, q, K.l_Ma, K.l_Jaref);
@@ -1627,7 +1640,7 @@ TM_DEV void tmw_solve_down(WCtx &c, const WLayout &K, int x, int out) {
 // qfrc_constraint = J^T f at the current Jaref;  w = ut - D^-1 N^T qfrc_constraint;  returns gn = w.D w (= grad.M^-1 grad) and,
 // through `num`, w.D (w - w_prev) with w_prev = l_tmp (Polak-Ribiere numerator); `improvement < last_if`: qfrc_constraint only, returns -1
 TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num, float improvement = 0.f, float last_if = -INFINITY) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
   tmw_jt_force(c, K, K.l_qfrc_constraint);
   TMW_TICK2(16);
@@ -1763,7 +1776,7 @@ TM_DEV void tmw_ls_points(WCtx &c, const WLayout &K, const TmwLSRows &R, const f
 // the wave reductions: WIDTH = 16 / 32 when all active rows sit in the first 16 / 32 lanes (the usual case), else 64
 template <int WIDTH>
 TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0, float g1, float g2, float gtol) {
-  const DModel &m = *c.mp; float *L = c.L;
+  TmwModel &m = *c.mp; float *L = c.L;
   TmwLS pt[3];
   float al[3] = {0.f, 0.f, 0.f};
   tmw_ls_points<1, WIDTH>(c, K, R, al, g0, g1, g2, pt);
@@ -1817,7 +1830,7 @@ TM_DEV float tmw_ls_core(WCtx &c, const WLayout &K, const TmwLSRows &R, float g0
 // returns the cost of the new iterate and its Gauss term through `gauss` (what _update_constraint recomputes after the step:
 // 1/2 sum D ja^2 over the active rows + 1/2 ut.D ut, from the rows and vectors already in registers)
 TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
   tmw_solve_down(c, K, K.l_mv, K.l_search);            // search_q = N s
   TMW_TICK2(32);
@@ -1877,7 +1890,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   return 0.5f * tmw_sum(pc) + gauss;
 }
 TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float gauss, scale = m.meaninertia * (float)(K.nv > 1 ? K.nv : 1);
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
   if (c.prof && c.lane == 0) { c.prof[10] += (c.nact <= 16) ? 1000 : 0; c.prof[18] += (c.nact > 16 && c.nact <= 32) ? 1000 : 0; }   // histogram of active rows (x1000) in two unused slots
@@ -1945,7 +1958,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
 
 // ------------------------------------------------------------------------------------------ forward / euler
 TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK(12);
 #ifndef TMW_STOP
 #define TMW_STOP 99      // instruction-count experiments (tools/scratch/valu_phases.sh): leave the substep after phase TMW_STOP
@@ -1962,7 +1975,7 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
     // (the warm start comes from the env's global record into the solver's iterate vector — region A is free here, l_Ma below is written
     // by the product anyway; its load is in flight across the copy loop.  Keeping it in two registers across the substeps, like qfrc_smooth,
     // was tried: 172 VGPRs, i.e. two instead of three waves per SIMD)
-    const DModel &m = *c.mp;
+    TmwModel &m = *c.mp;
     TMW_REG(float, w0); TMW_REG(float, w1);
     TMW_FOR { w0[TMW_LI] = WST(m.s_warm, lane); w1[TMW_LI] = lane + 64 < K.nv ? WST(m.s_warm, lane + 64) : 0.f; }
     TMW_FOR { for (int i = lane; i < K.nnz; i += 64) c.mspill[i] = L[K.l_M + i]; }
@@ -1986,7 +1999,7 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   tmw_solve_cg(c, K);
 }
 TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float h = m.timestep;
   // qfrc_constraint of the final iterate is in LDS (last tmw_update_gradient); keep the rhs out of the LD alias
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = TMW_QFS(i) + L[K.l_qfrc_constraint + i]; }
@@ -2051,7 +2064,7 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
 // copies solver-stage intermediates of the last forward from LDS to the lane-per-env workspace rows so that the same
 // named arrays (tmjx_debug_rows) can be compared with the oracle; never called on the timed path
 TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
-  const DModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
 #define WDUMP(row, i) ws[(size_t)((row) + (i)) * (size_t)c.n + (size_t)c.e]
   TMW_FOR {
     for (int i = lane; i < K.nnz; i += 64) WDUMP(m.w_M, i) = K.m_spilled() ? c.mspill[i] : L[K.l_M + i];
