@@ -1388,24 +1388,30 @@ TM_DEV void tmw_jmul(WCtx &c, const WLayout &K, int v, int out) {
 // out = J^T f where f_r = active ? -D_r Jaref_r : 0 is formed on the fly (efc_force is never stored)
 TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  // (branch-free on purpose: written with `if (penetrating) { .. if (ja < 0) .. }` the compiler emitted a chain of ten dependent LDS round
+  // trips, each behind its own exec-mask branch and lgkmcnt(0) wait; here every load of a contact is issued up front — inactive slots read
+  // row 0 / their stale frame and select zero at the end)
   TMW_FOR {
     for (int cc = lane; cc < K.ncon; cc += 64) {
-      float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (L[K.l_con_dist + cc] < 0.f) {
-        int r0 = TMW_CCROW(K)[cc];      // first of the contact's four compact rows
-        float f[4];
-        for (int e = 0; e < 4; e++) { float ja = L[K.l_Jaref + r0 + e]; f[e] = ja < 0.f ? -L[K.l_efc_D + r0 + e] * ja : 0.f; }
-        float mu = L[K.l_con_mu + cc], c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
-        const float *off = L + K.l_con_off + cc * 3;
-        float fr[9];
-        tmw_get_con_frame(L, K, cc, fr);
-        tm_cross(fr + 6, fr, fr + 3);
-        float F[3], T[3];
-        for (int k = 0; k < 3; k++) F[k] = c0 * fr[k] + c1 * fr[3 + k] + c2 * fr[6 + k];
-        tm_cross(T, off, F);
-        for (int k = 0; k < 3; k++) { w[k] = T[k]; w[3 + k] = F[k]; }
-      }
-      for (int k = 0; k < 6; k++) L[K.l_wr + cc * 6 + k] = w[k];
+      const bool on = L[K.l_con_dist + cc] < 0.f;
+      const int r0b = TMW_CCROW(K)[cc], r0 = on ? r0b : 0;      // first of the contact's four compact rows (255: none)
+      float ja[4], D[4], f[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { ja[e] = L[K.l_Jaref + r0 + e]; D[e] = L[K.l_efc_D + r0 + e]; }
+      const float mu = L[K.l_con_mu + cc];
+      const float *off = L + K.l_con_off + cc * 3;
+      const float o0 = off[0], o1 = off[1], o2 = off[2];
+      float fr[9];
+      tmw_get_con_frame(L, K, cc, fr);
+#pragma unroll
+      for (int e = 0; e < 4; e++) f[e] = ja[e] < 0.f ? -D[e] * ja[e] : 0.f;
+      float c0 = f[0] + f[1] + f[2] + f[3], c1 = mu * (f[0] - f[1]), c2 = mu * (f[2] - f[3]);
+      tm_cross(fr + 6, fr, fr + 3);
+      float F[3], T[3];
+      const float ov[3] = {o0, o1, o2};
+      for (int k = 0; k < 3; k++) F[k] = c0 * fr[k] + c1 * fr[3 + k] + c2 * fr[6 + k];
+      tm_cross(T, ov, F);
+      for (int k = 0; k < 3; k++) { L[K.l_wr + cc * 6 + k] = on ? T[k] : 0.f; L[K.l_wr + cc * 6 + 3 + k] = on ? F[k] : 0.f; }
     }
   }
   TMW_SYNC();
@@ -1443,9 +1449,12 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
     for (int i = lane; i < K.nv; i += 64) {
       float s = 0.f;
       int lr = TMW_LIMROW1(TMW_W0(i)) - 1, su = TMW_WSUB1(TMW_W1(i)) - 1;
-      if (lr >= 0) {     // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise
-        float sv = (float)TMW_LIMSIGN(K)[lr];
-        if (sv != 0.f) { int kr = (int)fabsf(sv) - 1; float ja = L[K.l_Jaref + kr]; if (ja < 0.f) s = (sv > 0.f ? 1.f : -1.f) * (-L[K.l_efc_D + kr] * ja); }
+      {                  // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise (branch-free: see above)
+        const int svb = TMW_LIMSIGN(K)[lr >= 0 ? lr : 0], sv = lr >= 0 ? svb : 0;
+        const int kr = sv != 0 ? (sv < 0 ? -sv : sv) - 1 : 0;
+        const float ja = L[K.l_Jaref + kr], D = L[K.l_efc_D + kr];
+        const float fl = -D * ja;
+        s = (sv != 0 && ja < 0.f) ? (sv > 0 ? fl : -fl) : 0.f;
       }
       if (su >= 0) { const float *w = L + K.l_wr + su * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
       L[out + i] = s;
