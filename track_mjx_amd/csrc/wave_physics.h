@@ -835,18 +835,24 @@ TM_DEV tmw_f2 tmw_fnma2(float ax, float ay, float bx, float by, tmw_f2 c) { tmw_
 #define TMW_ROW(arr, k) (((k) & 1) ? arr[(k) >> 1][TMW_LI].y : arr[(k) >> 1][TMW_LI].x)
 #define TMW_SET_ROW(arr, k, v) do { if ((k) & 1) arr[(k) >> 1][TMW_LI].y = (v); else arr[(k) >> 1][TMW_LI].x = (v); } while (0)
 // rows [0, CNT) of the paired register array T -= L(k, .) * (pivot row): multipliers are lanes BASE + row of `rs`
+// (software-pipelined by hand: the two multipliers of pair p - 1 are read BEFORE the update of pair p is issued.  Read right in front of
+// their use, every pair was `v_readlane, v_readlane, s_nop 1, v_pk_fma` through the same SGPR pair — a VALU instruction may read an SGPR
+// only two wait states after a VALU instruction wrote it, and the allocator re-used s[0:1] for every pair)
 template <typename F>
 TM_DEV void tmw_rank1_rows(tmw_f2 (*T)[TMW_NL], const int CNT, const int BASE, const float *rs, const float *rk, F after_top) {
+  const int top = (CNT - 1) / 2;
+  float alo = tmw_readlane(rs, BASE + 2 * top), ahi = 2 * top + 1 < CNT ? tmw_readlane(rs, BASE + 2 * top + 1) : 0.f;
 #pragma unroll
-  for (int p = (CNT - 1) / 2; p >= 0; p--) {
+  for (int p = top; p >= 0; p--) {
+    float nlo = 0.f, nhi = 0.f;
+    if (p > 0) { nlo = tmw_readlane(rs, BASE + 2 * p - 2); nhi = tmw_readlane(rs, BASE + 2 * p - 1); }
     if (2 * p + 1 < CNT) {
-      float alo = tmw_readlane(rs, BASE + 2 * p), ahi = tmw_readlane(rs, BASE + 2 * p + 1);
       TMW_FOR { T[p][TMW_LI] = tmw_fnma2(alo, ahi, rk[TMW_LI], rk[TMW_LI], T[p][TMW_LI]); TMW_PIN2(T[p][TMW_LI]); }
     } else {
-      float alo = tmw_readlane(rs, BASE + 2 * p);
       TMW_FOR { T[p][TMW_LI].x -= alo * rk[TMW_LI]; TMW_PIN2(T[p][TMW_LI]); }
     }
-    if (p == (CNT - 1) / 2) after_top();
+    if (p == top) after_top();
+    alo = nlo; ahi = nhi;
   }
 }
 // EULER = false: plain M (no damping term, no right-hand side)
