@@ -811,7 +811,16 @@ TM_DEV float tmw_rcp(float x) {
 #define TMW_SCHED_FENCE() do { } while (0)
 #define TMW_PIN(x) do { } while (0)
 #else
-#define TMW_MASK(m64) __builtin_amdgcn_inverse_ballot_w64((unsigned long long)(m64))
+// A 64-bit literal whose upper 33 bits are all ones (lanes 31..63 set, e.g. "every lane from 18 up") is materialised by hipcc (LLVM 22 /
+// ROCm 7.2) as ONE `s_mov_b64 s[..], <32-bit literal>` that it expects the hardware to sign-extend; gfx950 ZERO-extends it and lanes
+// 32-63 silently drop out of the mask (tools/micro/literal64.hip shows both).  Such masks get their upper half through an opaque SGPR,
+// which makes the compiler emit two s_mov_b32.
+TM_DEV unsigned long long tmw_lit64(unsigned long long m64) {
+  unsigned hi = (unsigned)(m64 >> 32);
+  asm("" : "+s"(hi));
+  return ((unsigned long long)hi << 32) | (unsigned)m64;
+}
+#define TMW_MASK(m64) __builtin_amdgcn_inverse_ballot_w64((((unsigned long long)(m64)) >> 31) == 0x1ffffffffull ? tmw_lit64((unsigned long long)(m64)) : (unsigned long long)(m64))
 // keep LLVM from sinking every rank-1 update down to the pivot step of its target row (which turns the elimination into a
 // left-looking one whose ~600 multipliers all stay live in SGPRs): an empty volatile asm that "modifies" the target pins
 // the FMA to its place in program order
