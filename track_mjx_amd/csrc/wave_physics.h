@@ -1704,62 +1704,52 @@ struct TmwLS { float alpha, cost, d0, d1; };
 // t0 = D ja^2 / 2, t1 = D ja jv, t2 = D jv^2 / 2 and (ja, jv) for the activity test ja + alpha jv < 0.
 #define TMW_LS_SLOTS 4        // up to 256 constraint rows
 struct TmwLSRows { float ja[TMW_NL][TMW_LS_SLOTS], jv[TMW_NL][TMW_LS_SLOTS], D[TMW_NL][TMW_LS_SLOTS], t0[TMW_NL][TMW_LS_SLOTS], t1[TMW_NL][TMW_LS_SLOTS], t2[TMW_NL][TMW_LS_SLOTS]; };
-// sums over the three 16-lane rows 0 / 1 / 2 of the wave (lanes 0-15, 16-31, 32-47): four row-local DPP steps, then one readlane per row
+// three row sums side by side, IN PLACE: afterwards lane 16 r + 15 of each array holds the sum over row r.  Written step-interleaved: a
+// DPP operand needs two wait states after the instruction that wrote it, and the three independent chains fill each other's slots (one
+// after the other they were 8 s_nop per evaluation)
 #ifdef TM_HOST_EMU
-template <int NROW> TM_DEV void tmw_rowsum16(const float *v, float *out) { for (int r = 0; r < NROW; r++) { float s = 0.f; for (int l = 0; l < 16; l++) s += v[16 * r + l]; out[r] = s; } }
-#else
-template <int NROW> TM_DEV void tmw_rowsum16(const float *vp, float *out) {
-  float v = vp[0];
-  v = tmw_dpp_add<0x111, 0xf, 0xf>(v);
-  v = tmw_dpp_add<0x112, 0xf, 0xf>(v);
-  v = tmw_dpp_add<0x114, 0xf, 0xf>(v);
-  v = tmw_dpp_add<0x118, 0xf, 0xf>(v);
-#pragma unroll
-  for (int r = 0; r < NROW; r++) out[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(v), 16 * r + 15));
-}
-#endif
-// three row sums side by side, written step-interleaved: a DPP operand needs two wait states after the instruction that wrote it, and the
-// three independent chains fill each other's slots (one after the other they were 8 s_nop per evaluation)
-#ifdef TM_HOST_EMU
-template <int NROW> TM_DEV void tmw_rowsum16x3(const float *a, const float *b, const float *d, float *oa, float *ob, float *od) {
-  tmw_rowsum16<NROW>(a, oa); tmw_rowsum16<NROW>(b, ob); tmw_rowsum16<NROW>(d, od);
+TM_DEV void tmw_rowscan16x3(float *a, float *b, float *d) {
+  for (int r = 0; r < 4; r++) { float sa = 0.f, sb = 0.f, sd = 0.f; for (int l = 0; l < 16; l++) { sa += a[16 * r + l]; sb += b[16 * r + l]; sd += d[16 * r + l]; }
+    a[16 * r + 15] = sa; b[16 * r + 15] = sb; d[16 * r + 15] = sd; }
 }
 #else
-template <int NROW> TM_DEV void tmw_rowsum16x3(const float *a, const float *b, const float *d, float *oa, float *ob, float *od) {
+TM_DEV void tmw_rowscan16x3(float *a, float *b, float *d) {
   float x = a[0], y = b[0], z = d[0];
   x = tmw_dpp_add<0x111, 0xf, 0xf>(x); y = tmw_dpp_add<0x111, 0xf, 0xf>(y); z = tmw_dpp_add<0x111, 0xf, 0xf>(z);
   x = tmw_dpp_add<0x112, 0xf, 0xf>(x); y = tmw_dpp_add<0x112, 0xf, 0xf>(y); z = tmw_dpp_add<0x112, 0xf, 0xf>(z);
   x = tmw_dpp_add<0x114, 0xf, 0xf>(x); y = tmw_dpp_add<0x114, 0xf, 0xf>(y); z = tmw_dpp_add<0x114, 0xf, 0xf>(z);
   x = tmw_dpp_add<0x118, 0xf, 0xf>(x); y = tmw_dpp_add<0x118, 0xf, 0xf>(y); z = tmw_dpp_add<0x118, 0xf, 0xf>(z);
-#pragma unroll
-  for (int r = 0; r < NROW; r++) {
-    oa[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(x), 16 * r + 15));
-    ob[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(y), 16 * r + 15));
-    od[r] = tm_i2f(__builtin_amdgcn_readlane(tm_f2i(z), 16 * r + 15));
-  }
+  a[0] = x; b[0] = y; d[0] = z;
 }
 #endif
 // At most 16 active rows (the usual case): the rows are replicated in lanes 0-15, 16-31 and 32-47 (tmw_linesearch) and the three
-// candidates of an iteration are evaluated side by side, one per 16-lane row — 3 masked sums and 3 row reductions instead of 9 + 9
+// candidates of an iteration are evaluated side by side, one per 16-lane row — 3 masked sums and 3 row reductions instead of 9 + 9.
+// Cost and derivatives are then formed IN the last lane of each row, for the row's own alpha, by one instruction stream for all three
+// candidates; only those three numbers per candidate are broadcast (broadcasting the sums and repeating the arithmetic per candidate on
+// wave-uniform values was 36 instead of 12 vector instructions per evaluation).
 template <int NP>
 TM_DEV void tmw_ls_points16(WCtx &c, const TmwLSRows &R, const float *a, float g0, float g1, float g2, TmwLS *out) {
   TMW_LANE_DECL
-  TMW_REG(float, q0); TMW_REG(float, q1); TMW_REG(float, q2);
+  TMW_REG(float, q0); TMW_REG(float, q1); TMW_REG(float, q2); TMW_REG(float, av);
   TMW_FOR {
     float al = a[0];
     if (NP > 1) al = TMW_MASK(TMW_M_LT(16)) ? a[0] : (TMW_MASK(TMW_M_LT(32)) ? a[1] : a[2]);
     bool act = R.ja[TMW_LI][0] + al * R.jv[TMW_LI][0] < 0.f;
     q0[TMW_LI] = act ? R.t0[TMW_LI][0] : 0.f; q1[TMW_LI] = act ? R.t1[TMW_LI][0] : 0.f; q2[TMW_LI] = act ? R.t2[TMW_LI][0] : 0.f;
+    av[TMW_LI] = al;
   }
-  float s0[NP], s1[NP], s2[NP];
-  tmw_rowsum16x3<NP>(q0, q1, q2, s0, s1, s2);
+  tmw_rowscan16x3(q0, q1, q2);
+  TMW_REG(float, pc); TMW_REG(float, pd0); TMW_REG(float, pd1);
+  TMW_FOR {
+    float r0 = g0 + q0[TMW_LI], r1 = g1 + q1[TMW_LI], r2 = g2 + q2[TMW_LI], al = av[TMW_LI];
+    pc[TMW_LI] = al * al * r2 + al * r1 + r0;
+    pd0[TMW_LI] = tmw_round(2.f * al * r2) + r1;
+    pd1[TMW_LI] = 2.f * r2 + (r2 == 0.f ? TM_MINVAL : 0.f);
+  }
 #pragma unroll
   for (int p = 0; p < NP; p++) {
-    float r0 = g0 + s0[p], r1 = g1 + s1[p], r2 = g2 + s2[p], al = a[p];
-    out[p].alpha = al;
-    out[p].cost = al * al * r2 + al * r1 + r0;
-    out[p].d0 = tmw_round(2.f * al * r2) + r1;
-    out[p].d1 = 2.f * r2 + (r2 == 0.f ? TM_MINVAL : 0.f);
+    out[p].alpha = a[p];
+    out[p].cost = tmw_readlane(pc, 16 * p + 15); out[p].d0 = tmw_readlane(pd0, 16 * p + 15); out[p].d1 = tmw_readlane(pd1, 16 * p + 15);
   }
 }
 // NP line-search points evaluated together (alphas a[0..NP-1]): 3 NP partial sums over the rows, reduced together
