@@ -125,11 +125,13 @@ def test_substep_worst_env_and_solver_integers(scale):
         assert np.mean(g[k] <= 1e-5) >= np.mean(f[k] <= 1e-5) - 0.12, (k, np.mean(g[k] <= 1e-5), np.mean(f[k] <= 1e-5))
     assert niter_between >= 0.97 * total and niter_eq64 >= 0.8 * total
     # the line search stops when no candidate tightens the bracket any more — a comparison of derivatives that differ by rounding noise
-    # near the minimum, so the count is not reproducible across precisions or formulations (the two oracles differ from each other as
-    # much); what is bounded: at most about one extra refinement per CG iteration, and the same mean within 50 % (observed: HIP 7.5 / 12.6 / 17.5 iterations per solve at action scale 0.03 / 0.3 / 1.0, float32 oracle 6.8 / 10.5 / 13.5,
-    # float64 oracle 4.5 / 7.6 / 10.2)
-    assert ls_loose >= 0.6 * total
-    assert 0.7 * min(ls_sum[1:]) <= ls_sum[0] <= 1.5 * max(ls_sum[1:])
+    # near the minimum, so the count is not reproducible across precisions (the two oracles differ from each other as much).  Since the
+    # derivative's product is rounded on its own (wave_physics.h: tmw_round — fused, the converged bracket kept being refined: 7.5 / 12.6 / 17.5
+    # iterations per solve) the kernel sits BETWEEN the oracles: observed HIP 5.6 / 9.8 / 13.1 at action scale 0.03 / 0.3 / 1.0, float32 oracle
+    # 6.8 / 10.5 / 13.5, float64 oracle 4.5 / 7.6 / 10.2; within +-2 of the oracles' range on 92 - 96 % of the env-substeps, within one
+    # refinement per CG iteration on > 99 %
+    assert ls_between >= 0.88 * total and ls_loose >= 0.97 * total, (ls_between, ls_loose, total)
+    assert 0.95 * ls_sum[2] <= ls_sum[0] <= 1.05 * ls_sum[1], ls_sum
     assert n_final_mismatch <= 2e-3 * n_rows
 
 
