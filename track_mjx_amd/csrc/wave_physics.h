@@ -1271,16 +1271,16 @@ TM_DEV void tmw_row_runs2(const float *L, const WLayout &K, int A, int x, int la
 #pragma unroll 4
   for (int q = 1; q <= maxr1; q++) {
     float u0 = A0[q], v0 = x0[-q], u1 = A1[q], v1 = x1[-q];
-    a0 += q <= r0 ? u0 * v0 : 0.f; a1 += q <= r1 ? u1 * v1 : 0.f;
+    a0 = fmaf(q <= r0 ? u0 : 0.f, v0, a0); a1 = fmaf(q <= r1 ? u1 : 0.f, v1, a1);      // (select, fma: one instruction less than product, select, add)
   }
 #pragma unroll 8
-  for (int q = maxr1 + 1; q <= maxr0; q++) { float u0 = A0[q], v0 = x0[-q]; a0 += q <= r0 ? u0 * v0 : 0.f; }
+  for (int q = maxr1 + 1; q <= maxr0; q++) { float u0 = A0[q], v0 = x0[-q]; a0 = fmaf(q <= r0 ? u0 : 0.f, v0, a0); }
   const float *B0 = A0 + r0 + 1, *y0 = L + x + j0 - 1, *B1 = A1 + r1 + 1, *y1 = L + x + j1 - 1;
   const int n0 = d0 - r0, n1 = d1 - r1;
 #pragma unroll 4
   for (int t = 0; t < maxt; t++) {
     float u0 = B0[t], v0 = y0[-t], u1 = B1[t], v1 = y1[-t];
-    a0 += t < n0 ? u0 * v0 : 0.f; a1 += t < n1 ? u1 * v1 : 0.f;
+    a0 = fmaf(t < n0 ? u0 : 0.f, v0, a0); a1 = fmaf(t < n1 ? u1 : 0.f, v1, a1);
   }
   z0 = a0; z1 = a1;
 }
