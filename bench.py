@@ -146,7 +146,7 @@ def main(argv=None, runner=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2, help="env groups per GPU whose roll-outs are pipelined on separate HIP streams (1 = off)")
+    ap.add_argument("--pipeline", type=int, default=0, help="env groups per GPU whose roll-outs are pipelined on separate HIP streams (0 = ppo.default_groups: 3 at 4096 envs, 2 at 8192; 1 = off; sizes: ppo.group_sizes)")
     ap.add_argument("--no-rollout-only", action="store_true", help="skip the extra roll-out-only measurement (tools/profile_gpu.sh: keeps the "
                     "rocprofv3 kernel averages those of the timed training steps)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
@@ -190,13 +190,18 @@ def main(argv=None, runner=None):
     n_local = args.envs_per_gpu
     # the rank's envs as `--pipeline` equal groups (same clips, same model): the learner pipelines their roll-outs on separate
     # HIP streams so that one group's kernel tail + reward/obs kernels + policy inference run next to the other group's physics
-    ngrp = args.pipeline if args.pipeline >= 1 and n_local % max(args.pipeline, 1) == 0 else 1
+    ngrp = args.pipeline if args.pipeline >= 1 else ppo.default_groups(n_local, device, widest_layer=max(max(v) for k, v in bc["nets"].items() if k.endswith("_layer_sizes")))
     from track_mjx_amd import clips as _clips
     from track_mjx_amd.walker import Rodent
     table = _clips.make_synthetic_clips(Rodent(**cfg["walker_config"]).model, bc["n_clips"], n_frames=cfg["reference_config"]["clip_length"],
                                         mocap_hz=cfg["env_config"]["env_args"]["mocap_hz"])
-    envs = [wrap(build_env(cfg, n_local // ngrp, device, reference_clip=table), episode_length=195)]
-    envs += [wrap(build_env(cfg, n_local // ngrp, device, reference_clip=table, share_clips_with=envs[0]), episode_length=195) for _ in range(1, ngrp)]      # one clip upload per rank
+    sizes = ppo.group_sizes(n_local, ngrp)
+    if os.environ.get("TMJX_GROUP_SIZES"):       # experiments: explicit group sizes, e.g. 1408,1408,1280
+        sizes = [int(x) for x in os.environ["TMJX_GROUP_SIZES"].split(",")]
+        assert sum(sizes) == n_local, (sizes, n_local)
+    ngrp = len(sizes)
+    envs = [wrap(build_env(cfg, sizes[0], device, reference_clip=table), episode_length=195)]
+    envs += [wrap(build_env(cfg, sizes[k], device, reference_clip=table, share_clips_with=envs[0]), episode_length=195) for k in range(1, ngrp)]      # one clip upload per rank
     env = envs[0]
     nc = cfg["network_config"]
     learner = ppo.PPOLearner(envs if ngrp > 1 else env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"],
@@ -208,9 +213,10 @@ def main(argv=None, runner=None):
     # deterministic synthetic reset inputs: clip = env % 64, start_frame = env % 44; cfg5: clip ~ U{0..1023}
     g = torch.Generator().manual_seed(1 + rank)
     idx = torch.arange(n_local, dtype=torch.int32) + rank * n_local
-    per = n_local // ngrp
+    starts = [sum(sizes[:k]) for k in range(ngrp + 1)]
     for k, e in enumerate(envs):
-        sub = idx[k * per:(k + 1) * per]
+        sub = idx[starts[k]:starts[k + 1]]
+        per = sizes[k]
         clip_idx = torch.randint(0, bc["n_clips"], (per,), generator=g, dtype=torch.int32) if bc["random_clips"] else (sub % bc["n_clips"]).to(torch.int32)
         learner.states[k] = e.reset(g, clip_idx, start_frame=(sub % 44).to(torch.int32))
 
@@ -251,7 +257,7 @@ def main(argv=None, runner=None):
     env_steps = learner.env_steps_per_training_step * args.steps
     ev = [p for e in envs for p in e._physics_events]
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)      # per launch (n_local / ngrp envs each), launches of the groups overlap
-    per_launch = n_local // ngrp
+    per_launch = n_local / ngrp          # (groups differ by at most 4 envs: ppo.group_sizes)
     for e in envs:
         e._physics_events = None
     # d1 of the measurement contract also asks for the ROLL-OUT-ONLY rate (random actions, no policy, no learner): the same env
@@ -262,7 +268,8 @@ def main(argv=None, runner=None):
         try:
             gen = torch.Generator(device=device).manual_seed(5)
             acts = [torch.randn((38, e.num_envs), generator=gen, device=device).clamp(-1, 1) * 0.3 for e in envs]
-            streams = [torch.cuda.Stream(device=device) for _ in envs]
+            # the learner's own group streams: new streams could land on a hardware queue that two groups then share (they would serialise)
+            streams = list(learner._streams) if getattr(learner, "_streams", None) else [torch.cuda.Stream(device=device) for _ in envs]
             sts = list(learner.states)
             nroll = 40
             for _rep in range(2):                 # first repetition = warm-up
@@ -324,7 +331,7 @@ def main(argv=None, runner=None):
                        "rollout_only_env_steps_per_s_per_gpu": rollout_only, "rollout_only_error": rollout_err,
                        "note": "one box of the pool differs from the next by about 3 % on this line (1.17-1.22 M env-steps/s seen for one build in round 1, 1.25-1.27 M for round 2's final build)"},
             # 15 644 algorithmic bytes per env-step (K2 + K3 together) x the envs of one physics launch / that
-            # launch's average duration (HIP events on its launch stream; with --pipeline 2 the two groups' launches share the GPU)
+            # launch's average duration (HIP events on its launch stream; the env groups' launches share the GPU)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_build_id": pmc.get("so_build_id") if pmc else None,
@@ -332,9 +339,11 @@ def main(argv=None, runner=None):
                          "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (FETCH_SIZE doubled, the gfx950 correction), NOT collected by this run; bytes per launch scaled to this launch's env count",
                          "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env)",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * per_launch,
-                         "avg_launch_ms": kernel_ms, "avg_launch_ms_is": f"shared-GPU duration: {ngrp} launches of {per_launch} envs run concurrently (plus the other group's K3 / inference); the HIP events also span the two record-transpose launches (< 1 %)",
+                         "avg_launch_ms": kernel_ms, "avg_launch_ms_is": f"shared-GPU duration: {ngrp} launches of {' / '.join(str(x) for x in sizes)} envs run concurrently (plus the other group's K3 / inference); the HIP events also span the two record-transpose launches (< 1 %)",
+                         "concurrent_launches": ngrp,
+                         "frac_of_the_concurrent_launches_together": achieved * ngrp / HBM_PEAK_GBS,     # the launches share the GPU: per launch the figure above FALLS when a third group is added although the chip does more
                          "avg_launch_ms_isolated": isolated_ms,
-                         "frac_isolated": (ALGO_BYTES_PER_ENV_STEP * per_launch / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if isolated_ms else None,
+                         "frac_isolated": (ALGO_BYTES_PER_ENV_STEP * sizes[0] / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if isolated_ms else None,
                          "k2_only": {"algorithmic_bytes_per_env_step": K2_ALGO_BYTES_PER_ENV_STEP, "achieved": k2_achieved, "frac": k2_achieved / HBM_PEAK_GBS},
                          "chip_level_frac_at_rollout_only_rate": ALGO_BYTES_PER_ENV_STEP * rate_rollout / 1e9 / HBM_PEAK_GBS,
                          "chip_level_frac_at_training_rate": ALGO_BYTES_PER_ENV_STEP * (env_steps / elapsed / world) / 1e9 / HBM_PEAK_GBS},

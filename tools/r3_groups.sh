@@ -1,10 +1,20 @@
 #!/bin/bash
-# roll-out pipelining depth: the bench line with 2, 3 (n/a unless divisible), 4 env groups per GPU, same box
+# roll-out pipelining depth: the bench line with 2 / 3 / 4 env groups per GPU (sizes: ppo.group_sizes), other 3-way splits, and the
+# self-launched one-rank RCCL run (the stream layout of a multi-GPU rank: one more stream, the communicator's), same box
 mkdir -p gpurun_out/groups
-for g in 2 4 2 4 8; do
-  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --pipeline $g 2>gpurun_out/groups/g$g.err | python -c "
+rm -f gpurun_out/groups/summary.txt
+run() {  # label, env assignments...
+  L=$1; shift
+  env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs $PIPE 2>gpurun_out/groups/$L.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']
-print('groups $g value %.0f  rollout_ms %.1f sgd_ms %.1f' % (d['value'], c['rollout_ms_per_step'], c['sgd_ms_per_step']))" >> gpurun_out/groups/summary.txt
-done
+print('$L value %.0f  rollout_ms %.1f sgd_ms %.1f rollout_only %.0f' % (d['value'], c['rollout_ms_per_step'], c['sgd_ms_per_step'], c['rollout_only_env_steps_per_s_per_gpu'] or 0))" >> gpurun_out/groups/summary.txt
+}
+PIPE="--pipeline 3" run g3 A=1
+PIPE="--pipeline 2" run g2 A=1
+PIPE="--pipeline 3" run g3_1408_1408_1280 TMJX_GROUP_SIZES=1408,1408,1280
+PIPE="--pipeline 3 --gpus 1" run g3_rccl_one_rank TMJX_FORCE_SPAWN=1 TMJX_COLLECTIVES_ALWAYS=1
+PIPE="--pipeline 2 --gpus 1" run g2_rccl_one_rank TMJX_FORCE_SPAWN=1 TMJX_COLLECTIVES_ALWAYS=1
+PIPE="--pipeline 3 --config cfg5" run g3_cfg5 A=1
+PIPE="--pipeline 2 --config cfg5" run g2_cfg5 A=1
 cat gpurun_out/groups/summary.txt

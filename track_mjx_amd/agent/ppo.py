@@ -150,6 +150,45 @@ class FlatAdam:
         return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
 
 
+RESIDENT_ENVS_PER_CU = 11      # csrc/wave_layout.h: 14 080 B of LDS per env = 11 of a CU's 128 granules
+
+
+def default_groups(n_envs: int, device=None, widest_layer: int = 256) -> int:
+    """How many env groups collect() should pipeline: enough that the groups NOT in their serial reward / inference phase still fill the
+    GPU's resident-env slots (11 per CU) — three for 4096 envs on an MI355X (2816 slots; measured 173.7 -> 166.1 ms per roll-out against two),
+    two once two groups alone exceed the slots (8192 envs: 358 ms with two, 363 ms with three) or when the acting policy is wide (config 4's
+    1024 / 512-wide layers: its inference is a larger share of a group's cycle and runs worse on 1365-row batches: 200 ms with two, 207 ms
+    with three).  Never more than three: see group_sizes."""
+    cus = 256
+    if device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available():
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+    slots = RESIDENT_ENVS_PER_CU * cus
+    if n_envs < 8:
+        return 1
+    return 2 if (n_envs // 2 >= slots or widest_layer > 512) else 3
+
+
+def group_sizes(n_envs: int, n_groups: int) -> list[int]:
+    """A rank's envs as `n_groups` env groups for the pipelined roll-out (collect()): as equal as multiples of 4 allow, the remainder in the
+    first groups (4096 envs, 3 groups -> 1368, 1364, 1364).  Three groups, not two: while one group is in its serial reward / observation /
+    inference phase the other two still fill 97 % of the GPU's 2816 resident-env slots (two groups: 73 %) — roll-out 173.6 -> 166.3 ms at
+    config 2.  Not four: with the default stream that is more HIP streams than hardware queues, and groups that share a queue serialise
+    (287 ms)."""
+    n_groups = max(1, min(int(n_groups), n_envs // 4 if n_envs >= 4 else 1))
+    base = (n_envs // n_groups) // 4 * 4
+    if base == 0:
+        return [n_envs]
+    sizes = [base] * n_groups
+    rest = n_envs - base * n_groups
+    k = 0
+    while rest > 0:
+        add_ = min(4, rest)
+        sizes[k % n_groups] += add_
+        rest -= add_
+        k += 1
+    return sizes
+
+
 def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous env range [lo, hi) owned by `rank` (reference: reshape (local_devices, num_envs/devices), ppo.py:477-480)."""
     if total % world:

@@ -77,13 +77,15 @@ def main(argv=None, runner=None):
         dist.init_process_group("nccl", device_id=device)
     tc = cfg["train_setup"]["train_config"]
     lo, hi = ppo.shard_range(int(tc["num_envs"]), int(os.environ.get("RANK", "0")), world)
-    # `rollout_groups` equal env groups per rank (default 2): their roll-outs are pipelined on separate HIP streams (agent/ppo.py)
-    ngrp = int(cfg.get("rollout_groups", 2))
-    if ngrp < 1 or (hi - lo) % ngrp:
-        ngrp = 1
+    # `rollout_groups` env groups per rank (default: ppo.default_groups — 3 at 4096 envs; sizes: ppo.group_sizes): their roll-outs are pipelined on
+    # separate HIP streams (agent/ppo.py: collect)
+    nc_ = cfg["network_config"]
+    widest = max(max(nc_[k]) for k in ("encoder_layer_sizes", "decoder_layer_sizes"))
+    sizes = ppo.group_sizes(hi - lo, int(cfg.get("rollout_groups", 0)) or ppo.default_groups(hi - lo, device, widest_layer=widest))
+    ngrp = len(sizes)
     train_clips, test_clips = load_clip_sets(cfg, int(cfg.get("n_synthetic_clips", 64)))
-    envs = [build_env(cfg, (hi - lo) // ngrp, device, reference_clip=train_clips)]
-    envs += [build_env(cfg, (hi - lo) // ngrp, device, reference_clip=train_clips, share_clips_with=envs[0]) for _ in range(1, ngrp)]      # one clip upload per rank
+    envs = [build_env(cfg, sizes[0], device, reference_clip=train_clips)]
+    envs += [build_env(cfg, sizes[k], device, reference_clip=train_clips, share_clips_with=envs[0]) for k in range(1, ngrp)]      # one clip upload per rank
     env = envs[0]
     rc, ts = cfg["reference_config"], cfg["train_setup"]
     # train.py:221-225
