@@ -77,13 +77,10 @@ def cpu_baseline(blob, clip, seconds_budget: float = 15.0, action_scale: float =
 
 
 def so_build_id() -> str:
-    """First 16 hex digits of the sha256 of the HIP library this run loads: ties the numbers read from profiles/*.json to a build."""
-    import hashlib
+    """Build id of the HIP library this run loads (hip.build_id: hash of the sources it was compiled from): ties the numbers read from
+    profiles/*.json to a build."""
     from track_mjx_amd import hip
-    try:
-        return hashlib.sha256(Path(hip.SO_PATH).read_bytes()).hexdigest()[:16]
-    except OSError:
-        return "missing"
+    return hip.build_id()
 
 
 def mjx_cpu_probe() -> str:

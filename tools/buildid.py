@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build id of the HIP library (first 16 hex digits of its sha256) — the tie between a counter summary under profiles/ and the kernel it
+"""Build id of the HIP library (the source-derived id written by hip.build(), see build_id) — the tie between a counter summary under profiles/ and the kernel it
 was measured on.
 
   python tools/buildid.py                 print the id of track_mjx_amd/libtmjx_hip.so (or $TMJX_SO)
@@ -20,8 +20,14 @@ def so_path() -> Path:
 
 
 def build_id(path: Path | None = None) -> str:
+    """The source-derived id hip.build() wrote next to the library (<lib>.id: hash of flags + sources + include closure — hipcc's objects are not
+    bit-reproducible, a hash of the .so would change with every rebuild of unchanged sources); a library without one: the hash of its bytes."""
+    path = Path(path or so_path())
+    side = Path(str(path) + ".id")
     try:
-        return hashlib.sha256(Path(path or so_path()).read_bytes()).hexdigest()[:16]
+        if side.exists() and side.stat().st_mtime >= path.stat().st_mtime - 1:
+            return side.read_text().strip()
+        return hashlib.sha256(path.read_bytes()).hexdigest()[:16]
     except OSError:
         return "missing"
 

@@ -131,7 +131,24 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise TmjxError("hipcc link failed:\n" + res.stderr[-4000:])
+    # the build id: a hash of WHAT was compiled (flags + every source with its include closure, the object cache keys), written next to the
+    # library.  hipcc's objects are not bit-reproducible, so a hash of the .so would change with every recompilation of unchanged sources —
+    # and the counters under profiles/ are tied to a build by this id (tools/buildid.py, bench.py)
+    Path(str(out) + ".id").write_text(hashlib.sha256(" ".join(o.name for o in objs).encode()).hexdigest()[:16] + "\n")
     return out
+
+
+def build_id(path: Path | None = None) -> str:
+    """Id of a built library: the source-derived id `build` wrote next to it, else (a library from elsewhere) the hash of its bytes."""
+    import hashlib
+    path = Path(SO_PATH if path is None else path)
+    side = Path(str(path) + ".id")
+    try:
+        if side.exists() and side.stat().st_mtime >= path.stat().st_mtime - 1:
+            return side.read_text().strip()
+        return hashlib.sha256(path.read_bytes()).hexdigest()[:16]
+    except OSError:
+        return "missing"
 
 
 def lib():
