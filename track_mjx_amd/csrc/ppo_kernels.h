@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void k_silu_ln_fwd(const float *__restrict__ z
   float b[VPT], g[VPT], be[VPT];
 #pragma unroll
   for (int k = 0; k < VPT; k++) { int c = lane * VPT + k; b[k] = bias[c]; g[k] = gamma[c]; be[k] = beta[c]; }
-  for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+  const int wpb = blockDim.x >> 6;         // waves (= rows in flight) per block: 4, or 1 for the acting policy (tmjx_silu_ln_fwd)
+  for (int r = blockIdx.x * wpb + w; r < rows; r += gridDim.x * wpb) {
     float a[VPT], s = 0.f;
 #pragma unroll
     for (int k = 0; k < VPT; k++) { float v = z[(size_t)r * H + lane * VPT + k] + b[k]; a[k] = v / (1.f + expf(-v)); s += a[k]; }
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__
   // holds no torch generator (two state fills per replay) and no normal_ launch; the pad columns [W, x_stride) are written as zeros
   const int W = Z + obs_w - ref_w;
   const unsigned long long ctr = rng_state ? (unsigned long long)rng_state[0] : 0ull;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * x_stride; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * x_stride; i += (size_t)gridDim.x * blockDim.x) {
     int c = (int)(i % x_stride); size_t e = i / x_stride;
     float v = 0.f;
     if (c < Z) {
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_sample_action(const float *__rest
                                                              unsigned long long seed, long long *__restrict__ rng_state) {
   // noise == nullptr: drawn here (Philox stream 3 of (seed, rng_state[0])); the workgroup that finishes last then advances the draw counter
   // for the next inference (every workgroup has read it by then; ticket in rng_state[1])
-  const int gid = blockIdx.x * PPO_BLOCK + threadIdx.x, e = gid / PPO_G, sub = gid % PPO_G;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, e = gid / PPO_G, sub = gid % PPO_G;
   const unsigned long long ctr = rng_state ? (unsigned long long)rng_state[0] : 0ull;
   float lp = 0.f;
   if (e < n) {

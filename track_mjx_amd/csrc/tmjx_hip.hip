@@ -44,6 +44,7 @@ static int launch_wave(const tmjx_model *m, float *state, const float *action, i
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // the library's other translation units (tmjx_bf16.hip) record their failures in the same per-thread message
+#define TMJX_SMALL_BATCH 8192      // rows up to which the acting-path element-wise kernels launch one-wave blocks
 extern "C" int tmjx_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
@@ -569,8 +570,11 @@ int tmjx_silu_ln_fwd(const float *z, const float *bias, const float *gamma, cons
   if (!z || !bias || !gamma || !beta || !y || !stats) return fail(TMJX_EINVAL, "null argument");
   if (rows < 1) return fail(TMJX_EINVAL, "rows must be >= 1");
   hipStream_t s = (hipStream_t)stream;
-  int grid = (rows + 3) / 4; if (grid > 4096) grid = 4096;
-#define TMJX_FWD(V) hipLaunchKernelGGL(k_silu_ln_fwd<V>, dim3(grid), dim3(256), 0, s, z, bias, gamma, beta, y, stats, rows, eps)
+  // One-wave blocks for the acting policy's batches (an env group's rows): next to a GPU full of physics waves — 504 of 512 VGPRs taken on three
+  // SIMDs of every CU — a CU has room for new waves on ONE SIMD only, and a 256-thread block wants all four
+  const int bt = rows <= TMJX_SMALL_BATCH ? 64 : 256, wpb = bt / 64;
+  int grid = (rows + wpb - 1) / wpb; if (grid > 4096) grid = 4096;
+#define TMJX_FWD(V) hipLaunchKernelGGL(k_silu_ln_fwd<V>, dim3(grid), dim3(bt), 0, s, z, bias, gamma, beta, y, stats, rows, eps)
   switch (H) { case 64: TMJX_FWD(1); break; case 128: TMJX_FWD(2); break; case 256: TMJX_FWD(4); break; case 512: TMJX_FWD(8); break;
                case 1024: TMJX_FWD(16); break; default: return fail(TMJX_EINVAL, "H must be 64, 128, 256, 512 or 1024"); }
 #undef TMJX_FWD
@@ -690,8 +694,9 @@ int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, flo
   if (!eps && !rng_state) return fail(TMJX_EINVAL, "tmjx_latent_concat: eps == NULL needs rng_state");
   if (n < 1 || Z < 1 || ref_w < 0 || obs_w < ref_w || x_stride < Z + obs_w - ref_w) return fail(TMJX_EINVAL, "bad sizes");
   size_t total = (size_t)n * x_stride;
-  int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3(256), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1, mean, std, x_stride,
+  const size_t bt = n <= TMJX_SMALL_BATCH ? 64 : 256;        // (one-wave blocks for an env group's rows: see tmjx_silu_ln_fwd)
+  int grid = (int)((total + bt - 1) / bt < 4096 ? (total + bt - 1) / bt : 4096);
+  hipLaunchKernelGGL(k_latent_concat, dim3(grid), dim3((unsigned)bt), 0, (hipStream_t)stream, fc2, eps, obs, x, n, Z, obs_w, ref_w, (long long)obs_s0, (long long)obs_s1, mean, std, x_stride,
                      (unsigned long long)seed, (const long long *)rng_state);
   return check_launch("k_latent_concat");
 }
@@ -710,7 +715,8 @@ int tmjx_sample_action(const float *logits, const float *noise, float *raw, floa
   if (!logits || !raw || !action_t || !logp) return fail(TMJX_EINVAL, "null argument");
   if (!noise && !rng_state) return fail(TMJX_EINVAL, "tmjx_sample_action: noise == NULL needs rng_state");
   if (n < 1 || A < 1) return fail(TMJX_EINVAL, "bad sizes");
-  hipLaunchKernelGGL(k_sample_action, dim3((n * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK), dim3(PPO_BLOCK), 0, (hipStream_t)stream, logits, noise, raw, action_t, logp, n, A,
+  const int sbt = n <= TMJX_SMALL_BATCH ? 64 : PPO_BLOCK;      // (one-wave blocks for an env group's rows: see tmjx_silu_ln_fwd)
+  hipLaunchKernelGGL(k_sample_action, dim3((n * PPO_G + sbt - 1) / sbt), dim3(sbt), 0, (hipStream_t)stream, logits, noise, raw, action_t, logp, n, A,
                      (unsigned long long)seed, (long long *)(noise ? nullptr : rng_state));
   return check_launch("k_sample_action");
 }
