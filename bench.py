@@ -143,7 +143,7 @@ def main(argv=None, runner=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=0, help="env groups per GPU whose roll-outs are pipelined on separate HIP streams (0 = ppo.default_groups: 3 at 4096 envs, 2 at 8192; 1 = off; sizes: ppo.group_sizes)")
+    ap.add_argument("--pipeline", type=int, default=0, help="env groups per GPU whose roll-outs are pipelined on separate HIP streams (0 = ppo.default_groups: 3; 1 = off; sizes: ppo.group_sizes)")
     ap.add_argument("--no-rollout-only", action="store_true", help="skip the extra roll-out-only measurement (tools/profile_gpu.sh: keeps the "
                     "rocprofv3 kernel averages those of the timed training steps)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",

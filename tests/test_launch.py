@@ -79,12 +79,11 @@ def test_self_launched_two_ranks_really_run_and_rank0_line_comes_back():
 
 def test_env_group_sizes_for_the_pipelined_rollout():
     """ppo.group_sizes / default_groups: every env in exactly one group, sizes multiples of 4 (but for a remainder), at most 4 apart; three groups
-    at 4096 envs per GPU, two at 8192 (bench.py --pipeline 0, train.py rollout_groups)."""
+    by default (bench.py --pipeline 0, train.py rollout_groups)."""
     from track_mjx_amd.agent import ppo
     assert ppo.group_sizes(4096, 3) == [1368, 1364, 1364] and ppo.group_sizes(4096, 2) == [2048, 2048] and ppo.group_sizes(8192, 3) == [2732, 2732, 2728]
     for n in (1, 2, 6, 16, 64, 130, 4095, 4096, 8192):
         for g in (1, 2, 3, 4):
             s = ppo.group_sizes(n, g)
             assert sum(s) == n and all(x > 0 for x in s) and len(s) <= g and max(s) - min(s) <= 4, (n, g, s)
-    assert ppo.default_groups(4096) == 3 and ppo.default_groups(8192) == 2 and ppo.default_groups(2048) == 3 and ppo.default_groups(4) == 1
-    assert ppo.default_groups(4096, widest_layer=1024) == 2          # wide acting policy (config 4): two groups
+    assert ppo.default_groups(4096) == 3 and ppo.default_groups(8192) == 3 and ppo.default_groups(2048) == 3 and ppo.default_groups(4) == 1

@@ -154,18 +154,13 @@ RESIDENT_ENVS_PER_CU = 11      # csrc/wave_layout.h: 14 080 B of LDS per env = 1
 
 
 def default_groups(n_envs: int, device=None, widest_layer: int = 256) -> int:
-    """How many env groups collect() should pipeline: enough that the groups NOT in their serial reward / inference phase still fill the
-    GPU's resident-env slots (11 per CU) — three for 4096 envs on an MI355X (2816 slots; measured 173.7 -> 166.1 ms per roll-out against two),
-    two once two groups alone exceed the slots (8192 envs: 358 ms with two, 363 ms with three) or when the acting policy is wide (config 4's
-    1024 / 512-wide layers: its inference is a larger share of a group's cycle and runs worse on 1365-row batches: 200 ms with two, 207 ms
-    with three).  Never more than three: see group_sizes."""
-    cus = 256
-    if device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available():
-        cus = torch.cuda.get_device_properties(device).multi_processor_count
-    slots = RESIDENT_ENVS_PER_CU * cus
-    if n_envs < 8:
-        return 1
-    return 2 if (n_envs // 2 >= slots or widest_layer > 512) else 3
+    """How many env groups collect() should pipeline: THREE.  While one group is in its serial reward / observation / inference phase the
+    others should still fill the GPU's resident-env slots (11 per CU: 2816 on an MI355X): two of three groups of 4096 envs fill 97 %, one of
+    two 73 % (config 2: roll-out 170.1 ms with two groups, 159.8 ms with three; config 5, 8192 envs: 345.8 -> 330.5 ms; config 4's wide
+    policy: 194.2 / 195.3 ms, a tie).  Never more than three: see group_sizes.  (`device`, `widest_layer`: kept for callers that tune per
+    model; both configurations that once preferred two groups — 8192 envs, the wide policy — stopped doing so when the acting path's
+    element-wise kernels went to one-wave blocks.)"""
+    return 1 if n_envs < 8 else 3
 
 
 def group_sizes(n_envs: int, n_groups: int) -> list[int]:
