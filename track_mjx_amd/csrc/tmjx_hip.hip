@@ -125,6 +125,31 @@ __global__ void k_obs(const DModel *__restrict__ mp, float *st, const int *is, f
   int clip = is[(size_t)m.i_clip_idx * n + e], start = is[(size_t)m.i_start_frame * n + e];
   tm_get_obs(m, r, clip, tm_cur_frame(m, ST(m.s_time, 0), start), obs, true, part);
 }
+// k_window, k_obs and k_post_parts in ONE launch (blockIdx.y picks the piece): the three read the post-physics state and write disjoint
+// outputs, so a group's serial phase between two physics launches is one launch latency shorter twice over.  (Measured in round 1, when
+// such launches mostly waited for wave slots: no gain; re-measured in round 3 with three env groups and one-wave blocks everywhere.)
+__global__ __launch_bounds__(64) void k_step_parts(const DModel *__restrict__ mp, float *st, const int *is, const float *action, float *win, float *obs,
+                                                   float *P, int n, int n_obs_parts) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, nullptr, n, e};
+  int y = blockIdx.y;
+  if (y < m.nu) {
+    float vi, ji;
+    tm_window_dim(m, r, y, is[(size_t)m.i_buffer_index * n + e], action[(size_t)y * n + e], vi, ji);
+    win[(size_t)y * n + e] = vi;
+    win[(size_t)(m.nu + y) * n + e] = ji;
+    return;
+  }
+  y -= m.nu;
+  if (y < n_obs_parts) {
+    int clip = is[(size_t)m.i_clip_idx * n + e], start = is[(size_t)m.i_start_frame * n + e];
+    tm_get_obs(m, r, clip, tm_cur_frame(m, ST(m.s_time, 0), start), obs, true, y);
+    return;
+  }
+  tm_post_part(m, r, is, y - n_obs_parts, P);
+}
 // auto-reset of the envs that are done: physics state, observation and prev_ctrl <- the snapshot taken at reset
 // (wrappers.py:104-144), one lane per (env, block of 16 rows)
 __global__ void k_autoreset(const DModel *__restrict__ mp, float *st, float *obs, const float *done, int n) {
@@ -460,6 +485,20 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
     if (int rc = launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env))) return rc;
     // 64-lane workgroups like the other K3 kernels: next to the other env group's physics kernel (up to 3 waves of 168 VGPRs per SIMD) a
     // 256-lane workgroup had to wait for four wave slots WITH registers on one CU — 245 us on average instead of 30
+    static const bool merged = !getenv("TMJX_K3_SEPARATE");
+    if (merged) {
+      const DModel &h = m->h;
+      const int nobs = TM_OBS_PARTS(h.traj_length);
+      hipLaunchKernelGGL(k_step_parts, dim3((n_env + 63) / 64, h.nu + nobs + TM_NPOST), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action,
+                         workspace, obs, workspace + (size_t)2 * h.nu * n_env, n_env, nobs);
+      hipLaunchKernelGGL(k_post, dim3((n_env + 63) / 64), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation, metrics,
+                         (const float *)workspace, 1, n_env);
+      if (h.auto_reset) {
+        int total = h.nphys + h.obs_size + h.nu;
+        hipLaunchKernelGGL(k_autoreset, dim3((n_env + 63) / 64, (total + 15) / 16), dim3(64), 0, (hipStream_t)stream, m->d, state, obs, done, n_env);
+      }
+      return check_launch("k_step(wave, merged parts)");
+    }
     hipLaunchKernelGGL(k_window, dim3((n_env + 63) / 64, m->h.nu), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action,
                        workspace, n_env);
     launch_post_split(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
