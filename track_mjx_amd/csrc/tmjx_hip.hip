@@ -462,12 +462,22 @@ int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip
 #endif
 }
 
-// K3 as four launches: observation parts, reward / termination, auto-reset copies (the window statistics were launched before)
-static void launch_post_split(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
-                              float *truncation, float *metrics, float *workspace, int n_env, hipStream_t stream) {
+// K3 behind the physics launch: window statistics + observation parts + reward partial sums (ONE launch, k_step_parts; TMJX_K3_SEPARATE=1:
+// three), reward / termination, auto-reset copies.  64-lane workgroups throughout: next to the other env groups' physics kernel (up to 3 waves
+// of 168 VGPRs per SIMD) a 256-lane workgroup had to wait for four wave slots WITH registers on one CU — 245 us on average instead of 30
+static void launch_k3(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
+                      float *truncation, float *metrics, float *workspace, int n_env, hipStream_t stream) {
   const DModel &h = m->h;
-  hipLaunchKernelGGL(k_obs, dim3((n_env + 63) / 64, TM_OBS_PARTS(h.traj_length)), dim3(64), 0, stream, m->d, state, istate, obs, n_env);
-  hipLaunchKernelGGL(k_post_parts, dim3((n_env + 63) / 64, TM_NPOST), dim3(64), 0, stream, m->d, state, istate, workspace + (size_t)2 * h.nu * n_env, n_env);
+  static const bool merged = !getenv("TMJX_K3_SEPARATE");
+  const int nobs = TM_OBS_PARTS(h.traj_length);
+  float *parts = workspace + (size_t)2 * h.nu * n_env;
+  if (merged) {
+    hipLaunchKernelGGL(k_step_parts, dim3((n_env + 63) / 64, h.nu + nobs + TM_NPOST), dim3(64), 0, stream, m->d, state, istate, action, workspace, obs, parts, n_env, nobs);
+  } else {
+    hipLaunchKernelGGL(k_window, dim3((n_env + 63) / 64, h.nu), dim3(64), 0, stream, m->d, state, istate, action, workspace, n_env);
+    hipLaunchKernelGGL(k_obs, dim3((n_env + 63) / 64, nobs), dim3(64), 0, stream, m->d, state, istate, obs, n_env);
+    hipLaunchKernelGGL(k_post_parts, dim3((n_env + 63) / 64, TM_NPOST), dim3(64), 0, stream, m->d, state, istate, parts, n_env);
+  }
   hipLaunchKernelGGL(k_post, dim3((n_env + 63) / 64), dim3(64), 0, stream, m->d, state, istate, action, obs, reward, done, truncation, metrics,
                      (const float *)workspace, 1, n_env);
   if (h.auto_reset) {
@@ -483,25 +493,7 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
   if (m->wave) {
     if (int rc = launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env))) return rc;
-    // 64-lane workgroups like the other K3 kernels: next to the other env group's physics kernel (up to 3 waves of 168 VGPRs per SIMD) a
-    // 256-lane workgroup had to wait for four wave slots WITH registers on one CU — 245 us on average instead of 30
-    static const bool merged = !getenv("TMJX_K3_SEPARATE");
-    if (merged) {
-      const DModel &h = m->h;
-      const int nobs = TM_OBS_PARTS(h.traj_length);
-      hipLaunchKernelGGL(k_step_parts, dim3((n_env + 63) / 64, h.nu + nobs + TM_NPOST), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action,
-                         workspace, obs, workspace + (size_t)2 * h.nu * n_env, n_env, nobs);
-      hipLaunchKernelGGL(k_post, dim3((n_env + 63) / 64), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation, metrics,
-                         (const float *)workspace, 1, n_env);
-      if (h.auto_reset) {
-        int total = h.nphys + h.obs_size + h.nu;
-        hipLaunchKernelGGL(k_autoreset, dim3((n_env + 63) / 64, (total + 15) / 16), dim3(64), 0, (hipStream_t)stream, m->d, state, obs, done, n_env);
-      }
-      return check_launch("k_step(wave, merged parts)");
-    }
-    hipLaunchKernelGGL(k_window, dim3((n_env + 63) / 64, m->h.nu), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action,
-                       workspace, n_env);
-    launch_post_split(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
+    launch_k3(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
     return check_launch("k_step(wave)");
   }
 #ifdef TMJX_LANE_IMPL
@@ -562,11 +554,7 @@ int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *a
   if (!m || !state || !istate || !action || !obs || !reward || !done || !truncation || !metrics) return fail(TMJX_EINVAL, "null argument");
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
-  if (workspace) {
-    hipLaunchKernelGGL(k_window, dim3((n_env + 63) / 64, m->h.nu), dim3(64), 0, (hipStream_t)stream, m->d, state, istate, action,
-                       workspace, n_env);
-  }
-  if (workspace) launch_post_split(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
+  if (workspace) launch_k3(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
   else hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
                           metrics, (const float *)nullptr, 0, n_env);
   return check_launch("k_post");
