@@ -95,7 +95,10 @@ def _make_learner(world_batch, groups=1):
     from tests.common import StubEnv, torch_gae
     from track_mjx_amd.agent.ppo import PPOLearner
     # `groups` env groups per rank (rollout_groups of train.py / bench.py --pipeline): the rank's envs as a LIST of equal parts
-    envs = StubEnv(_NLOC, _OBS, _REF, _NU) if groups == 1 else [StubEnv(_NLOC // groups, _OBS, _REF, _NU) for _ in range(groups)]
+    # (three groups: the bench / train default — of UNEQUAL size when the count does not divide: here 2 + 1 + 1 envs)
+    sizes = [_NLOC // groups] * groups if _NLOC % groups == 0 else [_NLOC - (groups - 1)] + [1] * (groups - 1)
+    assert sum(sizes) == _NLOC and len(sizes) == groups
+    envs = StubEnv(_NLOC, _OBS, _REF, _NU) if groups == 1 else [StubEnv(k, _OBS, _REF, _NU) for k in sizes]
     ln = PPOLearner(envs, **_NETS, unroll_length=_T, batch_size=world_batch, num_minibatches=2, num_updates_per_batch=2,
                     learning_rate=1e-2, use_graph=False, seed=3)
     ln.gae_fn = torch_gae
@@ -133,9 +136,10 @@ def _learner_worker(rank, world, port, q, groups=1):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("groups", [1, 2, 3])
 def test_two_rank_learner_update_matches_manual_gradient_average(groups):
-    """groups = 2: two ranks x two env groups per rank (the layout of the 8-GPU bench: rollout_groups = 2 on every rank) — the roll-out buffer rows
+    """groups = 2 / 3: two ranks x two / three env groups per rank (the layout of the 8-GPU bench: three groups on every rank, of unequal size when the
+    env count does not divide) — the roll-out buffer rows
     of a rank are its groups' slices side by side, the update must not depend on how the rank's envs are grouped."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
