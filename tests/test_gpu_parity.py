@@ -552,11 +552,13 @@ def test_fused_inference_tail_matches_torch_path():
 
 
 @pytest.mark.gpu
-def test_pipelined_rollout_two_env_groups():
-    """PPOLearner with a LIST of envs (bench.py --pipeline 2): the groups' roll-outs run on separate HIP streams with the LDS-free
-    inference.  The roll-out buffer must hold each group's rows in its own slice, and a full training step must stay finite."""
+@pytest.mark.parametrize("sizes", [(64, 64), (48, 44, 36)])
+def test_pipelined_rollout_env_groups(sizes):
+    """PPOLearner with a LIST of envs (bench.py --pipeline N; the default is three groups, of unequal size when the env count does not divide —
+    ppo.group_sizes): the groups' roll-outs run on separate HIP streams with the LDS-free inference.  The roll-out buffer must hold each
+    group's rows in its own slice, and a full training step must stay finite."""
     from track_mjx_amd.agent import ppo
-    envs = [make_env_and_oracle(num_envs=64, n_clips=4, wrappers=True, seed=k)[0] for k in range(2)]
+    envs = [make_env_and_oracle(num_envs=n, n_clips=4, wrappers=True, seed=k)[0] for k, n in enumerate(sizes)]
     L = ppo.PPOLearner(envs, encoder_layers=(64, 64), decoder_layers=(64, 64), critic_layers=(64, 64), latents=60, unroll_length=5,
                        batch_size=32, num_minibatches=4, num_updates_per_batch=2, seed=3)
     assert L.lds_free and L.n_local == 128 and L.unrolls == 1
@@ -567,9 +569,10 @@ def test_pipelined_rollout_two_env_groups():
     before = L.grads.params[0].detach().clone()
     L.collect()
     torch.cuda.synchronize()
-    for k in range(2):
-        assert torch.equal(L.buf["observation"][0, 64 * k:64 * (k + 1)], first[k])
-        assert torch.equal(L.buf["next_observation_last"][64 * k:64 * (k + 1)], L.states[k].obs)
+    offs = [sum(sizes[:k]) for k in range(len(sizes) + 1)]
+    for k in range(len(sizes)):
+        assert torch.equal(L.buf["observation"][0, offs[k]:offs[k + 1]], first[k])
+        assert torch.equal(L.buf["next_observation_last"][offs[k]:offs[k + 1]], L.states[k].obs)
     for name, v in L.buf.items():
         assert torch.isfinite(v).all(), name
     m = L.update(1)
