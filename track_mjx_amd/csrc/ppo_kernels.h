@@ -169,14 +169,106 @@ __global__ __launch_bounds__(1024) void k_ppo_b(PpoCfg c, const float *__restric
   }
 }
 
+// B, many blocks (the single 1024-thread block above took 31 us of every minibatch step: one CU, two block-wide reductions and a second pass over the
+// advantages in global memory): one 64-thread block per 64 columns.  Each block leaves a RECORD {n, mean, M2, sum v_err^2, ent, kl0, klt} of its
+// columns (mean / M2 of the advantages two-pass within the block, from registers) and of its slice of A's partial sums; C and D combine the
+// records (Chan's update for the variance).  T <= PPO_TMAX (24) only; longer unrolls take k_ppo_b.
+#define PPO_TMAX 24
+#define PPO_REC 8
+__device__ __forceinline__ float ppo_wave_sum(float x) { for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off); return x; }
+__global__ __launch_bounds__(64) void k_ppo_b2(PpoCfg c, const float *__restrict__ baseline, const float *__restrict__ bootstrap,
+                                               const float *__restrict__ reward, const float *__restrict__ discount,
+                                               const float *__restrict__ truncation, float *scratch, int nblk, float *rec) {
+  const int N = c.T * c.B, b = blockIdx.x * 64 + threadIdx.x;
+  float *vs = scratch + N, *adv = scratch + 2 * (size_t)N;
+  const float *part = scratch + 4 * (size_t)N;
+  float ad[PPO_TMAX], s_ad = 0.f, s_ve = 0.f;
+#pragma unroll
+  for (int t = 0; t < PPO_TMAX; t++) ad[t] = 0.f;
+  const bool on = b < c.B;
+  if (on) {
+    const float bv = bootstrap[b];
+    float rw[PPO_TMAX], te[PPO_TMAX], tm[PPO_TMAX], vv[PPO_TMAX], vsr[PPO_TMAX];
+#pragma unroll
+    for (int t = 0; t < PPO_TMAX; t++) {
+      size_t i = (size_t)(t < c.T ? t : 0) * c.B + b;
+      float tr = truncation[i];
+      rw[t] = reward[i] * c.reward_scaling; te[t] = (1.f - discount[i]) * (1.f - tr); tm[t] = 1.f - tr; vv[t] = baseline[i];
+    }
+    float a = 0.f, vnext = bv;
+#pragma unroll
+    for (int t = PPO_TMAX - 1; t >= 0; t--) {
+      if (t < c.T) {
+        float delta = (rw[t] + c.discounting * (1.f - te[t]) * vnext - vv[t]) * tm[t];
+        a = delta + c.discounting * (1.f - te[t]) * tm[t] * c.gae_lambda * a;
+        vsr[t] = a + vv[t];
+        vs[(size_t)t * c.B + b] = vsr[t];
+        vnext = vv[t];
+      }
+    }
+    float vsn = bv;
+#pragma unroll
+    for (int t = PPO_TMAX - 1; t >= 0; t--) {
+      if (t < c.T) {
+        ad[t] = (rw[t] + c.discounting * (1.f - te[t]) * vsn - vv[t]) * tm[t];
+        adv[(size_t)t * c.B + b] = ad[t];
+        s_ad += ad[t];
+        float ve = vsr[t] - vv[t];
+        s_ve += ve * ve;
+        vsn = vsr[t];
+      }
+    }
+  }
+  const int cols = min(64, c.B - (int)blockIdx.x * 64);
+  const float n_b = (float)(cols * c.T);
+  const float mean_b = ppo_wave_sum(s_ad) / n_b;
+  float m2 = 0.f;
+  if (on) {
+#pragma unroll
+    for (int t = 0; t < PPO_TMAX; t++) if (t < c.T) { float d = ad[t] - mean_b; m2 += d * d; }
+  }
+  m2 = ppo_wave_sum(m2);
+  s_ve = ppo_wave_sum(s_ve);
+  // this block's slice of A's per-block partial sums (entropy, kl0, klt)
+  const int k0 = (int)((long long)nblk * blockIdx.x / gridDim.x), k1 = (int)((long long)nblk * (blockIdx.x + 1) / gridDim.x);
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+  for (int k = k0 + threadIdx.x; k < k1; k += 64) { e0 += part[4 * k]; e1 += part[4 * k + 1]; e2 += part[4 * k + 2]; }
+  e0 = ppo_wave_sum(e0); e1 = ppo_wave_sum(e1); e2 = ppo_wave_sum(e2);
+  if (threadIdx.x == 0) {
+    float *r = rec + (size_t)PPO_REC * blockIdx.x;
+    r[0] = n_b; r[1] = mean_b; r[2] = m2; r[3] = s_ve; r[4] = e0; r[5] = e1; r[6] = e2; r[7] = 0.f;
+  }
+}
+// the records of k_ppo_b2 -> the five scalars k_ppo_b leaves in scal[] (one thread)
+__device__ __forceinline__ void ppo_combine_records(const PpoCfg &c, const float *rec, int nrec, float *scal) {
+  float n = 0.f, sm = 0.f, ve = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f;
+  for (int k = 0; k < nrec; k++) { const float *r = rec + PPO_REC * k; n += r[0]; sm += r[0] * r[1]; ve += r[3]; e0 += r[4]; e1 += r[5]; e2 += r[6]; }
+  const float mean = sm / n;
+  float m2 = 0.f;
+  for (int k = 0; k < nrec; k++) { const float *r = rec + PPO_REC * k; const float d = r[1] - mean; m2 += r[2] + r[0] * d * d; }
+  scal[0] = mean;
+  scal[1] = sqrtf(m2 / n);
+  scal[2] = ve / n * 0.25f;
+  scal[3] = e0 / n;
+  float kl0 = -0.5f * e1 / (float)(c.B * c.Z), kl = kl0;
+  if (c.T > 1) { float klt = 0.5f * e2 / (float)((c.T - 1) * c.B * c.Z); kl = (kl0 + klt * (float)(c.T - 1)) / (float)c.T; }
+  scal[4] = c.kl_weight * kl;
+}
+
 // C: per (t, b) (PPO_G lanes each): surrogate loss term and every gradient w.r.t. logits, baseline, fc2
 __global__ __launch_bounds__(PPO_BLOCK) void k_ppo_c(PpoCfg c, const float *__restrict__ logits, const float *__restrict__ raw_action,
                                                      const float *__restrict__ behaviour_logp, const float *__restrict__ noise,
                                                      const float *__restrict__ baseline, const float *__restrict__ fc2, float *dlogits,
-                                                     float *dbaseline, float *dfc2, float *scratch, int nblk) {
+                                                     float *dbaseline, float *dfc2, float *scratch, int nblk, const float *rec = nullptr, int nrec = 0) {
   __shared__ float lds[32];
+  __shared__ float scal_s[8];
   const int N = c.T * c.B, gid = blockIdx.x * PPO_BLOCK + threadIdx.x, i = gid / PPO_G, sub = gid % PPO_G;
   const float *vs = scratch + N, *adv = scratch + 2 * (size_t)N, *scal = scratch + 4 * (size_t)N + (size_t)4 * nblk;
+  if (rec) {       // k_ppo_b2's records: every block combines them itself (a few dozen words)
+    if (threadIdx.x == 0) ppo_combine_records(c, rec, nrec, scal_s);
+    __syncthreads();
+    scal = scal_s;
+  }
   float acc[1] = {0.f};
   if (i < N) {
     const float Nf = (float)N;
@@ -217,10 +309,16 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_ppo_c(PpoCfg c, const float *__re
 }
 
 // D: final scalars
-__global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk) {
+__global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk, const float *rec = nullptr, int nrec = 0) {
   __shared__ float lds[16];
+  __shared__ float scal_s[8];
   const int N = c.T * c.B;
   const float *part = scratch + 4 * (size_t)N, *scal = part + (size_t)4 * nblk;
+  if (rec) {
+    if (threadIdx.x == 0) ppo_combine_records(c, rec, nrec, scal_s);
+    __syncthreads();
+    scal = scal_s;
+  }
   float acc[1] = {0.f};
   for (int k = threadIdx.x; k < nblk; k += blockDim.x) acc[0] += part[4 * k + 3];
   ppo_block_sum<1>(acc, lds);

@@ -569,7 +569,7 @@ int tmjx_gae(const float *truncation, const float *termination, const float *rew
   return check_launch("k_gae");
 }
 
-int tmjx_ppo_scratch_floats(int T, int B) { return 4 * T * B + 4 * ((T * B * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK) + 16; }
+int tmjx_ppo_scratch_floats(int T, int B) { return 4 * T * B + 4 * ((T * B * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK) + 16 + PPO_REC * ((B + 63) / 64); }
 
 int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *raw_action, const float *behaviour_logp,
                   const float *noise, const float *baseline, const float *bootstrap, const float *reward, const float *discount,
@@ -583,10 +583,21 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
   const int N = c.T * c.B, nblk = (N * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_ppo_a, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, noise, fc2, scratch, nblk);
+  static const bool one_block_b = getenv("TMJX_PPO_ONE_BLOCK_B") != nullptr;
+  if (c.T <= PPO_TMAX && !one_block_b) {
+    // GAE / advantage statistics by one 64-thread block per 64 columns, combined by the consumers (csrc/ppo_kernels.h: k_ppo_b2)
+    const int nrec = (c.B + 63) / 64;
+    float *rec = scratch + 4 * (size_t)N + (size_t)4 * nblk + 16;
+    hipLaunchKernelGGL(k_ppo_b2, dim3(nrec), dim3(64), 0, s, c, baseline, bootstrap, reward, discount, truncation, scratch, nblk, rec);
+    hipLaunchKernelGGL(k_ppo_c, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, behaviour_logp, noise, baseline, fc2, dlogits, dbaseline,
+                       dfc2, scratch, nblk, (const float *)rec, nrec);
+    hipLaunchKernelGGL(k_ppo_d, dim3(1), dim3(256), 0, s, c, (const float *)scratch, out, nblk, (const float *)rec, nrec);
+    return check_launch("k_ppo");
+  }
   hipLaunchKernelGGL(k_ppo_b, dim3(1), dim3(1024), 0, s, c, baseline, bootstrap, reward, discount, truncation, scratch, nblk);
   hipLaunchKernelGGL(k_ppo_c, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, behaviour_logp, noise, baseline, fc2, dlogits, dbaseline,
-                     dfc2, scratch, nblk);
-  hipLaunchKernelGGL(k_ppo_d, dim3(1), dim3(256), 0, s, c, (const float *)scratch, out, nblk);
+                     dfc2, scratch, nblk, (const float *)nullptr, 0);
+  hipLaunchKernelGGL(k_ppo_d, dim3(1), dim3(256), 0, s, c, (const float *)scratch, out, nblk, (const float *)nullptr, 0);
   return check_launch("k_ppo");
 }
 
