@@ -45,7 +45,9 @@ TM_DEV float tm_nan_to_num(float x) {
 // TM_OBS_PARTS(T) = 3 T + 3 pieces the split kernel k_obs runs in parallel (one per blockIdx.y): 3 t + {0: root position +
 // quaternion, 1: joints, 2: bodies} of trajectory frame t, then 3 T + {0: qpos, 1: qvel, 2: actuator forces + torso + end effectors}.
 #define TM_OBS_PARTS(T) (3 * (T) + 3)
-TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *obs, bool sanitize, int part = -1) {
+// (`obs` is restrict: the observation rows overlap nothing this function reads — without that every PUT orders the loads behind it, and the
+// 67-element proprioception pieces were 67 load -> store round trips in a row)
+TM_DEV void tm_get_obs(const DModel &m, EnvRef r, int clip, int frame, float *__restrict__ obs, bool sanitize, int part = -1) {
   int nj = m.nq - 7, nbp = m.nbody - 1, T = m.traj_length, o = 0;
   int start = tm_clampi(frame + 1, 0, m.n_frames_clip - T);
   float root[3], quat[4];

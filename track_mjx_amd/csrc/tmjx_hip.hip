@@ -117,7 +117,7 @@ __global__ void k_post_parts(const DModel *__restrict__ mp, float *st, const int
   tm_post_part(*mp, r, is, blockIdx.y, P);
 }
 // observation, one lane per (env, part): TM_OBS_PARTS(T) = 18 pieces (env_core.h: tm_get_obs); rows of obs stay coalesced over envs
-__global__ void k_obs(const DModel *__restrict__ mp, float *st, const int *is, float *obs, int n) {
+__global__ void k_obs(const DModel *__restrict__ mp, float *st, const int *is, float *__restrict__ obs, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x, part = blockIdx.y;
   if (e >= n) return;
   const DModel &m = *mp;
@@ -128,8 +128,8 @@ __global__ void k_obs(const DModel *__restrict__ mp, float *st, const int *is, f
 // k_window, k_obs and k_post_parts in ONE launch (blockIdx.y picks the piece): the three read the post-physics state and write disjoint
 // outputs, so a group's serial phase between two physics launches is one launch latency shorter twice over.  (Measured in round 1, when
 // such launches mostly waited for wave slots: no gain; re-measured in round 3 with three env groups and one-wave blocks everywhere.)
-__global__ __launch_bounds__(64) void k_step_parts(const DModel *__restrict__ mp, float *st, const int *is, const float *action, float *win, float *obs,
-                                                   float *P, int n, int n_obs_parts) {
+__global__ __launch_bounds__(64) void k_step_parts(const DModel *__restrict__ mp, float *st, const int *is, const float *action, float *win,
+                                                   float *__restrict__ obs, float *P, int n, int n_obs_parts) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const DModel &m = *mp;
