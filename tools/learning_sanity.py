@@ -19,7 +19,8 @@ dev = torch.device("cuda:0")
 cfg = _config.default_config()
 cfg["network_config"].update(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256])
 tc, nc = cfg["train_setup"]["train_config"], cfg["network_config"]
-envs = [wrap(build_env(cfg, 2048, dev), episode_length=195) for _ in range(2)]
+sizes = ppo.group_sizes(4096, ppo.default_groups(4096, dev))           # the bench's env groups (three since round 3)
+envs = [wrap(build_env(cfg, n, dev), episode_length=195) for n in sizes]
 L = ppo.PPOLearner(envs, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"], critic_layers=nc["critic_layer_sizes"],
                    latents=nc["intention_size"], learning_rate=tc["learning_rate"], entropy_cost=tc["entropy_cost"], discounting=tc["discounting"],
                    unroll_length=tc["unroll_length"], batch_size=tc["batch_size"], num_minibatches=tc["num_minibatches"],
