@@ -1168,7 +1168,7 @@ TM_DEV void tmw_rows_subst(WCtx &c, const WLayout &K, const float *xt, float *z,
 #pragma unroll
   for (int q = D0; q < QMAX; q++) {
     float xq = tmw_readlane(z, q - D0);                                 // row q - D0 is final: rows below it take its term
-    TMW_FOR { float v = L[tm_f2i(bv[TMW_LI]) + (QMAX - q)]; z[TMW_LI] = TMW_MASK(~TMW_M_LT(q - D0 + 1)) ? z[TMW_LI] - v * xq : z[TMW_LI]; }
+    TMW_FOR { float v = L[tm_f2i(bv[TMW_LI]) + (QMAX - q)]; z[TMW_LI] = TMW_MASK(TMW_M_RANGE(q - D0 + 1, N)) ? z[TMW_LI] - v * xq : z[TMW_LI]; }       // (rows q - D0 + 1 .. N - 1: lanes beyond the chain are never stored, and a mask with its upper half set costs an SGPR pair — tmw_lit64)
   }
   TMW_FOR { if (TMW_MASK(TMW_M_LT(N))) L[x + FIRST + lane] = z[TMW_LI]; }
 }
