@@ -59,6 +59,12 @@ int tmjx_layout(const tmjx_model *m, tmjx_layout_t *out);
  * brax EpisodeWrapper's step counter / truncation at `episode_length`, and the (LSTM)AutoResetWrapperTracking restore on done).  Only
  * the two constants change; the clip table of the handle stays resident.  Blocking; not to be called with launches in flight. */
 int tmjx_set_wrappers(tmjx_model *m, int episode_length, int auto_reset);
+/* `action_repeat` of wrappers.wrap (track_mjx/environment/wrappers.py:21,43 -> brax EpisodeWrapper.step [3P]): tmjx_step then runs the
+ * tracking env's own step `action_repeat` times with the same action (no termination check in between), returns the SUM of the repeats'
+ * rewards, advances the episode's step counter by `action_repeat`, and takes observation / done / truncation / metrics from the last
+ * repeat; the auto-reset follows the last repeat.  Default 1.  Host-side only (nothing is copied); tmjx_reward_obs, the K3-alone entry,
+ * is one inner step whatever the repeat count. */
+int tmjx_set_action_repeat(tmjx_model *m, int action_repeat);
 
 /* Upload the ReferenceClip table (HOST pointers, float32, shapes (C,F,3) (C,F,4) (C,F,nq-7)
  * (C,F,nbody-1,3) (C,F,3)); the table becomes a resident device constant of the handle.

@@ -47,6 +47,7 @@ class Oracle:
         L.oracle_env_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _DP, _DP]
         L.oracle_env_step.argtypes = [C.c_void_p, C.c_void_p, _DP]
         L.oracle_env_step_ex.argtypes = [C.c_void_p, C.c_void_p, _DP, C.c_int]
+        L.oracle_set_action_repeat.argtypes = [C.c_void_p, C.c_int]
         L.oracle_env_set.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, _DP, C.c_int]
         L.oracle_env_get.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, _DP, C.c_int]
         L.oracle_obs_size.argtypes = [C.c_void_p]
@@ -117,6 +118,10 @@ class Oracle:
     def env_step(self, envs, i, action):
         a = np.ascontiguousarray(action, dtype=np.float64)
         self.L.oracle_env_step(self.m, self.env_ptr(envs, i), _dp(a))
+
+    def set_action_repeat(self, action_repeat):
+        """brax EpisodeWrapper's repeat count for env_step (wrappers.py:43)."""
+        self.L.oracle_set_action_repeat(self.m, int(action_repeat))
 
     def env_post(self, envs, i, action):
         """K3 alone: everything in env.step except the physics substeps."""

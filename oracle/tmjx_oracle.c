@@ -121,7 +121,7 @@ OModel *oracle_model_create(const void *blob, size_t n) {
   int envi[7];
   BI("env_i", envi, 7);
   m->mocap_hz = envi[0]; m->clip_length = envi[1]; m->traj_length = envi[2]; m->window = envi[3];
-  m->torso_idx = envi[4]; m->episode_length = envi[5]; m->auto_reset = envi[6];
+  m->torso_idx = envi[4]; m->episode_length = envi[5]; m->auto_reset = envi[6]; m->action_repeat = 1;
   m->n_joint_idx = blob_i(blob, n, "joint_idxs", m->joint_idxs, O_MAXV);
   m->n_body_idx = blob_i(blob, n, "body_idxs", m->body_idxs, O_MAXB);
   m->n_endeff_idx = blob_i(blob, n, "endeff_idxs", m->endeff_idxs, 16);

@@ -63,6 +63,7 @@ typedef struct {
   int iterations, ls_iterations, n_frames;
   /* env / task config */
   int mocap_hz, clip_length, traj_length, window, torso_idx, episode_length, auto_reset;
+  int action_repeat;   /* brax EpisodeWrapper's repeat count (wrappers.py:43); 1 unless oracle_set_action_repeat changed it */
   int n_joint_idx, n_body_idx, n_endeff_idx;
   int joint_idxs[O_MAXV], body_idxs[O_MAXB], endeff_idxs[16];
   real rw[32];
@@ -118,6 +119,7 @@ void oracle_env_reset(const OModel *m, OEnv *e, int clip_idx, int start_frame,
 void oracle_env_step(const OModel *m, OEnv *e, const double *action);
 /* do_physics = 0: everything except pipeline_step (K3 alone: frame gather, rewards, obs, wrappers) */
 void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_physics);
+void oracle_set_action_repeat(OModel *m, int action_repeat);
 int oracle_env_set(const OModel *m, OEnv *e, const char *name, const double *in, int n);
 int oracle_env_get(const OModel *m, const OEnv *e, const char *name, double *out, int cap);
 int oracle_obs_size(const OModel *m);

@@ -55,6 +55,11 @@ int tmjx_set_wrappers(tmjx_model *m, int episode_length, int auto_reset) {
   m->o->episode_length = episode_length; m->o->auto_reset = auto_reset ? 1 : 0;
   return TMJX_OK;
 }
+int tmjx_set_action_repeat(tmjx_model *m, int action_repeat) {
+  if (!m || action_repeat < 1) return fail(TMJX_EINVAL, "bad argument");
+  oracle_set_action_repeat(m->o, action_repeat);
+  return TMJX_OK;
+}
 int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quaternion, const float *joints, const float *body_positions,
                       const float *angular_velocity, int n_clips, int n_frames) {
   if (!m || !position || !quaternion || !joints || !body_positions || !angular_velocity) return fail(TMJX_EINVAL, "null argument");

@@ -165,14 +165,11 @@ void oracle_env_reset(const OModel *m, OEnv *e, int clip_idx, int start_frame, c
   memset(e->first_prev_ctrl, 0, sizeof(e->first_prev_ctrl));
 }
 
-void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_physics) {
+/* The tracking env's own step (single_clip_tracking.py:207-320): physics, info updates, reward, termination, metrics; leaves the
+ * step's `done` in e->done and its reward in e->reward.  The episode / auto-reset wrappers are in oracle_env_step_ex below. */
+static void env_inner_step(const OModel *m, OEnv *e, const real *a, int do_physics) {
   OData *d = &e->d;
   int nu = m->nu, W = m->window;
-  real a[O_MAXU];
-  for (int i = 0; i < nu; i++) a[i] = (real)action[i];
-  /* auto-reset wrapper prologue: zero steps of envs that finished on the previous call; clear done */
-  if (e->done != 0) e->steps = 0;
-  e->done = 0;
   /* pipeline_step: n_frames x (ctrl = action; mjx.step) */
   for (int i = 0; i < nu; i++) d->ctrl[i] = a[i];
   if (do_physics) for (int f = 0; f < m->n_frames; f++) oracle_step(m, d);
@@ -252,8 +249,25 @@ void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_p
   M[6] = -ctrl_cost; M[7] = -ctrl_diff_cost; M[8] = -energy_cost; M[9] = done; M[10] = too_far; M[11] = bad_pose; M[12] = bad_quat;
   M[13] = fall; M[14] = nanf_; M[15] = joint_distance; M[16] = spd; M[17] = quat_distance; M[18] = -var_cost; M[19] = -jerk_cost;
   e->reward = reward;
-  /* brax EpisodeWrapper */
-  e->steps += 1;
+  e->done = done;
+}
+
+void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_physics) {
+  OData *d = &e->d;
+  real a[O_MAXU];
+  for (int i = 0; i < m->nu; i++) a[i] = (real)action[i];
+  /* auto-reset wrapper prologue (wrappers.py:104-118): zero steps of envs that finished on the previous call; clear done */
+  if (e->done != 0) e->steps = 0;
+  e->done = 0;
+  /* brax EpisodeWrapper.step [3P, brax 0.12.x envs/wrappers/training.py]: lax.scan of env.step over `action_repeat` repeats of the same
+   * action (no termination check between them), reward = sum of the repeats' rewards, steps += action_repeat; everything else (obs,
+   * done, metrics, info) is the LAST repeat's.  The K3-alone entry (do_physics == 0) is one inner step whatever the repeat count. */
+  int R = do_physics && m->action_repeat > 1 ? m->action_repeat : 1;
+  real total = 0;
+  for (int r = 0; r < R; r++) { env_inner_step(m, e, a, do_physics); total += e->reward; }
+  e->reward = total;
+  real done = e->done;
+  e->steps += (real)R;
   int over = e->steps >= (real)m->episode_length;
   e->truncation = over ? 1 - done : (real)0;
   if (over) done = 1;
@@ -265,6 +279,8 @@ void oracle_env_step_ex(const OModel *m, OEnv *e, const double *action, int do_p
     memcpy(e->prev_ctrl, e->first_prev_ctrl, sizeof(e->prev_ctrl));
   }
 }
+
+void oracle_set_action_repeat(OModel *m, int action_repeat) { m->action_repeat = action_repeat > 1 ? action_repeat : 1; }
 
 void oracle_env_step(const OModel *m, OEnv *e, const double *action) { oracle_env_step_ex(m, e, action, 1); }
 

@@ -76,6 +76,12 @@ class Emu:
         self.L.emu_step(self.m, _f(self.st), _i(self.ist), _f(a), _f(self.obs), _f(self.reward), _f(self.done),
                         _f(self.trunc), _f(self.metrics), _f(self.ws), self.n)
 
+    def step_repeat(self, action, action_repeat):
+        """step with brax EpisodeWrapper's action_repeat (tmjx_set_action_repeat)."""
+        a = np.ascontiguousarray(action, np.float32)
+        self.L.emu_step_repeat(self.m, _f(self.st), _i(self.ist), _f(a), _f(self.obs), _f(self.reward), _f(self.done),
+                               _f(self.trunc), _f(self.metrics), _f(self.ws), self.n, int(action_repeat))
+
     def physics(self, action, nsub, do_euler=True):
         a = None if action is None else np.ascontiguousarray(action, np.float32)
         self.L.emu_physics(self.m, _f(self.st), _f(a) if a is not None else None, nsub, int(do_euler), _f(self.ws), self.n)

@@ -60,6 +60,19 @@ void emu_step(EmuModel *mm, float *st, int *is, const float *action, float *obs,
     tm_step_post(m, r, is, action, obs, rew, done, trunc, metrics);
   }
 }
+// tmjx_step with action_repeat = R (tmjx_hip.hip): per repeat the physics, then K3 told which repeat it is
+void emu_step_repeat(EmuModel *mm, float *st, int *is, const float *action, float *obs, float *rew, float *done, float *trunc, float *metrics, float *ws, int n, int R) {
+  const DModel &m = mm->h;
+  for (int e = 0; e < n; e++) {
+    EnvRef r{st, ws, n, e};
+    for (int k = 0; k < R; k++) {
+      if (k == 0) tm_step_prologue(m, r);
+      for (int a = 0; a < m.nu; a++) WS(m.w_ctrl, a) = action[(size_t)a * n + e];
+      for (int f = 0; f < m.n_frames; f++) { tm_forward(m, r); tm_euler(m, r); }
+      tm_step_post(m, r, is, action, obs, rew, done, trunc, metrics, nullptr, false, nullptr, TM_REP(R, k == 0, k == R - 1));
+    }
+  }
+}
 void emu_physics(EmuModel *mm, float *st, const float *action, int nsub, int do_euler, float *ws, int n) {
   const DModel &m = mm->h;
   for (int e = 0; e < n; e++) {

@@ -104,4 +104,5 @@ def test_argument_validation_of_the_learner_entry_points_without_gpu():
     assert L.tmjx_stats_sums(one, one, one, one, 10, 6, None) == -22                     # W not a multiple of 4
     assert L.tmjx_stats_apply(one, 0.0, one, one, one, one, 4, 1e-6, 1e6, None) == -22   # n_added must be positive
     assert L.tmjx_set_wrappers(None, 195, 1) == -22
+    assert L.tmjx_set_action_repeat(None, 2) == -22
     assert L.tmjx_last_error()

@@ -85,7 +85,7 @@ def test_abi_twin_exports_the_env_entry_points_and_matches_the_native_oracle():
     n = 6
     H = _np_harness(blob, clip, n)
     sym = subprocess.run(["nm", "-D", "--defined-only", str(ABI_SO)], capture_output=True, text=True, check=True).stdout
-    for name in ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_set_wrappers", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
+    for name in ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_set_wrappers", "tmjx_set_action_repeat", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
                  "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_last_error", "tmjx_version"):
         assert f" T {name}" in sym, name
     ci, sf, qn, vn, acts = _inputs(n)

@@ -1050,3 +1050,67 @@ def test_device_side_noise_of_the_acting_policy():
     acts = [Ln._act_graphed(st.obs, 0)[1]["raw_action"].clone() for _ in range(4)]       # capture happens on the first call
     torch.cuda.synchronize()
     assert all(not torch.equal(acts[i], acts[j]) for i in range(4) for j in range(i)), "every inference must draw fresh noise"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [2, 3])
+def test_action_repeat_of_the_episode_wrapper(R):
+    """wrappers.wrap(env, action_repeat=R) (wrappers.py:21,43 -> brax EpisodeWrapper.step): the env's own step R times with the same action (an
+    env that terminates in an early repeat keeps stepping, as in brax's scan), rewards summed, step counter += R, observation / done /
+    truncation / metrics of the last repeat, auto-reset after the last repeat.  Checked bit for bit against R launches of the same kernels
+    through an un-wrapped twin restarted from the same buffers every call, and on the first (contact-free) call against the oracle."""
+    from track_mjx_amd.environment import wrap
+    n, ep = 32, 7
+    env1, O, cl = make_env_and_oracle(num_envs=n, wrappers=False)                # no episode end, no auto-reset
+    envR, _, _ = make_env_and_oracle(num_envs=n, wrappers=False)
+    envR = wrap(envR, episode_length=ep, action_repeat=R)
+    O = make_oracle(envR._blob, cl, "f32")
+    O.set_action_repeat(R)
+    g = torch.Generator().manual_seed(11)
+    clip = torch.randint(0, 4, (n,), generator=g, dtype=torch.int32); start = torch.randint(0, 30, (n,), generator=g, dtype=torch.int32)
+    qn = (torch.rand((74, n), generator=g) * 2 - 1) * 1e-3; vn = (torch.rand((73, n), generator=g) * 2 - 1) * 1e-3
+    qn[2] += 0.05       # start 5 cm up: the first call's R env steps are contact-free, so the values can be held against the oracle tightly
+    s1 = env1.reset(g, clip, start_frame=start, qpos_noise=qn, qvel_noise=vn)
+    sR = envR.reset(g, clip, start_frame=start, qpos_noise=qn, qvel_noise=vn)
+    first_obs = sR.obs.clone()
+    envs = O.new_envs(n)
+    for e in range(n):
+        O.env_reset(envs, e, int(clip[e]), int(start[e]), qn[:, e].numpy(), vn[:, e].numpy())
+    L = envR.layout
+    steps, prev_done = np.zeros(n, np.float32), np.zeros(n, bool)
+    seen_trunc = seen_term = seen_restart = False
+    for call in range(10):
+        a = (torch.randn((38, n), generator=g) * (0.03 if call < 4 else 1.0)).clamp(-1, 1).to(DEV)
+        env1.state_buf.copy_(envR.state_buf); env1.istate_buf.copy_(envR.istate_buf)
+        total = torch.zeros(n, device=DEV)
+        for r in range(R):
+            s1 = env1.step(s1, a); total = total + s1.reward
+        inner_done = s1.done.cpu().numpy() > 0
+        sR = envR.step(sR, a); torch.cuda.synchronize()
+        seen_restart |= bool((prev_done & (steps > 0)).any())
+        steps = np.where(prev_done, 0, steps) + R
+        over = steps >= ep
+        done = inner_done | over
+        assert np.array_equal(envR.state_buf[L.steps_f].cpu().numpy(), steps)
+        assert np.array_equal(sR.done.cpu().numpy() > 0, done) and np.array_equal(sR.info["truncation"].cpu().numpy() > 0, over & ~inner_done)
+        assert torch.equal(sR.reward, total) and torch.equal(envR.metrics_buf, env1.metrics_buf)
+        keep, gone = torch.from_numpy(~done).to(DEV), torch.from_numpy(done).to(DEV)
+        assert torch.equal(sR.obs[keep], s1.obs[keep]) and torch.equal(sR.obs[gone], first_obs[gone])
+        assert torch.equal(envR.state_buf[L.qpos:L.qpos + 259][:, keep], env1.state_buf[L.qpos:L.qpos + 259][:, keep])
+        assert torch.equal(envR.state_buf[L.qpos:L.qpos + 259][:, gone], envR.state_buf[L.first_phys:L.first_phys + 259][:, gone])
+        seen_trunc |= bool((over & ~inner_done).any()); seen_term |= bool(inner_done.any())
+        prev_done = done
+        if call == 0:
+            for e in range(n):
+                O.env_step(envs, e, a[:, e].cpu().numpy())
+            assert np.array_equal(np.array([O.env_get(envs, e, "steps")[0] for e in range(n)]), steps)
+            assert np.array_equal(np.array([O.env_get(envs, e, "done")[0] for e in range(n)]) > 0, done)
+            rew_err = np.abs(sR.reward.cpu().numpy() - np.array([O.env_get(envs, e, "reward")[0] for e in range(n)])).max()
+            obs_err = rel_err(sR.obs.cpu().numpy(), np.stack([O.env_get(envs, e, "obs") for e in range(n)], 0))
+            print(f"action_repeat {R}: summed reward err {rew_err:.2e}, obs rel err {obs_err:.2e} against the float32 oracle")
+            assert rew_err < 1e-4 * R and obs_err < 2e-4
+    assert seen_trunc and seen_term and seen_restart, (seen_trunc, seen_term, seen_restart)
+    with pytest.raises(NotImplementedError):
+        wrap(envR, episode_length=ep, randomization_fn=lambda m: m)
+    with pytest.raises(ValueError):
+        wrap(envR, episode_length=ep, action_repeat=0)

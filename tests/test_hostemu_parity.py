@@ -160,3 +160,58 @@ def test_many_active_rows_multi_slot(setup):
     for name, tol in (("efc_D", 5e-5), ("efc_aref", 5e-5), ("qacc_smooth", 5e-4), ("efc_force", 5e-3), ("qacc", 5e-3)):
         ref = np.stack([O64.get(d, name) for d in ds], 1)
         assert rel_err(E.rows(name), ref) < tol, (name, rel_err(E.rows(name), ref))
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_action_repeat_of_the_episode_wrapper(setup, R):
+    """wrappers.wrap(env, action_repeat=R) (wrappers.py:21,43 -> brax EpisodeWrapper.step): the kernel's K3 flags (env_core.h: TM_REP_*) against
+    (1) R single steps of the same functions WITHOUT wrappers' resets in between (a twin restarted from the same buffers every call: an env
+    that terminates in an early repeat keeps stepping, as in brax's scan) and (2) the oracle's EpisodeWrapper restatement; episode_length 7
+    -> truncation once the counter, advancing by R, reaches it; the counter restarts after a done."""
+    _, _, clip = setup
+    n, ep = 4, 7
+    blob = default_blob(episode_length=ep)
+    E = Emu(blob, n); E1 = Emu(default_blob(episode_length=1000, auto_reset=False), n); O = make_oracle(blob, clip, "f32")
+    O.set_action_repeat(R)
+    E.set_clips(clip.as_dict()); E1.set_clips(clip.as_dict())
+    rng = np.random.default_rng(5)
+    ci = (np.arange(n) % 4).astype(np.int32); sf = ((np.arange(n) * 7) % 30).astype(np.int32)
+    qn = rng.uniform(-1e-3, 1e-3, (74, n)).astype(np.float32); vn = rng.uniform(-1e-3, 1e-3, (73, n)).astype(np.float32)
+    qn[2] += 0.05       # start 5 cm up: the first call's R env steps are contact-free, so the values can be held against the oracle tightly
+    E.reset(ci, sf, qn, vn)
+    first_obs = E.obs.copy()
+    envs = O.new_envs(n)
+    for e in range(n):
+        O.env_reset(envs, e, ci[e], sf[e], qn[:, e], vn[:, e])
+    steps, prev_done, seen_trunc, seen_term, seen_restart = np.zeros(n, np.float32), np.zeros(n, bool), False, False, False
+    for call in range(10):
+        a = np.clip(rng.normal(size=(38, n)) * 0.03, -1, 1).astype(np.float32)
+        E1.st[:] = E.st; E1.ist[:] = E.ist
+        total = np.zeros(n, np.float32)
+        for r in range(R):
+            E1.step(a); total = total + E1.reward
+        inner_done = E1.done > 0
+        E.step_repeat(a, R)
+        seen_restart |= bool((prev_done & (steps > 0)).any())
+        steps = np.where(prev_done, 0, steps) + R
+        over = steps >= ep
+        done = inner_done | over
+        assert np.array_equal(E.rows("steps")[0], steps)
+        assert np.array_equal(E.done > 0, done) and np.array_equal(E.trunc > 0, over & ~inner_done)
+        assert np.array_equal(E.reward, total) and np.array_equal(E.metrics, E1.metrics)
+        assert np.array_equal(E.obs[:, ~done], E1.obs[:, ~done]) and np.array_equal(E.obs[:, done], first_obs[:, done])
+        assert np.array_equal(E.rows("qpos")[:, ~done], E1.rows("qpos")[:, ~done]) and np.array_equal(E.rows("qvel")[:, ~done], E1.rows("qvel")[:, ~done])
+        seen_trunc |= bool((over & ~inner_done).any()); seen_term |= bool(inner_done.any())
+        prev_done = done
+        if call == 0:
+            # against the oracle on the first call only: once the feet load up, the synthetic poses' contacts make free-running float32
+            # trajectories part ways within one env step (single steps too)
+            for e in range(n):
+                O.env_step(envs, e, a[:, e])
+            assert np.array_equal(np.array([O.env_get(envs, e, "steps")[0] for e in range(n)]), steps)
+            assert np.array_equal(np.array([O.env_get(envs, e, "done")[0] for e in range(n)]) > 0, done)
+            rew_err = np.abs(E.reward - np.array([O.env_get(envs, e, "reward")[0] for e in range(n)])).max()
+            obs_err = rel_err(E.obs, np.stack([O.env_get(envs, e, "obs") for e in range(n)], 1))
+            print(f"action_repeat {R}: summed reward err {rew_err:.2e}, obs rel err {obs_err:.2e} against the float32 oracle")
+            assert rew_err < 2e-5 * R and obs_err < 2e-4
+    assert seen_trunc and seen_restart, (seen_trunc, seen_term, seen_restart)

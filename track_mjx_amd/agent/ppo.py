@@ -677,7 +677,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
           intention_latent_size: int = 60, progress_fn: Callable[[int, dict], None] = lambda *a: None,
           max_training_steps: int | None = None, eval_env=None, num_eval_envs: int = 128, deterministic_eval: bool = False,
           matmul_dtype: torch.dtype | None = None, group=None, checkpoint_path: str | None = None, restore_from: str | None = None,
-          shuffle_rng: str = "torch", act_rng: str = "device", **unused):
+          shuffle_rng: str = "torch", act_rng: str = "device", action_repeat: int = 1, **unused):
     """ppo.train(environment, num_timesteps, episode_length, ...) -> (make_policy, params, metrics)  (ppo.py:128-172,809).
 
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
@@ -693,7 +693,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     ppo.py:670-677, and would then collide with the existing steps of the same directory)."""
     from ..environment import wrap
     # a list of environments = equal groups of this rank's envs whose roll-outs are pipelined on separate HIP streams (collect())
-    env_list = [wrap(e, episode_length=int(episode_length), action_repeat=1) for e in (environment if isinstance(environment, (list, tuple)) else [environment])]
+    env_list = [wrap(e, episode_length=int(episode_length), action_repeat=int(action_repeat)) for e in (environment if isinstance(environment, (list, tuple)) else [environment])]
     env = env_list[0]
     learner = PPOLearner(env_list if len(env_list) > 1 else env, encoder_layers=encoder_hidden_layer_sizes, decoder_layers=decoder_hidden_layer_sizes,
                          critic_layers=value_hidden_layer_sizes, latents=intention_latent_size, learning_rate=learning_rate,
@@ -714,7 +714,7 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
         if checkpoint_path is None or learner.rank != 0:
             return None
         return _ckpt.save_step_dir(checkpoint_path, it, learner, config=config_dict, env_steps=env_steps)
-    env_step_per_training_step = learner.env_steps_per_training_step
+    env_step_per_training_step = learner.env_steps_per_training_step * int(action_repeat)      # ppo.py:260-262
     num_evals_after_init = max(num_evals - 1, 1)
     steps_per_epoch = int(math.ceil(num_timesteps / (num_evals_after_init * env_step_per_training_step * max(num_resets_per_eval, 1))))
     kl_schedule = _losses.create_ramp_schedule(max_value=kl_weight, ramp_steps=max(int(num_evals * 0.25), 1)) if use_kl_schedule else None
@@ -729,8 +729,9 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     if eval_env is not None and learner.rank == 0:
         from .evaluator import Evaluator
         eval_gen = torch.Generator(device=learner.dev).manual_seed(seed * 1000 + 991)   # not the roll-out generators (registered with hipGraphs)
-        evaluator = Evaluator(wrap(eval_env, episode_length=int(episode_length), action_repeat=1),
-                              lambda obs: learner.act(obs, deterministic=deterministic_eval, gen=eval_gen), episode_length=int(episode_length), seed=seed + 7)
+        evaluator = Evaluator(wrap(eval_env, episode_length=int(episode_length), action_repeat=int(action_repeat)),
+                              lambda obs: learner.act(obs, deterministic=deterministic_eval, gen=eval_gen), episode_length=int(episode_length),
+                              action_repeat=int(action_repeat), seed=seed + 7)
     metrics: dict = {}
     total_steps, done_steps = int(restored.get("env_steps") or 0), 0       # TrainingState.env_steps continues across a resume
     if restore_from is None:

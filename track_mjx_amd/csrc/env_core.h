@@ -186,11 +186,21 @@ TM_DEV void tm_post_part(const DModel &m, EnvRef r, const int *r_is, int part, f
     OUTROW(P, part) = bad ? 1.f : 0.f;
   }
 }
+// `rep`: which of brax EpisodeWrapper's `action_repeat` inner steps this call is (wrappers.py:43; EpisodeWrapper.step [3P] scans env.step over
+// the repeats with no termination check between them, sums their rewards and adds action_repeat to the step counter): the first repeat
+// follows the auto-reset prologue, the later ones add their reward to the sum in `reward`, and only the last one runs the episode counter,
+// the truncation and the auto-reset; observation, done and metrics are therefore the last repeat's.
+#define TM_REP_FIRST 1
+#define TM_REP_LAST 2
+#define TM_REP_MAX 1024
+#define TM_REP(R, first, last) (((R) << 2) | ((first) ? TM_REP_FIRST : 0) | ((last) ? TM_REP_LAST : 0))
+#define TM_REP_ONE TM_REP(1, 1, 1)
 // `win`: per-(dim, env) partials [2*nu][n] produced by the (env x action-dim)-parallel window kernel, or nullptr to
 // compute the window terms inline (lane-per-env path).
 // `split`: the observation was written by k_obs and the auto-reset copies are left to k_autoreset (tmjx_hip.hip).
 TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *action, float *obs, float *reward, float *done_out,
-                         float *trunc_out, float *metrics, const float *win = nullptr, bool split = false, const float *P = nullptr) {
+                         float *trunc_out, float *metrics, const float *win = nullptr, bool split = false, const float *P = nullptr,
+                         int rep = TM_REP_ONE) {
   int nu = m.nu, W = m.window, nj = m.nq - 7, nbp = m.nbody - 1;
   int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame), bi = IS(m.i_buffer_index);
   int frame = tm_cur_frame(m, ST(m.s_time, 0), start);
@@ -284,7 +294,9 @@ TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *acti
   OUTROW(metrics, 13) = fall; OUTROW(metrics, 14) = nanf_; OUTROW(metrics, 15) = joint_distance; OUTROW(metrics, 16) = spd;
   OUTROW(metrics, 17) = quat_distance; OUTROW(metrics, 18) = -var_cost; OUTROW(metrics, 19) = -jerk_cost;
   // EpisodeWrapper
-  float steps = ST(m.s_steps, 0) + 1.f;
+  if (!(rep & TM_REP_FIRST)) rew += reward[r.e];
+  if (!(rep & TM_REP_LAST)) { reward[r.e] = rew; return; }
+  float steps = ST(m.s_steps, 0) + (float)(rep >> 2);
   ST(m.s_steps, 0) = steps;
   bool over = steps >= (float)m.episode_length;
   float trunc = over ? 1.f - done : 0.f;

@@ -362,7 +362,7 @@ inline std::vector<NamedRows> debug_rows(const DModel &m) {
   return {
       {"qpos", m.s_qpos, m.nq, true}, {"qvel", m.s_qvel, m.nv, true}, {"act", m.s_act, m.nu, true},
       {"qacc_warmstart", m.s_warm, m.nv, true}, {"time", m.s_time, 1, true}, {"xpos", m.s_xpos, m.nbody * 3, true},
-      {"xmat_torso", m.s_xmat_torso, 9, true}, {"qfrc_actuator", m.s_qfrc_actuator, m.nv, true},
+      {"xmat_torso", m.s_xmat_torso, 9, true}, {"qfrc_actuator", m.s_qfrc_actuator, m.nv, true}, {"steps", m.s_steps, 1, true},
       {"xquat", m.w_xquat, m.nbody * 4, false}, {"cinert", m.w_cinert, m.nbody * 10, false}, {"cdof", m.w_cdof, m.nv * 6, false},
       {"qM", m.w_M, m.nnz, false}, {"qfrc_smooth", m.w_qfrc_smooth, m.nv, false}, {"qacc_smooth", m.w_qacc_smooth, m.nv, false},
       {"qacc", m.w_qacc, m.nv, false}, {"qfrc_constraint", m.w_qfrc_constraint, m.nv, false},

@@ -32,6 +32,7 @@ struct tmjx_model {
   mutable float *mspill = nullptr;
   mutable int mspill_envs = 0;
   bool clips_owned = true;   // false: the clip table belongs to another handle of the same device (tmjx_clips_share)
+  int action_repeat = 1;     // brax EpisodeWrapper's repeat count (tmjx_set_action_repeat)
 };
 #define WAVE_SPILL_STRIDE(m) ((((m)->h.nnz) + 63) & ~63)
 // record stride: state rows qpos .. qfrc_actuator, then the action, rounded up to 16 words
@@ -100,14 +101,14 @@ __global__ void k_window(const DModel *__restrict__ mp, float *st, const int *is
   win[(size_t)(m.nu + i) * n + e] = ji;
 }
 __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const float *action, float *obs, float *reward,
-                       float *done, float *trunc, float *metrics, const float *win, int split, int n) {
+                       float *done, float *trunc, float *metrics, const float *win, int split, int rep, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const DModel &m = *mp;
   EnvRef r{st, nullptr, n, e};
-  tm_step_prologue(m, r);
+  if (rep & TM_REP_FIRST) tm_step_prologue(m, r);
   // split: the long sums were computed by k_post_parts into the workspace rows behind the 2 nu window partials
-  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win, split != 0, split ? win + (size_t)2 * m.nu * n : nullptr);
+  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win, split != 0, split ? win + (size_t)2 * m.nu * n : nullptr, rep);
 }
 // the long reductions of the reward / termination step, one lane per (env, part) (env_core.h: tm_post_part)
 __global__ void k_post_parts(const DModel *__restrict__ mp, float *st, const int *is, float *P, int n) {
@@ -352,6 +353,14 @@ int tmjx_set_wrappers(tmjx_model *m, int episode_length, int auto_reset) {
   return TMJX_OK;
 }
 
+int tmjx_set_action_repeat(tmjx_model *m, int action_repeat) {
+  if (!m) return fail(TMJX_EINVAL, "null argument");
+  if (action_repeat < 1 || action_repeat > TM_REP_MAX) return fail(TMJX_EINVAL, "action_repeat must be in 1 .. " + std::to_string(TM_REP_MAX));
+  if (action_repeat > 1 && !m->wave) return fail(TMJX_EINVAL, "action_repeat > 1 needs the wave-per-env implementation");
+  m->action_repeat = action_repeat;
+  return TMJX_OK;
+}
+
 int tmjx_clips_upload(tmjx_model *m, const float *position, const float *quaternion, const float *joints,
                       const float *body_positions, const float *angular_velocity, int n_clips, int n_frames) {
   if (!m || !position || !quaternion || !joints || !body_positions || !angular_velocity) return fail(TMJX_EINVAL, "null argument");
@@ -466,7 +475,7 @@ int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip
 // three), reward / termination, auto-reset copies.  64-lane workgroups throughout: next to the other env groups' physics kernel (up to 3 waves
 // of 168 VGPRs per SIMD) a 256-lane workgroup had to wait for four wave slots WITH registers on one CU — 245 us on average instead of 30
 static void launch_k3(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done,
-                      float *truncation, float *metrics, float *workspace, int n_env, hipStream_t stream) {
+                      float *truncation, float *metrics, float *workspace, int n_env, hipStream_t stream, int rep = TM_REP_ONE) {
   const DModel &h = m->h;
   static const bool merged = !getenv("TMJX_K3_SEPARATE");
   const int nobs = TM_OBS_PARTS(h.traj_length);
@@ -479,8 +488,8 @@ static void launch_k3(tmjx_model *m, float *state, int32_t *istate, const float 
     hipLaunchKernelGGL(k_post_parts, dim3((n_env + 63) / 64, TM_NPOST), dim3(64), 0, stream, m->d, state, istate, parts, n_env);
   }
   hipLaunchKernelGGL(k_post, dim3((n_env + 63) / 64), dim3(64), 0, stream, m->d, state, istate, action, obs, reward, done, truncation, metrics,
-                     (const float *)workspace, 1, n_env);
-  if (h.auto_reset) {
+                     (const float *)workspace, 1, rep, n_env);
+  if (h.auto_reset && (rep & TM_REP_LAST)) {
     int total = h.nphys + h.obs_size + h.nu;
     hipLaunchKernelGGL(k_autoreset, dim3((n_env + 63) / 64, (total + 15) / 16), dim3(64), 0, stream, m->d, state, obs, done, n_env);
   }
@@ -492,8 +501,14 @@ int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action,
   if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
   if (m->wave) {
-    if (int rc = launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env))) return rc;
-    launch_k3(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
+    // action_repeat (brax EpisodeWrapper): the env's own step R times with the same action; K3 sums the rewards and applies the episode
+    // counter / truncation / auto-reset after the last repeat only (env_core.h: tm_step_post, TM_REP_*)
+    const int R = m->action_repeat;
+    for (int r = 0; r < R; r++) {
+      if (int rc = launch_wave(m, state, action, m->h.n_frames, 1, (float *)nullptr, n_env, (hipStream_t)stream, wave_record(m, workspace, n_env))) return rc;
+      launch_k3(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream,
+                TM_REP(R, r == 0, r == R - 1));
+    }
     return check_launch("k_step(wave)");
   }
 #ifdef TMJX_LANE_IMPL
@@ -556,7 +571,7 @@ int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *a
   if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");
   if (workspace) launch_k3(m, state, istate, action, obs, reward, done, truncation, metrics, workspace, n_env, (hipStream_t)stream);
   else hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
-                          metrics, (const float *)nullptr, 0, n_env);
+                          metrics, (const float *)nullptr, 0, TM_REP_ONE, n_env);
   return check_launch("k_post");
 }
 

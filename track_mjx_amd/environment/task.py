@@ -250,6 +250,8 @@ class MultiClipTracking:
             raise ValueError(f"action must be [{n},{L.nu}] or [{L.nu},{n}]")
         a = a.to(device=self.device, dtype=torch.float32)
         if self._physics_events is not None:
+            if getattr(self, "_action_repeat", 1) != 1:
+                raise RuntimeError("the K2-bracketing measurement mode steps the physics once: action_repeat must be 1")
             # measurement mode (bench.py): the same kernels as tmjx_step, issued as K2 then K3 so that HIP events on the
             # launch stream bracket the physics kernel alone
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -303,13 +305,16 @@ class MultiClipTracking:
         t = self.state_buf[L.time] * float(self._mocap_hz)
         return torch.floor(t + self.istate_buf[L.i_start_frame].float()).to(torch.int32)
 
-    def configure_wrappers(self, episode_length: int, auto_reset: bool) -> None:
+    def configure_wrappers(self, episode_length: int, auto_reset: bool, action_repeat: int = 1) -> None:
         """Switch the Episode / AutoReset wrapper semantics of the handle (wrappers.wrap): two constants of the device model change,
-        the clip table stays resident (tmjx_set_wrappers)."""
-        self._episode_length, self._auto_reset = int(episode_length), bool(auto_reset)
+        the clip table stays resident (tmjx_set_wrappers); `action_repeat` is brax EpisodeWrapper's (tmjx_set_action_repeat)."""
+        if int(action_repeat) < 1:
+            raise ValueError("action_repeat must be >= 1")
+        self._episode_length, self._auto_reset, self._action_repeat = int(episode_length), bool(auto_reset), int(action_repeat)
         with torch.cuda.device(self.device):
             torch.cuda.synchronize(self.device)        # no launch of this handle may be in flight while its constants change
             _hip.check(self._L.tmjx_set_wrappers(self._handle, self._episode_length, int(self._auto_reset)), "tmjx_set_wrappers")
+            _hip.check(self._L.tmjx_set_action_repeat(self._handle, self._action_repeat), "tmjx_set_action_repeat")
         self._blob = build_blob(self.walker, n_frames=self._n_frames, mocap_hz=self._mocap_hz, clip_length=self._clip_length,
                                 traj_length=self._ref_len, window=int(self._reward_config.var_window_size),
                                 episode_length=self._episode_length, reward_f=self._reward_config.vector(),

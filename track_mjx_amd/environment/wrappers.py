@@ -3,7 +3,9 @@
 In the reference `wrap` stacks brax's EpisodeWrapper and VmapWrapper and then the
 (LSTM)AutoResetWrapperTracking.  Here batching is native and the episode / auto-reset logic runs
 inside the K3 kernel (csrc/env_core.h: tm_step_prologue / tm_step_post), so `wrap` only switches
-those semantics on for the env's handle and returns the env itself.
+those semantics on for the env's handle and returns the env itself.  `action_repeat` is brax EpisodeWrapper's: the env's own step
+runs that many times per `step` with the same action, rewards summed, the step counter advanced by `action_repeat`
+(include/tmjx.h: tmjx_set_action_repeat).
 """
 from __future__ import annotations
 
@@ -17,9 +19,9 @@ def wrap(env: MultiClipTracking, episode_length: int = 1000, action_repeat: int 
     `use_lstm`, `hidden_state_dim`, `hidden_layer_num` are accepted for signature parity: the LSTM
     auto-reset wrapper differs from the plain one only by an unused `info["hidden_state"]`
     (wrappers.py:59-144 vs 278-310), which is not materialised."""
-    if action_repeat != 1:
-        raise NotImplementedError("action_repeat != 1 is not used by any shipped reference config")
     if randomization_fn is not None:
-        raise NotImplementedError("domain randomisation is outside the hot path")
-    env.configure_wrappers(int(episode_length), auto_reset=True)
+        # brax's DomainRandomizationVmapWrapper steps every env with its own copy of the mjx.Model; the physics kernel reads ONE model
+        # from constant memory (csrc/dmodel.h), and no reference config or call site passes a randomization_fn (ppo.py:466-474)
+        raise NotImplementedError("domain randomisation (a per-env model) is not supported: the device model is one constant per handle")
+    env.configure_wrappers(int(episode_length), auto_reset=True, action_repeat=int(action_repeat))
     return env

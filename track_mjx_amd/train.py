@@ -112,7 +112,7 @@ def main(argv=None, runner=None):
               encoder_hidden_layer_sizes=nc["encoder_layer_sizes"], decoder_hidden_layer_sizes=nc["decoder_layer_sizes"],
               value_hidden_layer_sizes=nc["critic_layer_sizes"], intention_latent_size=nc["intention_size"], progress_fn=progress,
               max_training_steps=cfg.get("max_training_steps"), eval_env=eval_env, num_eval_envs=num_eval_envs,
-              deterministic_eval=bool(tc.get("deterministic_eval", False)), config_dict=cfg,
+              deterministic_eval=bool(tc.get("deterministic_eval", False)), config_dict=cfg, action_repeat=int(tc.get("action_repeat", 1)),
               checkpoint_path=cfg.get("checkpoint_path"), restore_from=cfg.get("restore_from"), shuffle_rng=str(cfg.get("shuffle_rng", "torch")), act_rng=str(cfg.get("act_rng", "device")),
               matmul_dtype=torch.bfloat16 if str(cfg.get("mlp_gemm_inputs", "f32")).lower() in ("bf16", "bfloat16") else None)
     if world > 1:
