@@ -173,13 +173,20 @@ def main(argv=None, runner=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    device = torch.device(f"cuda:{local_rank}")
+    # TMJX_REHEARSE_ON_ONE_GPU=1: every rank on cuda:0 with gloo collectives on the device tensors — the N > 1 call path of this file (rank
+    # seeding, normaliser / gradient all-reduces between graph replays, barriers, max-over-ranks timing, rank-0 reporting) on a ONE-GPU box,
+    # where RCCL refuses two ranks on one device.  A rehearsal of the plumbing, never a measurement (the line says so).
+    rehearse = bool(os.environ.get("TMJX_REHEARSE_ON_ONE_GPU"))
+    device = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     # TMJX_COLLECTIVES_ALWAYS=1 under torch.distributed.run with ONE rank: RCCL is initialised and C1 / C2 / the timing reductions are
     # issued on the one-rank group — the multi-GPU call path on a single-GPU box (the numbers equal the plain N=1 run's)
     use_dist = world > 1 or ("RANK" in os.environ and bool(os.environ.get("TMJX_COLLECTIVES_ALWAYS")))
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     cfg = _config.default_config()
     cfg["network_config"].update(**bc["nets"])
@@ -323,6 +330,7 @@ def main(argv=None, runner=None):
                        "n_clips": bc["n_clips"], "mlp_gemm_inputs": bc["matmul_dtype"] or "f32",
                        "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
                        "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
+                       **({"rehearsal": "all ranks on cuda:0 with gloo collectives (TMJX_REHEARSE_ON_ONE_GPU): plumbing check, NOT a measurement"} if rehearse else {}),
                        "policy_params": learner.n_params(), "envs_per_physics_launch": per_launch, "concurrent_physics_launches": ngrp,
                        "rollout_ms_per_step": rollout_ms, "sgd_ms_per_step": sgd_ms, "sgd_ms_per_minibatch_step": sgd_ms / sgd_steps,
                        "rollout_only_env_steps_per_s_per_gpu": rollout_only, "rollout_only_error": rollout_err,
