@@ -71,10 +71,16 @@ def main(argv=None, runner=None):
         return launch.spawn_ranks(num_gpus, ["-m", "track_mjx_amd.train"], full_argv, runner=runner)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(f"cuda:{local_rank}")
+    # TMJX_REHEARSE_ON_ONE_GPU=1 (tools/r3_rehearse.sh): every rank on cuda:0 with gloo collectives on the device tensors — the multi-rank path on
+    # a one-GPU box, where RCCL refuses two ranks on a device; a plumbing check, not a way to train
+    rehearse = bool(os.environ.get("TMJX_REHEARSE_ON_ONE_GPU"))
+    device = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     tc = cfg["train_setup"]["train_config"]
     lo, hi = ppo.shard_range(int(tc["num_envs"]), int(os.environ.get("RANK", "0")), world)
     # `rollout_groups` env groups per rank (default: ppo.default_groups — 3 at 4096 envs; sizes: ppo.group_sizes): their roll-outs are pipelined on
