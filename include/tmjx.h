@@ -173,6 +173,10 @@ int tmjx_philox4x32_10(const uint32_t *ctr_key_dev, uint32_t *out_dev, void *str
 /* Backward of the latent sample inside tmjx_latent_concat (reparameterize, intention_network.py:78-88): from d x [n][dx_stride]
  * to d fc2 [n][2 Z] = [d mean | d logvar]. */
 int tmjx_latent_concat_bwd(const float *dx, const float *eps, const float *fc2, float *dfc2, int n, int Z, int dx_stride, void *stream);
+/* The same with a second gradient of fc2 summed in (`add` [n][2 Z]: the KL term's, compute_ppo_loss's kl_latent_loss, losses.py:196-237): d fc2 =
+ * add + the sample's gradient, as jax.grad sums the two uses of the encoder's output (intention_network.py:128-139). */
+int tmjx_latent_concat_bwd_add(const float *dx, const float *eps, const float *fc2, const float *add, float *dfc2, int n, int Z, int dx_stride,
+                               void *stream);
 
 /* Policy inference tails (ppo_networks.py:46-96, intention_network.py:78-88).
  * tmjx_latent_concat: x[i] = [ mean_i + eps_i * exp(logvar_i / 2) | obs_i[ref_w:] ], fc2 [n][2Z] = mean | logvar, eps [n][Z], obs

@@ -903,6 +903,21 @@ def test_fused_latent_concat_forward_backward_matches_torch():
     gr = torch.autograd.grad((rl * up).sum() + rf.square().sum(), list(pol.parameters()))
     for a, b in zip(g, gr):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max() + 1e-6)
+    # the second gradient of fc2 handed to the backward kernel (tmjx_latent_concat_bwd_add, what the learner does with the KL term's) instead of
+    # seeding autograd with it: the same sum, bit for bit
+    from track_mjx_amd.agent.networks import _LatentConcatFn
+    logits, fc2 = pol(obs, eps=eps, return_fc2=True)
+    g2 = 2 * fc2.detach()
+    g_seed = torch.autograd.grad([logits, fc2], list(pol.parameters()), grad_outputs=[up, g2])
+    logits, fc2 = pol(obs, eps=eps, return_fc2=True)
+    assert _LatentConcatFn.last_forward == fc2.data_ptr()
+    _LatentConcatFn.pending_add = (fc2.data_ptr(), g2.view(-1, 120))
+    g_add = torch.autograd.grad([logits], list(pol.parameters()), grad_outputs=[up])
+    assert _LatentConcatFn.pending_add is None
+    for a, b in zip(g_add, g_seed):
+        assert torch.equal(a, b)
+    l8, _ = pol(obs[0, :8], eps=eps[0, :8], return_fc2=True)      # the unfused path (few rows) leaves no handle behind
+    assert _LatentConcatFn.last_forward is None
 
 
 @pytest.mark.gpu

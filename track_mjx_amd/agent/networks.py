@@ -856,6 +856,11 @@ class _LatentConcatFn(torch.autograd.Function):
         ctx.save_for_backward(fc2, eps)
         return x[:, :wd]
 
+    # (fc2 storage pointer, gradient): a second gradient of this fc2 that the caller wants summed into the one computed here instead of seeding
+    # autograd with it (losses.ppo_loss_and_output_grads: the KL term's, from the loss head) — autograd would add the two with a launch of its own
+    pending_add = None
+    last_forward = None       # storage pointer of the fc2 the latest policy forward sent through this function (None: it took the unfused path)
+
     @staticmethod
     def backward(ctx, dx):
         import ctypes as C
@@ -865,9 +870,15 @@ class _LatentConcatFn(torch.autograd.Function):
         dx = dx.contiguous()
         dfc2 = torch.empty_like(fc2)
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        add, _LatentConcatFn.pending_add = _LatentConcatFn.pending_add, None
+        if add is not None and (add[0] != fc2.data_ptr() or add[1].shape != fc2.shape or not add[1].is_contiguous()):
+            raise RuntimeError("_LatentConcatFn: the pending fc2 gradient belongs to another forward pass")
         with torch.cuda.device(fc2.device):
-            _hip.check(_hip.lib().tmjx_latent_concat_bwd(p(dx), p(eps), p(fc2), p(dfc2), n, Z, dx.shape[1],
-                                                         C.c_void_p(torch.cuda.current_stream(fc2.device).cuda_stream)), "tmjx_latent_concat_bwd")
+            stream = C.c_void_p(torch.cuda.current_stream(fc2.device).cuda_stream)
+            if add is None:
+                _hip.check(_hip.lib().tmjx_latent_concat_bwd(p(dx), p(eps), p(fc2), p(dfc2), n, Z, dx.shape[1], stream), "tmjx_latent_concat_bwd")
+            else:
+                _hip.check(_hip.lib().tmjx_latent_concat_bwd_add(p(dx), p(eps), p(fc2), p(add[1]), p(dfc2), n, Z, dx.shape[1], stream), "tmjx_latent_concat_bwd_add")
         return dfc2, None, None, None
 
 
@@ -895,6 +906,7 @@ class IntentionPolicy(nn.Module):
         """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar), or (logits, mean | logvar as
         one [.., 2*latents] tensor) with `return_fc2` (what the fused loss head consumes)."""
         traj = obs[..., :self.reference_obs_size]
+        _LatentConcatFn.last_forward = _LatentConcatFn.pending_add = None      # (see _LatentConcatFn.pending_add: valid for the latest forward only)
         chains = _bf16_chain_ok(obs) and all(m.out_features % 4 == 0 for m in (self.fc2, self.head))
         if chains:                 # bf16 GEMM-input mode: the encoder (+ fc2) as ONE autograd function (fused epilogues, bf16 hidden activations)
             if getattr(self, "_enc_chain", None) is None:
@@ -913,6 +925,8 @@ class IntentionPolicy(nn.Module):
             if eps is None:
                 eps = torch.randn_like(mean)
             x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size)
+            if fc2.requires_grad and fc2.is_contiguous():
+                _LatentConcatFn.last_forward = fc2.data_ptr()
             x = x.view(*lead, x.shape[-1])
             if chains:
                 logits = bf16_chain(x, self._dec_chain, dx_cols=self.latents)

@@ -655,13 +655,17 @@ __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__
 }
 // gradient of the latent sample w.r.t. the two halves of fc2 = [mean | logvar] from d x (the decoder-input gradient, row stride
 // dx_stride): d mean = dx[:, :Z];  d logvar = dx[:, :Z] * eps * exp(logvar / 2) / 2   (reparameterize, intention_network.py:78-88)
+// `add` (optional, [n][2 Z]): another gradient of fc2 — the KL term's, from the loss head — summed in here, so that autograd has ONE gradient for
+// fc2 and launches no element-wise add for the two (7.5 us per minibatch step, the last torch element-wise kernel of the captured SGD step)
 __global__ __launch_bounds__(256) void k_latent_concat_bwd(const float *__restrict__ dx, const float *__restrict__ eps, const float *__restrict__ fc2,
-                                                           float *__restrict__ dfc2, int n, int Z, int dx_stride) {
+                                                           float *__restrict__ dfc2, int n, int Z, int dx_stride, const float *__restrict__ add) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * Z; i += (size_t)gridDim.x * 256) {
     int c = (int)(i % Z); size_t e = i / Z;
     float g = dx[e * (size_t)dx_stride + c];
-    dfc2[e * 2 * Z + c] = g;
-    dfc2[e * 2 * Z + Z + c] = g * eps[e * Z + c] * (0.5f * expf(0.5f * fc2[e * 2 * Z + Z + c]));
+    float gm = g, gv = g * eps[e * Z + c] * (0.5f * expf(0.5f * fc2[e * 2 * Z + Z + c]));
+    if (add) { gm = add[e * 2 * Z + c] + gm; gv = add[e * 2 * Z + Z + c] + gv; }
+    dfc2[e * 2 * Z + c] = gm;
+    dfc2[e * 2 * Z + Z + c] = gv;
   }
 }
 // action sample, tanh post-processing and log-prob of the sample: one lane group of PPO_G per env

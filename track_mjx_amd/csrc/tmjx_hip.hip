@@ -754,13 +754,20 @@ int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, flo
   return check_launch("k_latent_concat");
 }
 
-int tmjx_latent_concat_bwd(const float *dx, const float *eps, const float *fc2, float *dfc2, int n, int Z, int dx_stride, void *stream) {
+static int launch_latent_concat_bwd(const float *dx, const float *eps, const float *fc2, const float *add, float *dfc2, int n, int Z, int dx_stride, void *stream) {
   if (!dx || !eps || !fc2 || !dfc2) return fail(TMJX_EINVAL, "null argument");
   if (n < 1 || Z < 1 || dx_stride < Z) return fail(TMJX_EINVAL, "bad sizes");
   size_t total = (size_t)n * Z;
   int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_latent_concat_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, eps, fc2, dfc2, n, Z, dx_stride);
+  hipLaunchKernelGGL(k_latent_concat_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, dx, eps, fc2, dfc2, n, Z, dx_stride, add);
   return check_launch("k_latent_concat_bwd");
+}
+int tmjx_latent_concat_bwd(const float *dx, const float *eps, const float *fc2, float *dfc2, int n, int Z, int dx_stride, void *stream) {
+  return launch_latent_concat_bwd(dx, eps, fc2, nullptr, dfc2, n, Z, dx_stride, stream);
+}
+int tmjx_latent_concat_bwd_add(const float *dx, const float *eps, const float *fc2, const float *add, float *dfc2, int n, int Z, int dx_stride, void *stream) {
+  if (!add) return fail(TMJX_EINVAL, "null argument");
+  return launch_latent_concat_bwd(dx, eps, fc2, add, dfc2, n, Z, dx_stride, stream);
 }
 
 int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, uint64_t seed,
