@@ -98,7 +98,7 @@ def other_configs(timeout_s: float = 150.0) -> dict:
     import subprocess
     res = {}
     for cfg in ("cfg4", "cfg5"):
-        cmd = [sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-rollout-only"]
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-rollout-only"]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -371,6 +371,21 @@ def main(argv=None, runner=None):
                               "gemm_flops_per_minibatch_step": gemm_flops_step, "sgd_ms_per_minibatch_step": sgd_ms / sgd_steps,
                               "mfma_util_inside_gemm_kernels": mf.get("mfma_util") if mf else None},
         }
+        # the extras below (CPU baselines, child runs of cfg4 / cfg5) take a minute: if the caller's time-out ends this process during them
+        # (SIGTERM / SIGINT), the headline measured above is printed as it stands instead of being lost — still exactly one JSON line
+        import signal
+        printed = []
+
+        def emit(*_sig):
+            if not printed:
+                printed.append(1)
+                if _sig:
+                    out["config"]["extras_cut_short_by_signal"] = int(_sig[0])
+                print(json.dumps(out), flush=True)
+            if _sig:
+                os._exit(0)
+        for _s in (signal.SIGTERM, signal.SIGINT):
+            signal.signal(_s, emit)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # same action regime as the roll-out-only leg (0.3 * N(0,1)); the full-scale regime of BASELINE config 1 beside it
@@ -383,7 +398,7 @@ def main(argv=None, runner=None):
         # CHILD process of this script after the timed region (own process: its failure or time-out cannot touch the headline), 2 timed steps
         if world == 1 and args.config == "cfg2" and not args.no_other_configs and not args.no_cpu_baseline:
             out["config"]["other_configs"] = other_configs()
-        print(json.dumps(out), flush=True)
+        emit()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -87,3 +87,34 @@ def test_env_group_sizes_for_the_pipelined_rollout():
             s = ppo.group_sizes(n, g)
             assert sum(s) == n and all(x > 0 for x in s) and len(s) <= g and max(s) - min(s) <= 4, (n, g, s)
     assert ppo.default_groups(4096) == 3 and ppo.default_groups(8192) == 3 and ppo.default_groups(2048) == 3 and ppo.default_groups(4) == 1
+
+
+def test_killing_the_parent_takes_the_ranks_with_it(tmp_path):
+    """A driver time-out SIGTERMs (or SIGKILLs) `python bench.py --gpus N`: the launcher and its ranks must not be left holding the GPUs.
+    The child here is a sleeper that writes its pid; the parent runs launch.run_in_own_group on it and is then killed both ways."""
+    import signal
+    import time
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        pidfile = tmp_path / f"pid_{int(sig)}"
+        child = f"import os,time; open({str(pidfile)!r},'w').write(str(os.getpid())); time.sleep(120)"
+        parent = ("import sys; sys.path.insert(0, %r); from track_mjx_amd import launch; import os; "
+                  "sys.exit(launch.run_in_own_group([sys.executable, '-c', %r], dict(os.environ)))") % (str(ROOT), child)
+        p = subprocess.Popen([sys.executable, "-c", parent])
+        t0 = time.time()
+        while not pidfile.exists() or not pidfile.read_text():
+            assert time.time() - t0 < 30 and p.poll() is None
+            time.sleep(0.05)
+        cpid = int(pidfile.read_text())
+        os.kill(p.pid, sig)
+        p.wait(timeout=30)
+        t0 = time.time()
+        while True:
+            try:
+                os.kill(cpid, 0)
+                st = Path(f"/proc/{cpid}/stat").read_text().split()[2]
+                if st == "Z":
+                    break
+            except (ProcessLookupError, FileNotFoundError):
+                break
+            assert time.time() - t0 < 15, f"child {cpid} survived its parent's {sig!r}"
+            time.sleep(0.05)

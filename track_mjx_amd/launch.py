@@ -12,6 +12,7 @@ It must be called before anything initialises the GPU in this process (the calle
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -37,14 +38,66 @@ def rank_command(n_gpus: int, target: Sequence[str], args: Sequence[str], port: 
             "--master-addr", "127.0.0.1", "--master-port", str(free_port() if port is None else port), *target, *args]
 
 
+def _set_pdeathsig():
+    """preexec of the child: own session (= own process group: one killpg reaches torchrun AND its ranks) and PR_SET_PDEATHSIG so that the
+    launcher dies with this process even when this process is SIGKILLed (no handler runs then)."""
+    os.setsid()
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG = 1
+    except Exception:  # noqa: BLE001 — not Linux / no libc: the signal handlers below still cover SIGTERM and SIGINT
+        pass
+
+
+def run_in_own_group(cmd: Sequence[str], env: dict) -> int:
+    """Run `cmd` as the leader of a new process group and wait for it.  SIGTERM / SIGINT / SIGHUP received by this process are answered by
+    killing the whole group (torchrun and every rank: orphaned ranks would keep holding the GPUs), and so is every other way out of the
+    wait (an exception, KeyboardInterrupt)."""
+    proc = subprocess.Popen(list(cmd), env=env, preexec_fn=_set_pdeathsig)      # stdout / stderr inherited
+
+    def kill_group(sig=signal.SIGTERM):
+        try:
+            os.killpg(proc.pid, sig)
+        except ProcessLookupError:
+            pass
+
+    def on_signal(signum, _frame):
+        kill_group(signal.SIGTERM)
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            kill_group(signal.SIGKILL)
+        os._exit(128 + signum)
+
+    old = {}
+    for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            old[s] = signal.signal(s, on_signal)
+        except ValueError:          # not the main thread: the finally clause below is the cover
+            pass
+    try:
+        return int(proc.wait())
+    finally:
+        if proc.poll() is None:     # leaving with the child alive (exception in the wait)
+            kill_group(signal.SIGTERM)
+            try:
+                proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                kill_group(signal.SIGKILL)
+        else:                       # torchrun has exited: no rank of its group may outlive it
+            kill_group(signal.SIGKILL)
+        for s, h in old.items():
+            signal.signal(s, h)
+
+
 def spawn_ranks(n_gpus: int, target: Sequence[str], args: Sequence[str], runner: Callable | None = None, env: dict | None = None) -> int:
     """Start the ranks as a child process and wait for them; returns the exit code.  `runner(cmd, env=...) -> int` is the process
-    starter (tests pass a recorder)."""
+    starter (tests pass a recorder); the default is `run_in_own_group`."""
     cmd = rank_command(n_gpus, target, args)
     child_env = dict(os.environ if env is None else env)
     child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
     child_env.setdefault("OMP_NUM_THREADS", "4")
     if runner is None:
-        runner = lambda c, env: subprocess.call(c, env=env)      # noqa: E731  (stdout / stderr inherited)
+        runner = run_in_own_group
     print(f"[launch] {n_gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     return int(runner(cmd, env=child_env))
