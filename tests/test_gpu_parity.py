@@ -129,7 +129,9 @@ def test_substep_teacher_forced(variant, monkeypatch):
             e_gpu, e_32 = rel_err(got, ref[k], axis=0), rel_err(r32[k], ref[k], axis=0)
             worst.append((k, np.median(e_gpu), e_gpu.max(), e_32.max()))
             assert np.median(e_gpu) <= 1e-5, (sub, k, np.median(e_gpu))
-            assert np.quantile(e_gpu, 0.9) <= 4 * np.quantile(e_32, 0.9) + 1e-5, (sub, k, e_gpu.max(), e_32.max())
+            # (product: trunk block of the factorisation in float64, at least as accurate as the float32 oracle on the typical env; the generic-tree and
+            # lane-per-env kernels keep the plain float32 leaf -> root L^T D L, ~3 x above it)
+            assert np.quantile(e_gpu, 0.9) <= (2 if variant == "product" else 4) * np.quantile(e_32, 0.9) + 1e-5, (sub, k, e_gpu.max(), e_32.max())
     ncon = sum((O64.get(d, "con_dist") < 0).sum() for d in d64)
     assert ncon > 0, "trajectory must reach contact"
     print("substep parity (median, max, f32-oracle max):", max(w[1] for w in worst), max(w[2] for w in worst), max(w[3] for w in worst))

@@ -108,21 +108,21 @@ def test_substep_worst_env_and_solver_integers(scale):
     print(f"  solver_niter == float64 oracle on {niter_eq64}/{total}, within [float32, float64] oracle counts on {niter_between}/{total}; "
           f"ls_total within the oracles' range +-2 on {ls_between}/{total}, +-(1 + niter) on {ls_loose}/{total}, mean per solve HIP {ls_sum[0] / total:.2f} / "
           f"float32 oracle {ls_sum[1] / total:.2f} / float64 oracle {ls_sum[2] / total:.2f}; final active-row bitmap differs in {n_final_mismatch}/{n_rows} rows")
-    # floors on the fraction of env-substeps inside the 1e-5 contract (measured round 3, 64 envs x 40 substeps through contact: qpos 1.000 / 0.990 /
-    # 0.943, qvel 0.906 / 0.795 / 0.629 at the three action scales; the float32 restatement of MJX's dense path itself reaches 0.931 / 0.840 / 0.739
+    # floors on the fraction of env-substeps inside the 1e-5 contract (measured round 4, 64 envs x 40 substeps through contact: qpos 1.000 / 0.997 /
+    # 0.973, qvel 0.922 / 0.865 / 0.786 at the three action scales; the float32 restatement of MJX's dense path itself reaches 0.931 / 0.840 / 0.739
     # for qvel: no float32 implementation keeps every env-substep of this model inside 1e-5 of a float64 run)
-    floor_qvel = {0.03: 0.88, 0.3: 0.76, 1.0: 0.59}[scale]
+    floor_qvel = {0.03: 0.90, 0.3: 0.84, 1.0: 0.75}[scale]
     for k in ("qpos", "qvel"):
         # the contract (BASELINE north_star: 1e-5 rel) holds for the typical env; the WORST env is bounded against what MJX's own
         # formulation reaches in float32 (dense restatement, same inputs): 5 CG iterations do not converge, rounding is amplified.
-        # The typical env sits 2.5 - 3 x above the float32 dense restatement: the price of the fill-free leaf -> root elimination order
-        # (tests/diagnostics/ldl_vs_cholesky.py: 4.4 x for a plain float32 L^T D L against dense Cholesky on the same matrices)
+        # Since round 4 (trunk block of the L^T D L in float64, csrc/wave_physics.h) the typical env is MORE accurate than the float32 dense
+        # restatement: qvel median 0.73 / 0.56 / 0.65 x the float32 oracle's (round 3: 2.5 x), the fraction inside 1e-5 -0.01 / +0.03 / +0.05
         assert np.median(g[k]) <= 1e-5, (k, np.median(g[k]))
-        assert np.median(g[k]) <= 4 * np.median(f[k]) + 1e-7, (k, np.median(g[k]), np.median(f[k]))
+        assert np.median(g[k]) <= 1.25 * np.median(f[k]) + 1e-7, (k, np.median(g[k]), np.median(f[k]))
         assert g[k].max() <= 2 * f[k].max() + 1e-5, (k, g[k].max(), f[k].max())
-        assert np.quantile(g[k], 0.99) <= 3 * np.quantile(f[k], 0.99) + 1e-5, (k, np.quantile(g[k], 0.99), np.quantile(f[k], 0.99))
-        assert np.mean(g[k] <= 1e-5) >= (0.92 if k == "qpos" else floor_qvel), (k, np.mean(g[k] <= 1e-5))
-        assert np.mean(g[k] <= 1e-5) >= np.mean(f[k] <= 1e-5) - 0.12, (k, np.mean(g[k] <= 1e-5), np.mean(f[k] <= 1e-5))
+        assert np.quantile(g[k], 0.99) <= 1.5 * np.quantile(f[k], 0.99) + 1e-5, (k, np.quantile(g[k], 0.99), np.quantile(f[k], 0.99))
+        assert np.mean(g[k] <= 1e-5) >= (0.96 if k == "qpos" else floor_qvel), (k, np.mean(g[k] <= 1e-5))
+        assert np.mean(g[k] <= 1e-5) >= np.mean(f[k] <= 1e-5) - 0.03, (k, np.mean(g[k] <= 1e-5), np.mean(f[k] <= 1e-5))
     assert niter_between >= 0.97 * total and niter_eq64 >= 0.8 * total
     # the line search stops when no candidate tightens the bracket any more — a comparison of derivatives that differ by rounding noise
     # near the minimum, so the count is not reproducible across precisions (the two oracles differ from each other as much).  Since the
@@ -216,10 +216,13 @@ def test_config1_single_env_full_episode_teacher_forced():
     print(f"  K3: obs rel err max {max(obs_err):.3e}, reward abs err max {max(rew_err):.3e}")
     assert dones >= 1, "N(0,1) actions must end episodes (the reference's model is violent by construction)"
     assert (~okh).sum() <= (~ok32).sum() + 2
-    assert np.median(eq[both]) <= 1e-5 and np.median(ev[both]) <= 3e-5
+    # (round 4: HIP qvel median 4.0e-6 / 90th 4.9e-5 / 99th 4.6e-4 / worst 4.2e-2 against the float32 oracle's 5.6e-6 / 7.0e-5 / 6.4e-4 / 8.9e-2 —
+    # N(0,1) actions are the violent regime; ONE env, so the worst substep is a single sample of a non-converged solve: 4 x)
+    assert np.median(eq[both]) <= 1e-5 and np.median(ev[both]) <= 1e-5
     for g_, f_ in ((eq[both], e32q[both]), (ev[both], e32v[both])):
-        assert np.quantile(g_, 0.9) <= 4 * np.quantile(f_, 0.9) + 1e-5 and np.quantile(g_, 0.99) <= 8 * np.quantile(f_, 0.99) + 1e-5
-        assert g_.max() <= 16 * f_.max() + 1e-5
+        assert np.median(g_) <= 1.25 * np.median(f_) + 1e-7
+        assert np.quantile(g_, 0.9) <= 2 * np.quantile(f_, 0.9) + 1e-5 and np.quantile(g_, 0.99) <= 3 * np.quantile(f_, 0.99) + 1e-5
+        assert g_.max() <= 4 * f_.max() + 1e-5
     assert max(obs_err) < 2e-5 and max(rew_err) < 1e-4
 
 

@@ -865,7 +865,7 @@ TM_DEV void tmw_rank1_rows(tmw_f2 (*T)[TMW_NL], const int CNT, const int BASE, c
   }
 }
 // EULER = false: plain M (no damping term, no right-hand side)
-template <int FIRST, int N, int D0, bool EULER>
+template <int FIRST, int N, int D0, bool EULER, bool RHS = EULER>
 TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float hdamp, int rhs) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   const int adr0 = K.l_M + tmw_chain_madr(FIRST);
@@ -883,7 +883,7 @@ TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float 
     }
     if (N & 1) r[N >> 1][TMW_LI].y = 0.f;
   }
-  if (EULER) {
+  if (RHS) {
     // the right-hand side rides in lane TMW_RL of every row: one vector load of the chain's N values, then per row a v_readlane +
     // a masked move — no per-row LDS access (a uniform-address ds_read per row and, in the factorisation, an exec-masked ds_write
     // per row cost 9 k cycles per substep)
@@ -906,14 +906,28 @@ TM_DEV void tmw_rows_load(WCtx &c, const WLayout &K, tmw_f2 (*r)[TMW_NL], float 
 // Four finished rows are packed into one operand register (lanes 16 kk + i = row kk, trunk column i; two v_permlane16_swap + one
 // v_permlane32_swap) and go through v_mfma_f32_16x16x4_f32: 7 instructions per four rows instead of 4 x 18 (readlane + pk_fma).
 // The accumulator holds C[i][j] at (register i % 4, lane 16 (i / 4) + j) and is subtracted from the trunk rows once, at the end.
+// ---- The trunk block in FLOAT64 (round 4).  The trunk diagonal is what is left of the whole body's composite inertia once every limb has been
+// eliminated: a small difference of large terms, and in float32 the one place where the leaf -> root L^T D L loses against the dense Cholesky
+// that MJX's dense path runs (tests/diagnostics/ldl_vs_cholesky.py: accumulating the 12 trunk rows in float64 takes M^-1 b from 2.9e-6 to
+// 1.1e-6 median, 1.7e-5 to 2.9e-6 worst, on the rodent's own matrices; the float32 dense Cholesky: 6.8e-7).  The Schur accumulation is
+// v_mfma_f64_16x16x4_f64 on the float32 operands widened at the flush (their products are exact in float64), the twelve trunk rows are then
+// eliminated in float64 registers (v_fma_f64, pivots by v_rcp_f64 + two Newton steps) and leave as float32: L, D^-1 and the eliminated rhs are
+// stored exactly where the float32 path stores them.  -DTMW_TRUNK_F32 restores the float32 block (the diagnostics' "before" arm).
+#ifdef TMW_TRUNK_F32
+typedef float tmw_acc_t;
+#else
+typedef double tmw_acc_t;
+#endif
 struct TmwSchur {
 #ifdef TM_HOST_EMU
-  float C[16][16];
+  tmw_acc_t C[16][16];
+#elif defined(TMW_TRUNK_F32)
+  float __attribute__((ext_vector_type(4))) c;       // C[i][j] at (component i % 4, lane 16 (i / 4) + j)
 #else
-  float __attribute__((ext_vector_type(4))) c;
+  double __attribute__((ext_vector_type(4))) c;      // C[i][j] at (component i / 4, lane 16 (i % 4) + j): the f64 instruction's own layout
 #endif
   float qa[4][TMW_NL], qb[4][TMW_NL];      // operand queue: scaled rows (L) and unscaled rows (M') of the last <= 4 pivots
-  float yt[TMW_NL];                        // Euler: lane i = sum_k L(k, trunk_i) y_k   (forward elimination of the rhs on the trunk)
+  float yt[TMW_NL];                        // Euler: lane i = sum_k L(k, trunk_i) y_k - rhs_i  (forward elimination of the rhs on the trunk, running)
 };
 #ifndef TM_HOST_EMU
 TM_DEV float tmw_pack4(float x0, float x1, float x2, float x3) {     // [x0.row0 | x1.row0 | x2.row0 | x3.row0], row = 16 lanes
@@ -922,53 +936,139 @@ TM_DEV float tmw_pack4(float x0, float x1, float x2, float x3) {     // [x0.row0
   auto p = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
   return tm_i2f(p[0]);
 }
+// lanes of 16-lane row `blk` of x -> row 0 (the other rows of the result are unspecified)
+TM_DEV int tmw_row_to0(int x, const int blk) {
+  if (blk == 1) return __builtin_amdgcn_permlane16_swap(x, 0, false, false)[1];
+  if (blk >= 2) {
+    x = __builtin_amdgcn_permlane32_swap(x, 0, false, false)[1];
+    if (blk == 3) x = __builtin_amdgcn_permlane16_swap(x, 0, false, false)[1];
+  }
+  return x;
+}
+TM_DEV double tmw_row_to0_d(double x, const int blk) {
+  long long b; __builtin_memcpy(&b, &x, 8);
+  int lo = tmw_row_to0((int)(b & 0xffffffffll), blk), hi = tmw_row_to0((int)(b >> 32), blk);
+  b = ((long long)hi << 32) | (unsigned)lo;
+  __builtin_memcpy(&x, &b, 8);
+  return x;
+}
+TM_DEV double tmw_readlane_d(const double *v, int src) {
+  long long b; __builtin_memcpy(&b, v, 8);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  b = ((long long)hi << 32) | (unsigned)lo;
+  double r; __builtin_memcpy(&r, &b, 8);
+  return r;
+}
+// 1 / x in float64: v_rcp_f64 seed + two Newton steps (the pivots are positive, normal numbers)
+TM_DEV double tmw_rcp_d(double x) { double r = __builtin_amdgcn_rcp(x); r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r); return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r); }
+#else
+TM_DEV double tmw_readlane_d(const double *v, int src) { return v[src]; }
+TM_DEV double tmw_rcp_d(double x) { return 1.0 / x; }
 #endif
 // The accumulator STARTS from minus the trunk rows, so that the contributions are taken off the trunk block one group at a
-// time, in elimination order, exactly like the register version did (summing all 61 contributions first and subtracting them
-// from the large trunk entries at the end costs a factor ~1.4 in accuracy: the trunk diagonal is a small difference of large terms)
-TM_DEV void tmw_schur_init(WCtx &c, TmwSchur &S, tmw_f2 (*tr)[TMW_NL]) {
+// time, in elimination order (summing all 61 contributions first and subtracting them from the large trunk entries at the end costs a
+// factor ~1.4 in accuracy in float32: the trunk diagonal is a small difference of large terms); Euler's right-hand side likewise (S.yt)
+template <bool EULER>
+TM_DEV void tmw_schur_init(WCtx &c, const WLayout &K, TmwSchur &S, tmw_f2 (*tr)[TMW_NL], int rhs) {
+  float *L = c.L; TMW_LANE_DECL
 #ifdef TM_HOST_EMU
-  for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) S.C[i][j] = (i < TMW_RODENT_TRUNK) ? -((i & 1) ? tr[i >> 1][j].y : tr[i >> 1][j].x) : 0.f;
+  for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) S.C[i][j] = (i < TMW_RODENT_TRUNK) ? -(tmw_acc_t)((i & 1) ? tr[i >> 1][j].y : tr[i >> 1][j].x) : (tmw_acc_t)0;
   for (int q = 0; q < 4; q++) for (int l = 0; l < 64; l++) S.qa[q][l] = S.qb[q][l] = 0.f;
-  for (int l = 0; l < 64; l++) S.yt[l] = 0.f;
 #else
 #define TMW_TRROW(i) ((i) < TMW_RODENT_TRUNK ? -(((i) & 1) ? tr[(i) >> 1][0].y : tr[(i) >> 1][0].x) : 0.f)
+#ifdef TMW_TRUNK_F32
   S.c[0] = tmw_pack4(TMW_TRROW(0), TMW_TRROW(4), TMW_TRROW(8), TMW_TRROW(12));
   S.c[1] = tmw_pack4(TMW_TRROW(1), TMW_TRROW(5), TMW_TRROW(9), TMW_TRROW(13));
   S.c[2] = tmw_pack4(TMW_TRROW(2), TMW_TRROW(6), TMW_TRROW(10), TMW_TRROW(14));
   S.c[3] = tmw_pack4(TMW_TRROW(3), TMW_TRROW(7), TMW_TRROW(11), TMW_TRROW(15));
+#else
+  S.c[0] = (double)tmw_pack4(TMW_TRROW(0), TMW_TRROW(1), TMW_TRROW(2), TMW_TRROW(3));
+  S.c[1] = (double)tmw_pack4(TMW_TRROW(4), TMW_TRROW(5), TMW_TRROW(6), TMW_TRROW(7));
+  S.c[2] = (double)tmw_pack4(TMW_TRROW(8), TMW_TRROW(9), TMW_TRROW(10), TMW_TRROW(11));
+  S.c[3] = 0.0;
+#endif
 #undef TMW_TRROW
   for (int q = 0; q < 4; q++) S.qa[q][0] = S.qb[q][0] = 0.f;
-  S.yt[0] = 0.f;
 #endif
+  TMW_FOR { S.yt[TMW_LI] = EULER ? -L[rhs + (lane < TMW_RODENT_TRUNK ? lane : 0)] : 0.f; }
 }
 // C += sum over the queued rows of  qa (x) qb  (the queue slots not filled since the last flush must hold zeros)
 TM_DEV void tmw_schur_flush(TmwSchur &S) {
 #ifdef TM_HOST_EMU
-  for (int q = 0; q < 4; q++) for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) S.C[i][j] += S.qa[q][i] * S.qb[q][j];
+  for (int q = 0; q < 4; q++) for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) S.C[i][j] += (tmw_acc_t)S.qa[q][i] * (tmw_acc_t)S.qb[q][j];
   for (int q = 0; q < 4; q++) for (int l = 0; l < 64; l++) S.qa[q][l] = S.qb[q][l] = 0.f;
 #else
   float A = tmw_pack4(S.qa[0][0], S.qa[1][0], S.qa[2][0], S.qa[3][0]), B = tmw_pack4(S.qb[0][0], S.qb[1][0], S.qb[2][0], S.qb[3][0]);
+#ifdef TMW_TRUNK_F32
   S.c = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, S.c, 0, 0, 0);
+#else
+  S.c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)A, (double)B, S.c, 0, 0, 0);
+#endif
   for (int q = 0; q < 4; q++) S.qa[q][0] = S.qb[q][0] = 0.f;
 #endif
 }
-// trunk rows <- -C (and, Euler, their rhs lane -= yt): row i of C sits in register i % 4, lanes 16 (i / 4) ..
+// trunk rows t[i] <- -C[i][.] in lanes 0..15 (and, Euler, the eliminated rhs -yt_i in lane TMW_RL; every other lane: zero)
 template <bool EULER>
-TM_DEV void tmw_schur_apply(WCtx &c, TmwSchur &S, tmw_f2 (*tr)[TMW_NL]) {
+TM_DEV void tmw_schur_apply(WCtx &c, TmwSchur &S, tmw_acc_t (*t)[TMW_NL]) {
   TMW_LANE_DECL
 #pragma unroll
   for (int i = 0; i < TMW_RODENT_TRUNK; i++) {
 #ifdef TM_HOST_EMU
-    TMW_FOR { float v = TMW_ROW(tr, i); if (lane < 16) v = -S.C[i][lane]; if (EULER && lane == TMW_RL) v -= S.yt[i]; TMW_SET_ROW(tr, i, v); }
+    TMW_FOR { tmw_acc_t v = 0; if (lane < 16) v = -S.C[i][lane]; if (EULER && lane == TMW_RL) v = -(tmw_acc_t)S.yt[i]; t[i][TMW_LI] = v; }
 #else
-    float x = S.c[i & 3];
-    if (i / 4 == 1) x = tm_i2f(__builtin_amdgcn_permlane16_swap(tm_f2i(x), 0, false, false)[1]);        // row 1 of x -> row 0
-    else if (i / 4 == 2) x = tm_i2f(__builtin_amdgcn_permlane32_swap(tm_f2i(x), 0, false, false)[1]);   // rows 2, 3 -> rows 0, 1
-    float v = TMW_MASK(TMW_M_LT(16)) ? -x : TMW_ROW(tr, i);
-    if (EULER) { float y = tmw_readlane(S.yt, i); v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? v - y : v; }
-    TMW_SET_ROW(tr, i, v);
+#ifdef TMW_TRUNK_F32
+    float x = tm_i2f(tmw_row_to0(tm_f2i(S.c[i & 3]), i / 4));
+#else
+    double x = tmw_row_to0_d(S.c[i / 4], i & 3);
 #endif
+    tmw_acc_t v = TMW_MASK(TMW_M_LT(16)) ? -x : (tmw_acc_t)0;
+    if (EULER) { float y = tmw_readlane(S.yt, i); v = TMW_MASK(TMW_M_EQ(TMW_RL)) ? (tmw_acc_t)(-y) : v; }
+    t[i][0] = v;
+#endif
+  }
+}
+// the twelve trunk rows, leaf -> root, in the accumulator's precision: same outputs as tmw_rows_factor<0, TRUNK, 0, EULER> (strict part of L,
+// D^-1, the eliminated rhs — all stored as float32)
+template <bool EULER>
+TM_DEV void tmw_trunk_factor(WCtx &c, const WLayout &K, tmw_acc_t (*t)[TMW_NL], int rhs) {
+  float *L = c.L; TMW_LANE_DECL
+  constexpr int N = TMW_RODENT_TRUNK;
+  TMW_REG(float, dv); TMW_REG(float, yv);
+  TMW_REG(tmw_acc_t, rs);
+  TMW_FOR { dv[TMW_LI] = 0.f; yv[TMW_LI] = 0.f; }
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const int off = k * (k - 1) / 2 + k;          // Madr(k) of the trunk chain (depth = dof)
+#ifdef TMW_TRUNK_F32
+    const float inv = tmw_rcp(tmw_readlane(t[k], k));
+#else
+    const double inv = tmw_rcp_d(tmw_readlane_d(t[k], k));
+#endif
+    TMW_FOR { rs[TMW_LI] = t[k][TMW_LI] * inv; }
+#pragma unroll
+    for (int i = k - 1; i >= 0; i--) {
+#ifdef TMW_TRUNK_F32
+      const float a = tmw_readlane(rs, i);
+      TMW_FOR { t[i][TMW_LI] = fmaf(-a, t[k][TMW_LI], t[i][TMW_LI]); }
+#else
+      const double a = tmw_readlane_d(rs, i);
+      TMW_FOR { t[i][TMW_LI] = __builtin_fma(-a, t[k][TMW_LI], t[i][TMW_LI]); }
+#endif
+    }
+    float yk = 0.f;
+#ifdef TMW_TRUNK_F32
+    if (EULER) yk = tmw_readlane(t[k], TMW_RL);
+#else
+    if (EULER) yk = (float)tmw_readlane_d(t[k], TMW_RL);
+#endif
+    TMW_FOR {
+      if (EULER) yv[TMW_LI] = TMW_MASK(TMW_M_EQ(k)) ? yk : yv[TMW_LI];
+      if (k > 0 && TMW_MASK(TMW_M_LT(k))) L[K.l_LD - lane + (off + k)] = (float)rs[TMW_LI];
+      dv[TMW_LI] = TMW_MASK(TMW_M_EQ(k)) ? (float)inv : dv[TMW_LI];
+    }
+  }
+  TMW_FOR {
+    if (TMW_MASK(TMW_M_LT(N))) { L[K.l_Dinv + lane] = dv[TMW_LI]; if (EULER) L[rhs + lane] = yv[TMW_LI]; }
   }
 }
 
@@ -1025,16 +1125,19 @@ TM_DEV void tmw_chain_factor(WCtx &c, const WLayout &K, TmwSchur *S, float hdamp
 // read straight from l_M; same outputs as tmw_factor except that the diagonal words of LD are left alone
 template <bool EULER>
 TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs) {
-  tmw_f2 tr[(TMW_RODENT_TRUNK + 1) / 2][TMW_NL];
   TmwSchur S;
-  tmw_rows_load<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, hdamp, rhs);
-  tmw_schur_init(c, S, tr);
+  {
+    tmw_f2 tr[(TMW_RODENT_TRUNK + 1) / 2][TMW_NL];
+    tmw_rows_load<0, TMW_RODENT_TRUNK, 0, EULER, false>(c, K, tr, hdamp, rhs);
+    tmw_schur_init<EULER>(c, K, S, tr, rhs);
+  }
 #define TMW_X(first, n, d0) tmw_chain_factor<first, n, d0, EULER>(c, K, &S, hdamp, rhs);
   TMW_RODENT_LEAF_CHAINS(TMW_X)
 #undef TMW_X
   tmw_schur_flush(S);                       // the last, partly filled group (unused slots hold zeros)
-  tmw_schur_apply<EULER>(c, S, tr);
-  tmw_rows_factor<0, TMW_RODENT_TRUNK, 0, EULER>(c, K, tr, nullptr, rhs);
+  tmw_acc_t t[TMW_RODENT_TRUNK][TMW_NL];
+  tmw_schur_apply<EULER>(c, S, t);
+  tmw_trunk_factor<EULER>(c, K, t, rhs);
   TMW_SYNC();
 }
 // rows of N = L^-1, root -> leaf:  N(k,:) = e_k - sum_{j < depth_k} L(k, anc_j) N(anc_j, :).  `tn`: the finished trunk rows
