@@ -301,6 +301,60 @@ def test_full_size_properties():
     assert torch.isfinite(st.obs).all() and torch.isfinite(st.reward).all()
 
 
+def test_full_size_three_groups_against_the_oracle():
+    """BASELINE size, the bench's launch layout: 4096 envs as the THREE env groups ppo.group_sizes makes (1368 / 1364 / 1364), one shared clip table.
+    (1) reset + one control step (K1, 10 x K2, K3) of every group against the oracle's env for a sample of envs spread over all groups — first and
+    last envs of every launch included; (2) after three more control steps that reach contact, single-substep launches of ALL envs compared
+    teacher-forced with the float64 / float32 oracles on the same sample, at the strict test's kind of bounds.  A launch-size-dependent bug
+    (grid tail, record stride, a third group's buffers) fails here; the oracle comparisons elsewhere run at <= 100 envs.
+    Reference: track_mjx/environment/task/single_clip_tracking.py:207-320."""
+    from tests.common import assert_substep_sample_bounds, oracle_substep_sample, spread_sample
+    from track_mjx_amd import clips as _clips, config as _config
+    from track_mjx_amd.agent import ppo
+    from track_mjx_amd.environment import wrap
+    from track_mjx_amd.train import build_env
+    from track_mjx_amd.walker import Rodent
+    n, ncl = 4096, 64
+    c = _config.default_config()
+    table = _clips.make_synthetic_clips(Rodent(**c["walker_config"]).model, ncl, n_frames=c["reference_config"]["clip_length"], mocap_hz=c["env_config"]["env_args"]["mocap_hz"])
+    sizes = ppo.group_sizes(n, 3)
+    assert sizes == [1368, 1364, 1364]
+    envs = [wrap(build_env(c, sizes[0], DEV, reference_clip=table), episode_length=195)]
+    envs += [wrap(build_env(c, sz, DEV, reference_clip=table, share_clips_with=envs[0]), episode_length=195) for sz in sizes[1:]]
+    O32, O64 = make_oracle(envs[0]._blob, table, "f32"), make_oracle(envs[0]._blob, table, "f64")
+    g = torch.Generator().manual_seed(3)
+    obs_err, rew_err, checked = [], [], 0
+    states = []
+    for env in envs:
+        m = env.num_envs
+        clip = torch.randint(0, ncl, (m,), generator=g, dtype=torch.int32); start = torch.randint(0, 44, (m,), generator=g, dtype=torch.int32)
+        qn = (torch.rand((74, m), generator=g) * 2 - 1) * 1e-3; vn = (torch.rand((73, m), generator=g) * 2 - 1) * 1e-3
+        st = env.reset(g, clip, start_frame=start, qpos_noise=qn, qvel_noise=vn)
+        a = (torch.randn((38, m), generator=g) * 0.03).clamp(-1, 1)
+        st = env.step(st, a.to(DEV))
+        torch.cuda.synchronize()
+        idx = spread_sample(m, 22)
+        E = O32.new_envs(len(idx))
+        for j, e in enumerate(idx):
+            O32.env_reset(E, j, int(clip[e]), int(start[e]), qn[:, e].numpy(), vn[:, e].numpy())
+            O32.env_step(E, j, a[:, e].numpy())
+            o_ref = O32.env_get(E, j, "obs")
+            obs_err.append(rel_err(st.obs[e].cpu().numpy(), o_ref)); rew_err.append(abs(float(st.reward[e]) - O32.env_get(E, j, "reward")[0]))
+            assert float(st.done[e]) == O32.env_get(E, j, "done")[0]
+            checked += 1
+        states.append(st)
+    assert checked >= 60 and max(obs_err) < 2e-5 and max(rew_err) < 1e-4, (max(obs_err), max(rew_err))
+    for s in range(3):          # into contact, on the product path
+        for k, env in enumerate(envs):
+            states[k] = env.step(states[k], (torch.randn((38, env.num_envs), generator=g) * 0.5).clamp(-1, 1).to(DEV))
+    torch.cuda.synchronize()
+    errs = oracle_substep_sample(envs, O32, O64, np.random.default_rng(5), scale=0.3, per_group=22, substeps=3)
+    print(f"\nfull size, 3 groups: first control step obs rel err max {max(obs_err):.2e}, reward abs err max {max(rew_err):.2e} on {checked} envs; teacher-forced "
+          f"substeps on {len(errs['qvel'][0])} env-substeps: qvel median HIP {np.median(errs['qvel'][0]):.2e} / float32 oracle {np.median(errs['qvel'][1]):.2e}, "
+          f"worst {errs['qvel'][0].max():.2e} / {errs['qvel'][1].max():.2e}")
+    assert_substep_sample_bounds(errs)
+
+
 def test_error_paths():
     env, O, cl = make_env_and_oracle(num_envs=8, wrappers=False)
     with pytest.raises(ValueError):
@@ -720,15 +774,16 @@ def test_baseline_configs_4_and_5_at_full_size(cfg):
     tc, nc = c["train_setup"]["train_config"], c["network_config"]
     n = bc["envs_per_gpu"]
     table = _clips.make_synthetic_clips(Rodent(**c["walker_config"]).model, bc["n_clips"], n_frames=c["reference_config"]["clip_length"], mocap_hz=c["env_config"]["env_args"]["mocap_hz"])
-    e0 = wrap(build_env(c, n // 2, DEV, reference_clip=table), episode_length=195)
-    envs = [e0, wrap(build_env(c, n // 2, DEV, reference_clip=table, share_clips_with=e0), episode_length=195)]
+    sizes = ppo.group_sizes(n, 3)               # three env groups, as bench.py builds them
+    e0 = wrap(build_env(c, sizes[0], DEV, reference_clip=table), episode_length=195)
+    envs = [e0] + [wrap(build_env(c, sz, DEV, reference_clip=table, share_clips_with=e0), episode_length=195) for sz in sizes[1:]]
     L = ppo.PPOLearner(envs, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"], critic_layers=nc["critic_layer_sizes"],
                        latents=nc["intention_size"], unroll_length=tc["unroll_length"], batch_size=tc["batch_size"] * n // 4096, num_minibatches=tc["num_minibatches"],
                        num_updates_per_batch=1, kl_weight=nc["kl_weight"], seed=0, matmul_dtype=torch.bfloat16 if bc["matmul_dtype"] == "bf16" else None)
     assert L.n_params() == 4_294_853 and L.local_batch * L.T == (20480 if cfg == "cfg4" else 40960)
     g = torch.Generator().manual_seed(1)
     for k, e in enumerate(envs):
-        idx = torch.randint(0, bc["n_clips"], (n // 2,), generator=g, dtype=torch.int32)
+        idx = torch.randint(0, bc["n_clips"], (sizes[k],), generator=g, dtype=torch.int32)
         L.states[k] = e.reset(g, idx)
         assert int(e.istate_buf[e.layout.i_clip_idx].max()) < bc["n_clips"]
     before = L.opt.flat.clone()
@@ -739,6 +794,14 @@ def test_baseline_configs_4_and_5_at_full_size(cfg):
     if cfg == "cfg5":
         assert L.shadows is not None and all(w.dtype == torch.bfloat16 for w in L.shadows.w.values())
         assert int(envs[0].istate_buf[envs[0].layout.i_clip_idx].max()) > 64          # the 1024-clip table is really indexed
+    # the physics at this launch size against the oracle: after the training step's 20 control steps, single-substep launches of all envs of the
+    # three groups, a sample of envs (both ends of every launch + a spread) teacher-forced through the float64 / float32 oracles
+    from tests.common import assert_substep_sample_bounds, oracle_substep_sample
+    O32, O64 = make_oracle(e0._blob, None, "f32"), make_oracle(e0._blob, None, "f64")      # (physics only: no clip table)
+    errs = oracle_substep_sample(envs, O32, O64, np.random.default_rng(7), scale=0.3, per_group=22, substeps=2)
+    print(f"\n{cfg}: {n} envs in groups {sizes}: teacher-forced substeps on {len(errs['qvel'][0])} env-substeps: qvel median HIP {np.median(errs['qvel'][0]):.2e} / "
+          f"float32 oracle {np.median(errs['qvel'][1]):.2e}")
+    assert_substep_sample_bounds(errs)
 
 
 @pytest.mark.gpu
