@@ -93,7 +93,6 @@ void emu_physics_wave(EmuModel *mm, float *st, const float *action, int nsub, in
     const WLayout K = tmjx_host::make_wave_layout(mm->h, !getenv("TMJX_EMU_GENERIC"));
     float time = tmw_load_state(c, K, action);
     for (int f = 0; f < nsub; f++) { tmw_forward(c, K, f == nsub - 1); if (do_euler) time = tmw_euler(c, K, time); }
-    if (getenv("TMJX_EMU_DBG")) for (int i = 0; i < K.nv; i++) lds[K.l_qacc_smooth + i] = lds[K.l_tmp + i];
     if (ws_dump) tmw_dump(c, K, ws_dump);
     tmw_store_state(c, K, time);
   }

@@ -42,9 +42,9 @@ def test_no_product_import_of_oracle_or_emulation():
         assert "liboracle" not in src and "libhostemu" not in src, p
 
 
-def test_chain_layout_fits_eleven_envs_per_cu():
-    """The rodent (chain) LDS map of the wave kernel must stay within 11 of the CU's 128 LDS granules of 1280 bytes (measured granule:
-    tools/micro/lds_occupancy.hip), i.e. eleven resident envs per CU (csrc/wave_layout.h)."""
+def test_chain_layout_fits_twelve_envs_per_cu():
+    """The rodent (chain) LDS map of the wave kernel must stay within 10 of the CU's 128 LDS granules of 1280 bytes (measured granule:
+    tools/micro/lds_occupancy.hip), i.e. twelve resident envs per CU (csrc/wave_layout.h; eleven until round 4)."""
     import subprocess, tempfile, textwrap
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
@@ -58,8 +58,8 @@ def test_chain_layout_fits_eleven_envs_per_cu():
         (Path(d) / "l.cpp").write_text(src)
         subprocess.run(["g++", "-std=c++17", "-o", f"{d}/l", f"{d}/l.cpp"], check=True)
         chain, generic = (int(v) for v in subprocess.run([f"{d}/l"], check=True, capture_output=True, text=True).stdout.split())
-    # LDS is granted in 1280-byte granules on gfx950 (tools/micro/lds_occupancy.hip): 11 granules = eleven resident envs per CU
-    assert chain * 4 <= 11 * 1280 and generic * 4 <= 20 * 1024 + 2048
+    # LDS is granted in 1280-byte granules on gfx950 (tools/micro/lds_occupancy.hip): 10 granules = twelve resident envs per CU (128 // 10)
+    assert chain * 4 <= 10 * 1280 and generic * 4 <= 20 * 1024 + 2048
 
 
 def test_physics_kernel_resources_allow_ten_envs_per_cu(tmp_path):

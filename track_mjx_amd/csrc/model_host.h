@@ -36,6 +36,7 @@ inline bool rodent_chains_match(const DModel &m) {
     if (m.con_body1[cc] != m.con_body1[0] || m.body_moving[m.con_body1[cc]]) return false;
     for (int k = 0; k < 3; k++) if (m.con_g1_pos[cc][k] != m.con_g1_pos[0][k]) return false;
     for (int k = 0; k < 4; k++) if (m.con_g1_quat[cc][k] != m.con_g1_quat[0][k]) return false;
+    if (m.con_mu[cc] != m.con_mu[0]) return false;      // ... and reads ONE friction coefficient (TMW_MU)
   }
   return adr == m.nnz;
 }

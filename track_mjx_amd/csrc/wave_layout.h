@@ -12,8 +12,8 @@ struct WLayout {
   int l_qpos, l_qvel, l_act, l_cdof, l_M, l_con_dist, l_con_off, l_con_frame, l_lim_sign, l_qfrc_smooth,
       l_com, l_sv, l_wr, l_tdof, l_tgrp, l_hdamp, l_con_mu, l_con_grpb, l_rowmap, l_ccrow, l_dummy, l_alias0;
   // aliased region A (solver stage)
-  int l_LD, l_Dinv, l_efc_D, l_efc_aref, l_Jaref, l_jv, l_qacc_smooth, l_qacc, l_Ma, l_grad, l_Mgrad, l_search, l_mv,
-      l_qfrc_constraint, l_tmp;
+  int l_LD, l_Dinv, l_efc_D, l_efc_aref, l_Jaref, l_jv, l_qacc_smooth, l_qacc, l_Ma, l_Mgrad, l_search, l_mv,
+      l_qfrc_constraint;
   // aliased region B (position / velocity stage), same base as region A
   int l_scanA, l_scanB, l_jl_anchor, l_jl_axis, l_xipos, l_cinert, l_cfrc, l_dscanA, l_dscanB;
   int lds_floats;
@@ -26,8 +26,8 @@ struct WLayout {
         l_qpos(0), l_qvel(0), l_act(0), l_cdof(0), l_M(0), l_con_dist(0), l_con_off(0), l_con_frame(0),
         l_lim_sign(0), l_qfrc_smooth(0), l_com(0), l_sv(0), l_wr(0), l_tdof(0), l_tgrp(0), l_hdamp(0), l_con_mu(0), l_con_grpb(0), l_rowmap(0), l_ccrow(0), l_dummy(0),
         l_alias0(0), l_LD(0), l_Dinv(0), l_efc_D(0), l_efc_aref(0), l_Jaref(0), l_jv(0), l_qacc_smooth(0), l_qacc(0), l_Ma(0),
-        l_grad(0), l_Mgrad(0), l_search(0), l_mv(0), l_qfrc_constraint(0), l_tmp(0), l_scanA(0), l_scanB(0), l_jl_anchor(0),
-        l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0), lean(ch && 2 * nb * 8 <= nnz_ && nv_ * 7 <= nb * 8 && nu_ <= ng * 6), chains(ch) {
+        l_Mgrad(0), l_search(0), l_mv(0), l_qfrc_constraint(0), l_scanA(0), l_scanB(0), l_jl_anchor(0),
+        l_jl_axis(0), l_xipos(0), l_cinert(0), l_cfrc(0), l_dscanA(0), l_dscanB(0), lds_floats(0), lean(ch && 2 * nb * 8 <= nnz_ && nv_ * 7 <= nb * 8 && nu_ <= ng * 6 && nv_ * 7 + nb * 6 <= nnz_), chains(ch) {
     int l = 0;
     // NOT here (they were, 295 words): the warm start, ctrl, act_dot, qfrc_actuator and timestep * damping.  LDS is granted in 1280-byte
     // granules on gfx950 (tools/micro/lds_occupancy.hip): 16 284 bytes took 13 of the 128 granules of a CU, i.e. NINE resident envs, not the
@@ -42,7 +42,8 @@ struct WLayout {
     l_con_frame = l; l += lean ? 3 + ncon * 3 : ncon * 6; l_lim_sign = l; l += (nlim + 3) / 4; l_qfrc_smooth = l; l += lean ? 0 : nv;
     l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_tdof = l; l += nv * 2;
     l_tgrp = l; l += (ngroup + 3) / 4;      // bytes: last dof of each paw group (-1 = none)
-    l_con_mu = l; l += ncon;  // friction coefficient of every contact slot: a model constant the products with J / J^T need on every call
+    l_con_mu = l; l += lean ? 0 : ncon;  // friction coefficient of every contact slot: a model constant the products with J / J^T need on every call (lean: ONE
+                                         // coefficient for all slots, a uniform read of the model — model_host.h checks it)
     // byte tables: compact row -> original row of the ACTIVE constraint rows (wave_physics.h: tmw_make_constraint); contact -> its first
     // compact row (255 = none) and, behind it in the same array, contact -> paw group (a model constant)
     l_rowmap = l; l += (nefc + 3) / 4; l_ccrow = l; l_con_grpb = l; l += (2 * nc + 3) / 4;
@@ -52,8 +53,8 @@ struct WLayout {
     // liveness-based sharing: aref is dead once the CG start point is chosen -> J*search (jv) re-uses it; the per-contact
     // wrenches of J^T f (wr, 6*ncon <= nefc) are only live inside tmw_jt_force, never together with jv
     l_jv = l_efc_aref; l_wr = l_efc_aref;
-    l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
-    l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
+    l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv;
+    l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv;
     l_dummy = l_mv;   // per-lane source of masked LDS READS (never written through; needs 64 <= nv words)
     int endA = l;
     l = l_alias0;
@@ -79,17 +80,24 @@ struct WLayout {
       l = l_alias0;
       l_Dinv = l; l += nv; l_efc_D = l; l += nefc; l_efc_aref = l; l += nefc; l_Jaref = l; l += nefc;
       l_jv = l_efc_aref; l_wr = l_efc_aref;
-      l_qacc_smooth = l; l += nv; l_qacc = l; l += nv; l_Ma = l; l += nv; l_grad = l; l += nv;
-      l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv; l_qfrc_constraint = l; l += nv; l_tmp = l; l += nv;
+      // Solver vectors (round 4: 3 520 -> 3 199 words = 12 796 bytes = TEN granules of 1 280 bytes -> TWELVE envs per CU).  What left LDS or
+      // shares words: D = 1 / Dinv and the previous CG direction's w live in two registers per lane (WCtx::dg*, wp*: read lane-locally only);
+      // qacc_smooth (dead once the CG's start point is chosen) and qfrc_constraint (written by the LAST J^T f of a CG pass, after that pass's
+      // line search has consumed search_q; read by D^-1 N^T and, after the loop, by Euler's right-hand side before timestep * damping is
+      // staged there) share the words of l_search; Euler's right-hand side rides in l_Mgrad; the friction coefficient is a model scalar.
+      l_qacc = l; l += nv; l_Ma = l; l += nv;
+      l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv;
+      l_qacc_smooth = lean ? l_search : l; l += lean ? 0 : nv; l_qfrc_constraint = lean ? l_search : l; l += lean ? 0 : nv;
       l_dummy = l_mv;
       int eA = l;
       // region B: xipos | joint anchors | joint axes; cinert overlays the joint frames (dead once cdof is built) but not xipos,
-      // which the cinert step still reads; cfrc behind cinert
+      // which the cinert step still reads.  cfrc (lean) lives in the MATRIX region behind the dof-scan buffer (dead between Euler and the
+      // "M rows" step, which takes its bias forces into registers before it writes the first row of M); else behind cinert
       l = l_alias0;
       l_xipos = l; l += nbody * 3; l_jl_anchor = l; l += njnt * 3; l_jl_axis = l; l += njnt * 3;
       int eB1 = l;
-      l_cinert = l_alias0 + nbody * 3; l_cfrc = l_cinert + nbody * 10;
-      int eB2 = l_cfrc + nbody * 6;
+      l_cinert = l_alias0 + nbody * 3; l_cfrc = lean ? l_M + nv * 7 : l_cinert + nbody * 10;
+      int eB2 = lean ? l_cinert + nbody * 10 : l_cfrc + nbody * 6;
       lds_floats = eA > eB1 ? eA : eB1;
       if (eB2 > lds_floats) lds_floats = eB2;
     }

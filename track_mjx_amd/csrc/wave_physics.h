@@ -86,6 +86,8 @@ struct WCtx {
   unsigned kmask[TMW_NL];     // lane = (subset, component) of tmw_jt_force: contact mask (slots 0..31) of the subset (valid if n_wsub * 6 <= 64)
   const float *action;        // [nu][n] action rows (direct mode, c.rs == 0) or null
   float qfs0[TMW_NL], qfs1[TMW_NL];   // lean layout: qfrc_smooth of dof lane / lane + 64 (tmw_velocity_inertia -> solver, Euler)
+  float dg0[TMW_NL], dg1[TMW_NL];     // CG: D = 1 / Dinv of dof lane / lane + 64 (tmw_solve_cg; read lane-locally only)
+  float wp0[TMW_NL], wp1[TMW_NL];     // CG: w = D^-1 ghat of the PREVIOUS gradient (Polak-Ribiere numerator)
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
 // solver statistics of the last substep, kept in the spare LDS word behind the centre of mass (registers are what this kernel has none
@@ -110,6 +112,11 @@ struct WCtx {
 #define TMW_ACT(a) (*(K.lean ? &WST(m.s_act, (a)) : &L[K.l_act + (a)]))
 #define TMW_QFS(i) (K.lean ? ((i) < 64 ? c.qfs0[TMW_LI] : c.qfs1[TMW_LI]) : L[K.l_qfrc_smooth + (i)])
 #define TMW_QFS_SET(i, v) do { if (!K.lean) L[K.l_qfrc_smooth + (i)] = (v); else if ((i) < 64) c.qfs0[TMW_LI] = (v); else c.qfs1[TMW_LI] = (v); } while (0)
+#define TMW_DG(i) ((i) < 64 ? c.dg0[TMW_LI] : c.dg1[TMW_LI])
+#define TMW_WP(i) ((i) < 64 ? c.wp0[TMW_LI] : c.wp1[TMW_LI])
+#define TMW_WP_SET(i, v) do { if ((i) < 64) c.wp0[TMW_LI] = (v); else c.wp1[TMW_LI] = (v); } while (0)
+// friction coefficient of contact slot cc: lean layout = ONE coefficient for all slots (a uniform model read; tmjx_host::rodent_chains_match)
+#define TMW_MU(cc) (K.lean ? m.con_mu[0] : L[K.l_con_mu + (cc)])
 #define TMW_LIMSIGN(K) ((signed char *)(L + (K).l_lim_sign))      /* sign * (compact row + 1) of a violated limit, 0 otherwise */
 TM_DEV int tm_f2i(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
@@ -201,7 +208,7 @@ TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
       L[K.l_tdof + i] = tm_i2f(m.tdof[i] | (extra << 24));
     }
     for (int g = lane; g < K.ngroup; g += 64) ((signed char *)(L + K.l_tgrp))[g] = (signed char)m.grp_lastdof[g];
-    for (int cc = lane; cc < K.ncon; cc += 64) { L[K.l_con_mu + cc] = m.con_mu[cc]; TMW_CONGRP(K)[cc] = (unsigned char)m.con_grp[cc]; }
+    for (int cc = lane; cc < K.ncon; cc += 64) { if (!K.lean) L[K.l_con_mu + cc] = m.con_mu[cc]; TMW_CONGRP(K)[cc] = (unsigned char)m.con_grp[cc]; }
     {
       int su = lane / 6;
       bool ok = lane < m.n_wsub * 6;
@@ -618,13 +625,23 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
   if (K.lean) { TMW_FOR { for (int a = lane; a < K.nu; a += 64) L[K.l_sv + a] = WST(m.s_act, a); } }
   TMW_SYNC();
   TMW_TICK2(23);
-  // M rows, bias, passive, actuation -> qfrc_smooth; act_dot
+  // M rows, bias, passive, actuation -> qfrc_smooth; act_dot.  The bias forces first, into registers: in the lean layout the accumulated body
+  // forces sit INSIDE the matrix region (wave_layout.h), which the rows of M are about to overwrite
+  TMW_REG(float, bias0); TMW_REG(float, bias1);
+  TMW_FOR {
+    for (int i = lane; i < K.nv; i += 64) {
+      const int b = m.dof_bodyid[i];
+      float bias = 0.f;
+      for (int k = 0; k < 6; k++) bias += L[K.l_cdof + i * 6 + k] * L[K.l_cfrc + b * 6 + k];
+      if (i < 64) bias0[TMW_LI] = bias; else bias1[TMW_LI] = bias;
+    }
+  }
+  TMW_SYNC();
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       int b = m.dof_bodyid[i];
-      float I[10], fb[6], cd[6], buf[6];
+      float I[10], cd[6], buf[6];
       for (int k = 0; k < 10; k++) I[k] = L[K.l_cinert + b * 10 + k];
-      for (int k = 0; k < 6; k++) fb[k] = L[K.l_cfrc + b * 6 + k];
       for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
       tm_inert_mul(buf, I, cd);
       int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = TMW_DEPTH(w0);
@@ -635,8 +652,7 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
         if (k == 0) s += m.dof_armature[i];
         L[K.l_M + adr + k] = s;
       }
-      float bias = 0.f;
-      for (int k = 0; k < 6; k++) bias += cd[k] * fb[k];
+      const float bias = i < 64 ? bias0[TMW_LI] : bias1[TMW_LI];
       float fa = 0.f;
       for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[(K.lean ? K.l_sv : K.l_act) + u]); }
       WST(m.s_qfrc_actuator, i) = fa;
@@ -959,11 +975,22 @@ TM_DEV double tmw_readlane_d(const double *v, int src) {
   double r; __builtin_memcpy(&r, &b, 8);
   return r;
 }
-// 1 / x in float64: v_rcp_f64 seed + two Newton steps (the pivots are positive, normal numbers)
-TM_DEV double tmw_rcp_d(double x) { double r = __builtin_amdgcn_rcp(x); r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r); return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r); }
+// 1 / x in float64 to 2^-46: the float32 hardware reciprocal (1 ulp) as the seed + ONE float64 Newton step (v_rcp_f64 is a quarter-rate instruction
+// with a long latency, and it sits on the critical path of every trunk pivot; the pivots are positive, normal numbers well inside float32's range)
+TM_DEV double tmw_rcp_d(double x) { double r = (double)__builtin_amdgcn_rcpf((float)x); return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r); }
 #else
 TM_DEV double tmw_readlane_d(const double *v, int src) { return v[src]; }
 TM_DEV double tmw_rcp_d(double x) { return 1.0 / x; }
+#endif
+// arithmetic of the trunk block in the accumulator's precision
+#ifdef TMW_TRUNK_F32
+TM_DEV float tmw_acc_readlane(const float *v, int src) { return tmw_readlane(v, src); }
+TM_DEV float tmw_acc_rcp(float x) { return tmw_rcp(x); }
+TM_DEV float tmw_acc_fnma(float a, float b, float c) { return fmaf(-a, b, c); }
+#else
+TM_DEV double tmw_acc_readlane(const double *v, int src) { return tmw_readlane_d(v, src); }
+TM_DEV double tmw_acc_rcp(double x) { return tmw_rcp_d(x); }
+TM_DEV double tmw_acc_fnma(double a, double b, double c) { return __builtin_fma(-a, b, c); }
 #endif
 // The accumulator STARTS from minus the trunk rows, so that the contributions are taken off the trunk block one group at a
 // time, in elimination order (summing all 61 contributions first and subtracting them from the large trunk entries at the end costs a
@@ -1034,37 +1061,28 @@ TM_DEV void tmw_trunk_factor(WCtx &c, const WLayout &K, tmw_acc_t (*t)[TMW_NL], 
   float *L = c.L; TMW_LANE_DECL
   constexpr int N = TMW_RODENT_TRUNK;
   TMW_REG(float, dv); TMW_REG(float, yv);
-  TMW_REG(tmw_acc_t, rs);
+  tmw_acc_t rs[2][TMW_NL], inv[2];
   TMW_FOR { dv[TMW_LI] = 0.f; yv[TMW_LI] = 0.f; }
+  // software-pipelined like tmw_rows_factor: as soon as the first update of step k has finished row k - 1, that row's pivot chain (readlane ->
+  // reciprocal -> scale) is issued and the remaining updates of step k cover its latency
+  inv[(N - 1) & 1] = tmw_acc_rcp(tmw_acc_readlane(t[N - 1], N - 1));
+  TMW_FOR { rs[(N - 1) & 1][TMW_LI] = t[N - 1][TMW_LI] * inv[(N - 1) & 1]; }
 #pragma unroll
   for (int k = N - 1; k >= 0; k--) {
-    const int off = k * (k - 1) / 2 + k;          // Madr(k) of the trunk chain (depth = dof)
-#ifdef TMW_TRUNK_F32
-    const float inv = tmw_rcp(tmw_readlane(t[k], k));
-#else
-    const double inv = tmw_rcp_d(tmw_readlane_d(t[k], k));
-#endif
-    TMW_FOR { rs[TMW_LI] = t[k][TMW_LI] * inv; }
-#pragma unroll
-    for (int i = k - 1; i >= 0; i--) {
-#ifdef TMW_TRUNK_F32
-      const float a = tmw_readlane(rs, i);
-      TMW_FOR { t[i][TMW_LI] = fmaf(-a, t[k][TMW_LI], t[i][TMW_LI]); }
-#else
-      const double a = tmw_readlane_d(rs, i);
-      TMW_FOR { t[i][TMW_LI] = __builtin_fma(-a, t[k][TMW_LI], t[i][TMW_LI]); }
-#endif
+    const int off = k * (k - 1) / 2 + k, b = k & 1;          // Madr(k) of the trunk chain (depth = dof)
+    if (k > 0) {
+      { const tmw_acc_t a = tmw_acc_readlane(rs[b], k - 1); TMW_FOR { t[k - 1][TMW_LI] = tmw_acc_fnma(a, t[k][TMW_LI], t[k - 1][TMW_LI]); } }
+      inv[b ^ 1] = tmw_acc_rcp(tmw_acc_readlane(t[k - 1], k - 1));
+      TMW_FOR { rs[b ^ 1][TMW_LI] = t[k - 1][TMW_LI] * inv[b ^ 1]; }
     }
+#pragma unroll
+    for (int i = k - 2; i >= 0; i--) { const tmw_acc_t a = tmw_acc_readlane(rs[b], i); TMW_FOR { t[i][TMW_LI] = tmw_acc_fnma(a, t[k][TMW_LI], t[i][TMW_LI]); } }
     float yk = 0.f;
-#ifdef TMW_TRUNK_F32
-    if (EULER) yk = tmw_readlane(t[k], TMW_RL);
-#else
-    if (EULER) yk = (float)tmw_readlane_d(t[k], TMW_RL);
-#endif
+    if (EULER) yk = (float)tmw_acc_readlane(t[k], TMW_RL);
     TMW_FOR {
       if (EULER) yv[TMW_LI] = TMW_MASK(TMW_M_EQ(k)) ? yk : yv[TMW_LI];
-      if (k > 0 && TMW_MASK(TMW_M_LT(k))) L[K.l_LD - lane + (off + k)] = (float)rs[TMW_LI];
-      dv[TMW_LI] = TMW_MASK(TMW_M_EQ(k)) ? (float)inv : dv[TMW_LI];
+      if (k > 0 && TMW_MASK(TMW_M_LT(k))) L[K.l_LD - lane + (off + k)] = (float)rs[b][TMW_LI];
+      dv[TMW_LI] = TMW_MASK(TMW_M_EQ(k)) ? (float)inv[b] : dv[TMW_LI];
     }
   }
   TMW_FOR {
@@ -1490,7 +1508,7 @@ TM_DEV void tmw_jmul_stage2(WCtx &c, const WLayout &K, int v, int out) {
         float cr[3], vel[3];
         tm_cross(cr, sv, off);
         for (int k = 0; k < 3; k++) vel[k] = sv[3 + k] + cr[k];
-        float a0 = tm_dot3(fr, vel), at = tm_dot3(fr + 3 + 3 * (e >> 1), vel) * L[K.l_con_mu + cc];
+        float a0 = tm_dot3(fr, vel), at = tm_dot3(fr + 3 + 3 * (e >> 1), vel) * TMW_MU(cc);
         o = (e & 1) ? a0 - at : a0 + at;
       }
       L[out + kr] = o;
@@ -1516,7 +1534,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
       float ja[4], D[4], f[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) { ja[e] = L[K.l_Jaref + r0 + e]; D[e] = L[K.l_efc_D + r0 + e]; }
-      const float mu = L[K.l_con_mu + cc];
+      const float mu = TMW_MU(cc);
       const float *off = L + K.l_con_off + cc * 3;
       const float o0 = off[0], o1 = off[1], o2 = off[2];
       float fr[9];
@@ -1733,8 +1751,8 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool 
 // so one iteration costs ONE M^-1 product split into its two halves instead of M x + M^-1 x.  In exact arithmetic the
 // iterates are those of MJX's solver (same Polak-Ribiere directions: g.M^-1 g = ghat.D^-1 ghat, search.M search = s.D s, ...);
 // the state is self-consistent in fp32 (ut = y - y_s is advanced by the step actually taken).  LDS vectors of the y-space
-// quantities (names of the q-space vectors they replace): l_Ma = ut = y - y_s, l_Mgrad = w = D^-1 ghat, l_tmp = previous w,
-// l_mv = s, l_grad = D;  l_search = search_q, l_qacc, l_qfrc_constraint stay in q-space.
+// quantities (names of the q-space vectors they replace): l_Ma = ut = y - y_s, l_Mgrad = w = D^-1 ghat, registers wp* = previous w,
+// l_mv = s, registers dg* = D;  l_search = search_q, l_qacc, l_qfrc_constraint stay in q-space.
 // x -> out = D^-1 N^T x   (leaf -> root; out may alias x)
 TM_DEV void tmw_solve_up(WCtx &c, const WLayout &K, int x, int out) {
   float *L = c.L; TMW_LANE_DECL
@@ -1765,7 +1783,7 @@ TM_DEV void tmw_solve_down(WCtx &c, const WLayout &K, int x, int out) {
   TMW_SYNC();
 }
 // qfrc_constraint = J^T f at the current Jaref;  w = ut - D^-1 N^T qfrc_constraint;  returns gn = w.D w (= grad.M^-1 grad) and,
-// through `num`, w.D (w - w_prev) with w_prev = l_tmp (Polak-Ribiere numerator); `improvement < last_if`: qfrc_constraint only, returns -1
+// through `num`, w.D (w - w_prev) with w_prev = the wp registers (Polak-Ribiere numerator); `improvement < last_if`: qfrc_constraint only, returns -1
 TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num, float improvement = 0.f, float last_if = -INFINITY) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_TICK2(15);
@@ -1778,9 +1796,9 @@ TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num, float im
   TMW_FOR {
     float sa = 0.f, sb = 0.f;
     for (int i = lane; i < K.nv; i += 64) {
-      float w = L[K.l_Ma + i] - L[K.l_Mgrad + i], dw = L[K.l_grad + i] * w;
+      float w = L[K.l_Ma + i] - L[K.l_Mgrad + i], dw = TMW_DG(i) * w;
       L[K.l_Mgrad + i] = w;
-      sa += dw * w; sb += dw * (w - L[K.l_tmp + i]);
+      sa += dw * w; sb += dw * (w - TMW_WP(i));
     }
     pa[TMW_LI] = sa; pb[TMW_LI] = sb;
   }
@@ -1958,7 +1976,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   TMW_FOR {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int i = lane; i < K.nv; i += 64) {
-      float sq = L[K.l_search + i], ds = L[K.l_grad + i] * L[K.l_mv + i];
+      float sq = L[K.l_search + i], ds = TMW_DG(i) * L[K.l_mv + i];
       a0 += sq * sq; a1 += ds * L[K.l_Ma + i]; a2 += ds * L[K.l_mv + i];
     }
     p0[TMW_LI] = a0; p1[TMW_LI] = a1; p2[TMW_LI] = a2;
@@ -1993,7 +2011,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
     for (int i = lane; i < K.nv; i += 64) {
       float qa = L[K.l_qacc + i] + L[K.l_search + i] * ia, ut = L[K.l_Ma + i] + L[K.l_mv + i] * ia;
       L[K.l_qacc + i] = qa; L[K.l_Ma + i] = ut;
-      sg += L[K.l_grad + i] * ut * ut;
+      sg += TMW_DG(i) * ut * ut;
     }
 #pragma unroll
     for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
@@ -2012,7 +2030,14 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
 #if defined(TMW_PROFILE) && !defined(TM_HOST_EMU)
   if (c.prof && c.lane == 0) { c.prof[10] += (c.nact <= 16) ? 1000 : 0; c.prof[18] += (c.nact > 16 && c.nact <= 32) ? 1000 : 0; }   // histogram of active rows (x1000) in two unused slots
 #endif
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] = WST(m.s_warm, i); L[K.l_grad + i] = 1.f / L[K.l_Dinv + i]; L[K.l_tmp + i] = 0.f; } }
+  TMW_FOR {
+    c.dg1[TMW_LI] = 0.f; c.wp1[TMW_LI] = 0.f;
+    for (int i = lane; i < K.nv; i += 64) {
+      L[K.l_qacc + i] = WST(m.s_warm, i);
+      const float dgi = 1.f / L[K.l_Dinv + i];
+      if (i < 64) { c.dg0[TMW_LI] = dgi; c.wp0[TMW_LI] = 0.f; } else { c.dg1[TMW_LI] = dgi; c.wp1[TMW_LI] = 0.f; }
+    }
+  }
   TMW_SYNC();
   // start from the warm start unless the unconstrained acceleration has the lower cost (MJX evaluates warm, smooth and
   // then the winner again; evaluating smooth FIRST leaves M qacc / Jaref of the warm start — the usual winner — in place)
@@ -2046,8 +2071,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     float cost_new = tmw_linesearch(c, K, gauss);
     TMW_TICK(7);
     TMW_COUNT(36, 1000);
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = L[K.l_Mgrad + i]; }
-    TMW_SYNC();
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) TMW_WP_SET(i, L[K.l_Mgrad + i]); }      // (lane-local: the lane that wrote w_i reads it back)
     prev_cost = cost;
     cost = cost_new;
     float den = gn;
@@ -2070,6 +2094,8 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   }
   TMW_STATS(K) += 64.f * (float)it;
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) WST(m.s_warm, i) = L[K.l_qacc + i]; }
+  // (tests: qfrc_constraint shares its words with l_search = l_hdamp in the lean layout — Euler overwrites them)
+  if (c.dump) { TMW_FOR { for (int i = lane; i < K.nv; i += 64) c.dump[(size_t)(m.w_qfrc_constraint + i) * (size_t)c.n + (size_t)c.e] = L[K.l_qfrc_constraint + i]; } }
   TMW_SYNC();
 }
 
@@ -2112,16 +2138,30 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = TMW_QFS(i); }
   TMW_SYNC();
   tmw_solve(c, K, K.l_qacc_smooth);
+  // (tests: qacc_smooth shares its words with the CG's search vector in the lean layout — copied out while it is there)
+  if (c.dump) { TMW_FOR { for (int i = lane; i < K.nv; i += 64) c.dump[(size_t)(m.w_qacc_smooth + i) * (size_t)c.n + (size_t)c.e] = L[K.l_qacc_smooth + i]; } }
   TMW_TICK(5);
   tmw_solve_cg(c, K);
 }
 TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   float h = m.timestep;
-  // qfrc_constraint of the final iterate is in LDS (last tmw_update_gradient); keep the rhs out of the LD alias
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_tmp + i] = TMW_QFS(i) + L[K.l_qfrc_constraint + i]; }
+  // chain layout: the matrix region holds L^-1 of the solver stage, which is dead now; M comes back from the env's global copy in one sweep
+  // (all loads of a lane in flight together: one memory latency for the whole matrix).  The loads are issued FIRST, so that the right-hand side,
+  // timestep * damping and the activation update below run under their latency; Euler then factorises M + h D in place again
+  constexpr int MAXU = 20;                       // nnz <= 1280 (model_host.h)
+  float mr[TMW_NL][MAXU];
+  if (K.m_spilled()) {
+    TMW_FOR {
+#pragma unroll
+      for (int u = 0; u < MAXU; u++) { int i = lane + 64 * u; if (64 * u < K.nnz) mr[TMW_LI][u] = c.mspill[i < K.nnz ? i : K.nnz - 1]; }
+    }
+  }
+  // the right-hand side goes to l_Mgrad, dead since the CG loop ended; it is read here, lane by lane, BEFORE timestep * damping below overwrites
+  // the words l_qfrc_constraint shares with l_search = l_hdamp in the lean layout
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Mgrad + i] = TMW_QFS(i) + L[K.l_qfrc_constraint + i]; }
   // timestep * damping (the diagonal Euler adds to M) into the dead search vector; the activation state is advanced here already — nothing
-  // reads act between tmw_velocity_inertia and the end of the substep — so that ctrl's global load sits next to the loads below
+  // reads act between tmw_velocity_inertia and the end of the substep — so that ctrl's global load sits next to the loads above
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) L[K.l_hdamp + i] = m.timestep * m.dof_damping[i];
     for (int a = lane; a < K.nu; a += 64) {
@@ -2132,27 +2172,20 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
       TMW_ACT(a) = act + ((ctrl - act) / fmaxf(TM_MINVAL, m.act_tau[a])) * h;
     }
   }
-  TMW_SYNC();
-  TMW_TICK(8);
   if (K.m_spilled()) {
-    // the matrix region holds L^-1 of the solver stage, which is dead now: M comes back from the env's global copy in one sweep
-    // (all loads of a lane in flight together: one memory latency for the whole matrix), then Euler factorises it in place again
-    constexpr int MAXU = 20;                       // nnz <= 1280 (model_host.h)
-    float mr[TMW_NL][MAXU];
     TMW_FOR {
-#pragma unroll
-      for (int u = 0; u < MAXU; u++) { int i = lane + 64 * u; if (64 * u < K.nnz) mr[TMW_LI][u] = c.mspill[i < K.nnz ? i : K.nnz - 1]; }
 #pragma unroll
       for (int u = 0; u < MAXU; u++) { int i = lane + 64 * u; if (64 * u < K.nnz && i < K.nnz) L[K.l_M + i] = mr[TMW_LI][u]; }
     }
-    TMW_SYNC();
   }
-  if (K.chains) tmw_factor_chains<true>(c, K, h, K.l_tmp); else tmw_factor(c, K, h, K.l_tmp);
+  TMW_SYNC();
+  TMW_TICK(8);
+  if (K.chains) tmw_factor_chains<true>(c, K, h, K.l_Mgrad); else tmw_factor(c, K, h, K.l_Mgrad);
   TMW_TICK(9);
-  if (K.chains) tmw_subst_chains(c, K, K.l_tmp); else tmw_subst_down(c, K, K.l_tmp);
+  if (K.chains) tmw_subst_chains(c, K, K.l_Mgrad); else tmw_subst_down(c, K, K.l_Mgrad);
   TMW_TICK(11);
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) L[K.l_qvel + i] += L[K.l_tmp + i] * h;
+    for (int i = lane; i < K.nv; i += 64) L[K.l_qvel + i] += L[K.l_Mgrad + i] * h;
   }
   TMW_SYNC();
   TMW_FOR {
@@ -2187,8 +2220,8 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
     for (int i = lane; i < K.nnz; i += 64) WDUMP(m.w_M, i) = K.m_spilled() ? c.mspill[i] : L[K.l_M + i];
     for (int i = lane; i < K.nv * 6; i += 64) WDUMP(m.w_cdof, i) = L[K.l_cdof + i];
     for (int i = lane; i < K.nv; i += 64) {
-      WDUMP(m.w_qfrc_smooth, i) = TMW_QFS(i); WDUMP(m.w_qacc_smooth, i) = L[K.l_qacc_smooth + i];
-      WDUMP(m.w_qacc, i) = L[K.l_qacc + i]; WDUMP(m.w_qfrc_constraint, i) = L[K.l_qfrc_constraint + i];
+      WDUMP(m.w_qfrc_smooth, i) = TMW_QFS(i);        // (qacc_smooth, qfrc_constraint: written where they arise — tmw_forward, tmw_solve_cg)
+      WDUMP(m.w_qacc, i) = L[K.l_qacc + i];
     }
     for (int i = lane; i < K.ncon; i += 64) WDUMP(m.w_con_dist, i) = L[K.l_con_dist + i];
     for (int cc = lane; cc < K.ncon; cc += 64) {
