@@ -1241,7 +1241,8 @@ TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, tmw_f2 (*n)[TMW_NL], tmw_
     TMW_FOR {
       float v = acc[TMW_LI].x + acc[TMW_LI].y;
       TMW_SET_ROW(n, k, v);
-      if (dk > 0 && TMW_MASK(TMW_M_LT(dk))) L[adr0 - lane + (off + dk)] = v;
+      // (lane dk = the row's unit diagonal: stored too, so that the row products of wave_matvec.h can take N = L^-1 with its diagonal)
+      if (TMW_MASK(TMW_M_LT(dk + 1))) L[adr0 - lane + (off + dk)] = v;
     }
   }
 }
@@ -1410,10 +1411,22 @@ TM_DEV void tmw_rowpart_chains(WCtx &c, const WLayout &K, int A, int x, bool dia
   float *L = c.L; TMW_LANE_DECL
   TMW_FOR { tmw_row_runs2<tmw_chain_maxrun(0, 64), tmw_chain_maxrun(64, 73), TMW_RODENT_TRUNK>(L, K, A, x, lane, diag, z0[TMW_LI], z1[TMW_LI]); }
 }
-// x <- M^-1 x using N = L^-1:  x = N D^-1 N^T x   (two sparse mat-vecs; `x` is an LDS vector offset)
-TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
+// (the same mat-vecs on the matrix cores: measured SLOWER than the vector-ALU versions below — see the header — and compiled only with
+// -DTMW_MFMA_MATVEC; tests/test_hostemu_parity.py keeps that build honest)
+#include "wave_matvec.h"
+// x <- M^-1 x using N = L^-1:  x = N D^-1 N^T x   (two sparse mat-vecs; `x` is an LDS vector offset, `tmp` a free one)
+TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x, int tmp) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, z0); TMW_REG(float, z1);
+#ifdef TMW_MFMA_MATVEC
+  if (K.chains) {
+    TMW_TICK2(15);
+    tmw_colprod_mfma<1>(c, K, K.l_LD, x, tmp);
+    TMW_TICK2(26);
+    tmw_rowprod_mfma<true>(c, K, K.l_LD, tmp, x);
+    return;
+  }
+#endif
   if (K.chains) {
     TMW_TICK2(15);
     tmw_colpart_chains<true>(c, K, K.l_LD, x, x);
@@ -1453,6 +1466,15 @@ TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x) {
 // y = M x
 TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
   float *L = c.L; TMW_LANE_DECL
+#ifdef TMW_MFMA_MATVEC
+  if (K.chains) {
+    TMW_TICK2(15);
+    tmw_rowprod_mfma<true>(c, K, K.l_M, x, y);
+    tmw_colprod_mfma<2>(c, K, K.l_M, x, y);
+    TMW_TICK2(24);
+    return;
+  }
+#endif
   if (K.chains) {
     TMW_REG(float, z0); TMW_REG(float, z1);
     TMW_TICK2(15);
@@ -1604,6 +1626,16 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
 TM_DEV void tmw_mul_m_jmul(WCtx &c, const WLayout &K, int x, int y, int out) {
   float *L = c.L; TMW_LANE_DECL
   if (!K.chains) { tmw_mul_m(c, K, x, y); tmw_jmul(c, K, x, out); return; }
+#ifdef TMW_MFMA_MATVEC
+  TMW_TICK2(15);
+  tmw_jmul_stage1(c, K, x);
+  tmw_rowprod_mfma<true>(c, K, K.l_M, x, y);
+  tmw_colprod_mfma<2>(c, K, K.l_M, x, y);       // ends with a barrier: l_sv is complete as well
+  tmw_jmul_stage2(c, K, x, out);
+  TMW_SYNC();
+  TMW_TICK2(24);
+  return;
+#endif
   TMW_REG(float, z0); TMW_REG(float, z1);
   TMW_TICK2(15);
   tmw_jmul_stage1(c, K, x);
@@ -1756,6 +1788,9 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool 
 // x -> out = D^-1 N^T x   (leaf -> root; out may alias x)
 TM_DEV void tmw_solve_up(WCtx &c, const WLayout &K, int x, int out) {
   float *L = c.L; TMW_LANE_DECL
+#ifdef TMW_MFMA_MATVEC
+  if (K.chains) { tmw_colprod_mfma<1>(c, K, K.l_LD, x, out); return; }
+#endif
   if (K.chains) { tmw_colpart_chains<true>(c, K, K.l_LD, x, out); return; }
   TMW_REG(float, z0); TMW_REG(float, z1);
   TMW_FOR {
@@ -1772,6 +1807,9 @@ TM_DEV void tmw_solve_up(WCtx &c, const WLayout &K, int x, int out) {
 // out = N x   (root -> leaf; out may NOT alias x)
 TM_DEV void tmw_solve_down(WCtx &c, const WLayout &K, int x, int out) {
   float *L = c.L; TMW_LANE_DECL
+#ifdef TMW_MFMA_MATVEC
+  if (K.chains) { tmw_rowprod_mfma<true>(c, K, K.l_LD, x, out); return; }
+#endif
   if (K.chains) {
     TMW_REG(float, z0); TMW_REG(float, z1);
     tmw_rowpart_chains(c, K, K.l_LD, x, false, z0, z1);
@@ -2137,7 +2175,7 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   if (TMW_STOP <= 4) return;
   TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = TMW_QFS(i); }
   TMW_SYNC();
-  tmw_solve(c, K, K.l_qacc_smooth);
+  tmw_solve(c, K, K.l_qacc_smooth, K.l_Mgrad);
   // (tests: qacc_smooth shares its words with the CG's search vector in the lean layout — copied out while it is there)
   if (c.dump) { TMW_FOR { for (int i = lane; i < K.nv; i += 64) c.dump[(size_t)(m.w_qacc_smooth + i) * (size_t)c.n + (size_t)c.e] = L[K.l_qacc_smooth + i]; } }
   TMW_TICK(5);
