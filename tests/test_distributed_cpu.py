@@ -117,11 +117,15 @@ def _seeded(ln, rank):
     ln._minibatch_grads = f
 
 
-def _learner_worker(rank, world, port, q, groups=1):
+def _learner_worker(rank, world, port, q, groups=1, single_bucket=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ["TMJX_BUCKET_OVERLAP"] = "0" if single_bucket else "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ln = _make_learner(4 * world, groups)         # global batch_size; every rank takes batch_size / world rows of each minibatch
     assert ln.world == 2 and ln.local_batch == 4 and ln.unrolls == 2 and ln.n_local == _NLOC and len(ln.envs) == groups
+    # C1 runs as TWO buckets (value network | policy) unless switched off: the split sits where the value network's parameters begin
+    assert ln.overlap_c1 == (not single_bucket) and 0 < ln._bucket_split < ln.grads.flat.numel()
+    assert ln._bucket_split == sum((r * pc + 3) // 4 * 4 for _, r, _, pc in ln.grads.segs[:ln._n_policy_params])
     for k, v in _shard_data(rank).items():
         ln.buf[k].copy_(v)
     ln.perm_fn = _perm(rank)
@@ -184,3 +188,28 @@ def test_two_rank_learner_update_matches_manual_gradient_average(groups):
     np.testing.assert_allclose(got[0][0], ref, rtol=2e-4, atol=2e-6)
     moved = np.abs(ref - _make_learner(4).opt.flat.numpy()).max()
     assert moved > 1e-3, "the update must have moved the parameters"
+
+
+def test_bucketed_gradient_all_reduce_is_bit_identical_to_the_single_bucket():
+    """C1 as two all-reduces (the value network's bucket first: on the GPU it is issued behind the value network's backward graph and travels
+    while the policy's backward pass runs — PPOLearner._capture_split) against ONE all-reduce of the whole flat buffer
+    (TMJX_BUCKET_OVERLAP=0): an element-wise mean either way, so two gloo ranks must end on the same bits.
+    Reference: track_mjx/agent/mlp_ppo/ppo.py:621-623 (the pmean inside the jitted step, where XLA overlaps it)."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for single in (False, True):
+        q = ctx.Queue()
+        port = 33500 + (os.getpid() % 2000) + (11 if single else 0)
+        procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q, 1, single)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = dict()
+        for _ in range(2):
+            r = q.get(timeout=180)
+            got[r[0]] = r[1:]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert np.array_equal(got[0][0], got[1][0])
+        res[single] = got[0][0]
+    assert np.array_equal(res[False], res[True])

@@ -45,6 +45,7 @@ def test_training_step_with_rccl_collectives_on_one_rank(monkeypatch):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
     try:
         monkeypatch.setenv("TMJX_COLLECTIVES_ALWAYS", "1")
+        monkeypatch.setenv("TMJX_BUCKET_OVERLAP", "1")          # (the small test nets are below the size at which the learner buckets by itself)
         ones = torch.ones(4, device=dev)
         dist.all_reduce(ones)
         assert ones.tolist() == [1.0] * 4
@@ -53,13 +54,26 @@ def test_training_step_with_rccl_collectives_on_one_rank(monkeypatch):
         for it in range(2):
             m = L.training_step(it)
         torch.cuda.synchronize()
-        assert L._graph is not None, "the SGD step must still run as a captured graph with RCCL initialised"
+        # with collectives the step runs as THREE graphs (forward + loss head | value backward | policy backward) and C1 as two buckets, the value
+        # network's all-reduce issued behind ITS graph while the policy's backward graph runs (PPOLearner._capture_split)
+        assert L.overlap_c1 and L._split_graphs is not None and L._graph is None, "the bucketed SGD step must run as captured graphs with RCCL initialised"
         assert all(bool(torch.isfinite(v).all()) for v in m.values())
         dp = (L.opt.flat - want).abs().max().item()
         dm = (L.normalizer.mean - want_mean).abs().max().item()
         print(f"\n[rccl one rank] max |param diff| vs plain learner {dp:.3e}, max |obs-mean diff| {dm:.3e}")
         assert dm <= 1e-6 * (1 + want_mean.abs().max().item())
         assert dp <= 1e-5, "identity collectives changed the training step"
+        # the same kernels on the same data, cut into three graphs: bit-identical parameters
+        assert dp == 0.0, dp
+        # ... and the single-bucket path (TMJX_BUCKET_OVERLAP=0: one graph, one all-reduce of the whole buffer) likewise
+        monkeypatch.setenv("TMJX_BUCKET_OVERLAP", "0")
+        L1 = _learner(0)
+        assert L1.collectives and not L1.overlap_c1
+        for it in range(2):
+            L1.training_step(it)
+        torch.cuda.synchronize()
+        assert L1._graph is not None and L1._split_graphs is None
+        assert (L1.opt.flat - want).abs().max().item() == 0.0
     finally:
         dist.barrier()
         dist.destroy_process_group()

@@ -79,9 +79,23 @@ class FlatGrads:
             if not self.params[i].grad.is_contiguous():
                 self.params[i].grad.copy_(grads[i])
 
-    def all_reduce_mean(self, group=None, force: bool = False):
-        """`force`: issue the collective on a one-rank group too (identity) — lets a single-GPU box exercise the RCCL call path."""
+    def assign_subset(self, params, grads):
+        """`assign` for a subset of the parameters (one network's backward pass: PPOLearner's bucketed gradient all-reduce)."""
+        todo = [(p, g) for p, g in zip(params, grads) if g.data_ptr() != p.grad.data_ptr()]
+        dense = [(p, g) for p, g in todo if p.grad.is_contiguous()]
+        if dense:
+            torch._foreach_copy_([p.grad for p, _ in dense], [g for _, g in dense])
+        for p, g in todo:
+            if not p.grad.is_contiguous():
+                p.grad.copy_(g)
+
+    def all_reduce_mean(self, group=None, force: bool = False, lo: int | None = None, hi: int | None = None, async_op: bool = False):
+        """`force`: issue the collective on a one-rank group too (identity) — lets a single-GPU box exercise the RCCL call path.
+        `lo:hi`: one BUCKET of the flat buffer (the policy's or the value network's gradients); `async_op`: return the work handle(s) instead of
+        waiting — the caller overlaps the collective with the other network's backward pass and calls `.wait()` in front of the optimiser."""
+        works = []
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
+            buf = self.flat if lo is None else self.flat[lo:hi]
             if self._avg_ok is None:       # RCCL reduces with ncclAvg itself (no separate division launch); gloo (CPU tests) has no AVG
                 try:
                     probe = torch.ones(1, dtype=self.flat.dtype, device=self.flat.device)
@@ -90,10 +104,16 @@ class FlatGrads:
                 except Exception:  # noqa: BLE001 — backend without AVG: sum, then divide
                     self._avg_ok = False
             if self._avg_ok:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+                w = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-                self.flat.div_(dist.get_world_size(group))
+                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+                if async_op:
+                    w.wait()               # (gloo: CPU tests — the division needs the sum)
+                    w = None
+                buf.div_(dist.get_world_size(group))
+            if async_op and w is not None:
+                works.append(w)
+        return works
 
     def clip_by_global_norm(self, max_norm: float):
         norm = torch.linalg.vector_norm(self.flat)
@@ -231,6 +251,16 @@ class PPOLearner:
         self.value = ValueNet(obs, critic_layers).to(dev)
         self.params = list(self.policy.parameters()) + list(self.value.parameters())
         self.grads = FlatGrads(self.params)
+        self._n_policy_params = len(list(self.policy.parameters()))
+        # C1 in TWO buckets (the flat buffer is [policy | value]): the value network's gradients are reduced while the policy's backward pass
+        # still runs (update()).  The reference's pmean sits inside the jitted step where XLA overlaps it (ppo.py:621-623)
+        self._bucket_split = self.grads.segs[self._n_policy_params][0]
+        # Used when the gradient buffer is large (>= 8 MB: the rodent-mc-intention nets' 17.2 MB, ~ 0.2 ms on a ring) — cutting the captured
+        # step into three graphs and issuing two collectives costs ~ 0.15 ms per minibatch step (measured with a one-rank RCCL group,
+        # profiles/r04_bench_selflaunch_one_rank_bucketed.json), more than the 2.49 MB buffer of the 2x256 nets takes to reduce.  TMJX_BUCKET_OVERLAP=1 / 0 forces it
+        big = self.grads.flat.numel() * self.grads.flat.element_size() >= 8 << 20
+        force = os.environ.get("TMJX_BUCKET_OVERLAP")
+        self.overlap_c1 = self.collectives and (big if force is None else force == "1")
         self.opt = FlatAdam(self.grads, learning_rate, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0)   # optax.clip_by_global_norm(10.0) -> adam
         self.normalizer = RunningStatistics(obs, dev)
         self.gen = torch.Generator(device=dev).manual_seed(seed * 1000 + 17 + self.rank)
@@ -255,6 +285,8 @@ class PPOLearner:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)    # intentional: the value net's gradients arrive from the side stream
         self._metric_index = torch.tensor([0, 1, 2, 4, 3], dtype=torch.long, device=dev)    # METRIC_KEYS -> slots of tmjx_ppo_loss's output
         self.use_graph, self._graph, self._graph_kl, self._graph_selfadv = use_graph, None, None, None
+        self._split_graphs = None          # (forward + loss head, value backward, policy backward) of the bucketed step
+        self._c1_side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # self-advancing SGD step (tmjx_minibatch_begin): the epoch's permutation, {draw counter, slot, ticket}, the metric accumulator
         self._perm_static = torch.zeros(rows, dtype=torch.long, device=dev)
         self._mb_state = torch.zeros(16 + 16 * 64, dtype=torch.long, device=dev)     # TMJX_MINIBATCH_STATE_WORDS: {draw counter, slot, tickets ...}
@@ -548,10 +580,7 @@ class PPOLearner:
         return (self.dev.type == "cuda" and self.normalize_observations and self.buf["observation"].shape[-1] % 4 == 0
                 and all(v.is_contiguous() for v in self.buf.values()) and not os.environ.get("TMJX_NO_SELF_ADVANCE"))
 
-    def _minibatch_grads(self, idx: torch.Tensor | None, kl_w: float) -> torch.Tensor:
-        """Gather one minibatch, loss, gradients into the flat buffer; returns the 5 loss terms as one tensor.  idx None: the self-advancing
-        form — rows from the epoch's permutation at the device-side slot counter, noise from the device-side Philox stream, metrics added
-        to self._acc8: a captured graph of it replays with NO host input (no index copy, no torch generator state to refresh)."""
+    def _mb_data(self, idx):
         fused_gather = self.dev.type == "cuda" and self.normalize_observations and self.buf["observation"].shape[-1] % 4 == 0
         if idx is None:
             data = _losses.minibatch_begin({**self.buf, "_B": self.local_batch}, self._perm_static, self._mb_state, self._noise_seed, self.normalizer,
@@ -562,25 +591,116 @@ class PPOLearner:
             data = {k: (self.buf[k].index_select(1, idx) if k != "next_observation_last" else self.buf[k].index_select(0, idx)) for k in self.buf}
         if self.shadows is not None:
             self.shadows.refresh()          # one launch: the optimiser step behind the previous replay changed the master weights
+        return data
+
+    def _mb_forward(self, idx, kl_w):
+        """GPU: gather + both networks' forward passes + the loss head (outside autograd).  Returns (network outputs, their gradients, the loss
+        kernel's eight scalars) for _mb_backward."""
+        data = self._mb_data(idx)
         with gemm_inputs(self.matmul_dtype, self.shadows):
-            if self.dev.type == "cuda":
-                # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
-                m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,
-                                                                         side_stream=self._sgd_side, acc_out=self._acc8 if idx is None else None, **self.hp)
-                with deferred_weight_grads() as dwg:
-                    grads = torch.autograd.grad(outs, self.grads.params, grad_outputs=gouts)
-                if self._sgd_side is not None:
-                    torch.cuda.current_stream(self.dev).wait_stream(self._sgd_side)     # the value net's backward ran there
-                dwg.launch()             # every layer's (dW, db) in one grouped launch, straight into the flat gradient buffer
-                self._dwg = dwg          # (keeps the slab scratch alive until the next step)
-                self.grads.assign(grads)
-                if idx is None:
-                    return self._acc8                    # (the loss kernel added this step's scalars; reordered to METRIC_KEYS once per update())
-                return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
+            m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,
+                                                                     side_stream=self._sgd_side, acc_out=self._acc8 if idx is None else None, **self.hp)
+        return outs, gouts, out8
+
+    def _mb_backward(self, outs, gouts, which: str = "all"):
+        """One backward pass from the network outputs with the loss head's gradients as `grad_outputs`.  which = "all": both networks in one
+        autograd call (the single-GPU step); "value" / "policy": one network — its gradients land in its bucket of the flat buffer, so that the
+        bucket's all-reduce can start while the other network's pass still runs.  outs = (logits, baseline[, fc2])."""
+        npol = self._n_policy_params
+        if which == "all":
+            o, g, params = list(outs), list(gouts), self.grads.params
+        elif which == "value":
+            o, g, params = [outs[1]], [gouts[1]], self.grads.params[npol:]
+        else:
+            o, g, params = [outs[0]] + list(outs[2:]), [gouts[0]] + list(gouts[2:]), self.grads.params[:npol]
+        with gemm_inputs(self.matmul_dtype, self.shadows):
+            with deferred_weight_grads() as dwg:
+                grads = torch.autograd.grad(o, params, grad_outputs=g)
+            if which != "policy" and self._sgd_side is not None:
+                torch.cuda.current_stream(self.dev).wait_stream(self._sgd_side)     # the value net's backward ran there
+            dwg.launch()             # every layer's (dW, db) in one grouped launch, straight into the flat gradient buffer
+        setattr(self, "_dwg_" + which, dwg)          # (keeps the slab scratch alive until the next step)
+        if which == "all":
+            self.grads.assign(grads)
+        else:
+            self.grads.assign_subset(params, grads)
+
+    def _minibatch_grads(self, idx: torch.Tensor | None, kl_w: float) -> torch.Tensor:
+        """Gather one minibatch, loss, gradients into the flat buffer; returns the 5 loss terms as one tensor.  idx None: the self-advancing
+        form — rows from the epoch's permutation at the device-side slot counter, noise from the device-side Philox stream, metrics added
+        to self._acc8: a captured graph of it replays with NO host input (no index copy, no torch generator state to refresh)."""
+        if self.dev.type == "cuda":
+            # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
+            outs, gouts, out8 = self._mb_forward(idx, kl_w)
+            self._mb_backward(outs, gouts, "all")
+            if idx is None:
+                return self._acc8                    # (the loss kernel added this step's scalars; reordered to METRIC_KEYS once per update())
+            return out8[self._metric_index]          # (total, policy, v, kl, entropy) in METRIC_KEYS order: one gather
+        data = self._mb_data(idx)
+        with gemm_inputs(self.matmul_dtype, self.shadows):
             loss, m = _losses.compute_ppo_loss(self.policy, self.value, self.normalizer, data, kl_weight=kl_w, **self.hp,
                                                **({"gae_fn": self.gae_fn} if self.gae_fn is not None else {}))
         self.grads.assign(torch.autograd.grad(loss, self.grads.params))
         return torch.stack([m[k].float() for k in self.METRIC_KEYS])
+
+    def _bucketed_step_eager(self, idx, kl_w):
+        """The minibatch step with C1 in two buckets, launched eagerly (no hipGraph): forward + loss head, the value network's backward on the
+        side stream followed by ITS bucket's all-reduce, the policy's backward on the main stream meanwhile, then the policy bucket.  Returns
+        (metrics tensor, work handles to wait for in front of the optimiser)."""
+        cur = torch.cuda.current_stream(self.dev)
+        outs, gouts, out8 = self._mb_forward(idx, kl_w)
+        side = self._c1_side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._mb_backward(outs, gouts, "value")
+            works = self.grads.all_reduce_mean(self.group, force=True, lo=self._bucket_split, hi=None, async_op=True)
+        self._mb_backward(outs, gouts, "policy")
+        works += self.grads.all_reduce_mean(self.group, force=True, lo=0, hi=self._bucket_split, async_op=True)
+        cur.wait_stream(side)
+        return (self._acc8 if idx is None else out8[self._metric_index]), works
+
+    def _capture_split(self, kl_w: float):
+        """The bucketed step as THREE hipGraphs: G1 = gather + forward passes + loss head, Gv = the value network's backward (+ its weight
+        gradients), Gp = the policy's.  update() replays G1, then Gv on a side stream and Gp on the main stream CONCURRENTLY (as the two
+        branches of the single-GPU graph do), and issues each bucket's all-reduce eagerly behind its graph: the value bucket travels while Gp
+        runs.  No collective is captured; every graph has its own memory pool (Gv and Gp replay side by side and must not share scratch)."""
+        selfadv = self._self_advancing()
+        self._g_idx = None if selfadv else torch.zeros(self.local_batch, dtype=torch.long, device=self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        warm = torch.cuda.Stream(device=self.dev)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):
+            for _ in range(3):
+                if selfadv:
+                    self._mb_state[1:].zero_()
+                outs, gouts, _ = self._mb_forward(self._g_idx, kl_w)
+                self._mb_backward(outs, gouts, "value"); self._mb_backward(outs, gouts, "policy")
+        cur.wait_stream(warm)
+        torch.cuda.synchronize(self.dev)
+        g1, gv, gp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # thread_local: the RCCL watchdog thread polls events concurrently and must not invalidate the capture
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+            outs, gouts, out8 = self._mb_forward(self._g_idx, kl_w)
+            self._g_out = self._acc8 if selfadv else out8[self._metric_index]
+        with torch.cuda.graph(gv, capture_error_mode="thread_local"):
+            self._mb_backward(outs, gouts, "value")
+        with torch.cuda.graph(gp, capture_error_mode="thread_local"):
+            self._mb_backward(outs, gouts, "policy")
+        del outs, gouts
+        self._split_graphs, self._graph_kl, self._graph_selfadv = (g1, gv, gp), kl_w, selfadv
+
+    def _bucketed_step_replay(self):
+        g1, gv, gp = self._split_graphs
+        cur, side = torch.cuda.current_stream(self.dev), self._c1_side
+        g1.replay()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            gv.replay()
+            works = self.grads.all_reduce_mean(self.group, force=True, lo=self._bucket_split, hi=None, async_op=True)
+        gp.replay()
+        works += self.grads.all_reduce_mean(self.group, force=True, lo=0, hi=self._bucket_split, async_op=True)
+        cur.wait_stream(side)
+        return works
 
     METRIC_KEYS = ("total_loss", "policy_loss", "v_loss", "kl_latent_loss", "entropy_loss")
     # tests of the torch (CPU) branch only: a GAE implementation for hosts without the HIP kernel (the product default, tmjx_gae, raises there)
@@ -616,16 +736,16 @@ class PPOLearner:
         kl_w = kl_schedule(it) if kl_schedule is not None else self.kl_weight
         rows = self.buf["reward"].shape[1]
         use_graph = self.use_graph and self.dev.type == "cuda"
-        if use_graph and (self._graph is None or self._graph_kl != kl_w):
+        bucketed = self.overlap_c1 and self.dev.type == "cuda"          # C1 in two buckets, overlapped with the policy's backward pass
+        have = (self._split_graphs is not None) if bucketed else (self._graph is not None)
+        selfadv = self._self_advancing()
+        if use_graph and (not have or self._graph_kl != kl_w or self._graph_selfadv != selfadv):
             try:
-                self._capture(kl_w)
+                (self._capture_split if bucketed else self._capture)(kl_w)
             except Exception as e:  # noqa: BLE001 — capture is an optimisation: fall back to eager launches, loudly
                 print(f"[track_mjx_amd] hipGraph capture of the SGD step failed ({type(e).__name__}: {e}); running eagerly", flush=True)
                 self.use_graph = use_graph = False
                 torch.cuda.synchronize(self.dev)
-        selfadv = self._self_advancing()
-        if use_graph and self._graph_selfadv != selfadv:
-            self._capture(kl_w)
         acc = torch.zeros(len(self.METRIC_KEYS), dtype=torch.float32, device=self.dev)
         if selfadv:
             self._acc8.zero_()
@@ -637,14 +757,27 @@ class PPOLearner:
                 self._mb_state[1:2].zero_()                   # slot 0 of the new permutation
             for mb in range(self.num_minibatches):
                 idx = None if selfadv else perm[mb * self.local_batch:(mb + 1) * self.local_batch]
-                if use_graph:
-                    if not selfadv:
-                        self._g_idx.copy_(idx)
-                    self._graph.replay()
-                    out = self._g_out
+                if use_graph and not selfadv:
+                    self._g_idx.copy_(idx)
+                if bucketed:
+                    # C1 as two all-reduces, the value network's issued as soon as ITS backward pass is done (it overlaps the policy's)
+                    if use_graph:
+                        works, out = self._bucketed_step_replay(), self._g_out
+                    else:
+                        out, works = self._bucketed_step_eager(idx, kl_w)
+                    for w in works:
+                        w.wait()
                 else:
-                    out = self._minibatch_grads(idx, kl_w)
-                self.grads.all_reduce_mean(self.group, force=self.collectives)       # C1: one RCCL all-reduce per minibatch step
+                    if use_graph:
+                        self._graph.replay()
+                        out = self._g_out
+                    else:
+                        out = self._minibatch_grads(idx, kl_w)
+                    if self.overlap_c1:     # CPU (gloo tests): the same two buckets, nothing to overlap with
+                        self.grads.all_reduce_mean(self.group, force=True, lo=self._bucket_split, hi=None)
+                        self.grads.all_reduce_mean(self.group, force=True, lo=0, hi=self._bucket_split)
+                    else:
+                        self.grads.all_reduce_mean(self.group, force=self.collectives)       # C1: one RCCL all-reduce per minibatch step
                 self.opt.step()                               # clip_by_global_norm(10.0) -> adam (ppo.py:517-520), one fused launch
                 if not selfadv:
                     acc += out
