@@ -205,6 +205,14 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
 int tmjx_linear_nolds_norm(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
                            const float *mean, const float *inv_std, void *stream);
 
+/* The LDS-free dense layer in bf16 GEMM-input mode (BASELINE config 5): the fp32 activations are rounded to bf16 in registers, W is the layer's
+ * resident bf16 shadow [N][ldw] (tmjx_bf16_shadow: rows zero padded to ldw, a multiple of 64), fp32 accumulate on v_mfma_f32_16x16x32_bf16 — the
+ * operand rounding of the learner's tmjx_bgemm_* forward pass, so that the roll-out's behaviour log-prob and the learner's first-pass log-prob
+ * agree (reference: one jitted policy serves both, track_mjx/agent/mlp_ppo/ppo_networks.py:46-96).  mean / inv_std: NULL or the operand's
+ * normaliser as in tmjx_linear_nolds_norm. */
+int tmjx_linear_nolds_bf16(const float *A, int64_t sa_row, int64_t sa_k, const uint16_t *W, int ldw, const float *bias, float *C, int M, int N, int K,
+                           const float *mean, const float *inv_std, void *stream);
+
 /* out[width] = column sums of the row-major src[rows][width] (the bias gradient dy.sum(0) of a dense layer: flax nn.Dense's bias in
  * track_mjx/agent/mlp_ppo/intention_network.py:32-44 and brax's value MLP); `scratch`: tmjx_colsum_scratch_floats(width) floats. */
 int tmjx_colsum_scratch_floats(int width);

@@ -194,3 +194,104 @@ def test_bgemm_silu_forward_and_backward_epilogues(M, N, K, lda, yf32):
     rz = gy * (sig * (1 + v * (1 - sig)))
     assert ((dz.double() - rz).abs() <= 2.0 ** -8 * rz.abs() + 3e-5 * rz.abs().max()).all()
     assert (partial.double().sum(0) - rz.sum(0)).abs().max() <= 2e-3 * rz.sum(0).abs().max() + 1e-4
+
+
+@pytest.mark.parametrize("kmajor,norm", [(False, False), (True, True), (False, True)])
+@pytest.mark.parametrize("M,N,K", [(1368, 1024, 470), (2732, 512, 512), (1364, 256, 512), (1368, 120, 512), (1365, 76, 256), (100, 512, 286), (33, 40, 36)])
+def test_linear_nolds_bf16(M, N, K, kmajor, norm):
+    """tmjx_linear_nolds_bf16 (the acting policy's layer in bf16 GEMM-input mode, LDS-free): bf16-rounded activations x the bf16 shadow, fp32
+    accumulate, against float64 torch on the SAME rounded operands; row-major and [k][row] (the env's observation buffer) activations, with and
+    without the normaliser applied while the operand is loaded.  The learner's forward kernel on the same inputs must agree to fp32
+    accumulation error: ONE set of numerics for acting and learning."""
+    import ctypes as C
+    from track_mjx_amd import hip as _hip
+    from track_mjx_amd.agent.networks import Bf16Shadows, bgemm_nt, _dense
+    if kmajor and M % 4:
+        M = M // 4 * 4
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + int(kmajor))
+    lin = _dense(K, N).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn((N, K), generator=g, device=DEV) / K ** 0.5)
+        lin.bias.copy_(torch.randn(N, generator=g, device=DEV))
+    sh = Bf16Shadows([lin])
+    sh.refresh()
+    Kp = (K + 3) // 4 * 4
+    if kmajor:
+        buf = torch.randn((Kp + 8, M), generator=g, device=DEV)        # [k][row]: more rows than K, as the 696-row observation buffer behind the 470 reference rows
+        x = buf[:Kp].t()                                              # logical [M][Kp]
+        sa_row, sa_k = 1, M
+    else:
+        buf = torch.randn((M, Kp), generator=g, device=DEV)
+        buf[:, K:] = 0                                                # (activation rows are zero padded to a multiple of 4)
+        x = buf
+        sa_row, sa_k = Kp, 1
+    mean = torch.randn(Kp, generator=g, device=DEV) * 0.3 if norm else None
+    istd = (torch.rand(Kp, generator=g, device=DEV) + 0.5) if norm else None
+    if norm:
+        mean[K:] = 0; istd[K:] = 0
+    out = torch.empty((M, N), device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    w = sh.w[lin]
+    _hip.check(_hip.lib().tmjx_linear_nolds_bf16(p(buf), sa_row, sa_k, p(w), w.stride(0), p(lin.bias), p(out), M, N, Kp, p(mean), p(istd),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tmjx_linear_nolds_bf16")
+    torch.cuda.synchronize()
+    xa = ((x - mean) * istd) if norm else x          # fp32, as the kernel forms it
+    a64, w64 = _bf(xa[:, :K]).double(), _bf(lin.weight.detach()).double()
+    ref = a64 @ w64.t() + lin.bias.detach().double()
+    bound = (a64.abs() @ w64.abs().t()) * EPS * (K ** 0.5 + 4) * 2 + lin.bias.detach().abs().double() * EPS * 2 + 1e-30
+    err = (out.double() - ref).abs()
+    assert (err <= bound).all(), float((err / bound).max())
+    # the learner's forward kernel (LDS tiles, v_cvt at the LDS write) on the same operands
+    y = bgemm_nt(xa[:, :K].contiguous() if K % 4 == 0 else torch.nn.functional.pad(xa[:, :K], (0, Kp - K))[:, :K], w, N, K, lin.bias)
+    torch.cuda.synchronize()
+    assert ((y.double() - out.double()).abs() <= 2 * bound).all()
+
+
+def test_bf16_mode_acting_and_learning_share_their_numerics():
+    """BASELINE config 5's bf16 GEMM-input mode: the behaviour log-prob a roll-out stores (acting policy, LDS-free kernels) and the learner's
+    first-pass log-prob of the same actions must come from ONE set of numerics, so that the PPO ratio starts at 1 (round-3 advisor finding:
+    the acting path ran on the fp32 kernels and the ratio carried a bf16-sized bias).  (1) a pipelined roll-out (two env groups: the LDS-free
+    acting path) in bf16 mode runs and stores finite log-probs; (2) the encoder stack through the acting path's kernels
+    (tmjx_linear_nolds_bf16 + tmjx_silu_ln_fwd, layer by layer as PPOLearner._act_fused launches them) against the learner's bf16-mode forward
+    of the same observations: agreement far inside the gap that the fp32 acting kernels leave."""
+    import ctypes as C
+    from tests.common import make_env_and_oracle
+    from track_mjx_amd import hip as _hip
+    from track_mjx_amd.agent import ppo
+    from track_mjx_amd.agent.networks import gemm_inputs
+    envs = [make_env_and_oracle(num_envs=128, n_clips=4, wrappers=True, seed=k)[0] for k in range(2)]
+    L = ppo.PPOLearner(envs, encoder_layers=(256, 128), decoder_layers=(128, 128), critic_layers=(128, 128), latents=60, unroll_length=4,
+                       batch_size=256, num_minibatches=1, num_updates_per_batch=1, seed=5, matmul_dtype=torch.bfloat16)
+    assert L.shadows is not None and L.lds_free
+    for k, e in enumerate(envs):
+        L.states[k] = e.reset(torch.Generator().manual_seed(20 + k))
+    L.collect()
+    torch.cuda.synchronize()
+    assert torch.isfinite(L.buf["log_prob"]).all() and torch.isfinite(L.buf["raw_action"]).all()
+    obs = L.buf["observation"][0]
+    ref_w = L.policy.reference_obs_size
+    h = torch.nn.functional.pad(L.normalizer.normalize(obs)[:, :ref_w], (0, (-ref_w) % 4)).contiguous()      # rows padded to a multiple of 4 floats (zeros)
+    x = h[:, :ref_w]                                                                                          # (16-byte aligned rows, as the learner's gather makes them)
+    with torch.no_grad(), gemm_inputs(L.matmul_dtype, L.shadows):
+        fc2_learn = L.policy.fc2(L.policy.encoder(x))
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = x.shape[0]
+    lib = _hip.lib()
+    for blk in L.policy.encoder:
+        w = L.shadows.w[blk.dense]
+        z = torch.empty((n, blk.dense.out_features), device=DEV)
+        _hip.check(lib.tmjx_linear_nolds_bf16(p(h), h.shape[1], 1, p(w), w.stride(0), None, p(z), n, blk.dense.out_features, h.shape[1], None, None, stream), "nolds_bf16")
+        y = torch.empty_like(z); stats = torch.empty((n, 2), device=DEV)
+        _hip.check(lib.tmjx_silu_ln_fwd(p(z), p(blk.dense.bias), p(blk.norm.weight), p(blk.norm.bias), p(y), p(stats), n, blk.dense.out_features, float(blk.norm.eps), stream), "silu_ln")
+        h = y
+    w = L.shadows.w[L.policy.fc2]
+    fc2_act = torch.empty((n, L.policy.fc2.out_features), device=DEV)
+    _hip.check(lib.tmjx_linear_nolds_bf16(p(h), h.shape[1], 1, p(w), w.stride(0), p(L.policy.fc2.bias), p(fc2_act), n, L.policy.fc2.out_features, h.shape[1], None, None, stream), "nolds_bf16")
+    with torch.no_grad():
+        fc2_f32 = L.policy.fc2(L.policy.encoder(x))           # the fp32 kernels: what the acting path ran on before
+    torch.cuda.synchronize()
+    scale = fc2_learn.abs().max().item()
+    d_bf, d_f32 = (fc2_act - fc2_learn).abs().max().item() / scale, (fc2_f32 - fc2_learn).abs().max().item() / scale
+    print(f"\nbf16 mode, encoder output against the learner's forward pass (relative): bf16 acting kernels {d_bf:.2e}, fp32 acting kernels {d_f32:.2e}")
+    assert d_bf <= 0.25 * d_f32 and d_bf < 2e-3

@@ -386,7 +386,22 @@ class PPOLearner:
         with torch.cuda.device(self.dev):
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
+            # bf16 GEMM-input mode (BASELINE config 5): the acting policy's layers take the SAME operand rounding as the learner's forward pass
+            # (bf16 activations x the resident bf16 shadows, fp32 accumulate: tmjx_linear_nolds_bf16) — the behaviour log-prob stored with a
+            # roll-out and the learner's first-pass log-prob then come from one set of numerics and the PPO ratio starts at 1
+            bf = self.shadows if (lds_free and self.matmul_dtype == torch.bfloat16) else None
+
+            def linear_bf16(a, sa_row, sa_k, lin, bias, mean=None, inv_std=None):
+                wsh = bf.w[lin]
+                Kp = (lin.in_features + 3) // 4 * 4          # (activation rows are padded to a multiple of 4 with zeros; the shadow is zero there too)
+                out = torch.empty((n, lin.out_features), **f32)
+                _hip.check(L.tmjx_linear_nolds_bf16(p(a), sa_row, sa_k, p(wsh), wsh.stride(0), p(lin.bias) if bias else None, p(out), n, lin.out_features,
+                                                    Kp, p(mean), p(inv_std), stream), "tmjx_linear_nolds_bf16")
+                return out
+
             def linear(a, sa_row, sa_k, K, lin, bias=True):
+                if bf is not None and lin in bf.w:
+                    return linear_bf16(a, sa_row, sa_k, lin, bias)
                 # weights whose row length is not a multiple of 4 are used through a zero-padded copy (refreshed at the start of
                 # every collect()): the kernel then takes its float4 path; the extra k read finite activations x 0
                 w = self._padded_weight(lin)
@@ -396,7 +411,9 @@ class PPOLearner:
                 return out
 
             def block(a, sa_row, sa_k, K, blk, folded=False):
-                if folded:      # the operand is normalised while it is loaded (mean / inv_std padded with 0 / 0 to the weight's padded K)
+                if folded and bf is not None and blk.dense in bf.w:
+                    z, bias_v = linear_bf16(a, sa_row, sa_k, blk.dense, False, self._fold[0], self._fold[1]), blk.dense.bias
+                elif folded:      # the operand is normalised while it is loaded (mean / inv_std padded with 0 / 0 to the weight's padded K)
                     w = self._padded_weight(blk.dense)
                     z = torch.empty((n, blk.dense.out_features), **f32)
                     _hip.check(L.tmjx_linear_nolds_norm(p(a), sa_row, sa_k, p(w), None, p(z), n, blk.dense.out_features, w.shape[1],
@@ -482,6 +499,8 @@ class PPOLearner:
     def _refresh_padded_weights(self) -> None:
         for lin, buf in self._wpad.items():
             buf[:, :lin.in_features].copy_(lin.weight.detach())
+        if self.shadows is not None:
+            self.shadows.refresh()       # bf16 mode: the acting policy reads the shadows too (the SGD step refreshes them only at its START)
         # mean and 1 / std of the reference part of the observation for tmjx_linear_nolds_norm (padded to the first layer's padded K: the pad
         # columns of the weight are zero); persistent buffers (the inference graphs hold their addresses), rewritten in place
         if self.lds_free and self.normalize_observations:

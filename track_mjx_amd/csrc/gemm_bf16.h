@@ -735,3 +735,90 @@ __global__ __launch_bounds__(256) void k_bgemm_dw_reduce(const float *__restrict
   const float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   if (k < K) dW[(size_t)n * lddw + k] = v; else db[n] = v;
 }
+
+
+// ---- The ACTING policy's dense layer in bf16 GEMM-input mode, without LDS (the bf16 twin of csrc/ppo_kernels.h: k_linear_nolds_mfma; the acting
+// policy runs next to the other env groups' physics kernel, which owns every CU's LDS).  C[M][N] = A[M][K] W^T (+ bias): the fp32 activations are
+// rounded to bf16 in registers (v_cvt_pk_bf16_f32 — the rounding the learner's kernels apply when they stage a tile), W is the layer's resident
+// bf16 shadow [N][ldw] (zero padded to a multiple of 64 columns: tmjx_bf16_shadow), fp32 accumulate on v_mfma_f32_16x16x32_bf16: one
+// instruction per 32 k where the fp32 kernel needs eight, half the weight bytes — and the SAME operand rounding as the SGD forward pass, so that
+// the behaviour log-prob of a roll-out and the learner's first-pass log-prob agree (the PPO ratio starts at 1).
+// One wave per 32 x 32 output tile; a lane's 8 consecutive k (k = 32 s + 8 (lane / 16) ..) feed one operand register of each of the 2 x 2 tiles.
+// `mean` / `inv_std` (optional, [K]): the operand is (A - mean) * inv_std (the observation normaliser, first layer).
+template <bool A_KMAJOR>
+__global__ __launch_bounds__(64) void k_linear_nolds_bf16(const float *__restrict__ A, long long sa_row, long long sa_k, const bf16_t *__restrict__ W, int ldw,
+                                                          const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
+                                                          const float *__restrict__ mean, const float *__restrict__ inv_std) {
+  const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
+  int ar[2], wc[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) { int r = row0 + 16 * t + li; ar[t] = r < M ? r : M - 1; int c = col0 + 16 * t + li; wc[t] = c < N ? c : N - 1; }
+  bgf4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = bgf4{0.f, 0.f, 0.f, 0.f};
+  struct Frag { bgu4 a[2], w[2]; };
+  auto load = [&](Frag &f, int k0) {
+    const int k = k0 + 8 * kq;                   // K is a multiple of 4 (host check); the shadow's row is zero beyond K up to ldw (a multiple of 64)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      bgf4 v[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int kh = k + 4 * h;
+        const bool ok = kh < K;                  // a float4 of A is inside or outside as a whole
+        const int kc = ok ? kh : 0;
+        bgf4 x;
+        if (A_KMAJOR) {
+          x.x = A[(long long)kc * sa_k + ar[t]]; x.y = A[(long long)(kc + 1) * sa_k + ar[t]];
+          x.z = A[(long long)(kc + 2) * sa_k + ar[t]]; x.w = A[(long long)(kc + 3) * sa_k + ar[t]];
+        } else {
+          x = *reinterpret_cast<const bgf4 *>(A + (long long)ar[t] * sa_row + kc);
+        }
+        if (mean) {
+          const bgf4 mu = *reinterpret_cast<const bgf4 *>(mean + kc), is = *reinterpret_cast<const bgf4 *>(inv_std + kc);
+          x = (x - mu) * is;
+        }
+        v[h] = ok ? x : bgf4{0.f, 0.f, 0.f, 0.f};
+      }
+      f.a[t] = bg_pack8(v[0], v[1]);
+      f.w[t] = *reinterpret_cast<const bgu4 *>(W + (size_t)wc[t] * ldw + (k < ldw ? k : 0));      // (k < ldw always holds while k0 < K)
+    }
+  };
+  auto mma = [&](const Frag &f) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bgb8, f.a[a]), __builtin_bit_cast(bgb8, f.w[b]), acc[a][b], 0, 0, 0);
+  };
+  // three K steps in flight (a step is ONE matrix instruction per tile: what bounds a wave is the latency of its operand loads)
+  Frag f0, f1, f2;
+  load(f0, 0);
+  if (32 < K) load(f1, 32);
+  for (int k0 = 0; k0 < K; k0 += 96) {
+    if (k0 + 64 < K) load(f2, k0 + 64);
+    mma(f0);
+    if (k0 + 32 >= K) break;
+    if (k0 + 96 < K) load(f0, k0 + 96);
+    mma(f1);
+    if (k0 + 64 >= K) break;
+    if (k0 + 128 < K) load(f1, k0 + 128);
+    mma(f2);
+  }
+  // accumulator component r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const int c = col0 + 16 * b + li;
+      const float bv = (bias && c < N) ? bias[c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + 16 * a + 4 * kq + r;
+        if (row < M && c < N) C[(size_t)row * N + c] = acc[a][b][r] + bv;
+      }
+    }
+}

@@ -191,3 +191,17 @@ int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is
 }
 
 }  // extern "C"
+
+int tmjx_linear_nolds_bf16(const float *A, int64_t sa_row, int64_t sa_k, const uint16_t *W, int ldw, const float *bias, float *C, int M, int N, int K,
+                           const float *mean, const float *inv_std, void *stream) {
+  if (!A || !W || !C) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1) return fail(TMJX_EINVAL, "bad shape");
+  const bool kmajor = sa_k != 1;
+  if ((K & 3) || (ldw & 63) || ldw < K || ((uintptr_t)W & 15) || (!kmajor && ((sa_row & 3) || ((uintptr_t)A & 15))) || (mean && (((uintptr_t)mean | (uintptr_t)inv_std) & 15)) || (mean && !inv_std))
+    return fail(TMJX_EINVAL, "tmjx_linear_nolds_bf16: K % 4 == 0, a bf16 shadow with rows padded to a multiple of 64 (tmjx_bf16_shadow) and 16-byte aligned operands");
+  dim3 grid((M + 31) / 32, (N + 31) / 32);
+  hipStream_t s = (hipStream_t)stream;
+  if (kmajor) hipLaunchKernelGGL((k_linear_nolds_bf16<true>), grid, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, (const bf16_t *)W, ldw, bias, C, M, N, K, mean, inv_std);
+  else hipLaunchKernelGGL((k_linear_nolds_bf16<false>), grid, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, (const bf16_t *)W, ldw, bias, C, M, N, K, mean, inv_std);
+  return check_launch("k_linear_nolds_bf16");
+}
