@@ -970,19 +970,30 @@ def test_fused_latent_concat_forward_backward_matches_torch():
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max() + 1e-6)
     # the second gradient of fc2 handed to the backward kernel (tmjx_latent_concat_bwd_add, what the learner does with the KL term's) instead of
     # seeding autograd with it: the same sum, bit for bit
-    from track_mjx_amd.agent.networks import _LatentConcatFn
     logits, fc2 = pol(obs, eps=eps, return_fc2=True)
     g2 = 2 * fc2.detach()
     g_seed = torch.autograd.grad([logits, fc2], list(pol.parameters()), grad_outputs=[up, g2])
     logits, fc2 = pol(obs, eps=eps, return_fc2=True)
-    assert _LatentConcatFn.last_forward == fc2.data_ptr()
-    _LatentConcatFn.pending_add = (fc2.data_ptr(), g2.view(-1, 120))
+    h = pol.latent_grad_handle
+    assert h is not None and h.matches(fc2)
+    h.add(g2.view(-1, 120))
     g_add = torch.autograd.grad([logits], list(pol.parameters()), grad_outputs=[up])
-    assert _LatentConcatFn.pending_add is None
+    assert not h.pending
     for a, b in zip(g_add, g_seed):
         assert torch.equal(a, b)
+    # a parked gradient that no backward pass consumed must not be dropped silently: the next forward raises
+    logits, fc2 = pol(obs, eps=eps, return_fc2=True)
+    pol.latent_grad_handle.add(g2.view(-1, 120))
+    with pytest.raises(RuntimeError, match="never consumed"):
+        pol(obs, eps=eps, return_fc2=True)
+    pol.latent_grad_handle = None
+    # two policies in one process do not share the slot
+    pol2 = type(pol)(696, 470, 38, 60, (64, 64), (64, 64)).to(DEV)
+    lo1, f1 = pol(obs, eps=eps, return_fc2=True)
+    lo2, f2 = pol2(obs, eps=eps, return_fc2=True)
+    assert pol.latent_grad_handle is not pol2.latent_grad_handle and pol.latent_grad_handle.matches(f1) and pol2.latent_grad_handle.matches(f2)
     l8, _ = pol(obs[0, :8], eps=eps[0, :8], return_fc2=True)      # the unfused path (few rows) leaves no handle behind
-    assert _LatentConcatFn.last_forward is None
+    assert pol.latent_grad_handle is None
 
 
 @pytest.mark.gpu

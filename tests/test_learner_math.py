@@ -268,3 +268,39 @@ def test_checkpoint_step_directory_is_atomic_named_like_the_reference_and_never_
         ck.save_npz(tmp_path / "x.npz", a, step=5)
     assert ck.restore(tmp_path / "x.npz", make(5))["iteration"] == 1
     assert not [f for f in os.listdir(tmp_path) if f.startswith(".tmp")]
+
+
+def test_checkpointed_generator_states_do_not_collapse_the_ranks():
+    """agent/checkpoint.py: rank 0 writes the noise-stream positions; at resume every rank restores from that one tree.  The saving rank must
+    continue its torch generators exactly, every OTHER rank must get a stream of its own (derived from the saved state and its rank) — not a
+    copy of rank 0's (round-3 advisor finding: all ranks then drew identical shuffles / noise)."""
+    import torch
+    from track_mjx_amd.agent import checkpoint as ck
+
+    class Stub:
+        def __init__(self, rank):
+            self.rank = rank
+            self._mb_state = torch.zeros(16, dtype=torch.long)
+            self.gens = [torch.Generator().manual_seed(1000 + 17 + rank), torch.Generator().manual_seed(1000 + 17 + rank + 7919)]
+            self._act_rng = {}
+
+        def _act_rng_state(self, gen):
+            return self._act_rng.setdefault(id(gen), (torch.zeros(2, dtype=torch.long), 0))
+
+    saver = Stub(0)
+    torch.randn(5, generator=saver.gens[0])          # the run has advanced
+    saver._mb_state[0] = 77
+    tree = ck.rng_tree(saver)
+    want = [torch.randn(4, generator=g) for g in saver.gens]          # what rank 0 draws next
+    r0, r1, r2 = Stub(0), Stub(1), Stub(2)
+    for r in (r0, r1, r2):
+        ck.rng_from_tree(r, tree)
+        assert int(r._mb_state[0]) == 77
+    got = {r.rank: [torch.randn(4, generator=g) for g in r.gens] for r in (r0, r1, r2)}
+    assert all(torch.equal(a, b) for a, b in zip(got[0], want))
+    assert not torch.equal(got[1][0], got[0][0]) and not torch.equal(got[2][0], got[0][0]) and not torch.equal(got[1][0], got[2][0])
+    assert not torch.equal(got[1][0], got[1][1])
+    # deterministic: the same (tree, rank) gives the same stream again
+    r1b = Stub(1)
+    ck.rng_from_tree(r1b, tree)
+    assert torch.equal(torch.randn(4, generator=r1b.gens[0]), got[1][0])

@@ -129,7 +129,7 @@ def _moment_view(learner, buf: torch.Tensor):
 def rng_tree(learner) -> dict:
     """The noise-stream positions a resumed run continues from: the SGD step's device-side Philox draw counter (`_mb_state[0]`), the
     acting streams' counters (one per env group, in creation order) and the torch generators' states (shuffles, the non-default noise)."""
-    out = {"sgd_draw_counter": _np(learner._mb_state[:1]),
+    out = {"sgd_draw_counter": _np(learner._mb_state[:1]), "rank": np.asarray(int(getattr(learner, "rank", 0)), dtype=np.int64),
            "torch_generators": {str(i): g.get_state().cpu().numpy().copy() for i, g in enumerate(learner.gens)}}
     by_gen = {id(g): i for i, g in enumerate(learner.gens)}
     out["act_counters"] = {str(by_gen[k]): _np(v[0]) for k, v in learner._act_rng.items() if k in by_gen}
@@ -139,9 +139,20 @@ def rng_tree(learner) -> dict:
 @torch.no_grad()
 def rng_from_tree(learner, tree: dict) -> None:
     learner._mb_state[:1].copy_(torch.as_tensor(np.asarray(tree["sgd_draw_counter"]), device=learner._mb_state.device))
+    # the generator states are the SAVING rank's (rank 0 writes the checkpoint): that rank continues its streams exactly; every other rank
+    # derives its own continuation from (saved state, rank) — restoring rank 0's states everywhere would make all ranks draw identical
+    # shuffles / noise from here on (the learner seeds them seed * 1000 + 17 + rank).  The device-side Philox counters below are shared on
+    # purpose: their KEYS are per rank
+    saved_rank, rank = int(np.asarray(tree.get("rank", 0))), int(getattr(learner, "rank", 0))
     for i, st in tree.get("torch_generators", {}).items():
         if int(i) < len(learner.gens):
-            learner.gens[int(i)].set_state(torch.as_tensor(np.asarray(st), dtype=torch.uint8))
+            st = np.asarray(st).astype(np.uint8)
+            if rank == saved_rank:
+                learner.gens[int(i)].set_state(torch.as_tensor(st, dtype=torch.uint8))
+            else:
+                import hashlib
+                h = int.from_bytes(hashlib.blake2b(st.tobytes() + rank.to_bytes(4, "little") + int(i).to_bytes(4, "little"), digest_size=8).digest(), "little")
+                learner.gens[int(i)].manual_seed(h & (2 ** 63 - 1))
     for i, v in tree.get("act_counters", {}).items():
         if int(i) < len(learner.gens):
             rs = learner._act_rng_state(learner.gens[int(i)])

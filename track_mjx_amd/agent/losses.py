@@ -168,11 +168,13 @@ def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_
             ptr = [C.c_void_p(a.data_ptr()) for a in args + [dlogits, dbaseline, dfc2, scratch, out]]
             _hip.check(L.tmjx_ppo_loss(C.byref(c), *ptr, stream), "tmjx_ppo_loss")
     metrics = {"total_loss": out[0], "policy_loss": out[1], "v_loss": out[2], "kl_latent_loss": out[4], "entropy_loss": out[3]}
-    from .networks import _LatentConcatFn
-    if _LatentConcatFn.last_forward is not None and _LatentConcatFn.last_forward == fc2.data_ptr() and args[9].data_ptr() == fc2.data_ptr():
+    handle = getattr(policy, "latent_grad_handle", None)
+    if handle is not None and handle.matches(fc2) and args[9].data_ptr() == fc2.data_ptr():
         # fc2 has two gradients, the KL term's (here) and the latent sample's (tmjx_latent_concat_bwd): hand this one to that kernel, which sums
-        # them, instead of seeding autograd with it (autograd would add the two with an element-wise launch of its own; same sum, same bits)
-        _LatentConcatFn.pending_add = (fc2.data_ptr(), dfc2.view(-1, fc2.shape[-1]))
+        # them, instead of seeding autograd with it (autograd would add the two with an element-wise launch of its own; same sum, same bits).
+        # It is parked on THIS forward pass's handle: a backward pass that does not run through this forward leaves it there, and the policy's
+        # next forward raises instead of dropping it
+        handle.add(dfc2.view(-1, fc2.shape[-1]))
         return metrics, (logits, baseline), (dlogits.view_as(logits), dbaseline.view_as(baseline)), out
     return metrics, (logits, baseline, fc2), (dlogits.view_as(logits), dbaseline.view_as(baseline), dfc2.view_as(fc2)), out
 

@@ -840,9 +840,10 @@ class _LatentConcatFn(torch.autograd.Function):
     of chunk / exp / mul / add / cat and their five backward kernels.  obs is not differentiated (network input)."""
 
     @staticmethod
-    def forward(ctx, fc2, eps, obs, ref):
+    def forward(ctx, fc2, eps, obs, ref, handle=None):
         import ctypes as C
         from .. import hip as _hip
+        ctx.handle = handle
         n, Z = eps.shape
         W = obs.shape[1]
         fc2, eps, obs = fc2.contiguous(), eps.contiguous(), obs.contiguous()
@@ -856,11 +857,6 @@ class _LatentConcatFn(torch.autograd.Function):
         ctx.save_for_backward(fc2, eps)
         return x[:, :wd]
 
-    # (fc2 storage pointer, gradient): a second gradient of this fc2 that the caller wants summed into the one computed here instead of seeding
-    # autograd with it (losses.ppo_loss_and_output_grads: the KL term's, from the loss head) — autograd would add the two with a launch of its own
-    pending_add = None
-    last_forward = None       # storage pointer of the fc2 the latest policy forward sent through this function (None: it took the unfused path)
-
     @staticmethod
     def backward(ctx, dx):
         import ctypes as C
@@ -870,16 +866,44 @@ class _LatentConcatFn(torch.autograd.Function):
         dx = dx.contiguous()
         dfc2 = torch.empty_like(fc2)
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        add, _LatentConcatFn.pending_add = _LatentConcatFn.pending_add, None
-        if add is not None and (add[0] != fc2.data_ptr() or add[1].shape != fc2.shape or not add[1].is_contiguous()):
-            raise RuntimeError("_LatentConcatFn: the pending fc2 gradient belongs to another forward pass")
+        # a second gradient of this fc2 that the caller wants summed into the one computed here instead of seeding autograd with it
+        # (losses.ppo_loss_and_output_grads: the KL term's, from the loss head) — autograd would add the two with a launch of its own.  It
+        # travels on THIS forward pass's handle (LatentGradHandle), not in process-wide state
+        add = ctx.handle.take() if ctx.handle is not None else None
+        if add is not None and (add.shape != fc2.shape or not add.is_contiguous()):
+            raise RuntimeError("_LatentConcatFn: the pending fc2 gradient does not fit this forward pass")
         with torch.cuda.device(fc2.device):
             stream = C.c_void_p(torch.cuda.current_stream(fc2.device).cuda_stream)
             if add is None:
                 _hip.check(_hip.lib().tmjx_latent_concat_bwd(p(dx), p(eps), p(fc2), p(dfc2), n, Z, dx.shape[1], stream), "tmjx_latent_concat_bwd")
             else:
-                _hip.check(_hip.lib().tmjx_latent_concat_bwd_add(p(dx), p(eps), p(fc2), p(add[1]), p(dfc2), n, Z, dx.shape[1], stream), "tmjx_latent_concat_bwd_add")
-        return dfc2, None, None, None
+                _hip.check(_hip.lib().tmjx_latent_concat_bwd_add(p(dx), p(eps), p(fc2), p(add), p(dfc2), n, Z, dx.shape[1], stream), "tmjx_latent_concat_bwd_add")
+        return dfc2, None, None, None, None
+
+
+class LatentGradHandle:
+    """One policy forward pass's slot for a second gradient of its fc2 output (the KL term's): `policy.latent_grad_handle` after a forward that
+    went through the fused latent kernel, else None.  `add(g)` parks the gradient, the backward of THAT forward's _LatentConcatFn node takes
+    it.  A parked gradient that no backward pass consumed is an error at the policy's next forward (it would have been silently dropped)."""
+
+    def __init__(self, fc2: torch.Tensor):
+        self.ptr, self.shape, self._g = fc2.data_ptr(), tuple(fc2.shape), None
+
+    def matches(self, fc2: torch.Tensor) -> bool:
+        return fc2.data_ptr() == self.ptr
+
+    def add(self, g: torch.Tensor) -> None:
+        if self._g is not None:
+            raise RuntimeError("LatentGradHandle: a gradient is already parked on this forward pass")
+        self._g = g
+
+    def take(self):
+        g, self._g = self._g, None
+        return g
+
+    @property
+    def pending(self) -> bool:
+        return self._g is not None
 
 
 class IntentionPolicy(nn.Module):
@@ -906,7 +930,10 @@ class IntentionPolicy(nn.Module):
         """obs already normalised. Returns (logits [.., 2*nu], latent_mean, latent_logvar), or (logits, mean | logvar as
         one [.., 2*latents] tensor) with `return_fc2` (what the fused loss head consumes)."""
         traj = obs[..., :self.reference_obs_size]
-        _LatentConcatFn.last_forward = _LatentConcatFn.pending_add = None      # (see _LatentConcatFn.pending_add: valid for the latest forward only)
+        prev, self.latent_grad_handle = getattr(self, "latent_grad_handle", None), None
+        if prev is not None and prev.pending:
+            raise RuntimeError("IntentionPolicy: the fc2 gradient parked on the previous forward pass (LatentGradHandle.add) was never consumed by a "
+                               "backward pass through that forward — it would have been dropped")
         chains = _bf16_chain_ok(obs) and all(m.out_features % 4 == 0 for m in (self.fc2, self.head))
         if chains:                 # bf16 GEMM-input mode: the encoder (+ fc2) as ONE autograd function (fused epilogues, bf16 hidden activations)
             if getattr(self, "_enc_chain", None) is None:
@@ -924,9 +951,9 @@ class IntentionPolicy(nn.Module):
             lead = fc2.shape[:-1]
             if eps is None:
                 eps = torch.randn_like(mean)
-            x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size)
-            if fc2.requires_grad and fc2.is_contiguous():
-                _LatentConcatFn.last_forward = fc2.data_ptr()
+            handle = LatentGradHandle(fc2.reshape(-1, fc2.shape[-1])) if (fc2.requires_grad and fc2.is_contiguous()) else None
+            x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size, handle)
+            self.latent_grad_handle = handle
             x = x.view(*lead, x.shape[-1])
             if chains:
                 logits = bf16_chain(x, self._dec_chain, dx_cols=self.latents)
