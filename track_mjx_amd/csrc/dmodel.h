@@ -95,6 +95,19 @@ struct DModel {
   // every branch body p (more than one child), taken in DESCENDING order, adds the finished sums of its non-first children
   // (run heads fix_child[fix_adr[f] .. fix_adr[f+1])) to the bodies fix_r0[f] .. fix_p[f] of its own run.
   int n_fix, fix_p[TM_MAXB], fix_r0[TM_MAXB], fix_adr[TM_MAXB + 1], fix_child[TM_MAXB];
+  // Flat per-lane records of the wave kernel (round 4).  A dependent chain of per-lane model reads (body -> its joint -> the joint's qpos0 ..)
+  // costs about a thousand cycles PER LEVEL next to eleven other waves; everything a lane needs for one body / one dof sits in ONE record
+  // that it loads in one level.  body_kin[b] = { body_pos 3 | body_quat 4 | type of the body's FIRST joint (-1: none) | its qposadr | jnt_pos 3 |
+  // jnt_axis 3 | qpos0[qposadr] } (ints stored as their bits); bodies with more than one joint take the tables for the others.
+  float body_kin[TM_MAXB][16];
+  // dof_kin[i] = { type of the dof's joint | body of that joint | parent of that body | dof index inside the joint } (cdof stage);
+  // dof_dyn[i] = { body of the dof | armature | damping | stiffness | qposadr | spring reference | first actuator entry | entries end }
+  int dof_kin[TM_MAXV][4];
+  float dof_dyn[TM_MAXV][8];
+  // dof_lim[i] (hinge dofs with a limit) = { qposadr | range lo | range hi | margin | solref 2 | solimp 5 | dof_invweight0 }: the limit row of
+  // dof i in one read (make_constraint: row -> dof -> joint -> fields was three levels)
+  float dof_lim[TM_MAXV][12];
+  float dof_act_gain[128];      // act_gain[dof_act_id[e]] next to dof_act_coef[e]: one level fewer in the dof's actuator gather
   int lds_floats;
 };
 

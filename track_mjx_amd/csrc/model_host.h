@@ -230,6 +230,20 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
     for (int c = b; c > 0 && last < 0; c = m.body_parentid[c]) if (m.body_dofnum[c]) last = m.body_dofadr[c] + m.body_dofnum[c] - 1;
     m.body_lastdof[b] = last;
   }
+  for (int b = 0; b < m.nbody; b++) {      // flat kinematics record of every body (dmodel.h: body_kin)
+    float *r = m.body_kin[b];
+    for (int k = 0; k < 16; k++) r[k] = 0.f;
+    for (int k = 0; k < 3; k++) r[k] = m.body_pos[b][k];
+    for (int k = 0; k < 4; k++) r[3 + k] = m.body_quat[b][k];
+    int jt = -1, qa = 0;
+    if (m.body_jntnum[b] > 0) {
+      const int j = m.body_jntadr[b];
+      jt = m.jnt_type[j]; qa = m.jnt_qposadr[j];
+      for (int k = 0; k < 3; k++) { r[9 + k] = m.jnt_pos[j][k]; r[12 + k] = m.jnt_axis[j][k]; }
+      r[15] = m.qpos0[qa];
+    }
+    memcpy(&r[7], &jt, 4); memcpy(&r[8], &qa, 4);
+  }
   {  // children lists (body ids ascending)
     int a = 0;
     for (int p = 0; p < m.nbody; p++) {
@@ -298,6 +312,21 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
       }
     }
     m.dof_act_adr[m.nv] = a;
+    for (int e = 0; e < a; e++) m.dof_act_gain[e] = m.act_gain[m.dof_act_id[e]];
+    for (int i = 0; i < m.nv; i++) {      // flat per-dof records (dmodel.h: dof_kin, dof_dyn)
+      const int j = m.dof_jntid[i], b = m.jnt_bodyid[j];
+      m.dof_kin[i][0] = m.jnt_type[j]; m.dof_kin[i][1] = b; m.dof_kin[i][2] = m.body_parentid[b]; m.dof_kin[i][3] = i - m.jnt_dofadr[j];
+      float *r = m.dof_dyn[i];
+      const int ib[4] = {m.dof_bodyid[i], m.dof_qposadr[i], m.dof_act_adr[i], m.dof_act_adr[i + 1]};
+      memcpy(&r[0], &ib[0], 4); r[1] = m.dof_armature[i]; r[2] = m.dof_damping[i]; r[3] = m.dof_stiffness[i];
+      memcpy(&r[4], &ib[1], 4); r[5] = m.dof_qspring[i]; memcpy(&r[6], &ib[2], 4); memcpy(&r[7], &ib[3], 4);
+      float *q = m.dof_lim[i];
+      const int qa = m.jnt_qposadr[j];
+      memcpy(&q[0], &qa, 4); q[1] = m.jnt_range[j][0]; q[2] = m.jnt_range[j][1]; q[3] = m.jnt_margin[j];
+      q[4] = m.jnt_solref[j][0]; q[5] = m.jnt_solref[j][1];
+      for (int k = 0; k < 5; k++) q[6 + k] = m.jnt_solimp[j][k];
+      q[11] = m.dof_invweight0[m.jnt_dofadr[j]];
+    }
     int g = 0;
     for (int i = 0; i < m.nv; i++) {
       m.dof_grp_adr[i] = g;

@@ -256,14 +256,35 @@ TM_DEV void tmw_get_con_frame(const float *L, const WLayout &K, int cc, float *f
 // kinematics by pointer jumping; com; collision; cdof; cinert.  `emit`: also write xpos / torso xmat to global.
 TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
-  // (1) local transform of every body relative to its parent (absolute for the free-joint body)
+  // (1) local transform of every body relative to its parent (absolute for the free-joint body).  Everything the lane needs of the model for
+  // its bodies comes from ONE flat record per body (DModel::body_kin), both bodies' records loaded up front: the chain body -> joint ->
+  // joint fields -> qpos0[qposadr] was three dependent model reads per body, each about a thousand cycles next to eleven other waves
   TMW_FOR {
-    for (int b = lane; b < K.nbody; b += 64) {
-      float t[3] = {m.body_pos[b][0], m.body_pos[b][1], m.body_pos[b][2]};
-      float q[4] = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
+    float rec[2][16];
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+      const int b = lane + 64 * slot < K.nbody ? lane + 64 * slot : K.nbody - 1;
+#pragma unroll
+      for (int k = 0; k < 16; k++) rec[slot][k] = m.body_kin[b][k];
+    }
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+      const int b = lane + 64 * slot;
+      if (b >= K.nbody) continue;
+      const float *rc = rec[slot];
+      float t[3] = {rc[0], rc[1], rc[2]};
+      float q[4] = {rc[3], rc[4], rc[5], rc[6]};
       for (int jj = 0; jj < m.body_jntnum[b]; jj++) {
-        int j = m.body_jntadr[b] + jj, qa = m.jnt_qposadr[j];
-        if (m.jnt_type[j] == 0) {
+        int j = m.body_jntadr[b] + jj, qa, jtype;
+        float jpos[3], jaxis[3], q0;
+        if (jj == 0) {
+          jtype = tm_f2i(rc[7]); qa = tm_f2i(rc[8]); q0 = rc[15];
+          for (int k = 0; k < 3; k++) { jpos[k] = rc[9 + k]; jaxis[k] = rc[12 + k]; }
+        } else {          // (a body with several joints: the others through the tables)
+          jtype = m.jnt_type[j]; qa = m.jnt_qposadr[j]; q0 = m.qpos0[qa];
+          for (int k = 0; k < 3; k++) { jpos[k] = m.jnt_pos[j][k]; jaxis[k] = m.jnt_axis[j][k]; }
+        }
+        if (jtype == 0) {
           for (int k = 0; k < 3; k++) t[k] = L[K.l_qpos + qa + k];
           for (int k = 0; k < 4; k++) q[k] = L[K.l_qpos + qa + 3 + k];
           tm_normalize4(q);
@@ -271,15 +292,15 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
           for (int k = 0; k < 3; k++) { L[K.l_jl_anchor + j * 3 + k] = t[k]; L[K.l_jl_axis + j * 3 + k] = (k == 2) ? 1.f : 0.f; }
         } else {
           float r[3], an[3], ax[3], ql[4], q2[4];
-          { TMW_LOCAL(jp_, 3, m.jnt_pos[j]); tm_rotate(r, jp_, q); }
+          tm_rotate(r, jpos, q);
           for (int k = 0; k < 3; k++) an[k] = t[k] + r[k];
-          { TMW_LOCAL(ja_, 3, m.jnt_axis[j]); tm_rotate(ax, ja_, q); }
-          float ang = (L[K.l_qpos + qa] - m.qpos0[qa]) * 0.5f, sn, cs;
+          tm_rotate(ax, jaxis, q);
+          float ang = (L[K.l_qpos + qa] - q0) * 0.5f, sn, cs;
           sincosf(ang, &sn, &cs);      // one shared range reduction
-          ql[0] = cs; ql[1] = m.jnt_axis[j][0] * sn; ql[2] = m.jnt_axis[j][1] * sn; ql[3] = m.jnt_axis[j][2] * sn;
+          ql[0] = cs; ql[1] = jaxis[0] * sn; ql[2] = jaxis[1] * sn; ql[3] = jaxis[2] * sn;
           tm_quat_mul(q2, q, ql);
           for (int k = 0; k < 4; k++) q[k] = q2[k];
-          { TMW_LOCAL(jp_, 3, m.jnt_pos[j]); tm_rotate(r, jp_, q); }
+          tm_rotate(r, jpos, q);
           for (int k = 0; k < 3; k++) { t[k] = an[k] - r[k]; L[K.l_jl_anchor + j * 3 + k] = an[k]; L[K.l_jl_axis + j * 3 + k] = ax[k]; }
         }
       }
@@ -381,13 +402,23 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
     }
   }
   TMW_TICK2(30);
-  // (5) cdof: one lane per dof (joint anchors / axes are stored in the parent frame)
+  // (5) cdof: one lane per dof (joint anchors / axes are stored in the parent frame); the dof's joint type / body / parent body / index inside
+  // the joint from its flat record (DModel::dof_kin: one model read instead of dof -> joint -> body -> parent)
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) {
-      int j = m.dof_jntid[i], b = m.jnt_bodyid[j];
+    int dk[2][4];
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+      const int i = lane + 64 * slot < K.nv ? lane + 64 * slot : K.nv - 1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) dk[slot][k] = m.dof_kin[i][k];
+    }
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+      const int i = lane + 64 * slot;
+      if (i >= K.nv) continue;
+      const int jtype = dk[slot][0], b = dk[slot][1], p = dk[slot][2], k = dk[slot][3], j = m.dof_jntid[i];
       float cd[6];
-      if (m.jnt_type[j] == 0) {
-        int k = i - m.jnt_dofadr[j];
+      if (jtype == 0) {
         const float *s = L + K.l_scanA + b * 8;
         if (k < 3) { for (int r = 0; r < 6; r++) cd[r] = (r == 3 + k) ? 1.f : 0.f; }
         else {
@@ -398,7 +429,6 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
           for (int r = 0; r < 3; r++) { cd[r] = ax[r]; cd[3 + r] = cr[r]; }
         }
       } else {
-        int p = m.body_parentid[b];
         const float *sp = L + K.l_scanA + p * 8;
         float an[3], ax[3], off[3], cr[3];
         tm_rotate(an, L + K.l_jl_anchor + j * 3, sp + 3);
@@ -416,15 +446,18 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
   TMW_FOR {
     for (int b = lane; b < K.nbody; b += 64) {
       float ci[10];
-      if (!m.body_moving[b]) { for (int k = 0; k < 10; k++) ci[k] = 0.f; }
+      // (the model reads of a body are issued before the `moving` test: behind it they were a second dependent level)
+      const int moving = m.body_moving[b];
+      TMW_LOCAL(iq_, 4, m.body_iquat[b]);
+      TMW_LOCAL(in, 3, m.body_inertia[b]);
+      const float mass = m.body_mass[b];
+      if (!moving) { for (int k = 0; k < 10; k++) ci[k] = 0.f; }
       else {
         const float *s = L + K.l_scanA + b * 8;
         float q[4], X[9], off[3];
-        { TMW_LOCAL(iq_, 4, m.body_iquat[b]); tm_quat_mul(q, s + 3, iq_); }
+        tm_quat_mul(q, s + 3, iq_);
         tm_quat_to_mat(X, q);
-        float mass = m.body_mass[b];
         for (int k = 0; k < 3; k++) off[k] = L[K.l_xipos + b * 3 + k] - com[k];
-        TMW_LOCAL(in, 3, m.body_inertia[b]);
         float oo = tm_dot3(off, off);
         ci[0] = X[0] * in[0] * X[0] + X[1] * in[1] * X[1] + X[2] * in[2] * X[2] + (oo - off[0] * off[0]) * mass;
         ci[1] = X[3] * in[0] * X[3] + X[4] * in[1] * X[4] + X[5] * in[2] * X[5] + (oo - off[1] * off[1]) * mass;
@@ -638,8 +671,19 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
   }
   TMW_SYNC();
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) {
-      int b = m.dof_bodyid[i];
+    float dd[2][8];          // the dofs' flat records (DModel::dof_dyn), both slots up front
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+      const int i = lane + 64 * slot < K.nv ? lane + 64 * slot : K.nv - 1;
+#pragma unroll
+      for (int k = 0; k < 8; k++) dd[slot][k] = m.dof_dyn[i][k];
+    }
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+      const int i = lane + 64 * slot;
+      if (i >= K.nv) continue;
+      const float *rc = dd[slot];
+      const int b = tm_f2i(rc[0]);
       float I[10], cd[6], buf[6];
       for (int k = 0; k < 10; k++) I[k] = L[K.l_cinert + b * 10 + k];
       for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
@@ -649,15 +693,15 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       for (int k = 0; k <= d; k++) {
         const float *cj = L + K.l_cdof + tmw_anc(i, k, w1) * 6;
         float s = buf[0] * cj[0] + buf[1] * cj[1] + buf[2] * cj[2] + buf[3] * cj[3] + buf[4] * cj[4] + buf[5] * cj[5];
-        if (k == 0) s += m.dof_armature[i];
+        if (k == 0) s += rc[1];          // armature
         L[K.l_M + adr + k] = s;
       }
       const float bias = i < 64 ? bias0[TMW_LI] : bias1[TMW_LI];
       float fa = 0.f;
-      for (int e = m.dof_act_adr[i]; e < m.dof_act_adr[i + 1]; e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.act_gain[u] * L[(K.lean ? K.l_sv : K.l_act) + u]); }
+      for (int e = tm_f2i(rc[6]); e < tm_f2i(rc[7]); e++) { int u = m.dof_act_id[e]; fa += m.dof_act_coef[e] * (m.dof_act_gain[e] * L[(K.lean ? K.l_sv : K.l_act) + u]); }
       WST(m.s_qfrc_actuator, i) = fa;
-      float f = -m.dof_damping[i] * L[K.l_qvel + i] - bias + fa;
-      if (m.dof_stiffness[i] != 0.f) f += -m.dof_stiffness[i] * (L[K.l_qpos + m.dof_qposadr[i]] - m.dof_qspring[i]);
+      float f = -rc[2] * L[K.l_qvel + i] - bias + fa;
+      if (rc[3] != 0.f) f += -rc[3] * (L[K.l_qpos + tm_f2i(rc[4])] - rc[5]);
       TMW_QFS_SET(i, f);
     }
     // (act_dot = (clamp(ctrl) - act) / tau is formed in tmw_euler, where act is advanced: act does not change in between)
@@ -1696,12 +1740,12 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
       float k, b, imp, pos, iw;
       float solref[2], solimp[5];        // ONE impedance evaluation for limit and contact rows (both kinds share a wave)
       if (kr < c.nla) {
-        int j = m.dof_jntid[r & 0x7f];
-        float q = L[K.l_qpos + m.jnt_qposadr[j]], dmin = q - m.jnt_range[j][0], dmax = m.jnt_range[j][1] - q;
-        pos = fminf(dmin, dmax) - m.jnt_margin[j];
-        for (int t = 0; t < 2; t++) solref[t] = m.jnt_solref[j][t];
-        for (int t = 0; t < 5; t++) solimp[t] = m.jnt_solimp[j][t];
-        iw = m.dof_invweight0[m.jnt_dofadr[j]];
+        TMW_LOCAL(rec, 12, m.dof_lim[r & 0x7f]);      // the dof's limit record: one model read behind the row-map byte (was dof -> joint -> fields)
+        float q = L[K.l_qpos + tm_f2i(rec[0])], dmin = q - rec[1], dmax = rec[2] - q;
+        pos = fminf(dmin, dmax) - rec[3];
+        for (int t = 0; t < 2; t++) solref[t] = rec[4 + t];
+        for (int t = 0; t < 5; t++) solimp[t] = rec[6 + t];
+        iw = rec[11];
       } else {
         int cc = (r - K.nlim) >> 2;
         pos = L[K.l_con_dist + cc];
