@@ -170,13 +170,14 @@ class FlatAdam:
         return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
 
 
-RESIDENT_ENVS_PER_CU = 11      # csrc/wave_layout.h: 14 080 B of LDS per env = 11 of a CU's 128 granules
+RESIDENT_ENVS_PER_CU = 12      # csrc/wave_layout.h: 12 780 B of LDS per env = 10 of a CU's 128 granules of 1 280 B (round 4; 11 envs per CU before)
 
 
 def default_groups(n_envs: int, device=None, widest_layer: int = 256) -> int:
     """How many env groups collect() should pipeline: THREE.  While one group is in its serial reward / observation / inference phase the
-    others should still fill the GPU's resident-env slots (11 per CU: 2816 on an MI355X): two of three groups of 4096 envs fill 97 %, one of
-    two 73 % (config 2: roll-out 170.1 ms with two groups, 159.8 ms with three; config 5, 8192 envs: 345.8 -> 330.5 ms; config 4's wide
+    others should still fill the GPU's resident-env slots (12 per CU: 3072 on an MI355X; 2816 when this was measured): two of three groups
+    of 4096 envs fill 89 % (97 % of 2816), one of two 67 % (73 %); re-measured in round 4 at 12 per CU: equal thirds 157.9 ms, 1536 / 1536 / 1024
+    159.4 ms, two groups 169.1 ms, four 263.7 ms (tools/group_sizes_ab.sh) (config 2: roll-out 170.1 ms with two groups, 159.8 ms with three; config 5, 8192 envs: 345.8 -> 330.5 ms; config 4's wide
     policy: 194.2 / 195.3 ms, a tie).  Never more than three: see group_sizes.  (`device`, `widest_layer`: kept for callers that tune per
     model; both configurations that once preferred two groups — 8192 envs, the wide policy — stopped doing so when the acting path's
     element-wise kernels went to one-wave blocks.)"""

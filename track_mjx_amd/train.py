@@ -71,7 +71,7 @@ def main(argv=None, runner=None):
         return launch.spawn_ranks(num_gpus, ["-m", "track_mjx_amd.train"], full_argv, runner=runner)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # TMJX_REHEARSE_ON_ONE_GPU=1 (tools/r3_rehearse.sh): every rank on cuda:0 with gloo collectives on the device tensors — the multi-rank path on
+    # TMJX_REHEARSE_ON_ONE_GPU=1 (tools/gpu_lab.sh rehearse): every rank on cuda:0 with gloo collectives on the device tensors — the multi-rank path on
     # a one-GPU box, where RCCL refuses two ranks on a device; a plumbing check, not a way to train
     rehearse = bool(os.environ.get("TMJX_REHEARSE_ON_ONE_GPU"))
     device = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
