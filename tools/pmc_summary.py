@@ -15,7 +15,7 @@ from buildid import checked_id  # noqa: E402
 BUILD = checked_id(src, "--force" in sys.argv)
 ENVS = 4096
 K2_ALGO = 842 * 4 * ENVS
-step_kernels = ("void k_physics_wave", "k_rec_in", "k_rec_out", "k_window", "k_obs", "k_post_parts", "k_post", "k_autoreset")
+step_kernels = ("void k_physics_wave", "k_rec_in", "k_rec_out", "k_step_parts", "k_window", "k_obs", "k_post_parts", "k_post", "k_autoreset")
 out = {}
 for kind in ("fetch", "write"):
     f = max(glob.glob(str(src / f"pmc_{kind}" / "*" / "*_counter_collection.csv")), key=lambda p: Path(p).stat().st_mtime)   # newest run
@@ -33,7 +33,7 @@ dom = "k_physics_wave<true>"
 res = {
     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_gpu.sh) over tools/time_step.py --steps 4, 4096 envs; "
             "KB per dispatch -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950. K2 reads and writes the env-major physics "
-            "record (13.8 MB algorithmic per launch) and — the price of eleven resident envs per CU (LDS granules, wave_layout.h) — keeps what it touches "
+            "record (13.8 MB algorithmic per launch) and — the price of twelve (until round 4: eleven) resident envs per CU (LDS granules, wave_layout.h) — keeps what it touches "
             "once or twice per substep in global memory: every substep's inertia matrix (written, read back for Euler's factorisation: 89.5 KB per "
             "env-step at the L2), the warm start, qfrc_smooth, qfrc_actuator and the activation state (another ~25 KB per env-step at the L2); the "
             "write-back L2 / MALL absorb all but the bytes counted here (mostly writes).  In time: ~50 GB/s, 0.6 % of the HBM bandwidth.",
