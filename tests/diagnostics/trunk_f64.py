@@ -47,7 +47,8 @@ class EmuAt(_emu.Emu):
 w, cfg = default_walker()
 cl = _clips.make_synthetic_clips(w.model, 4, seed=0)
 blob = default_blob(w, cfg, auto_reset=False)
-arms = {"trunk f32 (round 3)": EmuAt(build("f32", ["-DTMW_TRUNK_F32"]), blob, n), "trunk f64": EmuAt(build("f64", []), blob, n)}
+arms = {"trunk f32 (round 3)": EmuAt(build("f32", ["-DTMW_TRUNK_F32"]), blob, n), "trunk f64": EmuAt(build("f64", []), blob, n),
+        "Schur f64, elimination f32": EmuAt(build("s64", ["-DTMW_TRUNK_ELIM_F32"]), blob, n)}
 O32, O64 = make_oracle(blob, cl, "f32"), make_oracle(blob, cl, "f64")
 for scale in (0.03, 0.3, 1.0):
     rng = np.random.default_rng(11)

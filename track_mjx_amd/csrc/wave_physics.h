@@ -1035,6 +1035,9 @@ TM_DEV float tmw_acc_fnma(float a, float b, float c) { return fmaf(-a, b, c); }
 TM_DEV double tmw_acc_readlane(const double *v, int src) { return tmw_readlane_d(v, src); }
 TM_DEV double tmw_acc_rcp(double x) { return tmw_rcp_d(x); }
 TM_DEV double tmw_acc_fnma(double a, double b, double c) { return __builtin_fma(-a, b, c); }
+TM_DEV float tmw_acc_readlane(const float *v, int src) { return tmw_readlane(v, src); }
+TM_DEV float tmw_acc_rcp(float x) { return tmw_rcp(x); }
+TM_DEV float tmw_acc_fnma(float a, float b, float c) { return fmaf(-a, b, c); }
 #endif
 // The accumulator STARTS from minus the trunk rows, so that the contributions are taken off the trunk block one group at a
 // time, in elimination order (summing all 61 contributions first and subtracting them from the large trunk entries at the end costs a
@@ -1100,12 +1103,12 @@ TM_DEV void tmw_schur_apply(WCtx &c, TmwSchur &S, tmw_acc_t (*t)[TMW_NL]) {
 }
 // the twelve trunk rows, leaf -> root, in the accumulator's precision: same outputs as tmw_rows_factor<0, TRUNK, 0, EULER> (strict part of L,
 // D^-1, the eliminated rhs — all stored as float32)
-template <bool EULER>
-TM_DEV void tmw_trunk_factor(WCtx &c, const WLayout &K, tmw_acc_t (*t)[TMW_NL], int rhs) {
+template <bool EULER, typename AT>
+TM_DEV void tmw_trunk_factor(WCtx &c, const WLayout &K, AT (*t)[TMW_NL], int rhs) {
   float *L = c.L; TMW_LANE_DECL
   constexpr int N = TMW_RODENT_TRUNK;
   TMW_REG(float, dv); TMW_REG(float, yv);
-  tmw_acc_t rs[2][TMW_NL], inv[2];
+  AT rs[2][TMW_NL], inv[2];
   TMW_FOR { dv[TMW_LI] = 0.f; yv[TMW_LI] = 0.f; }
   // software-pipelined like tmw_rows_factor: as soon as the first update of step k has finished row k - 1, that row's pivot chain (readlane ->
   // reciprocal -> scale) is issued and the remaining updates of step k cover its latency
@@ -1115,12 +1118,12 @@ TM_DEV void tmw_trunk_factor(WCtx &c, const WLayout &K, tmw_acc_t (*t)[TMW_NL], 
   for (int k = N - 1; k >= 0; k--) {
     const int off = k * (k - 1) / 2 + k, b = k & 1;          // Madr(k) of the trunk chain (depth = dof)
     if (k > 0) {
-      { const tmw_acc_t a = tmw_acc_readlane(rs[b], k - 1); TMW_FOR { t[k - 1][TMW_LI] = tmw_acc_fnma(a, t[k][TMW_LI], t[k - 1][TMW_LI]); } }
+      { const AT a = tmw_acc_readlane(rs[b], k - 1); TMW_FOR { t[k - 1][TMW_LI] = tmw_acc_fnma(a, t[k][TMW_LI], t[k - 1][TMW_LI]); } }
       inv[b ^ 1] = tmw_acc_rcp(tmw_acc_readlane(t[k - 1], k - 1));
       TMW_FOR { rs[b ^ 1][TMW_LI] = t[k - 1][TMW_LI] * inv[b ^ 1]; }
     }
 #pragma unroll
-    for (int i = k - 2; i >= 0; i--) { const tmw_acc_t a = tmw_acc_readlane(rs[b], i); TMW_FOR { t[i][TMW_LI] = tmw_acc_fnma(a, t[k][TMW_LI], t[i][TMW_LI]); } }
+    for (int i = k - 2; i >= 0; i--) { const AT a = tmw_acc_readlane(rs[b], i); TMW_FOR { t[i][TMW_LI] = tmw_acc_fnma(a, t[k][TMW_LI], t[i][TMW_LI]); } }
     float yk = 0.f;
     if (EULER) yk = (float)tmw_acc_readlane(t[k], TMW_RL);
     TMW_FOR {
@@ -1199,7 +1202,13 @@ TM_DEV void tmw_factor_chains(WCtx &c, const WLayout &K, float hdamp, int rhs) {
   tmw_schur_flush(S);                       // the last, partly filled group (unused slots hold zeros)
   tmw_acc_t t[TMW_RODENT_TRUNK][TMW_NL];
   tmw_schur_apply<EULER>(c, S, t);
-  tmw_trunk_factor<EULER>(c, K, t, rhs);
+#if defined(TMW_TRUNK_ELIM_F32) && !defined(TMW_TRUNK_F32)      // diagnostic arm (tests/diagnostics/trunk_f64.py): float64 Schur accumulation only
+  { float tf[TMW_RODENT_TRUNK][TMW_NL];
+    TMW_FOR { for (int i = 0; i < TMW_RODENT_TRUNK; i++) tf[i][TMW_LI] = (float)t[i][TMW_LI]; }
+    tmw_trunk_factor<EULER, float>(c, K, tf, rhs); }
+#else
+  tmw_trunk_factor<EULER, tmw_acc_t>(c, K, t, rhs);
+#endif
   TMW_SYNC();
 }
 // rows of N = L^-1, root -> leaf:  N(k,:) = e_k - sum_{j < depth_k} L(k, anc_j) N(anc_j, :).  `tn`: the finished trunk rows
