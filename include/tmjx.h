@@ -331,7 +331,7 @@ int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is
                   int M, int N, int K, void *stream);
 
 /* The stores of one env-group step into the roll-out buffers in one launch (the Transition of brax acting.actor_step, as the learner of
- * track_mjx/agent/mlp_ppo/ppo.py:330-348 collects it): obs [W][n] (env-minor) -> up to two row-major [n][W] destinations; raw [n][A],
+ * track_mjx/agent/mlp_ppo/ppo.py:330-348 collects it): obs [W][n] (env-minor) -> up to three row-major [n][W] destinations; raw [n][A],
  * logp [n], reward [n], trunc [n] copied; discount_dst = 1 - done.  Any destination may be NULL (skipped).  No LDS. */
 typedef struct tmjx_rollout_store_t {
   const float *obs; float *obs_dst0, *obs_dst1;
@@ -341,6 +341,7 @@ typedef struct tmjx_rollout_store_t {
   const float *done; float *discount_dst;
   const float *trunc; float *trunc_dst;
   int32_t n, W, A;
+  float *obs_dst2;      /* a third row-major destination (the acting policy's staging copy of the new observation), may be NULL */
 } tmjx_rollout_store_t;
 int tmjx_rollout_store(const tmjx_rollout_store_t *s, void *stream);
 /* `m` reads `owner`'s resident clip table instead of holding a copy of its own (the env groups of one rank: one upload per rank).  `owner`

@@ -662,6 +662,12 @@ def test_rollout_store_kernel_and_multi_unroll_buffer_rows():
     hip.check(hip.lib().tmjx_rollout_store(C.byref(q), None), "tmjx_rollout_store")
     torch.cuda.synchronize()
     assert torch.equal(o[1], rew)
+    # the third observation destination alone (the acting policy's row-major staging copy of the new observation)
+    d2 = torch.zeros((n, W), device=DEV)
+    q = hip.RolloutStore(p(obs), None, None, None, None, None, None, None, None, None, None, None, None, n, W, 0, p(d2))
+    hip.check(hip.lib().tmjx_rollout_store(C.byref(q), None), "tmjx_rollout_store")
+    torch.cuda.synchronize()
+    assert torch.equal(d2, obs.t())
     # two env groups sharing one clip table, two unrolls per training step
     e0 = make_env_and_oracle(num_envs=32, n_clips=4, wrappers=True, seed=0)[0]
     from track_mjx_amd.environment import MultiClipTracking, RewardConfig, wrap
@@ -675,9 +681,10 @@ def test_rollout_store_kernel_and_multi_unroll_buffer_rows():
     seen = []
     orig = L._store_transition
 
-    def spy(env, st, extra, d0_, d1_, t, sl):
+    def spy(env, st, extra, d0_, d1_, t, sl, d2_=None):
         seen.append((t, sl.start, st.obs.clone(), st.reward.clone(), st.done.clone(), extra["raw_action"].clone()))
-        orig(env, st, extra, d0_, d1_, t, sl)
+        orig(env, st, extra, d0_, d1_, t, sl, d2_)
+        assert d2_ is not None          # the acting policy's row-major staging copy of the group's new observation
     L._store_transition = spy
     for k, e in enumerate([e0, e1]):
         L.states[k] = e.reset(torch.Generator().manual_seed(20 + k), torch.arange(32, dtype=torch.int32) % 4)
@@ -691,6 +698,9 @@ def test_rollout_store_kernel_and_multi_unroll_buffer_rows():
         nxt = b["observation"][t + 1, sl] if t + 1 < 4 else b["next_observation_last"][sl]
         assert torch.equal(nxt, ob)
     assert len(seen) == 2 * 4 * 2
+    # the staging copies hold every group's newest observation, row-major: what the next inference reads (LDS-free acting path)
+    for k in range(2):
+        assert L._obs_rm is not None and torch.equal(L._obs_rm[k], L.states[k].obs)
     out = L.update(0)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(v).all()) for v in out.values())

@@ -316,6 +316,10 @@ class PPOLearner:
         for gen in self.gens:
             self._act_rng_state(gen)
         self.states = [None] * len(self.envs)
+        # LDS-free acting path: a ROW-major staging copy of every group's newest observation (third destination of the roll-out store): the acting
+        # policy's first layer then reads 16 bytes along K per lane instead of four strided words from the env's [obs][n_env] buffer
+        self._obs_rm = ([torch.zeros((e.num_envs, e.observation_size), dtype=torch.float32, device=dev) for e in self.envs]
+                        if (self.lds_free and env.observation_size % 4 == 0 and not os.environ.get("TMJX_NO_OBS_STAGING")) else None)
         self._streams = [torch.cuda.Stream(device=dev) for _ in self.envs] if (len(self.envs) > 1 and dev.type == "cuda") else None
 
     @property
@@ -343,7 +347,10 @@ class PPOLearner:
                                                  "latent_mean": mean, "latent_logvar": logvar}
         # (the acting policy runs on the fp32 LDS-free kernels in either GEMM-input mode: next to the physics kernel the matrix pipe is idle)
         if (not deterministic and self.dev.type == "cuda" and obs.dim() == 2 and obs.dtype == torch.float32):
-            if self.lds_free and obs.shape[0] % 4 == 0 and obs.stride(0) == 1:     # K-major float4 loads need 4 | n_env
+            # the RAW observation: the env's [obs][n_env] buffer (K-major float4 loads need 4 | n_env) or a row-major copy of it (collect()'s staging
+            # buffer, written by the roll-out store: 16-byte loads along K — the first layer read K-major took 44 us of a group's 338 us serial
+            # phase at config 2, and 530 us at config 5's 1024-wide first layer)
+            if self.lds_free and ((obs.shape[0] % 4 == 0 and obs.stride(0) == 1) or (obs.stride(1) == 1 and obs.stride(0) % 4 == 0 and obs.data_ptr() % 16 == 0)):
                 return self._act_fused(None, obs_raw=obs, gen=gen)
             return self._act_fused(self.normalizer.normalize(obs) if self.normalize_observations else obs, gen=gen)
         x = self.normalizer.normalize(obs) if self.normalize_observations else obs
@@ -472,7 +479,7 @@ class PPOLearner:
                                            (self._noise_seed ^ (0xD1B54A32D192ED03 * (len(self._act_rng) + 1))) & (2 ** 64 - 1), gen)
         return rs
 
-    def _store_transition(self, env, st, extra, obs_dst0, obs_dst1, t: int, sl: slice) -> None:
+    def _store_transition(self, env, st, extra, obs_dst0, obs_dst1, t: int, sl: slice, obs_dst2=None) -> None:
         import ctypes as C
         from .. import hip as _hip
         raw, logp = extra["raw_action"], extra["log_prob"]
@@ -482,7 +489,7 @@ class PPOLearner:
         b = self.buf
         q = _hip.RolloutStore(p(st.obs), p(obs_dst0), p(obs_dst1), p(raw), p(b["raw_action"][t, sl]), p(logp), p(b["log_prob"][t, sl]),
                               p(st.reward), p(b["reward"][t, sl]), p(st.done), p(b["discount"][t, sl]), p(st.info["truncation"]), p(b["truncation"][t, sl]),
-                              st.obs.shape[0], st.obs.shape[1], raw.shape[1])
+                              st.obs.shape[0], st.obs.shape[1], raw.shape[1], p(obs_dst2))
         with torch.cuda.device(self.dev):
             _hip.check(_hip.lib().tmjx_rollout_store(C.byref(q), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)), "tmjx_rollout_store")
 
@@ -578,17 +585,19 @@ class PPOLearner:
                         st = self.states[g]
                         if u == 0 and t == 0:
                             self.buf["observation"][0, sl] = st.obs          # (every later row is written by the step that produces it)
+                            if self._obs_rm is not None:
+                                self._obs_rm[g].copy_(st.obs)
                         if jax_noise:
                             action, extra = self.act(st.obs, draws=(eps_all[offs[g]:offs[g + 1]], noise_all[offs[g]:offs[g + 1]]))
                         else:
-                            action, extra = self._act_graphed(st.obs, g)
+                            action, extra = self._act_graphed(st.obs if self._obs_rm is None else self._obs_rm[g], g)
                         st = env.step(st, action)
                         # ONE launch stores this step's transition: the new observation (transposed into row t + 1 — or, at the end of an
                         # unroll, into next_observation_last and row 0 of the next unroll), raw action / log-prob of the acting policy
                         # (the inference graph's outputs are overwritten only by the next replay), reward, discount = 1 - done, truncation
                         nxt = self.buf["observation"][t + 1, sl] if t + 1 < T else self.buf["next_observation_last"][sl]
                         nxt1 = self.buf["observation"][0, slice(sl.start + n_local, sl.stop + n_local)] if (t + 1 == T and u + 1 < self.unrolls) else None
-                        self._store_transition(env, st, extra, nxt, nxt1, t, sl)
+                        self._store_transition(env, st, extra, nxt, nxt1, t, sl, None if self._obs_rm is None else self._obs_rm[g])
                         self.states[g] = st
         if self._streams:
             for sg in self._streams:

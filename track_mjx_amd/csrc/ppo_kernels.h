@@ -986,6 +986,7 @@ struct RolloutStore {
   const float *done; float *discount_dst;
   const float *trunc; float *trunc_dst;
   int n, W, A;
+  float *obs_dst2;
 };
 __global__ __launch_bounds__(64) void k_rollout_store(const RolloutStore s) {
   const int e = blockIdx.x * 64 + threadIdx.x, ny = gridDim.y - 1;
@@ -995,9 +996,9 @@ __global__ __launch_bounds__(64) void k_rollout_store(const RolloutStore s) {
     float v[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = k0 + j < s.W ? s.obs[(size_t)(k0 + j) * s.n + e] : 0.f;
-    float *d[2] = {s.obs_dst0, s.obs_dst1};
+    float *d[3] = {s.obs_dst0, s.obs_dst1, s.obs_dst2};
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < 3; q++) {
       if (!d[q]) continue;
       float *o = d[q] + (size_t)e * s.W + k0;
       if (!(s.W & 3) && k0 + 16 <= s.W) {

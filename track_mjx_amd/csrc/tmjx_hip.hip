@@ -1037,12 +1037,12 @@ int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
 int tmjx_rollout_store(const tmjx_rollout_store_t *q, void *stream) {
   if (!q) return fail(TMJX_EINVAL, "null argument");
   if (q->n < 1 || q->W < 0 || q->A < 0) return fail(TMJX_EINVAL, "bad sizes");
-  if ((q->obs_dst0 || q->obs_dst1) && (!q->obs || q->W < 1)) return fail(TMJX_EINVAL, "observation destination without a source");
+  if ((q->obs_dst0 || q->obs_dst1 || q->obs_dst2) && (!q->obs || q->W < 1)) return fail(TMJX_EINVAL, "observation destination without a source");
   if ((q->raw_dst && !q->raw) || (q->logp_dst && !q->logp) || (q->reward_dst && !q->reward) || (q->discount_dst && !q->done) || (q->trunc_dst && !q->trunc))
     return fail(TMJX_EINVAL, "destination without a source");
   RolloutStore s{q->obs, q->obs_dst0, q->obs_dst1, q->raw, q->raw_dst, q->logp, q->logp_dst, q->reward, q->reward_dst, q->done, q->discount_dst,
-                 q->trunc, q->trunc_dst, q->n, q->W, q->A};
-  const int ny = (q->obs_dst0 || q->obs_dst1) ? (q->W + 15) / 16 : 0;
+                 q->trunc, q->trunc_dst, q->n, q->W, q->A, q->obs_dst2};
+  const int ny = (q->obs_dst0 || q->obs_dst1 || q->obs_dst2) ? (q->W + 15) / 16 : 0;
   hipLaunchKernelGGL(k_rollout_store, dim3((q->n + 63) / 64, ny + 1), dim3(64), 0, (hipStream_t)stream, s);
   return check_launch("k_rollout_store");
 }

@@ -59,7 +59,7 @@ class DwProblem(C.Structure):
 class RolloutStore(C.Structure):
     """tmjx_rollout_store_t (include/tmjx.h)."""
     _fields_ = [(k, C.c_void_p) for k in ("obs", "obs_dst0", "obs_dst1", "raw", "raw_dst", "logp", "logp_dst", "reward", "reward_dst", "done", "discount_dst",
-                                          "trunc", "trunc_dst")] + [(k, C.c_int32) for k in ("n", "W", "A")]
+                                          "trunc", "trunc_dst")] + [(k, C.c_int32) for k in ("n", "W", "A")] + [("obs_dst2", C.c_void_p)]
 
 
 class Bf16Shadow(C.Structure):
