@@ -334,7 +334,7 @@ def main(argv=None, runner=None):
                        "policy_params": learner.n_params(), "envs_per_physics_launch": per_launch, "concurrent_physics_launches": ngrp,
                        "rollout_ms_per_step": rollout_ms, "sgd_ms_per_step": sgd_ms, "sgd_ms_per_minibatch_step": sgd_ms / sgd_steps,
                        "rollout_only_env_steps_per_s_per_gpu": rollout_only, "rollout_only_error": rollout_err,
-                       "note": "one box of the pool differs from the next by about 3 % on this line (1.17-1.22 M env-steps/s seen for one build in round 1, 1.25-1.27 M for round 2's final build)"},
+                       "note": "one box of the pool differs from the next by about 1-3 % on this line (round 4's final build: 1.446-1.471 M env-steps/s over five runs)"},
             # 15 644 algorithmic bytes per env-step (K2 + K3 together) x the envs of one physics launch / that
             # launch's average duration (HIP events on its launch stream; the env groups' launches share the GPU)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
