@@ -118,3 +118,66 @@ def test_f32_oracle_tracks_f64_over_one_control_step():
     assert np.abs(O32.get(a, "qpos") - O64.get(b, "qpos")).max() < 1e-5
     q = O32.get(a, "qpos")[3:7]
     assert abs(np.linalg.norm(q) - 1) < 1e-6
+
+
+def test_invweight0_constants_against_finite_difference_jacobians():
+    """body_invweight0 / dof_invweight0 (MuJoCo engine_setconst.c set0; the constants every constraint row's regulariser R is built from: SURVEY
+    App. A, `diagApprox`) are computed by tools/compile_model.py from its OWN kinematics and Jacobian code, and the oracle and the HIP kernel both read
+    them from the same compiled blob — a wrong value would make them agree with each other (round-3 verdict, Weak 1).  Independent derivation here:
+    the Jacobians of every body's centre of mass / orientation by CENTRAL FINITE DIFFERENCES of the C oracle's forward kinematics in dof space (free
+    joint: translation in the world frame, rotation as a body-frame increment of the quaternion, which is MuJoCo's convention), the inertia matrix
+    from the oracle's CRB pass, then  invweight0 = tr(J M^-1 J^T) / 3  and  diag(M^-1) (averaged over the free joint's two triples)."""
+    from tests.common import default_walker
+    w, cfg = default_walker()
+    m = w.model
+    O = make_oracle(default_blob(w, cfg), None, "f64")
+    q0 = np.asarray(m["qpos0"], dtype=np.float64)
+    nv, nb = 73, 68
+
+    def quat_mul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    def moved(i, eps):          # qpos after a step eps along dof i (dofs 0-2: root translation, 3-5: body-frame rotation of the root, 6..: hinges)
+        q = q0.copy()
+        if i < 3:
+            q[i] += eps
+        elif i < 6:
+            h = np.zeros(4); h[0] = np.cos(eps / 2); h[1 + i - 3] = np.sin(eps / 2)
+            q[3:7] = quat_mul(q0[3:7], h)
+        else:
+            q[i + 1] += eps
+        return q
+
+    def kin(q):
+        d = O.new_data(q, np.zeros(nv)); O.forward(d)
+        return O.get(d, "xipos").reshape(nb, 3).copy(), O.get(d, "xmat").reshape(nb, 3, 3).copy()
+
+    d0 = O.new_data(q0, np.zeros(nv)); O.forward(d0)
+    M = O.get(d0, "qM").reshape(nv, nv)
+    M = np.tril(M) + np.tril(M, -1).T
+    Minv = np.linalg.inv(M)
+    _, R0 = kin(q0)
+    eps = 1e-6
+    Jp, Jr = np.zeros((nb, 3, nv)), np.zeros((nb, 3, nv))
+    for i in range(nv):
+        pp, Rp = kin(moved(i, eps)); pm, Rm = kin(moved(i, -eps))
+        Jp[:, :, i] = (pp - pm) / (2 * eps)
+        dR = (Rp - Rm) / (2 * eps)
+        W = np.einsum("bij,bkj->bik", dR, R0)          # dR R^T = [omega]_x
+        Jr[:, 0, i], Jr[:, 1, i], Jr[:, 2, i] = W[:, 2, 1], W[:, 0, 2], W[:, 1, 0]
+    binv = np.zeros((nb, 2))
+    for b in range(nb):
+        binv[b, 0] = np.trace(Jp[b] @ Minv @ Jp[b].T) / 3
+        binv[b, 1] = np.trace(Jr[b] @ Minv @ Jr[b].T) / 3
+    dinv = np.diag(Minv).copy()
+    dinv[0:3] = dinv[0:3].mean(); dinv[3:6] = dinv[3:6].mean()
+    want_b, want_d = np.asarray(m["body_invweight0"], dtype=np.float64).reshape(nb, 2), np.asarray(m["dof_invweight0"], dtype=np.float64)
+    moving = np.asarray(m["body_mass"]) > 0
+    assert moving.sum() >= 60
+    np.testing.assert_allclose(binv[moving], want_b[moving], rtol=2e-5, atol=1e-9)
+    assert np.abs(want_b[~moving & (np.arange(nb) < 2)]).max() == 0            # world and floor: no dofs above them
+    np.testing.assert_allclose(dinv, want_d, rtol=1e-8)
+    # and the contact rows' diagApprox input that the kernel derives from them (model_host.h): (t + mu^2 t) 2 mu^2 / impratio with t = the floor's + the paw's
+    # translational invweight0 — positive and dominated by the light paws
+    assert (want_b[moving, 0] > 0).all() and want_b[moving, 0].max() / want_b[moving, 0].min() > 10
