@@ -138,6 +138,13 @@ int tmjx_silu_ln_fwd(const float *z, const float *bias, const float *gamma, cons
                      float eps, void *stream);
 int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, float *dz, float *grads,
                      float *partial, int rows, int H, void *stream);
+/* The same two kernels with a bf16 result (y16 / dz16: [rows][ld >= H], round to nearest even) for consumers that are bf16-operand GEMMs
+ * (tmjx_bgemm_*: the 1024-wide first encoder block of the rodent-mc-intention nets, which is not one GEMM tile wide): the bits those GEMMs would have
+ * made of the fp32 result when they stage it, without the fp32 round trip through memory.  Statistics and column sums stay fp32. */
+int tmjx_silu_ln_fwd_bf16(const float *z, const float *bias, const float *gamma, const float *beta, uint16_t *y16, int ldy16, float *stats, int rows, int H,
+                          float eps, void *stream);
+int tmjx_silu_ln_bwd_bf16(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, uint16_t *dz16, int lddz16, float *grads,
+                          float *partial, int rows, int H, void *stream);
 
 /* Minibatch gather fused with the observation normaliser (ppo.py:306-311 + running_statistics.normalize):
  * out[t][b][:] = (src[t][idx[b]][:] - mean) / std; src [T][R][W], idx int64 [B], out [T][B][W], W % 4 == 0. */
@@ -167,6 +174,10 @@ typedef struct tmjx_minibatch_t {
   int32_t T, R, B, W, A, Z, advance;
 } tmjx_minibatch_t;
 int tmjx_minibatch_begin(const tmjx_minibatch_t *mb, void *stream);
+/* The same launch with a bf16 TWIN of obs_n next to it (bf16 GEMM-input mode): obs_n16 [T B][ld16 >= W], the normalised observation rounded to
+ * nearest even — the operand the first layers' bf16 GEMMs (tmjx_bgemm_*) would have made of obs_n when they stage it.  Columns W .. ld16 - 1 are
+ * not written (the caller keeps them zero, so that a contraction may run to the next multiple of 64 by LDS-DMA). */
+int tmjx_minibatch_begin_bf16(const tmjx_minibatch_t *mb, uint16_t *obs_n16, int ld16, void *stream);
 /* Philox4x32-10 of (counter[4], key[2]) = six device words -> four device words: the generator above, exposed for its known-answer test */
 int tmjx_philox4x32_10(const uint32_t *ctr_key_dev, uint32_t *out_dev, void *stream);
 

@@ -295,3 +295,75 @@ def test_bf16_mode_acting_and_learning_share_their_numerics():
     d_bf, d_f32 = (fc2_act - fc2_learn).abs().max().item() / scale, (fc2_f32 - fc2_learn).abs().max().item() / scale
     print(f"\nbf16 mode, encoder output against the learner's forward pass (relative): bf16 acting kernels {d_bf:.2e}, fp32 acting kernels {d_f32:.2e}")
     assert d_bf <= 0.25 * d_f32 and d_bf < 2e-3
+
+
+@pytest.mark.parametrize("H", [64, 256, 512, 1024])
+def test_silu_ln_bf16_results_are_the_rounded_fp32_results(H):
+    """tmjx_silu_ln_fwd_bf16 / _bwd_bf16 (the row kernels of a Dense -> SiLU -> LayerNorm block that is not one GEMM tile wide, with a bf16
+    result for the bf16-operand GEMMs that consume it): bit for bit torch's .to(bfloat16) (round to nearest even) of what tmjx_silu_ln_fwd /
+    _bwd write as fp32 — the bits those GEMMs would have made when they stage the fp32 rows — with the same fp32 statistics and column sums.
+    Ragged row count (1000: the last 32-row block of the backward kernel is partial), output leading dimension wider than H."""
+    import ctypes as C
+    from track_mjx_amd import hip as _hip
+    lib = _hip.lib()
+    g = torch.Generator(device=DEV).manual_seed(H)
+    rows, ld = 1000, H + 8
+    z, dy = torch.randn(rows, H, generator=g, device=DEV), torch.randn(rows, H, generator=g, device=DEV)
+    bias, gamma, beta = 0.3 * torch.randn(H, generator=g, device=DEV), 1 + 0.2 * torch.randn(H, generator=g, device=DEV), 0.1 * torch.randn(H, generator=g, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y, st = torch.empty_like(z), torch.empty(rows, 2, device=DEV)
+    y16, st16 = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=DEV), torch.empty(rows, 2, device=DEV)
+    _hip.check(lib.tmjx_silu_ln_fwd(p(z), p(bias), p(gamma), p(beta), p(y), p(st), rows, H, 1e-6, stream), "fwd")
+    _hip.check(lib.tmjx_silu_ln_fwd_bf16(p(z), p(bias), p(gamma), p(beta), p(y16), ld, p(st16), rows, H, 1e-6, stream), "fwd16")
+    assert torch.equal(y16[:, :H], y.to(torch.bfloat16)) and torch.equal(st, st16) and bool((y16[:, H:] == 7.0).all())
+    y_ref = torch.nn.functional.layer_norm(torch.nn.functional.silu(z.double() + bias.double()), (H,), gamma.double(), beta.double(), 1e-6)
+    assert float((y.double() - y_ref).abs().max()) < 2e-5
+    npart = int(lib.tmjx_silu_ln_partial_floats(rows, H))
+    dz, g3, part = torch.empty_like(z), torch.empty(3, H, device=DEV), torch.empty(npart, device=DEV)
+    dz16, g316, part16 = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=DEV), torch.empty(3, H, device=DEV), torch.empty(npart, device=DEV)
+    _hip.check(lib.tmjx_silu_ln_bwd(p(dy), p(z), p(bias), p(gamma), p(st), p(dz), p(g3), p(part), rows, H, stream), "bwd")
+    _hip.check(lib.tmjx_silu_ln_bwd_bf16(p(dy), p(z), p(bias), p(gamma), p(st), p(dz16), ld, p(g316), p(part16), rows, H, stream), "bwd16")
+    assert torch.equal(dz16[:, :H], dz.to(torch.bfloat16)) and torch.equal(g3, g316) and bool((dz16[:, H:] == 7.0).all())
+    # error paths: a misaligned / too narrow bf16 destination is refused
+    assert lib.tmjx_silu_ln_fwd_bf16(p(z), p(bias), p(gamma), p(beta), p(y16), H - 4, p(st16), rows, H, 1e-6, stream) != 0
+    assert lib.tmjx_silu_ln_bwd_bf16(p(dy), p(z), p(bias), p(gamma), p(st), C.c_void_p(dz16.data_ptr() + 2), ld, p(g316), p(part16), rows, H, stream) != 0
+
+
+def test_minibatch_begin_bf16_twin_and_the_chain_that_stages_it():
+    """bf16 GEMM-input mode feeds its first layers from a bf16 TWIN of the minibatch's normalised observations, written by the gather launch
+    (tmjx_minibatch_begin_bf16) — bit-identical by construction: (1) the twin is torch's .to(bfloat16) of the fp32 rows, zero beyond the
+    observation width; (2) one SGD step's gradient buffer with the twin (first layers by LDS-DMA over whole K tiles, the 1024-wide encoder block's
+    row kernels with bf16 results) equals the step without it (TMJX_NO_BF16_TWIN=1: fp32 rows converted while they are staged) BIT FOR BIT."""
+    import os
+    from tests.common import make_env_and_oracle
+    from track_mjx_amd.agent import ppo
+    env = make_env_and_oracle(num_envs=256, n_clips=4, wrappers=True, seed=3)[0]
+    L = ppo.PPOLearner(env, encoder_layers=(1024, 512), decoder_layers=(512, 256), critic_layers=(512, 256), latents=60, unroll_length=4,
+                       batch_size=256, num_minibatches=1, num_updates_per_batch=1, seed=11, matmul_dtype=torch.bfloat16, use_graph=False)
+    assert L.shadows is not None and L._obs16 is not None and L._obs16.shape == (4 * 256, 704) and L._self_advancing()
+    L.states[0] = env.reset(torch.Generator().manual_seed(1))
+    L.collect()
+    L.normalizer.update(L.buf["observation"])
+    L._perm_static.copy_(torch.randperm(L._perm_static.numel(), generator=torch.Generator().manual_seed(2)).to(DEV))
+    state0 = L._mb_state.clone()
+    grads = []
+    for no_twin in (False, True):
+        L._mb_state.copy_(state0)
+        L._acc8.zero_()
+        if no_twin:
+            os.environ["TMJX_NO_BF16_TWIN"] = "1"
+        try:
+            L._minibatch_grads(None, 0.05)
+        finally:
+            os.environ.pop("TMJX_NO_BF16_TWIN", None)
+        torch.cuda.synchronize()
+        grads.append((L.grads.flat.clone(), L._acc8.clone()))
+    assert torch.isfinite(grads[0][0]).all() and float(grads[0][0].abs().max()) > 0
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    # (1): the twin against the fp32 rows of the same launch
+    L._mb_state.copy_(state0)
+    data = L._mb_data(None)
+    on, tw = data["observation_normalized"], data["observation_normalized_bf16"]
+    W = on.shape[-1]
+    assert torch.equal(tw[:, :W], on.reshape(-1, W).to(torch.bfloat16)) and bool((tw[:, W:] == 0).all())

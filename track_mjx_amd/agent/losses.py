@@ -64,7 +64,8 @@ def gather_minibatch(buf: dict, idx: torch.Tensor, normalizer) -> dict:
             "discount": sc[2], "truncation": sc[3]}
 
 
-def minibatch_begin(buf: dict, perm: torch.Tensor, state: torch.Tensor, seed: int, normalizer, latents: int, advance: bool = True) -> dict:
+def minibatch_begin(buf: dict, perm: torch.Tensor, state: torch.Tensor, seed: int, normalizer, latents: int, advance: bool = True,
+                    obs16: torch.Tensor | None = None) -> dict:
     """First launch of a self-advancing SGD step (tmjx_minibatch_begin): the minibatch rows perm[slot B : slot B + B] (slot = state[1], B =
     perm.numel() // num_minibatches is implied by the caller through `buf["_B"]`) of every leaf, observations normalised, plus the step's two
     N(0, 1) arrays ("latent_eps" [T, B, latents], "entropy_noise" [T, B, A]) from the device-side Philox stream; advances state[0:2]."""
@@ -78,10 +79,19 @@ def minibatch_begin(buf: dict, perm: torch.Tensor, state: torch.Tensor, seed: in
     d = lambda t: t.data_ptr()  # noqa: E731
     m = _hip.Minibatch(d(obs), d(nxt), d(act), d(buf["log_prob"]), d(buf["reward"]), d(buf["discount"]), d(buf["truncation"]), d(perm), d(normalizer.mean),
                        d(normalizer.std), d(obs_n), d(next_n), d(act_g), d(sc), d(eps), d(noise), d(state), seed & (2 ** 64 - 1), T, R, B, W, A, latents, int(advance))
+    out = {"observation_normalized": obs_n, "next_observation_last_normalized": next_n, "raw_action": act_g, "log_prob": sc[0], "reward": sc[1],
+           "discount": sc[2], "truncation": sc[3], "latent_eps": eps, "entropy_noise": noise}
     with torch.cuda.device(obs.device):
-        _hip.check(_hip.lib().tmjx_minibatch_begin(C.byref(m), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)), "tmjx_minibatch_begin")
-    return {"observation_normalized": obs_n, "next_observation_last_normalized": next_n, "raw_action": act_g, "log_prob": sc[0], "reward": sc[1],
-            "discount": sc[2], "truncation": sc[3], "latent_eps": eps, "entropy_noise": noise}
+        stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        if obs16 is not None:
+            # bf16 GEMM-input mode: the launch also writes the normalised observation as bf16 into the caller's [T B][ld >= W] buffer (zero
+            # beyond W), which the first layers' GEMMs stage instead of the fp32 rows (networks.py: gemm_inputs.twins)
+            assert obs16.dtype == torch.bfloat16 and obs16.shape[0] == T * B and obs16.shape[1] >= W and obs16.is_contiguous()
+            _hip.check(_hip.lib().tmjx_minibatch_begin_bf16(C.byref(m), C.c_void_p(obs16.data_ptr()), obs16.shape[1], stream), "tmjx_minibatch_begin_bf16")
+            out["observation_normalized_bf16"] = obs16
+        else:
+            _hip.check(_hip.lib().tmjx_minibatch_begin(C.byref(m), stream), "tmjx_minibatch_begin")
+    return out
 
 
 def create_ramp_schedule(max_value: float = 0.1, min_value: float = 0.0001, ramp_steps: int = 1000, warmup_steps: int = 0):

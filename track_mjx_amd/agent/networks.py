@@ -48,17 +48,37 @@ class gemm_inputs:
     take torch ops in fp32."""
     dtype = None
     shadows = None          # Bf16Shadows of the networks' dense layers (CUDA: the library's own bf16 kernels take every contraction)
+    # bf16 TWINS of fp32 network inputs, made by the kernel that wrote the input (tmjx_minibatch_begin_bf16: the normalised observation rounded to
+    # nearest even, [rows][ld >= ceil64(width)], zero beyond the width): {data_ptr of the fp32 tensor: (twin [rows, ld], width)}.  A chain whose
+    # input starts at a registered pointer stages the twin instead — the bits its GEMMs would have made of the fp32 rows themselves, half the
+    # bytes, and the LDS-DMA form of the kernels (whole 64-column K tiles: the twin's columns beyond the layer's K meet zero weight columns)
+    twins = None
 
-    def __init__(self, dtype, shadows=None):
-        self.new = (dtype, shadows if dtype is not None else None)
+    def __init__(self, dtype, shadows=None, twins=None):
+        self.new = (dtype, shadows if dtype is not None else None, twins if dtype is not None else None)
 
     def __enter__(self):
-        self.old = (gemm_inputs.dtype, gemm_inputs.shadows)
-        gemm_inputs.dtype, gemm_inputs.shadows = self.new
+        self.old = (gemm_inputs.dtype, gemm_inputs.shadows, gemm_inputs.twins)
+        gemm_inputs.dtype, gemm_inputs.shadows, gemm_inputs.twins = self.new
 
     def __exit__(self, *a):
-        gemm_inputs.dtype, gemm_inputs.shadows = self.old
+        gemm_inputs.dtype, gemm_inputs.shadows, gemm_inputs.twins = self.old
         return False
+
+    @staticmethod
+    def twin_of(x2: torch.Tensor, K: int):
+        """The bf16 twin's first ceil64(K) columns for the fp32 rows `x2` (a column prefix of a registered tensor), or None."""
+        tw = gemm_inputs.twins
+        if not tw or x2.dtype != torch.float32:
+            return None
+        hit = tw.get(x2.data_ptr())
+        if hit is None:
+            return None
+        t16, width = hit
+        Ke = _ceil64(K)
+        if t16.shape[0] != x2.shape[0] or x2.stride(0) != width or K > width or Ke > t16.shape[1] or os.environ.get("TMJX_NO_BF16_TWIN"):
+            return None
+        return t16[:, :Ke]
 
 
 def _hip_gemm_ok(*ts) -> bool:
@@ -372,25 +392,35 @@ class _BfChainFn(torch.autograd.Function):
         if x2.data_ptr() % 16 or x2.stride(0) % (4 if x2.dtype == torch.float32 else 8):
             x2 = x2.contiguous()
         saved, h = [], x2
+        t16 = gemm_inputs.twin_of(x2, layers[0].lin.weight.shape[1])
         for i, L in enumerate(layers):
             lin = L.lin
             N, K = lin.weight.shape
             last = i == len(layers) - 1
+            hx = h                 # the layer's input as the weight gradient wants it (true width)
+            if i == 0 and t16 is not None:
+                # columns K .. ceil64(K) of the twin (other observation columns, or its zero padding) meet the shadow's zero columns
+                h, hx, K = t16, t16[:, :K], t16.shape[1]
             if L.kind == "dense":
                 y = bgemm_nt(h, sh.w[lin], N, K, lin.bias)
-                saved.append((h, None, None))
+                saved.append((hx, None, None))
             elif L.kind == "silu":
                 z, y = bgemm_silu_fwd(h, sh.w[lin], N, K, lin.bias, y_f32=last and last_y_f32)
-                saved.append((h, z, None))
+                saved.append((hx, z, None))
             elif L.fused:
                 z, y, stats = bgemm_ln_fwd(h, sh.w[lin], N, K, lin.bias, L.norm.weight, L.norm.bias, L.norm.eps)
-                saved.append((h, z, stats))
+                saved.append((hx, z, stats))
             else:
+                # not one tile wide: plain GEMM + the row kernel, whose result goes out as bf16 — what the next GEMM would make of it anyway
                 z = bgemm_nt(h, sh.w[lin], N, K)
-                y = torch.empty_like(z)
                 stats = torch.empty((z.shape[0], 2), dtype=torch.float32, device=z.device)
-                _launch("tmjx_silu_ln_fwd", z.device, _p(z), _p(lin.bias), _p(L.norm.weight), _p(L.norm.bias), _p(y), _p(stats), z.shape[0], N, float(L.norm.eps))
-                saved.append((h, z, stats))
+                if last:
+                    y = torch.empty_like(z)
+                    _launch("tmjx_silu_ln_fwd", z.device, _p(z), _p(lin.bias), _p(L.norm.weight), _p(L.norm.bias), _p(y), _p(stats), z.shape[0], N, float(L.norm.eps))
+                else:
+                    y = torch.empty((z.shape[0], N), dtype=torch.bfloat16, device=z.device)
+                    _launch("tmjx_silu_ln_fwd_bf16", z.device, _p(z), _p(lin.bias), _p(L.norm.weight), _p(L.norm.bias), _p(y), N, _p(stats), z.shape[0], N, float(L.norm.eps))
+                saved.append((hx, z, stats))
             h = y
         ctx.layers, ctx.sh, ctx.dx_cols, ctx.saved, ctx.x_shape = layers, sh, dx_cols, saved, x.shape
         return h.view(*x.shape[:-1], h.shape[-1])
@@ -435,10 +465,11 @@ class _BfChainFn(torch.autograd.Function):
             if not g_is_dz:        # g = d loss / d y of this block: its own (unfused) backward
                 if L.kind == "ln":
                     gy = g if g.dtype == torch.float32 and g.is_contiguous() else g.float().contiguous()
-                    dz = torch.empty_like(z)
+                    # d loss / d z as bf16: its two consumers are bf16-operand GEMMs (this layer's weight gradient, the producer's input gradient)
+                    dz = torch.empty((M, N), dtype=torch.bfloat16, device=z.device)
                     g3 = torch.empty((3, N), dtype=torch.float32, device=z.device)
                     partial = torch.empty(int(Lh.tmjx_silu_ln_partial_floats(M, N)), dtype=torch.float32, device=z.device)
-                    _launch("tmjx_silu_ln_bwd", z.device, _p(gy), _p(z), _p(lin.bias), _p(L.norm.weight), _p(stats), _p(dz), _p(g3), _p(partial), M, N)
+                    _launch("tmjx_silu_ln_bwd_bf16", z.device, _p(gy), _p(z), _p(lin.bias), _p(L.norm.weight), _p(stats), _p(dz), N, _p(g3), _p(partial), M, N)
                     grads[id(L.norm.weight)], grads[id(L.norm.bias)], grads[id(lin.bias)] = g3[0], g3[1], g3[2]
                     g = dz
                 else:

@@ -281,6 +281,11 @@ class PPOLearner:
             lins = [m for net in (self.policy, self.value) for m in net.modules() if isinstance(m, torch.nn.Linear) and m.out_features % 4 == 0]
             first = {self.policy.encoder[0].dense, next(m for m in self.value.net if isinstance(m, torch.nn.Linear))}
             self.shadows = Bf16Shadows(lins, need_t=[m for m in lins if m not in first])
+        # ... and a bf16 twin of the minibatch's normalised observations, written by the gather launch (tmjx_minibatch_begin_bf16): [rows][ceil64(obs)],
+        # zero beyond the observation width for good (the launch never writes there)
+        self._obs16 = None
+        if self.shadows is not None and obs % 4 == 0 and not os.environ.get("TMJX_NO_BF16_TWIN"):
+            self._obs16 = torch.zeros((T * self.local_batch, (obs + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
         self._sgd_side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and os.environ.get("TMJX_SGD_TWO_STREAMS", "1") != "0") else None
         if self._sgd_side is not None and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)    # intentional: the value net's gradients arrive from the side stream
@@ -613,7 +618,7 @@ class PPOLearner:
         fused_gather = self.dev.type == "cuda" and self.normalize_observations and self.buf["observation"].shape[-1] % 4 == 0
         if idx is None:
             data = _losses.minibatch_begin({**self.buf, "_B": self.local_batch}, self._perm_static, self._mb_state, self._noise_seed, self.normalizer,
-                                           self.policy.latents)
+                                           self.policy.latents, obs16=self._obs16)
         elif fused_gather and all(v.is_contiguous() for v in self.buf.values()):
             data = _losses.gather_minibatch(self.buf, idx, self.normalizer)      # all seven leaves in one launch
         else:
@@ -626,7 +631,11 @@ class PPOLearner:
         """GPU: gather + both networks' forward passes + the loss head (outside autograd).  Returns (network outputs, their gradients, the loss
         kernel's eight scalars) for _mb_backward."""
         data = self._mb_data(idx)
-        with gemm_inputs(self.matmul_dtype, self.shadows):
+        twins = None
+        if "observation_normalized_bf16" in data:
+            on = data["observation_normalized"]
+            twins = {on.data_ptr(): (data["observation_normalized_bf16"], on.shape[-1])}
+        with gemm_inputs(self.matmul_dtype, self.shadows, twins):
             m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,
                                                                      side_stream=self._sgd_side, acc_out=self._acc8 if idx is None else None, **self.hp)
         return outs, gouts, out8

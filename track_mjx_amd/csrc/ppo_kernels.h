@@ -339,50 +339,96 @@ __global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk, co
 #define BLK_ROWS_PER_BLOCK 32
 __device__ __forceinline__ float wave_sum(float x) { for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off); return x; }
 
+// Column of register k of a lane: the lane's VPT columns are dealt in groups of four CONSECUTIVE ones, group j of lane l at column 4 (64 j + l):
+// a wave instruction then reads 64 adjacent 16-byte pieces = whole cache lines (VPT consecutive columns per lane — 32 / 64 bytes apart at H = 512 /
+// 1024 — used a quarter of every line per instruction: 2.3 TB/s; up to H = 256 the two mappings are the same).
+template <int VPT> __device__ __forceinline__ int silu_ln_col(int lane, int k) { return VPT >= 4 ? 4 * (64 * (k >> 2) + lane) + (k & 3) : lane * VPT + k; }
+// two floats -> two bf16 in one dword (lo in the low half), round to nearest even (v_cvt_pk_bf16_f32: the rounding csrc/gemm_bf16.h applies
+// when it stages an fp32 operand, so a bf16 output of these kernels feeds the bf16 GEMMs the bits they would have made themselves)
+typedef __bf16 slb2 __attribute__((ext_vector_type(2)));
+typedef float slf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned silu_ln_pack(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(slf2{lo, hi}, slb2)); }
+// store the VPT values of a lane to row `o` (fp32) or `o16` (bf16), in 16- / 8-byte pieces where the mapping has them
+template <int VPT, bool OUT16>
+__device__ __forceinline__ void silu_ln_store(const float (&v)[VPT], float *__restrict__ o, unsigned short *__restrict__ o16, int lane) {
+  if constexpr (VPT >= 4) {
+#pragma unroll
+    for (int j = 0; j < VPT / 4; j++) {
+      const int c = 4 * (64 * j + lane);
+      if constexpr (OUT16) *reinterpret_cast<uint2 *>(o16 + c) = uint2{silu_ln_pack(v[4 * j], v[4 * j + 1]), silu_ln_pack(v[4 * j + 2], v[4 * j + 3])};
+      else *reinterpret_cast<float4 *>(o + c) = float4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      if constexpr (OUT16) o16[lane * VPT + k] = (unsigned short)(silu_ln_pack(v[k], 0.f) & 0xffffu);
+      else o[lane * VPT + k] = v[k];
+    }
+  }
+}
 template <int VPT>
+__device__ __forceinline__ void silu_ln_load(float (&v)[VPT], const float *__restrict__ src, int lane) {
+  if constexpr (VPT >= 4) {
+#pragma unroll
+    for (int j = 0; j < VPT / 4; j++) {
+      const float4 q = *reinterpret_cast<const float4 *>(src + 4 * (64 * j + lane));
+      v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < VPT; k++) v[k] = src[lane * VPT + k];
+  }
+}
+
+// OUT16: y as bf16 to y16 (leading dimension ldy16) instead of fp32 to y
+template <int VPT, bool OUT16 = false>
 __global__ __launch_bounds__(256) void k_silu_ln_fwd(const float *__restrict__ z, const float *__restrict__ bias, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ stats, int rows,
-                                                     float eps) {
+                                                     float eps, unsigned short *__restrict__ y16 = nullptr, int ldy16 = 0) {
   constexpr int H = VPT * 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float b[VPT], g[VPT], be[VPT];
-#pragma unroll
-  for (int k = 0; k < VPT; k++) { int c = lane * VPT + k; b[k] = bias[c]; g[k] = gamma[c]; be[k] = beta[c]; }
+  silu_ln_load<VPT>(b, bias, lane); silu_ln_load<VPT>(g, gamma, lane); silu_ln_load<VPT>(be, beta, lane);
   const int wpb = blockDim.x >> 6;         // waves (= rows in flight) per block: 4, or 1 for the acting policy (tmjx_silu_ln_fwd)
   for (int r = blockIdx.x * wpb + w; r < rows; r += gridDim.x * wpb) {
     float a[VPT], s = 0.f;
+    silu_ln_load<VPT>(a, z + (size_t)r * H, lane);
 #pragma unroll
-    for (int k = 0; k < VPT; k++) { float v = z[(size_t)r * H + lane * VPT + k] + b[k]; a[k] = v / (1.f + expf(-v)); s += a[k]; }
+    for (int k = 0; k < VPT; k++) { float v = a[k] + b[k]; a[k] = v / (1.f + expf(-v)); s += a[k]; }
     float mean = wave_sum(s) / (float)H, q = 0.f;
 #pragma unroll
     for (int k = 0; k < VPT; k++) { float d = a[k] - mean; q += d * d; }
     float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
 #pragma unroll
-    for (int k = 0; k < VPT; k++) y[(size_t)r * H + lane * VPT + k] = (a[k] - mean) * rstd * g[k] + be[k];
+    for (int k = 0; k < VPT; k++) a[k] = (a[k] - mean) * rstd * g[k] + be[k];
+    silu_ln_store<VPT, OUT16>(a, OUT16 ? nullptr : y + (size_t)r * H, OUT16 ? y16 + (size_t)r * ldy16 : nullptr, lane);
     if (lane == 0) { stats[2 * (size_t)r] = mean; stats[2 * (size_t)r + 1] = rstd; }
   }
 }
 
-template <int VPT>
+// OUT16: d loss / d z as bf16 to dz16 (leading dimension lddz16) instead of fp32 to dz — the column sums are taken from the fp32 values either way
+template <int VPT, bool OUT16 = false>
 __global__ __launch_bounds__(256) void k_silu_ln_bwd(const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ bias,
                                                      const float *__restrict__ gamma, const float *__restrict__ stats, float *__restrict__ dz,
-                                                     float *__restrict__ partial, int rows) {
+                                                     float *__restrict__ partial, int rows, unsigned short *__restrict__ dz16 = nullptr, int lddz16 = 0) {
   constexpr int H = VPT * 64;
   __shared__ float lds[3 * H * 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float b[VPT], g[VPT], sg[VPT], sb[VPT], sz[VPT];
+  silu_ln_load<VPT>(b, bias, lane); silu_ln_load<VPT>(g, gamma, lane);
 #pragma unroll
-  for (int k = 0; k < VPT; k++) { int c = lane * VPT + k; b[k] = bias[c]; g[k] = gamma[c]; sg[k] = 0.f; sb[k] = 0.f; sz[k] = 0.f; }
+  for (int k = 0; k < VPT; k++) { sg[k] = 0.f; sb[k] = 0.f; sz[k] = 0.f; }
   const int r0 = blockIdx.x * BLK_ROWS_PER_BLOCK, r1 = min(rows, r0 + BLK_ROWS_PER_BLOCK);
   for (int r = r0 + w; r < r1; r += 4) {
     const float mean = stats[2 * (size_t)r], rstd = stats[2 * (size_t)r + 1];
     float v[VPT], sig[VPT], ah[VPT], da[VPT], m1 = 0.f, m2 = 0.f;
+    silu_ln_load<VPT>(v, z + (size_t)r * H, lane); silu_ln_load<VPT>(da, dy + (size_t)r * H, lane);
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
-      v[k] = z[(size_t)r * H + lane * VPT + k] + b[k];
+      v[k] += b[k];
       sig[k] = 1.f / (1.f + expf(-v[k]));
       ah[k] = (v[k] * sig[k] - mean) * rstd;
-      float d = dy[(size_t)r * H + lane * VPT + k];
+      const float d = da[k];
       sg[k] += d * ah[k]; sb[k] += d;
       da[k] = d * g[k];
       m1 += da[k]; m2 += da[k] * ah[k];
@@ -392,12 +438,13 @@ __global__ __launch_bounds__(256) void k_silu_ln_bwd(const float *__restrict__ d
     for (int k = 0; k < VPT; k++) {
       float dact = rstd * (da[k] - m1 - ah[k] * m2);
       float o = dact * (sig[k] * (1.f + v[k] * (1.f - sig[k])));
-      dz[(size_t)r * H + lane * VPT + k] = o;
+      da[k] = o;
       sz[k] += o;
     }
+    silu_ln_store<VPT, OUT16>(da, OUT16 ? nullptr : dz + (size_t)r * H, OUT16 ? dz16 + (size_t)r * lddz16 : nullptr, lane);
   }
 #pragma unroll
-  for (int k = 0; k < VPT; k++) { int c = lane * VPT + k; lds[(0 * 4 + w) * H + c] = sg[k]; lds[(1 * 4 + w) * H + c] = sb[k]; lds[(2 * 4 + w) * H + c] = sz[k]; }
+  for (int k = 0; k < VPT; k++) { int c = silu_ln_col<VPT>(lane, k); lds[(0 * 4 + w) * H + c] = sg[k]; lds[(1 * 4 + w) * H + c] = sb[k]; lds[(2 * 4 + w) * H + c] = sz[k]; }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * H; i += 256) {
     int which = i / H, c = i - which * H;
@@ -538,6 +585,7 @@ struct MinibatchGather {
   long long *state;           // device int64[TM_MB_STATE_HEAD + TM_MB_STATE_STRIDE * TM_MB_SUBTICKETS]: {draw counter, slot, ticket, .. | sub-tickets} or null
   unsigned long long seed;
   int T, R, B, W, A, Z, advance;
+  unsigned short *obs_n16; int ld16;      // optional bf16 twin of obs_n: [T B][ld16 >= W] (columns beyond W are the caller's: zeros)
 };
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 constants)
 __device__ __forceinline__ void tm_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned *out) {
@@ -583,6 +631,7 @@ __global__ __launch_bounds__(256) void k_gather_minibatch(MinibatchGather g) {
       const float4 m = reinterpret_cast<const float4 *>(g.mean)[c], s = reinterpret_cast<const float4 *>(g.stdv)[c];
       const float4 o = {(v.x - m.x) / s.x, (v.y - m.y) / s.y, (v.z - m.z) / s.z, (v.w - m.w) / s.w};
       reinterpret_cast<float4 *>((nx ? g.next_n : g.obs_n) + tb * g.W)[c] = o;
+      if (!nx && g.obs_n16) *reinterpret_cast<uint2 *>(g.obs_n16 + tb * g.ld16 + 4 * c) = uint2{silu_ln_pack(o.x, o.y), silu_ln_pack(o.z, o.w)};
     } else if (i < e1) {
       const size_t j = i - e0;
       const int c = (int)(j % g.A);

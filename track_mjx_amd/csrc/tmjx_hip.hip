@@ -618,34 +618,60 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
 
 int tmjx_silu_ln_partial_floats(int rows, int H) { return ((rows + BLK_ROWS_PER_BLOCK - 1) / BLK_ROWS_PER_BLOCK) * 3 * H; }
 
-int tmjx_silu_ln_fwd(const float *z, const float *bias, const float *gamma, const float *beta, float *y, float *stats, int rows, int H,
-                     float eps, void *stream) {
-  if (!z || !bias || !gamma || !beta || !y || !stats) return fail(TMJX_EINVAL, "null argument");
+static int silu_ln_fwd_any(const float *z, const float *bias, const float *gamma, const float *beta, float *y, uint16_t *y16, int ldy16, float *stats, int rows, int H,
+                           float eps, void *stream) {
+  if (!z || !bias || !gamma || !beta || (!y && !y16) || !stats) return fail(TMJX_EINVAL, "null argument");
   if (rows < 1) return fail(TMJX_EINVAL, "rows must be >= 1");
+  if (y16 && (ldy16 < H || (ldy16 & 3) || ((uintptr_t)y16 & 7))) return fail(TMJX_EINVAL, "tmjx_silu_ln_fwd_bf16: the output's rows must be 8-byte aligned and H wide");
   hipStream_t s = (hipStream_t)stream;
   // One-wave blocks for the acting policy's batches (an env group's rows): next to a GPU full of physics waves — 504 of 512 VGPRs taken on three
   // SIMDs of every CU — a CU has room for new waves on ONE SIMD only, and a 256-thread block wants all four
   const int bt = rows <= TMJX_SMALL_BATCH ? 64 : 256, wpb = bt / 64;
   int grid = (rows + wpb - 1) / wpb; if (grid > 4096) grid = 4096;
-#define TMJX_FWD(V) hipLaunchKernelGGL(k_silu_ln_fwd<V>, dim3(grid), dim3(bt), 0, s, z, bias, gamma, beta, y, stats, rows, eps)
+  unsigned short *o16 = (unsigned short *)y16;
+#define TMJX_FWD(V) do { if (o16) hipLaunchKernelGGL((k_silu_ln_fwd<V, true>), dim3(grid), dim3(bt), 0, s, z, bias, gamma, beta, y, stats, rows, eps, o16, ldy16); \
+                         else hipLaunchKernelGGL((k_silu_ln_fwd<V, false>), dim3(grid), dim3(bt), 0, s, z, bias, gamma, beta, y, stats, rows, eps, o16, 0); } while (0)
   switch (H) { case 64: TMJX_FWD(1); break; case 128: TMJX_FWD(2); break; case 256: TMJX_FWD(4); break; case 512: TMJX_FWD(8); break;
                case 1024: TMJX_FWD(16); break; default: return fail(TMJX_EINVAL, "H must be 64, 128, 256, 512 or 1024"); }
 #undef TMJX_FWD
   return check_launch("k_silu_ln_fwd");
 }
+int tmjx_silu_ln_fwd(const float *z, const float *bias, const float *gamma, const float *beta, float *y, float *stats, int rows, int H,
+                     float eps, void *stream) {
+  if (!y) return fail(TMJX_EINVAL, "null argument");
+  return silu_ln_fwd_any(z, bias, gamma, beta, y, nullptr, 0, stats, rows, H, eps, stream);
+}
+int tmjx_silu_ln_fwd_bf16(const float *z, const float *bias, const float *gamma, const float *beta, uint16_t *y16, int ldy16, float *stats, int rows, int H,
+                          float eps, void *stream) {
+  if (!y16) return fail(TMJX_EINVAL, "null argument");
+  return silu_ln_fwd_any(z, bias, gamma, beta, nullptr, y16, ldy16, stats, rows, H, eps, stream);
+}
 
-int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, float *dz, float *grads,
-                     float *partial, int rows, int H, void *stream) {
-  if (!dy || !z || !bias || !gamma || !stats || !dz || !grads || !partial) return fail(TMJX_EINVAL, "null argument");
+static int silu_ln_bwd_any(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, float *dz, uint16_t *dz16, int lddz16, float *grads,
+                           float *partial, int rows, int H, void *stream) {
+  if (!dy || !z || !bias || !gamma || !stats || (!dz && !dz16) || !grads || !partial) return fail(TMJX_EINVAL, "null argument");
   if (rows < 1) return fail(TMJX_EINVAL, "rows must be >= 1");
+  if (dz16 && (lddz16 < H || (lddz16 & 3) || ((uintptr_t)dz16 & 7))) return fail(TMJX_EINVAL, "tmjx_silu_ln_bwd_bf16: the output's rows must be 8-byte aligned and H wide");
   hipStream_t s = (hipStream_t)stream;
   const int nblk = (rows + BLK_ROWS_PER_BLOCK - 1) / BLK_ROWS_PER_BLOCK;
-#define TMJX_BWD(V) hipLaunchKernelGGL(k_silu_ln_bwd<V>, dim3(nblk), dim3(256), 0, s, dy, z, bias, gamma, stats, dz, partial, rows)
+  unsigned short *o16 = (unsigned short *)dz16;
+#define TMJX_BWD(V) do { if (o16) hipLaunchKernelGGL((k_silu_ln_bwd<V, true>), dim3(nblk), dim3(256), 0, s, dy, z, bias, gamma, stats, dz, partial, rows, o16, lddz16); \
+                         else hipLaunchKernelGGL((k_silu_ln_bwd<V, false>), dim3(nblk), dim3(256), 0, s, dy, z, bias, gamma, stats, dz, partial, rows, o16, 0); } while (0)
   switch (H) { case 64: TMJX_BWD(1); break; case 128: TMJX_BWD(2); break; case 256: TMJX_BWD(4); break; case 512: TMJX_BWD(8); break;
                case 1024: TMJX_BWD(16); break; default: return fail(TMJX_EINVAL, "H must be 64, 128, 256, 512 or 1024"); }
 #undef TMJX_BWD
   hipLaunchKernelGGL(k_colsum, dim3((3 * H + 31) / 32), dim3(256), 0, s, (const float *)partial, grads, nblk, 3 * H);
   return check_launch("k_silu_ln_bwd");
+}
+int tmjx_silu_ln_bwd(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, float *dz, float *grads,
+                     float *partial, int rows, int H, void *stream) {
+  if (!dz) return fail(TMJX_EINVAL, "null argument");
+  return silu_ln_bwd_any(dy, z, bias, gamma, stats, dz, nullptr, 0, grads, partial, rows, H, stream);
+}
+int tmjx_silu_ln_bwd_bf16(const float *dy, const float *z, const float *bias, const float *gamma, const float *stats, uint16_t *dz16, int lddz16, float *grads,
+                          float *partial, int rows, int H, void *stream) {
+  if (!dz16) return fail(TMJX_EINVAL, "null argument");
+  return silu_ln_bwd_any(dy, z, bias, gamma, stats, nullptr, dz16, lddz16, grads, partial, rows, H, stream);
 }
 
 int tmjx_gather_normalize(const float *src, const int64_t *idx, const float *mean, const float *std, float *out, int T, int R, int B,
@@ -675,7 +701,7 @@ int tmjx_gather_minibatch(const float *obs, const float *next_last, const float 
                           const float *truncation, const int64_t *idx, const float *mean, const float *std, float *obs_n, float *next_n, float *raw_action_g,
                           float *scalars_g, int T, int R, int B, int W, int A, void *stream) {
   MinibatchGather g{obs, next_last, raw_action, {log_prob, reward, discount, truncation}, (const long long *)idx, mean, std, obs_n, next_n, raw_action_g, scalars_g,
-                    nullptr, nullptr, nullptr, 0ull, T, R, B, W, A, 0, 0};
+                    nullptr, nullptr, nullptr, 0ull, T, R, B, W, A, 0, 0, nullptr, 0};
   return launch_minibatch(g, (hipStream_t)stream);
 }
 int tmjx_minibatch_begin(const tmjx_minibatch_t *m, void *stream) {
@@ -683,7 +709,16 @@ int tmjx_minibatch_begin(const tmjx_minibatch_t *m, void *stream) {
   if ((m->eps || m->noise || m->advance) && !m->state) return fail(TMJX_EINVAL, "tmjx_minibatch_begin: draws / advance need the device state");
   MinibatchGather g{m->obs, m->next_last, m->raw_action, {m->log_prob, m->reward, m->discount, m->truncation}, (const long long *)m->perm, m->mean, m->std, m->obs_n,
                     m->next_n, m->raw_action_g, m->scalars_g, m->eps, m->noise, (long long *)m->state, (unsigned long long)m->seed, m->T, m->R, m->B, m->W, m->A,
-                    m->Z, m->advance};
+                    m->Z, m->advance, nullptr, 0};
+  return launch_minibatch(g, (hipStream_t)stream);
+}
+int tmjx_minibatch_begin_bf16(const tmjx_minibatch_t *m, uint16_t *obs_n16, int ld16, void *stream) {
+  if (!m || !obs_n16) return fail(TMJX_EINVAL, "null argument");
+  if ((m->eps || m->noise || m->advance) && !m->state) return fail(TMJX_EINVAL, "tmjx_minibatch_begin_bf16: draws / advance need the device state");
+  if (ld16 < m->W || (ld16 & 3) || ((uintptr_t)obs_n16 & 7)) return fail(TMJX_EINVAL, "tmjx_minibatch_begin_bf16: the twin's rows must be 8-byte aligned and W wide");
+  MinibatchGather g{m->obs, m->next_last, m->raw_action, {m->log_prob, m->reward, m->discount, m->truncation}, (const long long *)m->perm, m->mean, m->std, m->obs_n,
+                    m->next_n, m->raw_action_g, m->scalars_g, m->eps, m->noise, (long long *)m->state, (unsigned long long)m->seed, m->T, m->R, m->B, m->W, m->A,
+                    m->Z, m->advance, (unsigned short *)obs_n16, ld16};
   return launch_minibatch(g, (hipStream_t)stream);
 }
 int tmjx_philox4x32_10(const uint32_t *ctr_key_dev, uint32_t *out_dev, void *stream) {
