@@ -335,6 +335,11 @@ int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *
 /* The Dense -> SiLU backward alone (the block's consumer is not a bf16 GEMM): dZ16 = dY silu'(z + bias) as bf16, partial[(M + 79) / 80][N] = column
  * sums of dZ per 80-row tile. */
 int tmjx_bf_silu_bwd(const float *dY, int ldy, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream);
+/* The same when the block's consumer is a 1-WIDE un-activated layer (the value head, brax make_value_network: MLP(hidden..., 1)): its input gradient
+ * is the outer product dy1[M] (d loss / d head output) x w1[N] (the head's weight row), formed inside the kernel — no [M][N] gradient array, no GEMM with
+ * a contraction length of one.  N a multiple of 4 up to 1024, 16-byte aligned rows. */
+int tmjx_bf_silu_bwd_rank1(const float *dy1, const float *w1, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N,
+                           void *stream);
 /* dW[N][lddw] = dY[M][N]^T . X[M][K] and db[N] = column sums of dY (NULL: no bias gradient; sums are taken over the values AS STORED, in
  * fp32) with bf16 operands (each of dY / X fp32 or bf16 in memory, rows 16-byte aligned); scratch >= tmjx_bgemm_dw_scratch_floats(M, N, K). */
 long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K);

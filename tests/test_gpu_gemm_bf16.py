@@ -367,3 +367,67 @@ def test_minibatch_begin_bf16_twin_and_the_chain_that_stages_it():
     on, tw = data["observation_normalized"], data["observation_normalized_bf16"]
     W = on.shape[-1]
     assert torch.equal(tw[:, :W], on.reshape(-1, W).to(torch.bfloat16)) and bool((tw[:, W:] == 0).all())
+
+
+@pytest.mark.parametrize("M,N", [(1000, 256), (163, 120), (4096, 1024)])
+def test_bf_silu_bwd_rank1_is_the_outer_product_through_the_plain_kernel(M, N):
+    """tmjx_bf_silu_bwd_rank1 (the value head's input gradient dy1 x w1 formed inside the last hidden layer's SiLU backward) against
+    tmjx_bf_silu_bwd on the materialised outer product: d loss / d z and the per-tile column sums bit for bit (one fp32 product per element either
+    way), and both against float64 torch."""
+    import ctypes as C
+    from track_mjx_amd import hip as _hip
+    lib = _hip.lib()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    dy1, w1 = torch.randn(M, generator=g, device=DEV), torch.randn(N, generator=g, device=DEV) * 0.1
+    z, bias = torch.randn(M, N, generator=g, device=DEV), 0.3 * torch.randn(N, generator=g, device=DEV)
+    dy = (dy1[:, None] * w1[None, :]).contiguous()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    npart = int(lib.tmjx_bgemm_partial_floats(M, N, 1))
+    ld = (N + 7) // 8 * 8
+    out = []
+    for rank1 in (False, True):
+        dz, part = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV), torch.empty(npart, device=DEV)
+        if rank1:
+            _hip.check(lib.tmjx_bf_silu_bwd_rank1(p(dy1), p(w1), p(z), N, p(bias), p(dz), ld, p(part), M, N, stream), "rank1")
+        else:
+            _hip.check(lib.tmjx_bf_silu_bwd(p(dy), N, p(z), N, p(bias), p(dz), ld, p(part), M, N, stream), "plain")
+        out.append((dz, part))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    v = z.double() + bias.double()
+    sig = torch.sigmoid(v)
+    ref = dy.double() * (sig * (1 + v * (1 - sig)))
+    assert torch.equal(out[1][0][:, :N], ref.float().to(torch.bfloat16)) or float((out[1][0][:, :N].double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+    tiles = (M + 79) // 80
+    ref_part = torch.stack([ref[80 * t:80 * (t + 1)].sum(0) for t in range(tiles)])
+    assert float((out[1][1].view(tiles, N).double() - ref_part).abs().max()) <= 1e-5 * float(ref_part.abs().max())
+    assert lib.tmjx_bf_silu_bwd_rank1(p(dy1), p(w1), p(z), N, p(bias), p(out[1][0]), ld, p(out[1][1]), M, N + 2, stream) != 0     # N not a multiple of 4
+
+
+def test_value_net_head_inside_the_bf16_chain_changes_no_bit():
+    """bf16 GEMM-input mode: the value MLP's 1-wide head runs inside the chain (its input gradient is never materialised: tmjx_bf_silu_bwd_rank1);
+    output and every parameter gradient equal the stand-alone head layer's (TMJX_NO_CHAIN_HEAD=1: tmjx_gemm_nn + tmjx_bf_silu_bwd) bit for bit."""
+    import os
+    from track_mjx_amd.agent.networks import Bf16Shadows, ValueNet, gemm_inputs
+    torch.manual_seed(3)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    obs, up = torch.randn(5, 400, 696, generator=g, device=DEV), torch.randn(5, 400, generator=g, device=DEV)
+    res = []
+    for no_head in (False, True):
+        torch.manual_seed(3)
+        net = ValueNet(696, (512, 256)).to(DEV)
+        lins = [m for m in net.modules() if isinstance(m, torch.nn.Linear) and m.out_features % 4 == 0]
+        sh = Bf16Shadows(lins, need_t=lins[1:])
+        sh.refresh()
+        if no_head:
+            os.environ["TMJX_NO_CHAIN_HEAD"] = "1"
+        try:
+            with gemm_inputs(torch.bfloat16, sh):
+                y = net(obs)
+                grads = torch.autograd.grad((y * up).sum(), list(net.parameters()))
+        finally:
+            os.environ.pop("TMJX_NO_CHAIN_HEAD", None)
+        assert (net._chain[-1].kind == "head") == (not no_head)
+        res.append([y.detach()] + [t.clone() for t in grads])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

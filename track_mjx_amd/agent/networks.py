@@ -361,7 +361,8 @@ class deferred_weight_grads:
 
 # ---- a whole MLP chain as ONE autograd function (bf16 GEMM-input mode) -------------------------------------------------------------------
 class _Layer:
-    """One layer of a chain: kind "ln" (Dense -> SiLU -> LayerNorm block), "silu" (Dense -> SiLU, brax value MLP) or "dense" (un-activated)."""
+    """One layer of a chain: kind "ln" (Dense -> SiLU -> LayerNorm block), "silu" (Dense -> SiLU, brax value MLP), "dense" (un-activated) or
+    "head" (the 1-wide un-activated last layer of the value MLP, on the fp32 kernels; behind a "silu" layer)."""
     __slots__ = ("kind", "lin", "norm", "fused")
 
     def __init__(self, kind, lin, norm=None):
@@ -396,7 +397,7 @@ class _BfChainFn(torch.autograd.Function):
         for i, L in enumerate(layers):
             lin = L.lin
             N, K = lin.weight.shape
-            last = i == len(layers) - 1
+            last = i == len(layers) - 1 or layers[i + 1].kind == "head"
             hx = h                 # the layer's input as the weight gradient wants it (true width)
             if i == 0 and t16 is not None:
                 # columns K .. ceil64(K) of the twin (other observation columns, or its zero padding) meet the shadow's zero columns
@@ -404,6 +405,9 @@ class _BfChainFn(torch.autograd.Function):
             if L.kind == "dense":
                 y = bgemm_nt(h, sh.w[lin], N, K, lin.bias)
                 saved.append((hx, None, None))
+            elif L.kind == "head":
+                y = gemm_nt(h, lin.weight, lin.bias)          # fp32 kernel on the fp32 activation of the last hidden layer (last_y_f32)
+                saved.append((h, None, None))
             elif L.kind == "silu":
                 z, y = bgemm_silu_fwd(h, sh.w[lin], N, K, lin.bias, y_f32=last and last_y_f32)
                 saved.append((hx, z, None))
@@ -435,7 +439,7 @@ class _BfChainFn(torch.autograd.Function):
         if g.data_ptr() % 16 or g.stride(0) % 4:
             g = g.contiguous()
         M = g.shape[0]
-        g_is_dz = layers[-1].kind == "dense"
+        g_is_dz = layers[-1].kind in ("dense", "head")
         grads = {}                 # id(param) -> gradient tensor
         colsums = []               # (partial, out, rows, width): reduced by one grouped launch
 
@@ -481,8 +485,11 @@ class _BfChainFn(torch.autograd.Function):
                     block_sums(L, partial.view(-1, N))
                     g = dz[:, :N]
             # g = d loss / d z of layer i
-            with_bias = L.kind == "dense"
-            dw, db = bgemm_dw(g, h, with_bias, out=dest(lin.weight), out_bias=dest(lin.bias) if with_bias else None)
+            with_bias = L.kind in ("dense", "head")
+            if L.kind == "head":
+                dw, db = gemm_dw(g, h, True)                  # fp32 kernels, as the stand-alone head layer's backward (_HipDenseFn)
+            else:
+                dw, db = bgemm_dw(g, h, with_bias, out=dest(lin.weight), out_bias=dest(lin.bias) if with_bias else None)
             grads[id(lin.weight)] = dw
             if with_bias:
                 grads[id(lin.bias)] = db
@@ -490,7 +497,18 @@ class _BfChainFn(torch.autograd.Function):
                 P = layers[i - 1]
                 Np = P.lin.out_features
                 ph, pz, pstats = saved[i - 1]
-                if P.fused and P.kind == "ln":
+                if L.kind == "head":
+                    # d loss / d y of the last hidden layer is the outer product g[:, 0] x (the head's weight row): formed inside that layer's SiLU
+                    # backward (tmjx_bf_silu_bwd_rank1) instead of by an input-gradient GEMM with a contraction length of one
+                    ld = (Np + 7) // 8 * 8
+                    dzp = torch.empty((M, ld), dtype=torch.bfloat16, device=g.device)
+                    partial = torch.empty(int(Lh.tmjx_bgemm_partial_floats(M, Np, 1)), dtype=torch.float32, device=g.device)
+                    g1 = g.reshape(-1)
+                    _launch("tmjx_bf_silu_bwd_rank1", g.device, _p(g1 if g1.is_contiguous() else g1.contiguous()), _p(lin.weight), _p(pz), pz.stride(0), _p(P.lin.bias), _p(dzp), ld,
+                            _p(partial), M, Np)
+                    block_sums(P, partial.view(-1, Np))
+                    g, g_is_dz = dzp[:, :Np], True
+                elif P.fused and P.kind == "ln":
                     g, partial = bgemm_ln_bwd(g, sh.wt[lin], Np, N, pz, P.lin.bias, P.norm.weight, pstats)
                     block_sums(P, partial)
                     g_is_dz = True
@@ -1030,7 +1048,12 @@ class ValueNet(nn.Module):
             if getattr(self, "_chain", None) is None:
                 dense = [m for m in self.net if isinstance(m, nn.Linear)]
                 self._chain = [_Layer("silu", m) for m in dense[:-1]]
+                head = dense[-1]
+                if head.out_features == 1 and head.in_features % 4 == 0 and head.in_features <= 1024 and not os.environ.get("TMJX_NO_CHAIN_HEAD"):
+                    self._chain.append(_Layer("head", head))         # the 1-wide head inside the chain: its input gradient is never materialised
             h = bf16_chain(obs, self._chain, last_y_f32=True)
+            if self._chain[-1].kind == "head":
+                return h.squeeze(-1)
             return self.net[-1](h).squeeze(-1)
         if obs.is_cuda and obs.dtype == torch.float32 and gemm_inputs.dtype is None:
             # fp32 on the GPU: every hidden layer is ONE launch forward (GEMM + SiLU epilogue), no torch element-wise kernel in either direction

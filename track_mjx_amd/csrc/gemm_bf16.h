@@ -541,6 +541,45 @@ __global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ d
   }
 }
 
+// The same with four consecutive columns per thread (16-byte loads of z and dy, 8-byte stores of dz; N a multiple of 4, <= 1024, aligned rows)
+// and the row tile's 80 rows dealt to 256 / (N / 4) row phases, whose column sums meet in LDS.  RANK1: the output gradient is the outer product
+// dy1[row] w1[col] — the block's consumer is a 1-wide un-activated layer (the value head: d loss / d y = d loss / d baseline x its weight row),
+// formed here instead of by an input-gradient GEMM with a contraction length of one that writes [M][N] floats for this kernel to read back.
+template <bool RANK1>
+__global__ __launch_bounds__(256) void k_bf_silu_bwd4(const float *__restrict__ dy, int ldy, const float *__restrict__ dy1, const float *__restrict__ w1,
+                                                      const float *__restrict__ z, int ldz, const float *__restrict__ bias, bf16_t *__restrict__ dz, int lddz,
+                                                      float *__restrict__ partial, int M, int N) {
+  __shared__ float red[256 * 4];
+  const int ncg = N >> 2, nph = 256 / ncg, t = threadIdx.x, cg = t % ncg, ph = t / ncg;
+  const int r0 = blockIdx.x * 80, r1 = min(M, r0 + 80);
+  if (ph < nph) {
+    const bgf4 b = *reinterpret_cast<const bgf4 *>(bias + 4 * cg);
+    bgf4 wv = {0.f, 0.f, 0.f, 0.f}, sum = {0.f, 0.f, 0.f, 0.f};
+    if (RANK1) wv = *reinterpret_cast<const bgf4 *>(w1 + 4 * cg);
+    for (int r = r0 + ph; r < r1; r += nph) {
+      const bgf4 zv = *reinterpret_cast<const bgf4 *>(z + (size_t)r * ldz + 4 * cg);
+      bgf4 d;
+      if (RANK1) { const float g = dy1[r]; d = bgf4{g * wv.x, g * wv.y, g * wv.z, g * wv.w}; }
+      else d = *reinterpret_cast<const bgf4 *>(dy + (size_t)r * ldy + 4 * cg);
+      bgf4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float v = zv[j] + b[j], sig = 1.f / (1.f + expf(-v));
+        o[j] = d[j] * (sig * (1.f + v * (1.f - sig)));
+      }
+      *reinterpret_cast<bgu2 *>(dz + (size_t)r * lddz + 4 * cg) = bgu2{bg_pack(o.x, o.y), bg_pack(o.z, o.w)};
+      sum += o;
+    }
+    *reinterpret_cast<bgf4 *>(red + 4 * t) = sum;
+  }
+  __syncthreads();
+  for (int c = t; c < N; c += 256) {
+    float v = 0.f;
+    for (int q = 0; q < nph; q++) v += red[4 * (q * ncg + (c >> 2)) + (c & 3)];
+    partial[(size_t)blockIdx.x * N + c] = v;
+  }
+}
+
 // ---- dW = dY^T X ----------------------------------------------------------------------------------------------------------------------
 // LDS image of a [rows][128 bf16] tile (256-byte rows) for transposed reads: byte offset of 16-byte chunk ch (0 .. 15) of row r; the XOR
 // makes the two 4-row blocks a 32-lane half reads (8 rows apart, same columns) land on disjoint banks

@@ -157,8 +157,19 @@ int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *
 int tmjx_bf_silu_bwd(const float *dY, int ldy, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream) {
   if (!dY || !z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd: null argument");
   if (M < 1 || N < 1 || ldy < N || ldz < N || lddz < N) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd: bad sizes / leading dimensions");
-  hipLaunchKernelGGL(k_bf_silu_bwd, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, z, ldz, bias, dZ16, lddz, partial, M, N);
+  const bool v4 = !(N & 3) && N <= 1024 && !(ldy & 3) && !(ldz & 3) && !(lddz & 3) && !(((uintptr_t)dY | (uintptr_t)z | (uintptr_t)bias) & 15) && !((uintptr_t)dZ16 & 7);
+  if (v4) hipLaunchKernelGGL(k_bf_silu_bwd4<false>, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, (const float *)nullptr, (const float *)nullptr, z, ldz, bias,
+                             dZ16, lddz, partial, M, N);
+  else hipLaunchKernelGGL(k_bf_silu_bwd, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, z, ldz, bias, dZ16, lddz, partial, M, N);
   return check_launch("k_bf_silu_bwd");
+}
+
+int tmjx_bf_silu_bwd_rank1(const float *dy1, const float *w1, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream) {
+  if (!dy1 || !w1 || !z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd_rank1: null argument");
+  if (M < 1 || N < 4 || (N & 3) || N > 1024 || ldz < N || lddz < N || (ldz & 3) || (lddz & 3) || (((uintptr_t)w1 | (uintptr_t)z | (uintptr_t)bias) & 15) || ((uintptr_t)dZ16 & 7))
+    return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd_rank1: N must be a multiple of 4 up to 1024, rows 16-byte aligned");
+  hipLaunchKernelGGL(k_bf_silu_bwd4<true>, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, 0, dy1, w1, z, ldz, bias, dZ16, lddz, partial, M, N);
+  return check_launch("k_bf_silu_bwd_rank1");
 }
 
 long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K) {
