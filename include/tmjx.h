@@ -311,34 +311,36 @@ int tmjx_bf16_shadow(const tmjx_bf16_shadow_t *items, int n, void *stream);
 int tmjx_bgemm_nt(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
                   void *stream);
 /* The same GEMM with a block epilogue on the accumulators (the hidden activations then exist in memory only as bf16, the operand format of
- * the next GEMM; z = the pre-activation WITHOUT the bias stays fp32 for the backward pass).  Row tiles are 80 rows high.
+ * the next GEMM, and so does z = the pre-activation WITHOUT the bias, saved for the backward pass — BASELINE config 5 is a bf16 MLP; Y and the row
+ * statistics are computed from the fp32 accumulators, the backward kernels evaluate silu' / the normalised activation from the bf16 z: 2 instead
+ * of 4 bytes written per element here and read, twice, there).  Row tiles are 80 rows high.  ldz in bf16 elements, a multiple of 4.
  *   tmjx_bgemm_ln_fwd   Dense -> SiLU -> LayerNorm forward (intention_network.py:32-44,68-76), N = 128, 256 or 512 (tmjx_bgemm_row_tile_ok):
- *                       Z[M][ldz] = A B^T;  Y16 = LayerNorm(silu(Z + bias)) * gamma + beta as bf16;  stats[M][2] = (mean, 1 / std).
+ *                       Z16[M][ldz] = A B^T as bf16;  Y16 = LayerNorm(silu(A B^T + bias)) * gamma + beta as bf16;  stats[M][2] = (mean, 1 / std).
  *   tmjx_bgemm_ln_bwd   A = dY[M][K] = gradient of the CONSUMER layer's output, Bt = the consumer's transposed shadow (N = the block's width):
  *                       the tile A Bt^T is d loss / d y of the block; stores dZ16[M][lddz] = d loss / d z of the block (its LayerNorm + SiLU
  *                       backward from z, bias, gamma, stats) as bf16 and partial[(M + 79) / 80][3][N] = the row tiles' column sums
  *                       (d gamma | d beta | d bias): reduce them with tmjx_colsum_grouped (rows = (M + 79) / 80, width = 3 N).
- *   tmjx_bgemm_silu_fwd Dense -> SiLU forward (brax value MLP, ppo_networks.py:180-184), any N: Z = A B^T, Y16 (or Yf, fp32) = silu(Z + bias).
+ *   tmjx_bgemm_silu_fwd Dense -> SiLU forward (brax value MLP, ppo_networks.py:180-184), any N: Z16 = A B^T as bf16, Y16 (or Yf, fp32) = silu(A B^T + bias).
  *   tmjx_bgemm_silu_bwd its backward in the consumer's input-gradient GEMM: dZ16 = (A Bt^T) silu'(z + bias), partial[(M + 79) / 80][N] = column sums
  *                       of dZ (d bias).
  * tmjx_bgemm_partial_floats(M, N, sums): floats of `partial` for sums = 3 (ln) or 1 (silu). */
 int tmjx_bgemm_row_tile_ok(int N);
 long long tmjx_bgemm_partial_floats(int M, int N, int sums);
-int tmjx_bgemm_ln_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, const float *gamma, const float *beta, float *Z, int ldz,
+int tmjx_bgemm_ln_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, const float *gamma, const float *beta, uint16_t *Z16, int ldz,
                       uint16_t *Y16, int ldy16, float *stats, int M, int N, int K, float eps, void *stream);
-int tmjx_bgemm_ln_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const float *z, int ldz, const float *bias, const float *gamma,
+int tmjx_bgemm_ln_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const uint16_t *z16, int ldz, const float *bias, const float *gamma,
                       const float *stats, uint16_t *dZ16, int lddz, float *partial, int M, int N, int K, void *stream);
-int tmjx_bgemm_silu_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, float *Z, int ldz, uint16_t *Y16, int ldy16,
+int tmjx_bgemm_silu_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, uint16_t *Z16, int ldz, uint16_t *Y16, int ldy16,
                         float *Yf, int ldyf, int M, int N, int K, void *stream);
-int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz,
+int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt, int ldb, const uint16_t *z16, int ldz, const float *bias, uint16_t *dZ16, int lddz,
                         float *partial, int M, int N, int K, void *stream);
-/* The Dense -> SiLU backward alone (the block's consumer is not a bf16 GEMM): dZ16 = dY silu'(z + bias) as bf16, partial[(M + 79) / 80][N] = column
+/* The Dense -> SiLU backward alone (the block's consumer is not a bf16 GEMM): dZ16 = dY silu'(z16 + bias) as bf16 (z16: what tmjx_bgemm_silu_fwd saved), partial[(M + 79) / 80][N] = column
  * sums of dZ per 80-row tile. */
-int tmjx_bf_silu_bwd(const float *dY, int ldy, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream);
+int tmjx_bf_silu_bwd(const float *dY, int ldy, const uint16_t *z16, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream);
 /* The same when the block's consumer is a 1-WIDE un-activated layer (the value head, brax make_value_network: MLP(hidden..., 1)): its input gradient
  * is the outer product dy1[M] (d loss / d head output) x w1[N] (the head's weight row), formed inside the kernel — no [M][N] gradient array, no GEMM with
  * a contraction length of one.  N a multiple of 4 up to 1024, 16-byte aligned rows. */
-int tmjx_bf_silu_bwd_rank1(const float *dy1, const float *w1, const float *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N,
+int tmjx_bf_silu_bwd_rank1(const float *dy1, const float *w1, const uint16_t *z16, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N,
                            void *stream);
 /* dW[N][lddw] = dY[M][N]^T . X[M][K] and db[N] = column sums of dY (NULL: no bias gradient; sums are taken over the values AS STORED, in
  * fp32) with bf16 operands (each of dY / X fp32 or bf16 in memory, rows 16-byte aligned); scratch >= tmjx_bgemm_dw_scratch_floats(M, N, K). */

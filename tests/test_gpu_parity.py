@@ -732,6 +732,7 @@ def test_bf16_gemm_inputs_match_fp32_gradients():
     g16 = L16.grads.flat.clone()
     assert torch.isfinite(g16).all() and g16.dtype == torch.float32
     cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    print(f"\nbf16 GEMM-input mode against fp32: gradient cosine {cos:.5f}, loss {float(m16[0]):.6f} vs {float(m32[0]):.6f}")
     assert cos > 0.98, cos
     assert abs(float(m16[0]) - float(m32[0])) <= 0.02 * abs(float(m32[0])) + 1e-3, (m16, m32)
     # the captured-graph path of a full update (what bench.py --config cfg5 runs)

@@ -178,11 +178,11 @@ def bgemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool, out: torch.Tens
 
 
 def bgemm_ln_fwd(x, wb, N: int, K: int, bias, gamma, beta, eps: float):
-    """Dense -> SiLU -> LayerNorm forward in one launch (tmjx_bgemm_ln_fwd; N = 128 / 256 / 512): returns (z fp32 [rows, N] without the bias,
+    """Dense -> SiLU -> LayerNorm forward in one launch (tmjx_bgemm_ln_fwd; N = 128 / 256 / 512): returns (z bf16 [rows, N] without the bias,
     y bf16 [rows, N], stats fp32 [rows, 2] = (mean, 1 / std))."""
     x = _rows2d(x)
     M = x.shape[0]
-    z = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    z = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
     _launch("tmjx_bgemm_ln_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(gamma), _p(beta), _p(z), N, _p(y), N,
@@ -205,13 +205,13 @@ def bgemm_ln_bwd(dy, wtb, N: int, K: int, z, bias, gamma, stats):
 
 
 def bgemm_silu_fwd(x, wb, N: int, K: int, bias, y_f32: bool = False):
-    """Dense -> SiLU forward in one launch (tmjx_bgemm_silu_fwd): (z fp32 without the bias, y = silu(z + bias) as bf16 — or fp32 with y_f32)."""
+    """Dense -> SiLU forward in one launch (tmjx_bgemm_silu_fwd): (z bf16 without the bias, y = silu(z + bias) as bf16 — or fp32 with y_f32)."""
     x = _rows2d(x)
     M = x.shape[0]
-    z = torch.empty((M, N), dtype=torch.float32, device=x.device)
     ld = (N + 7) // 8 * 8
+    z = torch.empty((M, ld), dtype=torch.bfloat16, device=x.device)[:, :N]
     y = torch.empty((M, ld), dtype=torch.float32 if y_f32 else torch.bfloat16, device=x.device)
-    _launch("tmjx_bgemm_silu_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(z), N,
+    _launch("tmjx_bgemm_silu_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(z), ld,
             None if y_f32 else _p(y), ld, _p(y) if y_f32 else None, ld, M, N, K)
     return z, y[:, :N]
 
@@ -378,12 +378,13 @@ class _Layer:
 class _BfChainFn(torch.autograd.Function):
     """y = chain(x) for a sequence of layers with every contraction on the bf16 kernels (csrc/gemm_bf16.h) and every block epilogue fused:
     forward one launch per layer (tmjx_bgemm_ln_fwd / _silu_fwd / _nt), the hidden activations exist only as bf16 (the next GEMM's operand),
-    the pre-activations z stay fp32 for the backward pass; backward per layer ONE launch for the input gradient with the PRODUCING block's
+    and so do the pre-activations z saved for the backward pass (the 1024-wide block's stay fp32); backward per layer ONE launch for the input gradient with the PRODUCING block's
     LayerNorm / SiLU backward in its epilogue (tmjx_bgemm_ln_bwd / _silu_bwd: d loss / d z as bf16 + column-sum partials) and one for the
     weight gradient (tmjx_bgemm_dw, transposed LDS reads), written straight into the flat gradient buffer's views where the learner provides
     them; all column-sum partials are reduced by one grouped launch at the end.  Layers that are not one tile wide (the 1024-wide first
-    encoder block) take the unfused kernels (tmjx_bgemm_nt + tmjx_silu_ln_fwd / _bwd, fp32 activations).  `last_y_f32`: the chain ends with
-    a block whose output goes to an fp32 kernel (the value net's last hidden layer in front of the 1-wide head)."""
+    encoder block) take the unfused kernels (tmjx_bgemm_nt + tmjx_silu_ln_fwd_bf16 / _bwd_bf16: fp32 z, bf16 results).  `last_y_f32`: the chain
+    ends with a block whose output goes to an fp32 kernel (the value net's last hidden layer in front of the 1-wide head, which runs inside the chain:
+    kind "head").  A first layer whose fp32 input has a registered bf16 twin (gemm_inputs.twins: the minibatch's normalised observations) stages the twin."""
 
     @staticmethod
     def forward(ctx, x, layers, sh, dx_cols, last_y_f32, *params):

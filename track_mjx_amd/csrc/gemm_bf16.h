@@ -35,6 +35,11 @@ typedef unsigned short bf16_t;
 __device__ __forceinline__ unsigned bg_pack(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(bgf2{lo, hi}, bgb2)); }
 __device__ __forceinline__ bgu4 bg_pack8(bgf4 a, bgf4 b) { return bgu4{bg_pack(a.x, a.y), bg_pack(a.z, a.w), bg_pack(b.x, b.y), bg_pack(b.z, b.w)}; }
 __device__ __forceinline__ float bg_f32(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+// four bf16 (two dwords, element 0 in the low half of the first) -> four floats
+__device__ __forceinline__ bgf4 bg_unpack4(bgu2 u) {
+  return bgf4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u), __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ bgu2 bg_pack4(bgf4 v) { return bgu2{bg_pack(v.x, v.y), bg_pack(v.z, v.w)}; }
 
 // byte offset of 16-byte chunk c (0 .. 7) of row r in a [rows][64 bf16] LDS image (128-byte rows, chunks XOR-swizzled)
 __device__ __forceinline__ int bg_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -76,7 +81,7 @@ struct BgEpi {
   float *stats;                   // EPI 1 writes (mean, 1 / std) per row, EPI 2 reads them
   bf16_t *y16; int ldy16;         // EPI 1 / 3: the activation as bf16 (the next layer's operand);  EPI 2 / 4: d loss / d z as bf16
   float *yf; int ldyf;            // EPI 3: the activation as fp32 instead (the consumer is an fp32 kernel)
-  const float *z; int ldz;        // EPI 2 / 4: the block's saved pre-activation (fp32, without the bias)
+  const bf16_t *z; int ldz;       // EPI 2 / 4: the block's saved pre-activation (bf16 as EPI 1 / 3 stored it, without the bias)
   float *partial;                 // EPI 2 / 4: per-row-tile column sums: [gridDim.x][3][N] (d gamma | d beta | d bias) resp. [gridDim.x][N] (d bias)
   float eps;
 };
@@ -95,13 +100,15 @@ template <int MI, int NI> struct BgCfg {
 };
 
 // EPI 0: C = acc (+ bias), fp32.
-// EPI 1: Dense -> SiLU -> LayerNorm forward (the tile spans whole rows: N == BN): z = acc to C (without the bias: what the backward kernels
-//        expect), y = LayerNorm(silu(z + bias)) as bf16 to y16, (mean, 1 / std) to stats.
+// EPI 1: Dense -> SiLU -> LayerNorm forward (the tile spans whole rows: N == BN): z = acc to C AS BF16 (C is a bf16 array here, ldc in elements;
+//        without the bias: what the backward kernels expect), y = LayerNorm(silu(z + bias)) — from the fp32 accumulators — as bf16 to y16,
+//        (mean, 1 / std) to stats.  The pre-activation is the block's only fp32-sized store: as bf16 ("bf16 MLP": BASELINE config 5) the forward
+//        kernels write 4 instead of 6 bytes per element and the backward epilogues read 2 instead of 4, twice.
 // EPI 2: the tile is d loss / d y of a Dense -> SiLU -> LayerNorm block (whole rows, N == BN = the block's width; this GEMM is the input
 //        gradient of the block's consumer): that block's LayerNorm + SiLU backward (the arithmetic of k_silu_ln_bwd) applied on the
 //        accumulators, d loss / d z stored as bf16 (the operand of the block's own input- and weight-gradient GEMMs) + the row tile's column
 //        sums (dy ahat | dy | dz).  C is not written.
-// EPI 3: Dense -> SiLU forward (brax value MLP): z = acc to C, y = silu(z + bias) as bf16 (or fp32).   EPI 4: its backward on the tile
+// EPI 3: Dense -> SiLU forward (brax value MLP): z = acc to C as bf16 (as EPI 1), y = silu(z + bias) as bf16 (or fp32).   EPI 4: its backward on the tile
 //        d loss / d y: dz = dy silu'(z + bias) as bf16 + column sums of dz.
 // DMA_A (bf16 A, K a multiple of 64): the activation tile goes global -> LDS by LDS-DMA as well; otherwise it is staged through registers (fp32 A:
 // converted at the LDS write; ragged K: masked).
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
       float p = 0.f;
 #pragma unroll
       for (int b = 0; b < NI; b++) {
-        if (row < M) *reinterpret_cast<bgf4 *>(C + (size_t)row * ldc + nw + 16 * b + 4 * kq) = acc[a][b];
+        if (row < M) *reinterpret_cast<bgu2 *>(reinterpret_cast<bf16_t *>(C) + (size_t)row * ldc + nw + 16 * b + 4 * kq) = bg_pack4(acc[a][b]);
 #pragma unroll
         for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
       }
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
 #pragma unroll
       for (int b = 0; b < NI; b++) {
         const int col = nw + 16 * b + 4 * kq;
-        const bgf4 z4 = *reinterpret_cast<const bgf4 *>(epi.z + rr * epi.ldz + col);
+        const bgf4 z4 = bg_unpack4(*reinterpret_cast<const bgu2 *>(epi.z + rr * epi.ldz + col));
         const bgf4 bv4 = *reinterpret_cast<const bgf4 *>(bias + col), gv4 = *reinterpret_cast<const bgf4 *>(epi.gamma + col);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
     // second pass column block by column block: the three column sums of ONE block are live at a time (all NI of them cost 12 NI registers).
     // z is RE-LOADED through an opaque pointer: otherwise the loads (and the sigmoid / ahat values computed from them) of the first pass are
     // kept live across the exchange for the second one — MI NI 12 registers, spilled at NI = 4
-    const float *z2 = epi.z;
+    const bf16_t *z2 = epi.z;
     asm volatile("" : "+s"(z2));
     float *pp = epi.partial + (size_t)blockIdx.x * 3 * BN;
 #pragma unroll
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
         const int row = m0 + 16 * a + li;
         const bool ok = row < M;
         const size_t rr = ok ? row : M - 1;
-        const bgf4 z4 = *reinterpret_cast<const bgf4 *>(z2 + rr * epi.ldz + col);
+        const bgf4 z4 = bg_unpack4(*reinterpret_cast<const bgu2 *>(z2 + rr * epi.ldz + col));
         const float mean_a = epi.stats[2 * rr], rstd_a = epi.stats[2 * rr + 1];
         bgf4 o;
 #pragma unroll
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
   }
   if constexpr (EPI == 3 || EPI == 4) {
     // element-wise on the tile (any N: columns beyond N are computed on clamped weight rows and never stored)
-    const bool vec = EPI == 3 ? (!(ldc & 3) && !((uintptr_t)C & 15)) : true;
+    const bool vec = EPI == 3 ? (!(ldc & 3) && !((uintptr_t)C & 7)) : true;
 #pragma unroll
     for (int b = 0; b < NI; b++) {
       const int col = n0 + nw + 16 * b + 4 * kq;
@@ -470,20 +477,20 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
 #pragma unroll
           for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[r]; o[r] = v / (1.f + expf(-v)); }
           if (ok) {
-            float *zo = C + (size_t)row * ldc + col;
-            if (vec && col + 3 < N) *reinterpret_cast<bgf4 *>(zo) = acc[a][b];
+            bf16_t *zo = reinterpret_cast<bf16_t *>(C) + (size_t)row * ldc + col;
+            if (vec && col + 3 < N) *reinterpret_cast<bgu2 *>(zo) = bg_pack4(acc[a][b]);
             else {
 #pragma unroll
-              for (int r = 0; r < 4; r++) if (col + r < N) zo[r] = acc[a][b][r];
+              for (int r = 0; r < 4; r++) if (col + r < N) zo[r] = (bf16_t)(bg_pack(acc[a][b][r], 0.f) & 0xffffu);
             }
           }
         } else {
           const size_t rr = ok ? row : M - 1;
           bgf4 z4 = {0.f, 0.f, 0.f, 0.f};
-          if (!(epi.ldz & 3) && col + 3 < N) z4 = *reinterpret_cast<const bgf4 *>(epi.z + rr * epi.ldz + col);       // (z's base is 16-byte aligned: checked by the entry point)
+          if (!(epi.ldz & 3) && col + 3 < N) z4 = bg_unpack4(*reinterpret_cast<const bgu2 *>(epi.z + rr * epi.ldz + col));       // (z's base is 8-byte aligned: checked by the entry point)
           else {
 #pragma unroll
-            for (int r = 0; r < 4; r++) if (col + r < N) z4[r] = epi.z[rr * epi.ldz + col + r];
+            for (int r = 0; r < 4; r++) if (col + r < N) z4[r] = bg_f32(epi.z[rr * epi.ldz + col + r]);
           }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
@@ -525,14 +532,14 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
 // Unfused backward of a Dense -> SiLU block whose output gradient does not come out of a bf16 GEMM (the value net's last hidden layer: its
 // consumer is the 1-wide head on the fp32 kernels): dz = dy silu'(z + bias) as bf16 + per-80-row-tile column sums.  One workgroup per row tile,
 // a thread per column (coalesced rows).
-__global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ dy, int ldy, const float *__restrict__ z, int ldz, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ dy, int ldy, const bf16_t *__restrict__ z, int ldz, const float *__restrict__ bias,
                                                      bf16_t *__restrict__ dz, int lddz, float *__restrict__ partial, int M, int N) {
   const int r0 = blockIdx.x * 80, r1 = min(M, r0 + 80);
   for (int c = threadIdx.x; c < N; c += 256) {
     const float b = bias[c];
     float sum = 0.f;
     for (int r = r0; r < r1; r++) {
-      const float v = z[(size_t)r * ldz + c] + b, sig = 1.f / (1.f + expf(-v));
+      const float v = bg_f32(z[(size_t)r * ldz + c]) + b, sig = 1.f / (1.f + expf(-v));
       const float o = dy[(size_t)r * ldy + c] * (sig * (1.f + v * (1.f - sig)));
       dz[(size_t)r * lddz + c] = (bf16_t)(bg_pack(o, 0.f) & 0xffffu);
       sum += o;
@@ -541,13 +548,13 @@ __global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ d
   }
 }
 
-// The same with four consecutive columns per thread (16-byte loads of z and dy, 8-byte stores of dz; N a multiple of 4, <= 1024, aligned rows)
+// The same with four consecutive columns per thread (8-byte loads of z, 16-byte loads of dy, 8-byte stores of dz; N a multiple of 4, <= 1024, aligned rows)
 // and the row tile's 80 rows dealt to 256 / (N / 4) row phases, whose column sums meet in LDS.  RANK1: the output gradient is the outer product
 // dy1[row] w1[col] — the block's consumer is a 1-wide un-activated layer (the value head: d loss / d y = d loss / d baseline x its weight row),
 // formed here instead of by an input-gradient GEMM with a contraction length of one that writes [M][N] floats for this kernel to read back.
 template <bool RANK1>
 __global__ __launch_bounds__(256) void k_bf_silu_bwd4(const float *__restrict__ dy, int ldy, const float *__restrict__ dy1, const float *__restrict__ w1,
-                                                      const float *__restrict__ z, int ldz, const float *__restrict__ bias, bf16_t *__restrict__ dz, int lddz,
+                                                      const bf16_t *__restrict__ z, int ldz, const float *__restrict__ bias, bf16_t *__restrict__ dz, int lddz,
                                                       float *__restrict__ partial, int M, int N) {
   __shared__ float red[256 * 4];
   const int ncg = N >> 2, nph = 256 / ncg, t = threadIdx.x, cg = t % ncg, ph = t / ncg;
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(256) void k_bf_silu_bwd4(const float *__restrict__ 
     bgf4 wv = {0.f, 0.f, 0.f, 0.f}, sum = {0.f, 0.f, 0.f, 0.f};
     if (RANK1) wv = *reinterpret_cast<const bgf4 *>(w1 + 4 * cg);
     for (int r = r0 + ph; r < r1; r += nph) {
-      const bgf4 zv = *reinterpret_cast<const bgf4 *>(z + (size_t)r * ldz + 4 * cg);
+      const bgf4 zv = bg_unpack4(*reinterpret_cast<const bgu2 *>(z + (size_t)r * ldz + 4 * cg));
       bgf4 d;
       if (RANK1) { const float g = dy1[r]; d = bgf4{g * wv.x, g * wv.y, g * wv.z, g * wv.w}; }
       else d = *reinterpret_cast<const bgf4 *>(dy + (size_t)r * ldy + 4 * cg);
