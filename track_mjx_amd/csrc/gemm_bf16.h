@@ -397,9 +397,11 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
         const bgf4 bv4 = *reinterpret_cast<const bgf4 *>(bias + col), gv4 = *reinterpret_cast<const bgf4 *>(epi.gamma + col);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          if (!ok) acc[a][b][r] = 0.f;                  // (rows past M: clamped duplicates of the last row — nothing of them may reach the column sums)
-          const float v = z4[r] + bv4[r];
-          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean_a) * rstd_a, da = acc[a][b][r] * gv4[r];
+          // (rows past M: clamped duplicates of the last row — nothing of them may reach the row / column sums.  Masked where it is used, in both
+          // passes: zeroing the accumulator in place made the compiler keep the masked AND the unmasked copy of some elements across the whole
+          // epilogue — 8 spilled registers at NI = 4)
+          const float v = z4[r] + bv4[r], dy = ok ? acc[a][b][r] : 0.f;
+          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean_a) * rstd_a, da = dy * gv4[r];
           s1 += da; s2 += da * ah;
         }
       }
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
         bgf4 o;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const float v = z4[r] + bv4[r], dy = acc[a][b][r];
+          const float v = z4[r] + bv4[r], dy = ok ? acc[a][b][r] : 0.f;
           const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean_a) * rstd_a, da = dy * gv4[r];
           const float dact = rstd_a * (da - m1[a] - ah * m2[a]);
           o[r] = ok ? dact * (sig * (1.f + v * (1.f - sig))) : 0.f;
