@@ -71,10 +71,17 @@ def test_physics_kernel_resources_allow_ten_envs_per_cu(tmp_path):
     if not (hip.SO_PATH.exists() and shutil.which("objcopy") and Path(bundler).exists() and Path(readelf).exists()):
         import pytest
         pytest.skip("library or LLVM tools missing")
-    fat, co = tmp_path / "fat.bin", tmp_path / "k.co"
+    fat = tmp_path / "fat.bin"
     subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(hip.SO_PATH), str(fat)], check=True)
-    subprocess.run([bundler, "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-    notes = subprocess.run([readelf, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+    # one offload bundle per translation unit of the library (the physics kernel has its own: csrc/tmjx_wave.hip)
+    blob, magic = fat.read_bytes(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)] + [len(blob)]
+    notes = ""
+    for k in range(len(starts) - 1):
+        part, co = tmp_path / f"fat{k}.bin", tmp_path / f"k{k}.co"
+        part.write_bytes(blob[starts[k]:starts[k + 1]])
+        subprocess.run([bundler, "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        notes += subprocess.run([readelf, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
     i = notes.index(".name:           _Z14k_physics_waveILb1EE")
     after = notes[i:i + 1500]          # the fields of a kernel's metadata map follow its .name line in alphabetical order
     vg = int(re.search(r"\.vgpr_count:\s+(\d+)", after).group(1))

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Per-phase instruction-class table of k_physics_wave<true> from its ISA: compile csrc/tmjx_hip.hip with -gline-tables-only --save-temps, map every
+"""Per-phase instruction-class table of k_physics_wave<true> from its ISA: compile csrc/tmjx_wave.hip with -gline-tables-only --save-temps (and the flags of track_mjx_amd/hip.py: SOURCE_FLAGS), map every
 instruction of the kernel to the source line of its innermost inlined location (.loc), and the line to the function of csrc/wave_physics.h that
 contains it.  STATIC counts (unrolled code counts once per copy, loop bodies once).
 
-usage: python tools/isa_phase_table.py <tmjx_hip-hip-amdgcn-amd-amdhsa-gfx950.s> [kernel mangled-name prefix]"""
+usage: python tools/isa_phase_table.py <tmjx_wave-hip-amdgcn-amd-amdhsa-gfx950.s> [kernel mangled-name prefix]"""
 import collections
 import re
 import sys

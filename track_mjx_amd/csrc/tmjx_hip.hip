@@ -204,42 +204,10 @@ __global__ __launch_bounds__(64) void k_rec_out(const DModel *__restrict__ mp, f
   for (int j = 0; j < REC_ROWS_PER_THREAD; j++) { int r = r0 + j; if (r < nrow) st[(size_t)(m.s_qpos + r) * n + e] = v[j]; }
 }
 
-// K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
-// STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
-// __launch_bounds__(64, 3): three waves per SIMD are what 11 envs per CU need, i.e. at most 168 VGPRs — as a bound the compiler
-// keeps, not a number a later edit silently exceeds (168 -> 173 registers means two waves per SIMD; tests/test_abi.py pins it too).
-template <bool STATIC>
-__global__ __launch_bounds__(64, 3) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
-                                                     int do_euler, float *ws_dump, int n, int e0, int rs, float *spill, int spill_stride) {
-  extern __shared__ float tmw_lds[];
-  WCtx c{(TmwModel *)mp, tmw_lds, st, n, (int)blockIdx.x + e0, (int)threadIdx.x, nullptr, 0ull, nullptr};
-  c.rs = rs;
-  c.mspill = spill ? spill + 64 + (size_t)(blockIdx.x + e0) * (size_t)spill_stride : nullptr;
-  c.action = action;
-#ifndef TMW_PROFILE
-  c.dump = ws_dump;
-#endif
-#ifdef TMW_PROFILE
-  if (ws_dump) { c.prof = (unsigned long long *)ws_dump + (size_t)(blockIdx.x + e0) * 40; c.tlast = __builtin_amdgcn_s_memtime(); }
-#endif
-  constexpr WLayout ks(TMW_RODENT_DIMS, 1);
-  const WLayout kd = STATIC ? ks : WLayout(mp->nbody, mp->njnt, mp->nq, mp->nv, mp->nu, mp->ncon, mp->nlim, mp->nnz, mp->ngroup,
-                                           mp->nround_body, mp->nround_dof);
-  const WLayout &K = STATIC ? ks : kd;
-  float time = tmw_load_state(c, K, action);
-  for (int f = 0; f < nsub; f++) {
-    // fresh, opaque copies of the lane id and the model pointer per substep: LICM otherwise hoists every lane-derived LDS /
-    // global address of the substep body (cheap adds) out of this loop, and the register allocator then SPILLS them
-    { int l = threadIdx.x; asm volatile("" : "+v"(l)); c.lane = l; TmwModel *q = (TmwModel *)mp; asm volatile("" : "+s"(q)); c.mp = q; }
-    tmw_forward(c, K, f == nsub - 1);
-    if (do_euler) time = tmw_euler(c, K, time);
-  }
-#ifndef TMW_PROFILE
-  if (ws_dump) tmw_dump(c, K, ws_dump);
-#endif
-  tmw_store_state(c, K, time);
-  TMW_TICK(12);
-}
+// K2, wave-per-env (k_physics_wave, csrc/wave_physics.h) is compiled in a translation unit of its own, csrc/tmjx_wave.hip — with a compiler
+// flag of its own (track_mjx_amd/hip.py) — and launched through this entry
+extern "C" void tmjx_internal_launch_physics_wave(int rodent, int cnt, size_t lds, hipStream_t stream, const DModel *mp, float *st, const float *action, int nsub,
+                                                  int do_euler, float *ws_dump, int n, int e0, int rs, float *spill, int spill_stride);
 
 __global__ void k_reset_pre(const DModel *__restrict__ mp, float *st, int *is, const int *clip, const int *start, const float *qn,
                             const float *vn, float *ws, int n) {
@@ -429,8 +397,7 @@ static int launch_wave(const tmjx_model *m, float *state, const float *action, i
   float *st = rec ? rec : state;
   for (int p = 0; p < parts; p++) {
     int cnt = n_env / parts, e0 = p * cnt;
-    if (m->rodent) hipLaunchKernelGGL(k_physics_wave<true>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs, spill, sstride);
-    else hipLaunchKernelGGL(k_physics_wave<false>, dim3(cnt), dim3(64), lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs, spill, sstride);
+    tmjx_internal_launch_physics_wave(m->rodent ? 1 : 0, cnt, lds, stream, m->d, st, action, nsub, do_euler, ws, n_env, e0, rs, spill, sstride);
   }
   if (rec) hipLaunchKernelGGL(k_rec_out, dim3((n_env + 63) / 64, (m->h.s_prev_ctrl - m->h.s_qpos + REC_ROWS_PER_THREAD - 1) / REC_ROWS_PER_THREAD), dim3(64), 0, stream, m->d, state, (const float *)rec, n_env, rs);
   return TMJX_OK;

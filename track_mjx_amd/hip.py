@@ -14,7 +14,9 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 SO_PATH = Path(os.environ.get("TMJX_SO", str(_PKG / "libtmjx_hip.so")))  # TMJX_SO: alternative build (profiling)
 CSRC = _PKG / "csrc"
-SOURCES = (CSRC / "tmjx_hip.hip", CSRC / "tmjx_bf16.hip")
+SOURCES = (CSRC / "tmjx_hip.hip", CSRC / "tmjx_bf16.hip", CSRC / "tmjx_wave.hip")
+# per-source compiler flags: the physics kernel's unit is built without machine LICM (csrc/tmjx_wave.hip says why)
+SOURCE_FLAGS = {"tmjx_wave.hip": ("-mllvm", "-disable-machine-licm")}
 
 
 class TmjxError(RuntimeError):
@@ -83,7 +85,7 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
     # -fno-slp-vectorize: the SLP vectoriser packs the two dof slots of the row products into v_pk_* with more v_mov shuffles than
     # it saves (measured 1.8 % on the physics kernel); the explicitly packed FMAs of the chain kernels are not affected
     out = SO_PATH if out is None else Path(out)
-    # two translation units compiled side by side (each hipcc run is single-threaded per offload arch), then linked into ONE library.
+    # three translation units compiled side by side (each hipcc run is single-threaded per offload arch), then linked into ONE library.
     # Objects are cached next to the library, keyed by a hash of the flags and of the source with every header it includes (recursively):
     # editing one kernel family recompiles one unit
     import hashlib
@@ -104,8 +106,11 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
     cache = out.parent / ".build"
     cache.mkdir(exist_ok=True)
     objs = []
+    def flags_of(src):
+        return [*flags, *SOURCE_FLAGS.get(src.name, ())]
+
     for src in SOURCES:
-        h = hashlib.sha256(" ".join(flags).encode())
+        h = hashlib.sha256(" ".join(flags_of(src)).encode())
         for pth, text in sorted(closure(src.resolve(), {}).items()):
             h.update(str(pth.name).encode()); h.update(text.encode())
         objs.append(cache / f"{src.stem}.{h.hexdigest()[:16]}.o")
@@ -117,7 +122,7 @@ def build(verbose: bool = False, out: Path | None = None, defines: tuple = ()) -
             if len(list(cache.glob(f"{src.stem}.*.o"))) > 6:
                 stale.unlink(missing_ok=True)
         tmp = obj.with_suffix(f".tmp{os.getpid()}.o")
-        cmd = ["hipcc", *flags, "-c", "-o", str(tmp), str(src)]
+        cmd = ["hipcc", *flags_of(src), "-c", "-o", str(tmp), str(src)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise TmjxError(f"hipcc failed on {src.name}:\n" + res.stderr[-4000:])
