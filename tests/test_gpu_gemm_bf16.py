@@ -431,3 +431,36 @@ def test_value_net_head_inside_the_bf16_chain_changes_no_bit():
         res.append([y.detach()] + [t.clone() for t in grads])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_bf16_mode_small_minibatch_takes_the_padded_copy():
+    """bf16 GEMM-input mode with a minibatch below the fused latent kernel's threshold (< 1024 rows): the decoder's input is a torch.cat of 286
+    columns, whose rows do not start on 16-byte boundaries — the chain stages a copy with padded rows (it used to hand the rows to tmjx_bgemm_ln_fwd
+    as they were: TMJX_EINVAL).  One update through the captured step: finite, and the gradient agrees with the fp32 learner's."""
+    from tests.common import make_env_and_oracle
+    from track_mjx_amd.agent import ppo
+    env = make_env_and_oracle(num_envs=128, n_clips=4, wrappers=True)[0]
+    kw = dict(encoder_layers=(256, 128), decoder_layers=(128, 128), critic_layers=(128, 128), latents=60, unroll_length=5, batch_size=128,
+              num_minibatches=4, num_updates_per_batch=1, seed=9)
+    L32 = ppo.PPOLearner(env, use_graph=False, **kw)
+    L16 = ppo.PPOLearner(env, matmul_dtype=torch.bfloat16, **kw)
+    L32.states[0] = env.reset(torch.Generator().manual_seed(1))
+    L32.collect()
+    for k in L32.buf:
+        L16.buf[k].copy_(L32.buf[k])
+    for n in (L32, L16):
+        n.normalizer.update(n.buf["observation"])
+    idx = torch.arange(L32.local_batch, device=env.device)
+    torch.manual_seed(0)
+    L32._minibatch_grads(idx, 0.1)
+    torch.manual_seed(0)
+    L16._minibatch_grads(idx, 0.1)
+    g32, g16 = L32.grads.flat, L16.grads.flat
+    cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    assert torch.isfinite(g16).all() and cos > 0.98, cos
+    draw0 = int(L16._mb_state[0])
+    out = L16.update(0)
+    torch.cuda.synchronize()
+    assert L16._graph is not None, "hipGraph capture of the small-minibatch bf16 step failed"
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())
+    assert int(L16._mb_state[0]) == draw0 + 4          # one draw per minibatch step: the capture's warm-up runs leave the draw counter where it was

@@ -391,8 +391,12 @@ class _BfChainFn(torch.autograd.Function):
         import ctypes as C
         from .. import hip as _hip
         x2 = _rows2d(x)
-        if x2.data_ptr() % 16 or x2.stride(0) % (4 if x2.dtype == torch.float32 else 8):
-            x2 = x2.contiguous()
+        q = 4 if x2.dtype == torch.float32 else 8
+        if x2.data_ptr() % 16 or x2.stride(0) % q or x2.stride(1) != 1:
+            # rows that do not start on 16-byte boundaries (a torch.cat of 286 columns: the policy's small-batch path): a copy with padded rows
+            padded = torch.empty((x2.shape[0], (x2.shape[1] + q - 1) // q * q), dtype=x2.dtype, device=x2.device)
+            padded[:, :x2.shape[1]].copy_(x2)
+            x2 = padded[:, :x2.shape[1]]
         saved, h = [], x2
         t16 = gemm_inputs.twin_of(x2, layers[0].lin.weight.shape[1])
         for i, L in enumerate(layers):

@@ -754,6 +754,7 @@ class PPOLearner:
         same graph serves any world size."""
         selfadv = self._self_advancing()
         self._g_idx = None if selfadv else torch.zeros(self.local_batch, dtype=torch.long, device=self.dev)
+        draw0 = self._mb_state[0:1].clone()         # the warm-up runs draw noise: the capture leaves the device-side draw counter where it found it
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
@@ -762,6 +763,7 @@ class PPOLearner:
                     self._mb_state[1:].zero_()          # (warm-up runs read slot 0 of whatever the permutation buffer holds: valid rows)
                 self._minibatch_grads(self._g_idx, kl_w)
         torch.cuda.current_stream(self.dev).wait_stream(side)
+        self._mb_state[0:1].copy_(draw0)
         graph = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread polls events concurrently (world > 1) and must not invalidate the capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
