@@ -705,6 +705,7 @@ class PPOLearner:
         selfadv = self._self_advancing()
         self._g_idx = None if selfadv else torch.zeros(self.local_batch, dtype=torch.long, device=self.dev)
         cur = torch.cuda.current_stream(self.dev)
+        draw0 = self._mb_state[0:1].clone()         # (as _capture: the warm-up runs leave the device-side draw counter where it was)
         warm = torch.cuda.Stream(device=self.dev)
         warm.wait_stream(cur)
         with torch.cuda.stream(warm):
@@ -714,6 +715,7 @@ class PPOLearner:
                 outs, gouts, _ = self._mb_forward(self._g_idx, kl_w)
                 self._mb_backward(outs, gouts, "value"); self._mb_backward(outs, gouts, "policy")
         cur.wait_stream(warm)
+        self._mb_state[0:1].copy_(draw0)
         torch.cuda.synchronize(self.dev)
         g1, gv, gp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread polls events concurrently and must not invalidate the capture
