@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Learning sanity of the whole path (physics kernel, K3, hipGraph inference, self-advancing SGD step with the hand-written GEMMs): the bench
 configuration (4096 envs, 2x256 nets, synthetic clips, random init) trained for N steps; prints the mean per-step roll-out reward, the
-losses and the NaN-guard rate every few steps.  GPU box: python tools/learning_sanity.py [steps=80] [bf16]   (bf16: the MLP GEMMs in bf16 GEMM-input mode,
+losses and the NaN-guard rate every few steps.  GPU box: python tools/learning_sanity.py [steps=80] [bf16 | cfg4 | cfg5]   (cfg4 / cfg5: that BASELINE
+configuration's env count, clip table and nets as bench.py --config builds them; bf16: the MLP GEMMs in bf16 GEMM-input mode,
 BASELINE config 5's numerics — bf16 operands, bf16 saved pre-activations — on the same configuration, for a like-for-like reward curve)"""
 import sys
 import time
@@ -16,16 +17,20 @@ from track_mjx_amd.environment import wrap  # noqa: E402
 from track_mjx_amd.train import build_env  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 80
-bf16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+mode = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+bf16 = mode in ("bf16", "cfg5")
 dev = torch.device("cuda:0")
 cfg = _config.default_config()
-cfg["network_config"].update(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256])
+import bench as _bench  # noqa: E402
+bc = _bench.CONFIGS[mode if mode in _bench.CONFIGS else "cfg2"]
+cfg["network_config"].update(**bc["nets"])
 tc, nc = cfg["train_setup"]["train_config"], cfg["network_config"]
-sizes = ppo.group_sizes(4096, ppo.default_groups(4096, dev))           # the bench's env groups (three since round 3)
-envs = [wrap(build_env(cfg, n, dev), episode_length=195) for n in sizes]
+n_envs = bc["envs_per_gpu"]
+sizes = ppo.group_sizes(n_envs, ppo.default_groups(n_envs, dev))           # the bench's env groups (three since round 3)
+envs = [wrap(build_env(cfg, n, dev, n_clips=min(bc["n_clips"], 64)), episode_length=195) for n in sizes]
 L = ppo.PPOLearner(envs, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"], critic_layers=nc["critic_layer_sizes"],
                    latents=nc["intention_size"], learning_rate=tc["learning_rate"], entropy_cost=tc["entropy_cost"], discounting=tc["discounting"],
-                   unroll_length=tc["unroll_length"], batch_size=tc["batch_size"], num_minibatches=tc["num_minibatches"],
+                   unroll_length=tc["unroll_length"], batch_size=tc["batch_size"] * n_envs // 4096, num_minibatches=tc["num_minibatches"],
                    num_updates_per_batch=tc["num_updates_per_batch"], normalize_observations=True, kl_weight=nc["kl_weight"], seed=0,
                    matmul_dtype=torch.bfloat16 if bf16 else None)
 g = torch.Generator().manual_seed(1)
