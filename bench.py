@@ -8,6 +8,9 @@ env steps on every env (each = 10 physics substeps + reward/obs), the normaliser
 num_updates_per_batch*num_minibatches = 64 minibatch SGD updates with the gradient all-reduce.
 value = env steps collected by all ranks / wall time (the reference's own `training/sps`, ppo.py:427-431).
 Weak scaling: 4096 envs and 1024 minibatch rows per GPU; global batch_size = 1024*N.
+`--config cfg3` = BASELINE configs[2] as SURVEY.md §8 d2 defines it (32 768 envs on 8 GPUs, the reference's batch_size 2048): 256 minibatch rows per GPU
+(5 120-row GEMMs), ONE unroll + 64 minibatch steps per training step, gradient all-reduce after each; on one GPU it runs one rank's share with the
+collectives issued on a one-rank RCCL group; `--gpus N --config cfg3` uses batch_size = 256*N.
 
 Usage: python bench.py [--gpus N --steps K --warmup W]
 N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py
@@ -36,19 +39,27 @@ ENVS_PER_GPU = 4096
 FULL_NETS = dict(encoder_layer_sizes=[1024, 512, 512, 512, 512], decoder_layer_sizes=[512, 512, 512, 256, 256],
                  critic_layer_sizes=[512, 512, 512, 512, 512, 256])            # rodent-full-clips.yaml:50-57
 # BASELINE.json configs: cfg2 = configs[1] is the line the metric is quoted on
+SMALL_NETS = dict(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256])
+# `rows_per_gpu`: minibatch rows (envs) per GPU and SGD step = the reference's batch_size / local devices.  cfg2 is this file's weak-scaling default
+# (1024 rows per GPU at any N).  cfg3 = BASELINE configs[2] as SURVEY.md §8 d2 defines it: 32 768 envs on 8 GPUs with the reference's batch_size = 2048,
+# i.e. ONE RANK'S SHARE is 4096 envs, 256 rows per minibatch (5 120-row GEMMs), one unroll and 64 minibatch steps (each with its gradient
+# all-reduce) per training step; `--config cfg3` on one GPU runs exactly that share with C1 / C2 issued on a one-rank RCCL group.
 CONFIGS = {
-    "cfg2": dict(envs_per_gpu=4096, n_clips=64, nets=dict(encoder_layer_sizes=[256, 256], decoder_layer_sizes=[256, 256], critic_layer_sizes=[256, 256]),
+    "cfg2": dict(envs_per_gpu=4096, n_clips=64, nets=SMALL_NETS, rows_per_gpu=1024,
                  matmul_dtype=None, random_clips=False, label="2x256 intention policy + critic, fp32"),
-    "cfg4": dict(envs_per_gpu=4096, n_clips=64, nets=FULL_NETS, matmul_dtype=None, random_clips=False,
+    "cfg3": dict(envs_per_gpu=4096, n_clips=64, nets=SMALL_NETS, rows_per_gpu=256, force_collectives=True,
+                 matmul_dtype=None, random_clips=False, label="one rank's share of 32768 envs / 8 GPUs at the reference's batch_size 2048 (256 minibatch rows per GPU), 2x256 nets, fp32, RCCL gradient all-reduce every minibatch step"),
+    "cfg4": dict(envs_per_gpu=4096, n_clips=64, nets=FULL_NETS, rows_per_gpu=1024, matmul_dtype=None, random_clips=False,
                  label="rodent-mc-intention nets (enc 1024-512x4, dec 512x3-256x2, critic 512x5-256), fp32"),
-    "cfg5": dict(envs_per_gpu=8192, n_clips=1024, nets=FULL_NETS, matmul_dtype="bf16", random_clips=True,
+    "cfg5": dict(envs_per_gpu=8192, n_clips=1024, nets=FULL_NETS, rows_per_gpu=2048, matmul_dtype="bf16", random_clips=True,
                  label="1024-clip table (per-env clip gather), rodent-mc-intention nets with bf16 GEMM inputs / fp32 accumulate"),
 }
 
 
-def cpu_baseline(blob, clip, seconds_budget: float = 15.0, action_scale: float = 0.3):
+def cpu_baseline(blob, clip, seconds_budget: float = 15.0, action_scale: float = 0.3, n_envs: int | None = None):
     """The oracle (CPU restatement, kind "port") stepping the same kind of workload on the host cores.  `action_scale`: actions are
-    clip(action_scale * N(0, 1), -1, 1) — 0.3 is the roll-out-only leg's regime (the cost of an env-step depends on it: DESIGN.md §7)."""
+    clip(action_scale * N(0, 1), -1, 1) — 0.3 is the roll-out-only leg's regime (the cost of an env-step depends on it: DESIGN.md §7).
+    `n_envs`: BASELINE.md §3 asks for N_env = 1 (one thread: a scalar port) and N_env = 4096 (OpenMP over envs on every host core)."""
     import numpy as np
     from oracle.oracle import Oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -60,20 +71,22 @@ def cpu_baseline(blob, clip, seconds_budget: float = 15.0, action_scale: float =
         pass
     O = Oracle(blob, "f32")
     O.set_clips(clip.as_dict())
-    n = max(cores * 4, 16)
+    n = max(cores * 4, 16) if n_envs is None else int(n_envs)
+    threads = min(cores, n)
     envs = O.new_envs(n)
     rng = np.random.default_rng(0)
     for e in range(n):
         O.env_reset(envs, e, e % clip.position.shape[0], e % 44, rng.uniform(-1e-3, 1e-3, 74), rng.uniform(-1e-3, 1e-3, 73))
     acts = np.clip(action_scale * rng.normal(size=(n, 38)), -1, 1)
-    O.env_step_batch(envs, n, acts, cores)  # warm up threads
+    if n <= 256:
+        O.env_step_batch(envs, n, acts, threads)  # warm up threads
     t0, steps = time.time(), 0
-    while time.time() - t0 < seconds_budget:
-        O.env_step_batch(envs, n, acts, cores)
+    while steps == 0 or time.time() - t0 < seconds_budget:
+        O.env_step_batch(envs, n, acts, threads)
         steps += n
     dt = time.time() - t0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port", "action_scale": action_scale,
-            "sample": f"{n} envs x {steps // n} control steps (10 substeps each), actions clip({action_scale} * N(0,1)), OpenMP over envs, oracle/liboracle_f32.so"}
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "host_cores": cores, "n_envs": n, "kind": "port", "action_scale": action_scale,
+            "sample": f"{n} envs x {steps // n} control steps (10 substeps each), actions clip({action_scale} * N(0,1)), {threads} OpenMP thread(s) over envs, oracle/liboracle_f32.so"}
 
 
 def so_build_id() -> str:
@@ -93,22 +106,39 @@ def mjx_cpu_probe() -> str:
         return f"unavailable ({type(e).__name__}: {e})"
 
 
+_CHILDREN: list = []        # child benches in flight (other_configs): the signal handler ends their process groups before it exits
+
+
 def other_configs(timeout_s: float = 150.0) -> dict:
-    """Short runs of `bench.py --config cfg4 / cfg5` as child processes; the fields of their lines that matter."""
+    """Short runs of `bench.py --config cfg3 / cfg4 / cfg5` as child processes (5 timed steps each); the fields of their lines that matter.
+    Every child runs in a process group of its own so that a signal that ends this process can end it too (killpg in main's handler)."""
+    import signal
     import subprocess
     res = {}
-    for cfg in ("cfg4", "cfg5"):
+    for cfg in ("cfg3", "cfg4", "cfg5"):
         cmd = [sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-rollout-only"]
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
-            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            _CHILDREN.append(p)
+            try:
+                so, se = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                so, se = p.communicate()
+                res[cfg] = {"error": f"timed out after {timeout_s:.0f} s"}
+                continue
+            finally:
+                if p.poll() is not None and p in _CHILDREN:
+                    _CHILDREN.remove(p)
+            line = [ln for ln in so.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not line:
-                res[cfg] = {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
+                res[cfg] = {"error": f"rc {p.returncode}: {se[-300:]}"}
                 continue
             o = json.loads(line[-1])
             c = o["config"]
             res[cfg] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "dtype": o["dtype"], "workload": c["workload"],
                         "rollout_ms_per_step": c["rollout_ms_per_step"], "sgd_ms_per_minibatch_step": c["sgd_ms_per_minibatch_step"], "steps": o["steps"],
+                        "minibatch_rows_x_unroll": c["minibatch_gemm_rows"], "ranks_seen": c["ranks_seen"], "collectives": c["collectives"],
                         "mlp_gemm_inputs": c["mlp_gemm_inputs"], "roofline_mfma_frac": o["roofline_mfma"]["frac"]}
         except Exception as e:  # noqa: BLE001 — a report beside the headline, never a reason to lose it
             res[cfg] = {"error": f"{type(e).__name__}: {e}"}
@@ -128,8 +158,13 @@ def dry_run_ranks(args) -> None:
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
     if int(os.environ.get("RANK", "0")) == 0:
+        bc = CONFIGS[args.config]
+        n_local = args.envs_per_gpu or bc["envs_per_gpu"]
+        batch_size = bc["rows_per_gpu"] * world * n_local // bc["envs_per_gpu"]          # as main() hands it to the learner
         print(json.dumps({"metric": "dry-run-ranks", "n_gpus": world, "asked_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-                          "config": {"ranks_seen": ranks_seen, "parallelism": f"dp{world}"}}), flush=True)
+                          "config": {"ranks_seen": ranks_seen, "parallelism": f"dp{world}", "workload": args.config, "envs_total": n_local * world,
+                                     "global_batch": batch_size, "minibatch_rows_per_gpu": batch_size // world,
+                                     "unrolls_per_training_step": batch_size * 16 // (n_local * world)}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -147,7 +182,7 @@ def main(argv=None, runner=None):
     ap.add_argument("--no-rollout-only", action="store_true", help="skip the extra roll-out-only measurement (tools/profile_gpu.sh: keeps the "
                     "rocprofv3 kernel averages those of the timed training steps)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
-                    help="BASELINE.json configs[1] (default, the headline line) / configs[3] / configs[4]; the others are extra measurements")
+                    help="BASELINE.json configs[1] (default, the headline line) / configs[2] (cfg3: one rank's share per GPU) / configs[3] / configs[4]; the others are extra measurements")
     ap.add_argument("--dry-run-ranks", action="store_true", help="launcher check on CPU: gloo ranks, no GPU work (tests)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short cfg4 / cfg5 measurements the default N = 1 line carries under config.other_configs")
     args = ap.parse_args(argv)
@@ -181,6 +216,12 @@ def main(argv=None, runner=None):
     torch.cuda.set_device(device)
     # TMJX_COLLECTIVES_ALWAYS=1 under torch.distributed.run with ONE rank: RCCL is initialised and C1 / C2 / the timing reductions are
     # issued on the one-rank group — the multi-GPU call path on a single-GPU box (the numbers equal the plain N=1 run's)
+    if bc.get("force_collectives") and world == 1 and not rehearse:
+        # cfg3 on ONE GPU is one rank's share of the 8-GPU job: the rank's collectives (C1 after every minibatch step, C2, the timing reductions)
+        # are issued on a one-rank RCCL group, started in-process when no launcher provided the rendezvous
+        os.environ["TMJX_COLLECTIVES_ALWAYS"] = "1"
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()))
     use_dist = world > 1 or ("RANK" in os.environ and bool(os.environ.get("TMJX_COLLECTIVES_ALWAYS")))
     if use_dist:
         if rehearse:
@@ -211,7 +252,7 @@ def main(argv=None, runner=None):
     learner = ppo.PPOLearner(envs if ngrp > 1 else env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"],
                              critic_layers=nc["critic_layer_sizes"], latents=nc["intention_size"], learning_rate=tc["learning_rate"],
                              entropy_cost=tc["entropy_cost"], discounting=tc["discounting"], unroll_length=tc["unroll_length"],
-                             batch_size=tc["batch_size"] * world * n_local // ENVS_PER_GPU, num_minibatches=tc["num_minibatches"],
+                             batch_size=bc["rows_per_gpu"] * world * n_local // bc["envs_per_gpu"], num_minibatches=tc["num_minibatches"],
                              num_updates_per_batch=tc["num_updates_per_batch"], normalize_observations=True, kl_weight=nc["kl_weight"],
                              seed=0, matmul_dtype=torch.bfloat16 if bc["matmul_dtype"] == "bf16" else None)
     # deterministic synthetic reset inputs: clip = env % 64, start_frame = env % 44; cfg5: clip ~ U{0..1023}
@@ -308,7 +349,10 @@ def main(argv=None, runner=None):
         achieved = ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
         k2_achieved = K2_ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
         pmc, sq, flc, mf = prof("pmc_traffic.json"), prof("sq_counters.json"), prof("oracle_flop_count.json"), prof("mfma_counters.json")
-        traffic = pmc.get("hbm_bytes_per_launch") * per_launch / pmc.get("envs_per_launch", ENVS_PER_GPU) if pmc else None
+        # counter bytes per launch, scaled to this launch's env count: K2 alone, and all kernels of one env.step (K2 + record transposes + K3)
+        pscale = per_launch / pmc.get("envs_per_launch", ENVS_PER_GPU) if pmc else None
+        k2_traffic = pmc.get("hbm_bytes_per_launch") * pscale if pmc else None
+        step_traffic = pmc.get("hbm_bytes_per_launch_all_step_kernels") * pscale if pmc and pmc.get("hbm_bytes_per_launch_all_step_kernels") else None
         rate_rollout = rollout_only if rollout_only else env_steps / elapsed / world
         flops_env_step = flc["flops_per_env_step"] if flc else None
         # MLP GEMM flops of one minibatch step: forward + d input + d weight = 3 x 2 x rows x weights (policy and value), plus the
@@ -329,6 +373,8 @@ def main(argv=None, runner=None):
             "config": {"workload": f"rodent tracking PPO training step ({args.config}): {n_local} envs/GPU, {learner.env_steps_per_training_step // (n_local * learner.T * world)}x{learner.T}-step unrolls (10 physics substeps each) + {sgd_steps} minibatch updates, {bc['label']}",
                        "n_clips": bc["n_clips"], "mlp_gemm_inputs": bc["matmul_dtype"] or "f32",
                        "envs_per_gpu": n_local, "global_batch": learner.local_batch * world, "unroll_length": learner.T,
+                       "minibatch_gemm_rows": learner.local_batch * learner.T, "collectives": bool(learner.collectives),
+                       "weak_scaling_rule": f"{bc['rows_per_gpu']} minibatch rows and {bc['envs_per_gpu']} envs per GPU at any N (global batch_size = {bc['rows_per_gpu']} x N)",
                        "env_steps_per_step": learner.env_steps_per_training_step, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                        **({"rehearsal": "all ranks on cuda:0 with gloo collectives (TMJX_REHEARSE_ON_ONE_GPU): plumbing check, NOT a measurement"} if rehearse else {}),
                        "policy_params": learner.n_params(), "envs_per_physics_launch": per_launch, "concurrent_physics_launches": ngrp,
@@ -338,7 +384,10 @@ def main(argv=None, runner=None):
             # 15 644 algorithmic bytes per env-step (K2 + K3 together) x the envs of one physics launch / that
             # launch's average duration (HIP events on its launch stream; the env groups' launches share the GPU)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
+                         # like with like: `achieved` prices K2 + K3's 15 644 algorithmic bytes, so `traffic` is the counter bytes of ALL kernels of
+                         # one env.step (K2, the two record transposes, K3's three launches); K2's own pair sits under "k2_only"
+                         "traffic": step_traffic,
+                         "traffic_over_algorithmic": (step_traffic / (ALGO_BYTES_PER_ENV_STEP * per_launch)) if step_traffic else None,
                          "traffic_build_id": pmc.get("so_build_id") if pmc else None,
                          "traffic_build_is_this_runs": bool(pmc and pmc.get("so_build_id") == so_build_id()),
                          "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (FETCH_SIZE doubled, the gfx950 correction), NOT collected by this run; bytes per launch scaled to this launch's env count",
@@ -349,7 +398,9 @@ def main(argv=None, runner=None):
                          "frac_of_the_concurrent_launches_together": achieved * ngrp / HBM_PEAK_GBS,     # the launches share the GPU: per launch the figure above FALLS when a third group is added although the chip does more
                          "avg_launch_ms_isolated": isolated_ms,
                          "frac_isolated": (ALGO_BYTES_PER_ENV_STEP * sizes[0] / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if isolated_ms else None,
-                         "k2_only": {"algorithmic_bytes_per_env_step": K2_ALGO_BYTES_PER_ENV_STEP, "achieved": k2_achieved, "frac": k2_achieved / HBM_PEAK_GBS},
+                         "k2_only": {"algorithmic_bytes_per_env_step": K2_ALGO_BYTES_PER_ENV_STEP, "algorithmic_bytes_per_launch": K2_ALGO_BYTES_PER_ENV_STEP * per_launch,
+                                     "achieved": k2_achieved, "frac": k2_achieved / HBM_PEAK_GBS, "traffic": k2_traffic,
+                                     "traffic_over_algorithmic": (k2_traffic / (K2_ALGO_BYTES_PER_ENV_STEP * per_launch)) if k2_traffic else None},
                          "chip_level_frac_at_rollout_only_rate": ALGO_BYTES_PER_ENV_STEP * rate_rollout / 1e9 / HBM_PEAK_GBS,
                          "chip_level_frac_at_training_rate": ALGO_BYTES_PER_ENV_STEP * (env_steps / elapsed / world) / 1e9 / HBM_PEAK_GBS},
             # what actually binds K2: the vector ALU / latency (about 660 flop per algorithmic byte).  Numerator: the instrumented operation
@@ -377,25 +428,38 @@ def main(argv=None, runner=None):
         printed = []
 
         def emit(*_sig):
-            if not printed:
-                printed.append(1)
-                if _sig:
-                    out["config"]["extras_cut_short_by_signal"] = int(_sig[0])
-                print(json.dumps(out), flush=True)
+            # (SIGTERM / SIGINT are blocked while the line is written: a signal that lands inside print() must not skip the flush)
             if _sig:
-                os._exit(0)
+                for p in list(_CHILDREN):            # a child bench still on the GPU: end its whole process group first
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)
+                    except Exception:  # noqa: BLE001
+                        pass
+            old = signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGINT})
+            try:
+                if not printed:
+                    if _sig:
+                        out["config"]["extras_cut_short_by_signal"] = int(_sig[0])
+                    print(json.dumps(out), flush=True)
+                    printed.append(1)
+            finally:
+                if _sig:
+                    os._exit(128 + int(_sig[0]))     # cut short: the headline line is out, the exit code says the run did not finish
+                signal.pthread_sigmask(signal.SIG_SETMASK, old)
         for _s in (signal.SIGTERM, signal.SIGINT):
             signal.signal(_s, emit)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # same action regime as the roll-out-only leg (0.3 * N(0,1)); the full-scale regime of BASELINE config 1 beside it
-                out["cpu_baseline"] = cpu_baseline(env._blob, env._reference_clips, 12.0, 0.3)
-                out["cpu_baseline"]["full_scale_actions"] = cpu_baseline(env._blob, env._reference_clips, 6.0, 1.0)
+                # N_env = 4096 on every host core (the headline `value`) and N_env = 1 on one thread
+                out["cpu_baseline"] = cpu_baseline(env._blob, env._reference_clips, 10.0, 0.3, n_envs=ENVS_PER_GPU)
+                out["cpu_baseline"]["n_env_1"] = cpu_baseline(env._blob, env._reference_clips, 4.0, 0.3, n_envs=1)
+                out["cpu_baseline"]["full_scale_actions"] = cpu_baseline(env._blob, env._reference_clips, 4.0, 1.0)
                 out["cpu_baseline"]["mjx_cpu"] = out["mjx_cpu"]
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        # BASELINE configs[3] / configs[4] beside the headline line (driver-visible: the default run is the only one the driver makes): each as a
-        # CHILD process of this script after the timed region (own process: its failure or time-out cannot touch the headline), 2 timed steps
+        # BASELINE configs[2] (one rank's share) / configs[3] / configs[4] beside the headline line (driver-visible: the default run is the only one the driver makes): each as a
+        # CHILD process of this script after the timed region (own process: its failure or time-out cannot touch the headline), 5 timed steps
         if world == 1 and args.config == "cfg2" and not args.no_other_configs and not args.no_cpu_baseline:
             out["config"]["other_configs"] = other_configs()
         emit()

@@ -104,6 +104,15 @@ int tmjx_forward(tmjx_model *m, float *state, float *workspace, int n_env, void 
 int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward,
                     float *done, float *truncation, float *metrics, float *workspace, int n_env, void *stream);
 
+/* compute_tracking_rewards as the reference calls it (task/reward.py:359-366; call site task/single_clip_tracking.py:239-246): the
+ * reward / termination part of K3 with the CALLER's gathered reference frame per env instead of the handle's own gather from the resident
+ * clip table.  frame_* are device pointers, row-major per env: position [n][3], quaternion [n][4], joints [n][nq-7], body_positions
+ * [n][nbody-1][3], angular_velocity [n][3] (ReferenceClip leaves of one frame, track_mjx/io/load.py:16-38).  Everything else as
+ * tmjx_reward_obs with workspace = NULL (the observation's trajectory part still reads the resident table). */
+int tmjx_reward_frame(tmjx_model *m, float *state, int32_t *istate, const float *action, const float *frame_pos,
+                      const float *frame_quat, const float *frame_joints, const float *frame_bodypos, const float *frame_angvel,
+                      float *obs, float *reward, float *done, float *truncation, float *metrics, int n_env, void *stream);
+
 /* GAE reverse scan: compute_gae (track_mjx/agent/mlp_ppo/losses.py:39-100). All arrays [T][B] row-major
  * (B contiguous), bootstrap [B]; outputs vs, advantages [T][B]. */
 int tmjx_gae(const float *truncation, const float *termination, const float *rewards, const float *values,

@@ -1,7 +1,7 @@
 #include <cstdlib>
 // tests/hostemu/hostemu.cpp — TEST-ONLY host emulation of the HIP kernel bodies.
 //
-// Compiles the very same per-env device functions (csrc/physics_core.h, csrc/env_core.h) with g++ and
+// Compiles the very same per-env device functions (tests/lane/physics_core.h, csrc/env_core.h) with g++ and
 // runs them lane-by-lane on host memory, so that the kernel source can be unit-tested against the
 // oracle in the GPU-less build container.  It is NOT a fallback: nothing in track_mjx_amd/ loads
 // this library and the product path fails loudly without libtmjx_hip.so.
@@ -14,7 +14,7 @@
 #include <string>
 
 #include "../../track_mjx_amd/csrc/env_core.h"
-#include "../../track_mjx_amd/csrc/physics_core.h"
+#include "../lane/physics_core.h"
 #include "../../track_mjx_amd/csrc/model_host.h"
 #include "../../track_mjx_amd/csrc/wave_physics.h"
 #include <algorithm>

@@ -1,4 +1,4 @@
-// csrc/physics_core.h — lane-per-env formulation of K2 (one full `mjx.step` per lane, everything through global memory): the first
+// tests/lane/physics_core.h — TEST INFRASTRUCTURE (lives under tests/, never compiled into the product library): lane-per-env formulation of K2 (one full `mjx.step` per lane, everything through global memory): the first
 // HIP implementation, kept as an independent cross-check of the wave-per-env product kernel (wave_physics.h).  NOT part of the
 // product library: compiled only with -DTMJX_LANE_IMPL (tests/lane/libtmjx_hip_lane.so) and by the host emulation.
 //
@@ -13,7 +13,7 @@
 //   * every per-env array is a row of an env-minor buffer: lane == env, all accesses coalesced.
 // This file holds the device functions only; launch code is in tmjx_hip.hip.
 #pragma once
-#include "tm_common.h"
+#include "../../track_mjx_amd/csrc/tm_common.h"
 
 // ------------------------------------------------------------------------------------------ fwd_position
 // smooth.kinematics + smooth.com_pos (subtree COM of the single moving tree, cinert, cdof)

@@ -62,7 +62,7 @@ def test_chain_layout_fits_twelve_envs_per_cu():
     assert chain * 4 <= 10 * 1280 and generic * 4 <= 20 * 1024 + 2048
 
 
-def test_physics_kernel_resources_allow_ten_envs_per_cu(tmp_path):
+def test_physics_kernel_resources_allow_three_waves_per_simd(tmp_path):
     """The rodent physics kernel in the built library must keep <= 168 VGPRs (three waves per SIMD: 3 x 168 <= 512) and no scratch:
     172 registers once silently cut the pipelined roll-out back to 8 envs per CU.  Read from the code object's metadata."""
     import shutil, subprocess

@@ -122,7 +122,7 @@ def _learner_worker(rank, world, port, q, groups=1, single_bucket=False):
     os.environ["TMJX_BUCKET_OVERLAP"] = "0" if single_bucket else "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ln = _make_learner(4 * world, groups)         # global batch_size; every rank takes batch_size / world rows of each minibatch
-    assert ln.world == 2 and ln.local_batch == 4 and ln.unrolls == 2 and ln.n_local == _NLOC and len(ln.envs) == groups
+    assert ln.world == world and ln.local_batch == 4 and ln.unrolls == 2 and ln.n_local == _NLOC and len(ln.envs) == groups
     # C1 runs as TWO buckets (value network | policy) unless switched off: the split sits where the value network's parameters begin
     assert ln.overlap_c1 == (not single_bucket) and 0 < ln._bucket_split < ln.grads.flat.numel()
     assert ln._bucket_split == sum((r * pc + 3) // 4 * 4 for _, r, _, pc in ln.grads.segs[:ln._n_policy_params])
@@ -140,29 +140,32 @@ def _learner_worker(rank, world, port, q, groups=1, single_bucket=False):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("groups", [1, 2, 3])
-def test_two_rank_learner_update_matches_manual_gradient_average(groups):
-    """groups = 2 / 3: two ranks x two / three env groups per rank (the layout of the 8-GPU bench: three groups on every rank, of unequal size when the
+@pytest.mark.parametrize("world,groups", [(2, 1), (2, 2), (2, 3), (8, 1), (8, 3)])
+def test_learner_update_over_gloo_ranks_matches_manual_gradient_average(world, groups):
+    """groups = 2 / 3: `world` ranks x two / three env groups per rank (the layout of the 8-GPU bench: three groups on every rank, of unequal size when the
     env count does not divide) — the roll-out buffer rows
-    of a rank are its groups' slices side by side, the update must not depend on how the rank's envs are grouped."""
+    of a rank are its groups' slices side by side, the update must not depend on how the rank's envs are grouped.
+    world = 8: BASELINE configs[2]'s rank count (32 768 envs on 8 GPUs; reference: one pmap over 8 local devices, ppo.py:409,477-480,621-623) —
+    every rank takes batch_size / 8 rows of each minibatch, C1 averages eight gradients, C2 sums eight shards' statistics."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + 37 * groups
-    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q, groups)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + 37 * groups + 101 * world
+    procs = [ctx.Process(target=_learner_worker, args=(r, world, port, q, groups)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict()
-    for _ in range(2):
-        r = q.get(timeout=180)
+    for _ in range(world):
+        r = q.get(timeout=300)
         got[r[0]] = r[1:]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     # replicas stay identical (the reference asserts this: ppo.py:805 pmap.assert_is_replicated)
-    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]) and got[0][3] == got[1][3] == 2 * _T * 2 * _NLOC
-    # one process: a learner per shard (same init), normaliser over both shards' observations, gradients averaged by hand
-    L = [_make_learner(4) for _ in range(2)]
-    data = [_shard_data(r) for r in range(2)]
+    for r in range(1, world):
+        assert np.array_equal(got[0][0], got[r][0]) and np.array_equal(got[0][1], got[r][1]) and got[0][3] == got[r][3] == world * _T * 2 * _NLOC
+    # one process: a learner per shard (same init), normaliser over all shards' observations, gradients averaged by hand
+    L = [_make_learner(4) for _ in range(world)]
+    data = [_shard_data(r) for r in range(world)]
     for r, (ln, d) in enumerate(zip(L, data)):
         for k, v in d.items():
             ln.buf[k].copy_(v)
@@ -174,13 +177,13 @@ def test_two_rank_learner_update_matches_manual_gradient_average(groups):
     np.testing.assert_allclose(got[0][2], L[0].normalizer.std.numpy(), rtol=1e-5, atol=1e-6)
     rows = 2 * _NLOC
     for upd in range(2):
-        perms = [_perm(r)(upd, rows) for r in range(2)]
+        perms = [_perm(r)(upd, rows) for r in range(world)]
         for mb in range(2):
             flats = []
             for r, ln in enumerate(L):
                 ln._minibatch_grads(perms[r][mb * 4:(mb + 1) * 4], ln.kl_weight)
                 flats.append(ln.grads.flat.clone())
-            mean = (flats[0] + flats[1]) / 2
+            mean = torch.stack(flats, 0).sum(0) / world
             for ln in L:
                 ln.grads.flat.copy_(mean)
                 ln.opt.step()

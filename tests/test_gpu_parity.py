@@ -39,14 +39,14 @@ def _init_states(cl, n, rng, sink=0.0):
 
 def test_product_handle_launches_the_static_rodent_kernel():
     """The rodent model must take the compile-time specialisation of the physics kernel (register-resident chain kernels, lean LDS map:
-    11 envs per CU).  model_host.h falls back to the generic kernel when the loaded model does not match its compile-time tables — silently,
+    at most 10 LDS granules of 1280 bytes = 12 envs per CU).  model_host.h falls back to the generic kernel when the loaded model does not match its compile-time tables — silently,
     and every parity test still passes on that path at 0.4 x the speed (it happened once, through an over-strict host check)."""
     import ctypes as C
     env, _, _ = make_env_and_oracle(num_envs=8, wrappers=True)
     r0, cnt = C.c_int32(), C.c_int32()
     assert env._L.tmjx_debug_rows(env._handle, b"k2_kernel", C.byref(r0), C.byref(cnt)) == 0
     assert r0.value == 1, "the rodent handle fell back to the generic physics kernel"
-    assert cnt.value <= 11 * 1280, cnt.value
+    assert cnt.value <= 10 * 1280, cnt.value
 
 
 @pytest.mark.gpu
@@ -93,7 +93,7 @@ def test_forward_intermediates():
 @pytest.mark.parametrize("variant", ["product", "generic-tree", "lane-per-env"])
 def test_substep_teacher_forced(variant, monkeypatch):
     """product: the static rodent kernel (register-resident chain path); generic-tree: TMJX_WAVE_DYNAMIC=1, the run-time-layout
-    wave kernel any other model gets (LDS-resident sparse factorisation); lane-per-env: TMJX_IMPL=lane (csrc/physics_core.h)."""
+    wave kernel any other model gets (LDS-resident sparse factorisation); lane-per-env: TMJX_IMPL=lane (tests/lane/physics_core.h)."""
     if variant == "generic-tree":
         monkeypatch.setenv("TMJX_WAVE_DYNAMIC", "1")
     elif variant == "lane-per-env":
@@ -376,6 +376,47 @@ def test_train_entrypoint_smoke():
                  "train_setup.train_config.num_timesteps=100000", "train_setup.eval_every=50000", "train_setup.reset_every=50000",
                  "max_training_steps=2", "n_synthetic_clips=4"]
     train.main(overrides)
+
+
+@pytest.mark.gpu
+def test_train_calls_policy_params_fn_after_every_eval(tmp_path):
+    """ppo.train(..., policy_params_fn=f, checkpoint_callback=c): f is called by process 0 after each eval epoch with the keyword arguments of
+    track_mjx/agent/mlp_ppo/ppo.py:762-781 (current_step, jit_logging_inference_fn, params, policy_params_fn_key, render_video by
+    env_config.render_interval), the logging policy evaluates the PASSED params deterministically (ppo_networks.py:103-149), and the
+    checkpoint callback follows every saved step (ppo.py:713-715,787-795)."""
+    import torch
+    from track_mjx_amd import config as _config
+    from track_mjx_amd.agent import ppo
+    from track_mjx_amd.train import build_env
+    cfg = _config.default_config()
+    cfg["env_config"]["render_interval"] = 2
+    dev = torch.device("cuda:0")
+    env = build_env(cfg, 64, dev, n_clips=4)
+    calls, saved = [], []
+
+    def f(**kw):
+        assert set(kw) == {"current_step", "jit_logging_inference_fn", "params", "policy_params_fn_key", "render_video"}
+        obs = torch.randn((5, env.observation_size), generator=torch.Generator().manual_seed(kw["current_step"]))
+        act, extra = kw["jit_logging_inference_fn"](kw["params"], obs, kw["policy_params_fn_key"])
+        act2, _ = kw["jit_logging_inference_fn"](kw["params"], obs, None)
+        assert act.shape == (5, 38) and torch.equal(act, act2) and (act.abs() <= 1).all()            # deterministic: the mode, tanh-squashed
+        assert extra["latent_mean"].shape == (5, 60) and extra["latent_logvar"].shape == (5, 60)
+        calls.append((kw["current_step"], kw["render_video"], kw["policy_params_fn_key"], act.cpu(), {k: v.clone() for k, v in kw["params"][1].items()}))
+
+    mk, params, metrics = ppo.train(env, num_timesteps=3 * 64 * 4 * 5, episode_length=195, config_dict=cfg, num_evals=4, unroll_length=5, batch_size=64,
+                                    num_minibatches=4, num_updates_per_batch=1, normalize_observations=True, encoder_hidden_layer_sizes=(64,),
+                                    decoder_hidden_layer_sizes=(64,), value_hidden_layer_sizes=(64,), learning_rate=1e-3, seed=1,
+                                    policy_params_fn=f, checkpoint_callback=saved.append, checkpoint_path=str(tmp_path / "ck"))
+    assert [c[0] for c in calls] == [1, 2, 3] and [c[1] for c in calls] == [False, True, False]
+    assert len({c[2] for c in calls}) == 3, "a fresh key per call"
+    assert saved == [0, 1, 2, 3]
+    # the params handed over are those of THAT eval: they change between calls and the last ones are what train() returns
+    w1, w3 = calls[0][4], calls[2][4]
+    assert any(not torch.equal(w1[k], w3[k]) for k in w1) and all(torch.equal(w3[k], params[1][k]) for k in w3)
+    # the same observations through the first call's params give the first call's actions again, whatever the learner holds now
+    obs = torch.randn((5, env.observation_size), generator=torch.Generator().manual_seed(1))
+    pol = mk(params=None, deterministic=True)
+    assert pol(obs.to(dev))[0].shape == (5, 38)
 
 
 @pytest.mark.gpu

@@ -314,6 +314,71 @@ def test_compute_tracking_rewards_entry_is_side_effect_free():
     assert torch.allclose(terms[6], ref_ctrl, rtol=1e-5, atol=1e-7)
 
 
+def test_compute_tracking_rewards_uses_the_reference_frame_the_caller_passes():
+    """The reference's own call: compute_tracking_rewards(data, reference_frame, walker, action, info, reward_config) with the frame gathered by
+    the caller (reward.py:359-366; single_clip_tracking.py:223-225,239-246).  The 24 golden cases (tests/golden/task_golden.npz) go through
+    an env whose RESIDENT clip table is a different one (seed 999): only if the kernel really takes the passed frame (C-ABI
+    tmjx_reward_frame) do the terms equal the golden ones; with None the same env computes different terms from its own table.  On an
+    env that holds the golden table the two paths agree bit for bit."""
+    from track_mjx_amd import clips as _clips
+    from track_mjx_amd.environment import MultiClipTracking, RewardConfig, compute_tracking_rewards, wrap
+    from track_mjx_amd.environment.reward import _NEGATED, _ROW, TERMS
+    G = np.load(Path(__file__).parent / "golden" / "task_golden.npz")
+    n = G["in_qpos"].shape[0]
+    w, cfg = default_walker()
+    golden_table = _clips.make_synthetic_clips(w.model, 3, seed=123)          # the table make_golden.py used
+    other_table = _clips.make_synthetic_clips(w.model, 3, seed=999)
+    assert not np.array_equal(golden_table.joints, other_table.joints)
+
+    def loaded_env(table):
+        env = wrap(MultiClipTracking(table, w, RewardConfig(**cfg["env_config"]["reward_weights"]), **cfg["env_config"]["env_args"],
+                                     **cfg["reference_config"], num_envs=n, device=DEV), episode_length=195)
+        L = env.layout
+        st = env.reset(0, torch.from_numpy(G["in_clip_idx"].astype(np.int32)), start_frame=torch.from_numpy(G["in_start_frame"].astype(np.int32)),
+                       qpos_noise=torch.zeros((74, n)), qvel_noise=torch.zeros((73, n)))
+        for k in ("qpos", "qvel", "xpos", "qfrc_actuator", "xmat_torso"):
+            env.rows(k).copy_(torch.from_numpy(np.ascontiguousarray(G["in_" + k].T)))
+        env.rows("time").copy_(torch.from_numpy(G["in_time"][None]))
+        env.state_buf[L.action_buffer:L.action_buffer + 1900].copy_(torch.from_numpy(np.ascontiguousarray(G["in_action_buffer"].T)))
+        env.istate_buf[L.i_buffer_index].copy_(torch.from_numpy(G["in_buffer_index"].astype(np.int32)))
+        return env, st
+    env, st = loaded_env(other_table)
+    # the caller's gather, as the reference does it: clip = clips[info["clip_idx"]], frame = tree_map(lambda x: x[cur_frame], clip)
+    frames = np.clip(env._get_cur_frame().cpu().numpy(), 0, golden_table.position.shape[1] - 1)
+    ci = G["in_clip_idx"].astype(np.int64)
+    frame = {k: torch.from_numpy(np.ascontiguousarray(getattr(golden_table, k)[ci, frames])) for k in ("position", "quaternion", "joints", "body_positions", "angular_velocity")}
+    assert frame["body_positions"].shape == (n, 67, 3)
+    action = torch.from_numpy(G["in_action"]).to(DEV)
+    before = (env.state_buf.clone(), env.istate_buf.clone(), env.obs_buf.clone())
+    terms = compute_tracking_rewards(st.pipeline_state, frame, env.walker, action, st.info, env._reward_config)
+    own = compute_tracking_rewards(st.pipeline_state, None, env.walker, action, st.info, env._reward_config)
+    torch.cuda.synchronize()
+    assert torch.equal(before[0], env.state_buf) and torch.equal(before[1], env.istate_buf) and torch.equal(before[2], env.obs_buf)
+    for i, k in enumerate(TERMS):
+        want = G["out_metrics"][:, _ROW[k]] * (-1.0 if k in _NEGATED else 1.0)
+        np.testing.assert_allclose(terms[i].cpu().numpy(), want, rtol=2e-5, atol=2e-6, err_msg=k)
+    for k in ("pos_reward", "joint_reward", "bodypos_reward", "endeff_reward", "joint_distance"):
+        i = TERMS.index(k)
+        assert not torch.allclose(own[i], terms[i], rtol=1e-3, atol=1e-6), f"{k}: the resident (different) table must give different terms"
+    # the frame object form (attribute access, as a ReferenceClip) and a wrong shape
+    class F:
+        pass
+    fo = F()
+    for k, v in frame.items():
+        setattr(fo, k, v.numpy())
+    terms2 = compute_tracking_rewards(st.pipeline_state, fo, env.walker, action, st.info, env._reward_config)
+    assert all(torch.equal(a, b) for a, b in zip(terms, terms2))
+    with pytest.raises(ValueError):
+        compute_tracking_rewards(st.pipeline_state, {**frame, "joints": frame["joints"][:, :60]}, env.walker, action, st.info, env._reward_config)
+    # golden table resident: the kernel's own gather (split K3 kernels) and the passed frame (inline form) agree bit for bit
+    env2, st2 = loaded_env(golden_table)
+    t_own = compute_tracking_rewards(st2.pipeline_state, None, env2.walker, action, st2.info, env2._reward_config)
+    t_fr = compute_tracking_rewards(st2.pipeline_state, frame, env2.walker, action, st2.info, env2._reward_config)
+    torch.cuda.synchronize()
+    for k, a, b in zip(TERMS, t_own, t_fr):
+        assert torch.equal(a, b), k
+
+
 def test_same_seed_rng_mode_rollout_noise_and_shuffles():
     """shuffle_rng = act_rng = "jax": the roll-out's latent / action noise and the minibatch permutations are the reference's own draws
     from the seed (jax_random.SgdKeys) — the raw actions stored in the roll-out buffer are loc + scale * that noise, the shuffles are

@@ -29,6 +29,20 @@ def _learner(seed_env):
     return L
 
 
+def _learner_cfg3_rank_share():
+    """One rank's share of BASELINE configs[2] (32 768 envs on 8 GPUs, the reference's batch_size 2048): 4096 envs in the bench's
+    three env groups, 2 x 256 nets, 256 minibatch rows (5 120-row GEMMs), ONE unroll of 20 steps + 4 x 16 minibatch updates per training step."""
+    from track_mjx_amd.agent import ppo
+    sizes = ppo.group_sizes(4096, 3)
+    envs = [make_env_and_oracle(num_envs=n, n_clips=4, wrappers=True, seed=0)[0] for n in sizes]
+    L = ppo.PPOLearner(envs, encoder_layers=(256, 256), decoder_layers=(256, 256), critic_layers=(256, 256), latents=60, unroll_length=20,
+                       batch_size=256, num_minibatches=16, num_updates_per_batch=4, seed=3, normalize_observations=True)
+    assert L.unrolls == 1 and L.local_batch == 256 and L.env_steps_per_training_step == 4096 * 20
+    for k, e in enumerate(envs):
+        L.states[k] = e.reset(torch.Generator().manual_seed(10 + k))
+    return L
+
+
 @pytest.mark.gpu
 def test_training_step_with_rccl_collectives_on_one_rank(monkeypatch):
     import torch.distributed as dist
@@ -74,6 +88,23 @@ def test_training_step_with_rccl_collectives_on_one_rank(monkeypatch):
         torch.cuda.synchronize()
         assert L1._graph is not None and L1._split_graphs is None
         assert (L1.opt.flat - want).abs().max().item() == 0.0
+        # BASELINE configs[2], one rank's share (`bench.py --config cfg3`): 64 gradient all-reduces per training step of 81 920 env-steps, each between two
+        # replays of the 5 120-row SGD graph — bit-identical to the same step without collectives
+        monkeypatch.delenv("TMJX_COLLECTIVES_ALWAYS")
+        monkeypatch.delenv("TMJX_BUCKET_OVERLAP")
+        P3 = _learner_cfg3_rank_share()
+        assert not P3.collectives
+        P3.training_step(0)
+        torch.cuda.synchronize()
+        want3 = P3.opt.flat.clone()
+        del P3
+        monkeypatch.setenv("TMJX_COLLECTIVES_ALWAYS", "1")
+        L3 = _learner_cfg3_rank_share()
+        assert L3.collectives and not L3.overlap_c1          # (2.49 MB of gradients and one rank: the single bucket)
+        m3 = L3.training_step(0)
+        torch.cuda.synchronize()
+        assert L3._graph is not None and all(bool(torch.isfinite(v).all()) for v in m3.values())
+        assert (L3.opt.flat - want3).abs().max().item() == 0.0
     finally:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,4 +1,4 @@
-"""CPU: the HIP kernel bodies (csrc/physics_core.h, csrc/env_core.h) compiled for the host by the TEST-ONLY emulation
+"""CPU: the HIP kernel bodies (tests/lane/physics_core.h, csrc/env_core.h) compiled for the host by the TEST-ONLY emulation
 harness tests/hostemu/ and compared with the oracle.  This is how the kernel source is unit-tested in the GPU-less build
 container; the same checks run on the real GPU in test_gpu_parity.py.  Nothing in the product loads the emulation."""
 import sys
@@ -35,7 +35,7 @@ def _states(clip, n, rng, sink):
 
 @pytest.mark.parametrize("impl", ["lane", "wave"])
 def test_forward_intermediates_sparse_vs_dense(setup, impl):
-    """impl = lane: csrc/physics_core.h (lane-per-env reference kernel body); impl = wave: csrc/wave_physics.h (the product
+    """impl = lane: tests/lane/physics_core.h (lane-per-env reference kernel body); impl = wave: csrc/wave_physics.h (the product
     kernel: 64 emulated lanes + an LDS image per env)."""
     w, blob, clip = setup
     n = 8

@@ -77,6 +77,25 @@ def test_self_launched_two_ranks_really_run_and_rank0_line_comes_back():
     assert "[launch] 2 ranks" in res.stderr
 
 
+def test_self_launched_eight_ranks_of_the_cfg3_bench_line():
+    """`python bench.py --gpus 8 --config cfg3 --dry-run-ranks`: BASELINE configs[2]'s launch — EIGHT real ranks through the self-launch path
+    (the driver's own command line, track_mjx_amd/launch.py), a gloo all-reduce over all of them, and the batch arithmetic the ranks would hand
+    the learner: 32 768 envs, the reference's batch_size 2048 = 256 minibatch rows per GPU, one unroll per training step
+    (track_mjx/agent/mlp_ppo/ppo.py:237-239,477-480)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--config", "cfg3", "--steps", "2", "--warmup", "1", "--dry-run-ranks"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == 8 and out["asked_gpus"] == 8 and c["ranks_seen"] == 8 and c["parallelism"] == "dp8"
+    assert c["envs_total"] == 32768 and c["global_batch"] == 2048 and c["minibatch_rows_per_gpu"] == 256 and c["unrolls_per_training_step"] == 1
+    assert "[launch] 8 ranks" in res.stderr
+
+
 def test_env_group_sizes_for_the_pipelined_rollout():
     """ppo.group_sizes / default_groups: every env in exactly one group, sizes multiples of 4 (but for a remainder), at most 4 apart; three groups
     by default (bench.py --pipeline 0, train.py rollout_groups)."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the learner's MFMA GEMM kernels (tmjx_gemm_nt / _nn / _dw) at the shapes of a PPO minibatch step, next to torch's library
-GEMMs on the same data (a yardstick for tuning, not the product path).  Run on the GPU box: python tools/gemm_bench.py [cfg2|cfg4]"""
+GEMMs on the same data (a yardstick for tuning, not the product path).  Run on the GPU box: python tools/gemm_bench.py [cfg2|cfg4] [rows]"""
 import sys
 import time
 from pathlib import Path
@@ -28,7 +28,8 @@ def timeit(fn, n=20):
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-    M = 20480
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 20480          # rows: 20 480 (cfg2 / cfg4), 5 120 (cfg3: one rank's share of batch_size 2048 on 8 GPUs)
+    print(f"M = {M}")
     if cfg == "cfg2":
         layers = [(256, 470, 696), (256, 256, 256), (120, 256, 256), (256, 286, 288), (256, 256, 256), (76, 256, 256), (256, 696, 696), (256, 256, 256), (1, 256, 256)]
     else:

@@ -30,7 +30,7 @@ def main():
     n = bc["envs_per_gpu"]
     env = wrap(build_env(cfg, n, dev, n_clips=min(bc["n_clips"], 64)), episode_length=195)
     L = ppo.PPOLearner(env, encoder_layers=nc["encoder_layer_sizes"], decoder_layers=nc["decoder_layer_sizes"], critic_layers=nc["critic_layer_sizes"],
-                       latents=nc["intention_size"], unroll_length=tc["unroll_length"], batch_size=tc["batch_size"] * n // 4096,
+                       latents=nc["intention_size"], unroll_length=tc["unroll_length"], batch_size=bc["rows_per_gpu"],
                        num_minibatches=tc["num_minibatches"], num_updates_per_batch=args.updates, kl_weight=nc["kl_weight"], seed=0,
                        matmul_dtype=torch.bfloat16 if bc["matmul_dtype"] == "bf16" else None, use_graph=args.graph)
     L.states[0] = env.reset(torch.Generator().manual_seed(0))

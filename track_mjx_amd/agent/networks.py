@@ -478,6 +478,8 @@ class _BfChainFn(torch.autograd.Function):
                     dz = torch.empty((M, N), dtype=torch.bfloat16, device=z.device)
                     g3 = torch.empty((3, N), dtype=torch.float32, device=z.device)
                     partial = torch.empty(int(Lh.tmjx_silu_ln_partial_floats(M, N)), dtype=torch.float32, device=z.device)
+                    # (the row kernel reads z as fp32; a FUSED ln block saves its z as bf16 — a chain that ends in one takes the upcast copy)
+                    z = z if z.dtype == torch.float32 else z.float()
                     _launch("tmjx_silu_ln_bwd_bf16", z.device, _p(gy), _p(z), _p(lin.bias), _p(L.norm.weight), _p(stats), _p(dz), N, _p(g3), _p(partial), M, N)
                     grads[id(L.norm.weight)], grads[id(L.norm.bias)], grads[id(lin.bias)] = g3[0], g3[1], g3[2]
                     g = dz

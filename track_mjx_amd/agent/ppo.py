@@ -261,7 +261,8 @@ class PPOLearner:
         # profiles/r04_bench_selflaunch_one_rank_bucketed.json), more than the 2.49 MB buffer of the 2x256 nets takes to reduce.  TMJX_BUCKET_OVERLAP=1 / 0 forces it
         big = self.grads.flat.numel() * self.grads.flat.element_size() >= 8 << 20
         force = os.environ.get("TMJX_BUCKET_OVERLAP")
-        self.overlap_c1 = self.collectives and (big if force is None else force == "1")
+        # (by default only with MORE than one rank: a one-rank group has nothing to overlap and pays the three-graph form's 0.15 ms)
+        self.overlap_c1 = self.collectives and ((big and self.world > 1) if force is None else force == "1")
         self.opt = FlatAdam(self.grads, learning_rate, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0)   # optax.clip_by_global_norm(10.0) -> adam
         self.normalizer = RunningStatistics(obs, dev)
         self.gen = torch.Generator(device=dev).manual_seed(seed * 1000 + 17 + self.rank)
@@ -788,6 +789,12 @@ class PPOLearner:
                 print(f"[track_mjx_amd] hipGraph capture of the SGD step failed ({type(e).__name__}: {e}); running eagerly", flush=True)
                 self.use_graph = use_graph = False
                 torch.cuda.synchronize(self.dev)
+                # a capture that died between the loss head (which parks the KL term's fc2 gradient) and the policy's backward pass leaves that
+                # gradient parked: drop it, or the first eager forward would raise "never consumed" instead of falling back
+                h = getattr(self.policy, "latent_grad_handle", None)
+                if h is not None:
+                    h.take()
+                    self.policy.latent_grad_handle = None
         acc = torch.zeros(len(self.METRIC_KEYS), dtype=torch.float32, device=self.dev)
         if selfadv:
             self._acc8.zero_()
@@ -852,7 +859,8 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
           intention_latent_size: int = 60, progress_fn: Callable[[int, dict], None] = lambda *a: None,
           max_training_steps: int | None = None, eval_env=None, num_eval_envs: int = 128, deterministic_eval: bool = False,
           matmul_dtype: torch.dtype | None = None, group=None, checkpoint_path: str | None = None, restore_from: str | None = None,
-          shuffle_rng: str = "torch", act_rng: str = "device", action_repeat: int = 1, **unused):
+          shuffle_rng: str = "torch", act_rng: str = "device", action_repeat: int = 1,
+          policy_params_fn: Callable[..., None] = lambda *args, **kwargs: None, checkpoint_callback: Callable[[int], None] | None = None, **unused):
     """ppo.train(environment, num_timesteps, episode_length, ...) -> (make_policy, params, metrics)  (ppo.py:128-172,809).
 
     `environment` is an un-wrapped MultiClipTracking holding THIS rank's envs; it is wrapped here exactly like
@@ -865,7 +873,13 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     path; orbax itself is not in this image.  `restore_from` = a step directory, a checkpoint directory (its latest step) or a .npz of
     save_npz: the whole training state comes back (checkpointing.load_training_state, ppo.py:561-567) — parameters, optimiser, env_steps,
     noise streams — and the run continues at the iteration after the restored one (the reference leaves its iteration restart as a TODO,
-    ppo.py:670-677, and would then collide with the existing steps of the same directory)."""
+    ppo.py:670-677, and would then collide with the existing steps of the same directory).
+
+    `policy_params_fn` (ppo.py:162,220-224): called by process 0 after every eval epoch exactly as ppo.py:762-781 does — keyword arguments
+    `current_step` (the eval iteration), `jit_logging_inference_fn` (the DETERMINISTIC logging policy of ppo_networks.py:103-149:
+    (params, observations, key_sample) -> (action, {"latent_mean", "latent_logvar"})), `params` ((normalizer, policy) state), a fresh
+    `policy_params_fn_key` per call, and `render_video` = `it % config_dict["env_config"]["render_interval"] == 0` (every call when the
+    config names no interval).  `checkpoint_callback(it)` follows every saved checkpoint (ppo.py:171,713-715; checkpointing.save)."""
     from ..environment import wrap
     # a list of environments = equal groups of this rank's envs whose roll-outs are pipelined on separate HIP streams (collect())
     env_list = [wrap(e, episode_length=int(episode_length), action_repeat=int(action_repeat)) for e in (environment if isinstance(environment, (list, tuple)) else [environment])]
@@ -888,7 +902,10 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     def save_checkpoint(it: int, env_steps: int):
         if checkpoint_path is None or learner.rank != 0:
             return None
-        return _ckpt.save_step_dir(checkpoint_path, it, learner, config=config_dict, env_steps=env_steps)
+        out = _ckpt.save_step_dir(checkpoint_path, it, learner, config=config_dict, env_steps=env_steps)
+        if checkpoint_callback is not None:
+            checkpoint_callback(it)
+        return out
     env_step_per_training_step = learner.env_steps_per_training_step * int(action_repeat)      # ppo.py:260-262
     num_evals_after_init = max(num_evals - 1, 1)
     steps_per_epoch = int(math.ceil(num_timesteps / (num_evals_after_init * env_step_per_training_step * max(num_resets_per_eval, 1))))
@@ -907,6 +924,28 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
         evaluator = Evaluator(wrap(eval_env, episode_length=int(episode_length), action_repeat=int(action_repeat)),
                               lambda obs: learner.act(obs, deterministic=deterministic_eval, gen=eval_gen), episode_length=int(episode_length),
                               action_repeat=int(action_repeat), seed=seed + 7)
+    render_interval = max(int(((config_dict or {}).get("env_config") or {}).get("render_interval", 1) or 1), 1)
+    ppf_calls = [0]
+
+    def current_policy_params():
+        return ({k: v.clone() for k, v in learner.normalizer.state_dict().items()}, {k: v.clone() for k, v in learner.policy.state_dict().items()})
+
+    @torch.no_grad()
+    def logging_inference_fn(params, observations, key_sample=None):
+        """make_logging_inference_fn(ppo_network)(deterministic=True) (ppo_networks.py:103-149, jitted at ppo.py:514-515): the mode of the action
+        distribution and the latent statistics, computed with `params` = (normalizer state, policy state) — functionally: the live
+        learner's networks are left as they were."""
+        import copy
+        norm_sd, pol_sd = params[0], params[1]
+        pol = copy.deepcopy(learner.policy)
+        pol.load_state_dict(pol_sd)
+        obs = torch.as_tensor(observations, dtype=torch.float32, device=learner.dev)
+        lead = obs.shape[:-1]
+        obs = obs.reshape(-1, obs.shape[-1])
+        if learner.normalize_observations:
+            obs = (obs - norm_sd["mean"].to(learner.dev)) / norm_sd["std"].to(learner.dev)
+        logits, mean, logvar = pol(obs, eps=torch.zeros((obs.shape[0], pol.latents), device=learner.dev), deterministic=True)
+        return (NormalTanh.mode(logits.float()).reshape(*lead, -1), {"latent_mean": mean.reshape(*lead, -1), "latent_logvar": logvar.reshape(*lead, -1)})
     metrics: dict = {}
     total_steps, done_steps = int(restored.get("env_steps") or 0), 0       # TrainingState.env_steps continues across a resume
     if restore_from is None:
@@ -936,6 +975,10 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
         if learner.rank == 0:
             if evaluator is not None:
                 metrics = evaluator.run_evaluation(metrics)
+            # ppo.py:759-781: the user's policy callback (rendering / logging in the reference's train.py:335-351) with the current parameters
+            ppf_calls[0] += 1
+            policy_params_fn(current_step=it, jit_logging_inference_fn=logging_inference_fn, params=current_policy_params(),
+                             policy_params_fn_key=(int(seed), ppf_calls[0]), render_video=(it % render_interval == 0))
             progress_fn(total_steps, metrics)
         save_checkpoint(it, total_steps)                  # ppo.py:787-795: after every eval epoch, process 0, step = the iteration
         if max_training_steps is not None and done_steps >= max_training_steps:

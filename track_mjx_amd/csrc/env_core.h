@@ -198,15 +198,23 @@ TM_DEV void tm_post_part(const DModel &m, EnvRef r, const int *r_is, int part, f
 // `win`: per-(dim, env) partials [2*nu][n] produced by the (env x action-dim)-parallel window kernel, or nullptr to
 // compute the window terms inline (lane-per-env path).
 // `split`: the observation was written by k_obs and the auto-reset copies are left to k_autoreset (tmjx_hip.hip).
+// `fo`: the CALLER's reference frame per env (row-major [n][3 | 4 | nq - 7 | (nbody - 1) * 3 | 3]) in place of the kernel's own gather from the
+// resident clip table — compute_tracking_rewards(data, reference_frame, ...) as the reference calls it (reward.py:359-366 with the frame of
+// single_clip_tracking.py:223-225); only the inline (lane-per-env) form takes it.
+struct TmFrame { const float *pos, *quat, *joints, *bodypos, *angvel; };
 TM_DEV void tm_step_post(const DModel &m, EnvRef r, int *r_is, const float *action, float *obs, float *reward, float *done_out,
                          float *trunc_out, float *metrics, const float *win = nullptr, bool split = false, const float *P = nullptr,
-                         int rep = TM_REP_ONE) {
+                         int rep = TM_REP_ONE, const TmFrame *fo = nullptr) {
   int nu = m.nu, W = m.window, nj = m.nq - 7, nbp = m.nbody - 1;
   int clip = IS(m.i_clip_idx), start = IS(m.i_start_frame), bi = IS(m.i_buffer_index);
   int frame = tm_cur_frame(m, ST(m.s_time, 0), start);
   size_t row = tm_clip_row(m, clip, frame);
   const float *rp = m.clip_pos + row * 3, *rq = m.clip_quat + row * 4, *rj = m.clip_joints + row * nj;
   const float *rb = m.clip_bodypos + row * (size_t)(nbp * 3), *rwv = m.clip_angvel + row * 3;
+  if (fo) {
+    const size_t e = (size_t)r.e;
+    rp = fo->pos + e * 3; rq = fo->quat + e * 4; rj = fo->joints + e * nj; rb = fo->bodypos + e * (size_t)(nbp * 3); rwv = fo->angvel + e * 3;
+  }
   const float *w = m.rw;
   // info updates precede the reward call
   float ctrl_sq = 0.f, ctrl_diff = 0.f;

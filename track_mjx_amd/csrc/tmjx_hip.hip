@@ -2,7 +2,7 @@
 //
 // The per-env bodies live in wave_physics.h (K2: one wavefront per env), env_core.h (K1 / K3: one lane per env or per (env, part), env
 // index = coalesced axis of every buffer, include/tmjx.h layout rules) and ppo_kernels.h (learner); this file launches them.
-// -DTMJX_LANE_IMPL additionally compiles the lane-per-env physics (physics_core.h; TMJX_IMPL=lane selects it): a second, independent
+// -DTMJX_LANE_IMPL additionally compiles the lane-per-env physics (tests/lane/physics_core.h; TMJX_IMPL=lane selects it): a second, independent
 // HIP implementation used by the tests as a cross-check — the product library is built without it.
 #include <hip/hip_runtime.h>
 
@@ -16,7 +16,7 @@
 #include "model_host.h"
 #include "wave_physics.h"
 #ifdef TMJX_LANE_IMPL
-#include "physics_core.h"
+#include "../../tests/lane/physics_core.h"
 #endif
 
 struct tmjx_model {
@@ -109,6 +109,16 @@ __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const 
   if (rep & TM_REP_FIRST) tm_step_prologue(m, r);
   // split: the long sums were computed by k_post_parts into the workspace rows behind the 2 nu window partials
   tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, win, split != 0, split ? win + (size_t)2 * m.nu * n : nullptr, rep);
+}
+// k_post's inline form with the CALLER's reference frame per env (tmjx_reward_frame; env_core.h: TmFrame)
+__global__ void k_post_frame(const DModel *__restrict__ mp, float *st, int *is, const float *action, float *obs, float *reward,
+                             float *done, float *trunc, float *metrics, TmFrame fo, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const DModel &m = *mp;
+  EnvRef r{st, nullptr, n, e};
+  tm_step_prologue(m, r);
+  tm_step_post(m, r, is, action, obs, reward, done, trunc, metrics, nullptr, false, nullptr, TM_REP_ONE, &fo);
 }
 // the long reductions of the reward / termination step, one lane per (env, part) (env_core.h: tm_post_part)
 __global__ void k_post_parts(const DModel *__restrict__ mp, float *st, const int *is, float *P, int n) {
@@ -540,6 +550,18 @@ int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *a
   else hipLaunchKernelGGL(k_post, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation,
                           metrics, (const float *)nullptr, 0, TM_REP_ONE, n_env);
   return check_launch("k_post");
+}
+
+int tmjx_reward_frame(tmjx_model *m, float *state, int32_t *istate, const float *action, const float *frame_pos, const float *frame_quat,
+                      const float *frame_joints, const float *frame_bodypos, const float *frame_angvel, float *obs, float *reward, float *done,
+                      float *truncation, float *metrics, int n_env, void *stream) {
+  if (!m || !state || !istate || !action || !obs || !reward || !done || !truncation || !metrics) return fail(TMJX_EINVAL, "null argument");
+  if (!frame_pos || !frame_quat || !frame_joints || !frame_bodypos || !frame_angvel) return fail(TMJX_EINVAL, "null reference-frame leaf");
+  if (n_env < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
+  if (!m->h.clip_pos) return fail(TMJX_EINVAL, "tmjx_clips_upload has not been called");      // (the observation's trajectory part still reads the table)
+  TmFrame fo{frame_pos, frame_quat, frame_joints, frame_bodypos, frame_angvel};
+  hipLaunchKernelGGL(k_post_frame, GRID(m, n_env), 0, (hipStream_t)stream, m->d, state, istate, action, obs, reward, done, truncation, metrics, fo, n_env);
+  return check_launch("k_post_frame");
 }
 
 int tmjx_gae(const float *truncation, const float *termination, const float *rewards, const float *values, const float *bootstrap,

@@ -12,7 +12,7 @@
 
 // K2, wave-per-env: one 64-lane workgroup per env, all per-substep state in LDS (csrc/wave_physics.h).
 // STATIC = true: the rodent's dims and LDS map are compile-time constants (wave_layout.h).
-// __launch_bounds__(64, 3): three waves per SIMD are what 11 envs per CU need, i.e. at most 168 VGPRs — as a bound the compiler
+// __launch_bounds__(64, 3): three waves per SIMD are what 12 envs per CU (10 LDS granules per env) need, i.e. at most 168 VGPRs — as a bound the compiler
 // keeps, not a number a later edit silently exceeds (168 -> 173 registers means two waves per SIMD; tests/test_abi.py pins it too).
 template <bool STATIC>
 __global__ __launch_bounds__(64, 3) void k_physics_wave(const DModel *__restrict__ mp, float *st, const float *action, int nsub,
