@@ -16,7 +16,9 @@ def _bound(a64, b64_t, K):
 
 
 @pytest.mark.parametrize("M,N,K,lda", [(20480, 256, 470, 696), (20480, 256, 256, 256), (20480, 120, 256, 256), (20480, 76, 256, 256), (20480, 1, 256, 256),
-                                       (20480, 512, 1024, 1024), (1000, 256, 286, 288), (37, 5, 7, 7), (81, 130, 33, 36), (1, 1, 1, 1)])
+                                       (20480, 512, 1024, 1024), (1000, 256, 286, 288), (37, 5, 7, 7), (81, 130, 33, 36), (1, 1, 1, 1),
+                                       # 5 120 rows = one rank's share of BASELINE configs[2] (batch_size 2048 / 8 GPUs x unroll_length 20): the 32-row tile (gemm_mt)
+                                       (5120, 256, 470, 696), (5120, 256, 256, 256), (5120, 120, 256, 256), (5120, 76, 256, 256), (5117, 256, 286, 288), (5120, 1, 256, 256)])
 def test_gemm_nt_forward(M, N, K, lda):
     from track_mjx_amd.agent.networks import gemm_nt
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
@@ -33,7 +35,8 @@ def test_gemm_nt_forward(M, N, K, lda):
 
 
 @pytest.mark.parametrize("M,N,K,cols", [(20480, 256, 256, None), (20480, 120, 256, None), (20480, 256, 286, 60), (20480, 1, 256, None), (20480, 76, 256, None),
-                                        (20480, 1024, 512, None), (53, 9, 21, None), (53, 9, 21, 5)])
+                                        (20480, 1024, 512, None), (53, 9, 21, None), (53, 9, 21, 5),
+                                        (5120, 256, 256, None), (5120, 120, 256, None), (5120, 256, 286, 60), (5120, 76, 256, None), (5117, 1, 256, None)])
 def test_gemm_nn_input_gradient(M, N, K, cols):
     from track_mjx_amd.agent.networks import gemm_nn
     g = torch.Generator(device=DEV).manual_seed(7 * M + N + K)
@@ -48,7 +51,8 @@ def test_gemm_nn_input_gradient(M, N, K, cols):
 
 @pytest.mark.parametrize("M,N,K,ldx,bias", [(20480, 256, 470, 696, True), (20480, 256, 256, 256, True), (20480, 120, 256, 256, True), (20480, 1, 256, 256, True),
                                             (20480, 256, 696, 696, True), (20480, 76, 256, 256, False), (40960, 512, 1024, 1024, True), (333, 76, 286, 288, True),
-                                            (31, 3, 5, 5, True), (20480, 256, 286, 288, True)])
+                                            (31, 3, 5, 5, True), (20480, 256, 286, 288, True),
+                                            (5120, 256, 470, 696, True), (5120, 256, 256, 256, True), (5120, 76, 256, 256, False), (5120, 256, 696, 696, True), (5117, 120, 256, 256, True)])
 def test_gemm_dw_weight_and_bias_gradient(M, N, K, ldx, bias):
     from track_mjx_amd.agent.networks import gemm_dw
     g = torch.Generator(device=DEV).manual_seed(3 * M + N + K)
@@ -121,7 +125,8 @@ def test_grouped_weight_gradients_match_individual_problems():
             assert ((b.grad.double() - dy.double().sum(0)).abs() <= dy.double().abs().sum(0) * EPS * (M ** 0.5 + 4) * 2).all()
 
 
-@pytest.mark.parametrize("M,N,K,lda", [(20480, 256, 470, 696), (20480, 256, 286, 288), (20480, 128, 256, 256), (1000, 64, 100, 100), (77, 256, 36, 36)])
+@pytest.mark.parametrize("M,N,K,lda", [(20480, 256, 470, 696), (20480, 256, 286, 288), (20480, 128, 256, 256), (1000, 64, 100, 100), (77, 256, 36, 36),
+                                       (5120, 256, 470, 696), (5120, 256, 286, 288), (5120, 128, 256, 256), (5117, 64, 256, 256)])
 def test_fused_dense_silu_layernorm_block(M, N, K, lda, monkeypatch):
     """tmjx_gemm_nt_silu_ln (the SiLU + LayerNorm epilogue on the GEMM tile) against the two-launch path (tmjx_gemm_nt + tmjx_silu_ln_fwd)
     and against float64 torch, forward and every gradient (reference block: intention_network.py:32-40 Dense -> silu -> LayerNorm)."""
@@ -162,7 +167,8 @@ def test_fused_dense_silu_layernorm_block(M, N, K, lda, monkeypatch):
         assert e_f <= max(3 * e_t, 2e-6), name
 
 
-@pytest.mark.parametrize("M,widths", [(20480, (470, 256, 256, 120)), (1000, (286, 256, 256, 76)), (163, (64, 256, 256, 256, 40))])
+@pytest.mark.parametrize("M,widths", [(20480, (470, 256, 256, 120)), (1000, (286, 256, 256, 76)), (163, (64, 256, 256, 256, 40)),
+                                      (5120, (470, 256, 256, 120)), (5117, (286, 256, 256, 76))])
 def test_layernorm_backward_fused_into_the_next_input_gradient(M, widths, monkeypatch):
     """tmjx_gemm_nn_ln_bwd: the LayerNorm + SiLU backward of a 256-wide block in the epilogue of its consumer's input-gradient GEMM (inside
     `ln_bwd_links()`), against the unfused chain (tmjx_gemm_nn + tmjx_silu_ln_bwd) and float64 torch: every parameter gradient and dx."""
@@ -260,7 +266,7 @@ def test_second_backward_through_a_retained_fused_chain():
         assert (a - b).abs().max() <= 2e-5 * (a.abs().max() + 1e-12), float((a - b).abs().max() / a.abs().max())
 
 
-@pytest.mark.parametrize("M,widths", [(20480, (696, 256, 256, 1)), (2048, (696, 512, 512, 256, 1)), (333, (40, 24, 8, 1))])
+@pytest.mark.parametrize("M,widths", [(20480, (696, 256, 256, 1)), (2048, (696, 512, 512, 256, 1)), (333, (40, 24, 8, 1)), (5120, (696, 256, 256, 1))])
 def test_value_net_silu_layers_without_torch_elementwise_kernels(M, widths):
     """brax value MLP (Dense -> SiLU ... Dense(1), track_mjx/agent/mlp_ppo/ppo_networks.py:180-184) on the GPU: forward one launch per hidden layer
     (tmjx_gemm_nt_silu), backward tmjx_silu_bwd + the MFMA input / weight gradient kernels; value and all gradients against float64 torch."""

@@ -223,35 +223,3 @@ def test_action_repeat_of_the_episode_wrapper(setup, R):
             print(f"action_repeat {R}: summed reward err {rew_err:.2e}, obs rel err {obs_err:.2e} against the float32 oracle")
             assert rew_err < 2e-5 * R and obs_err < 2e-4
     assert seen_trunc and seen_restart, (seen_trunc, seen_term, seen_restart)
-
-
-def test_mfma_matvec_experiment_build_matches_the_default(setup, tmp_path):
-    """csrc/wave_matvec.h (-DTMW_MFMA_MATVEC: the solver's tree-sparse mat-vecs as 16x16x4 matrix-instruction tiles; measured slower on the GPU and
-    off by default) must compute the same products: one forward pass of both builds of the kernel body, solver intermediates equal to rounding."""
-    import ctypes as C
-    import subprocess
-    import emu as _emu
-    w, blob, clip = setup
-    so = tmp_path / "libhostemu_mfma.so"
-    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DTMW_MFMA_MATVEC", "-o", str(so), str(Path(__file__).parent / "hostemu" / "hostemu.cpp")], check=True)
-
-    class EmuAt(Emu):
-        def __init__(self, blob, n):
-            orig = C.CDLL
-            try:
-                _emu.C.CDLL = lambda _p: orig(str(so))
-                super().__init__(blob, n)
-            finally:
-                _emu.C.CDLL = orig
-    n = 8
-    rng = np.random.default_rng(0)
-    qpos, qvel = _states(clip, n, rng, 0.012)
-    act = rng.uniform(-0.1, 0.1, size=(n, 38))
-    res = []
-    for E in (Emu(blob, n), EmuAt(blob, n)):
-        E.rows("qpos")[:] = qpos.T; E.rows("qvel")[:] = qvel.T; E.rows("act")[:] = act.T
-        E.physics_wave(None, 1, do_euler=False)
-        res.append({k: E.rows(k).copy() for k in ("qacc_smooth", "qacc", "efc_force")})
-    assert (res[0]["efc_force"] > 0).sum() > 0
-    for k in res[0]:
-        assert rel_err(res[1][k], res[0][k]) < (2e-5 if k == "qacc_smooth" else 5e-4), (k, rel_err(res[1][k], res[0][k]))

@@ -8,7 +8,7 @@ c = sqlite3.connect(sys.argv[1])
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 phys = [r for r in rows if "k_physics_wave" in r[0]]
-gaps = [(phys[i][2], phys[i + 1][1]) for i in range(len(phys) - 1) if phys[i + 1][1] - phys[i][2] > 30e6]
+gaps = [(phys[i][2], phys[i + 1][1]) for i in range(len(phys) - 1) if phys[i + 1][1] - phys[i][2] > 12e6]
 a, b = gaps[-1]
 win = [r for r in rows if r[1] >= a and r[2] <= b]
 adam = [i for i, r in enumerate(win) if "k_adam_clip" in r[0]]

@@ -594,8 +594,9 @@ def _dx_through_block(dy2, w, link):
     x2, wp, z, b, gamma, stats = link.ctx.saved_tensors
     M, H = z.shape
     dz = torch.empty_like(z)
-    nblk = (M + 79) // 80
-    partial = torch.empty(int(L.tmjx_gemm_nn_ln_bwd_partial_floats(M, H)), dtype=torch.float32, device=z.device)
+    nfl = int(L.tmjx_gemm_nn_ln_bwd_partial_floats(M, H))
+    nblk = nfl // (3 * H)          # one partial row per workgroup of the launch: 80- or 32-row tiles by M (csrc/tmjx_hip.hip: gemm_mt)
+    partial = torch.empty(nfl, dtype=torch.float32, device=z.device)
     grads = torch.empty((3, H), dtype=torch.float32, device=z.device)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     with torch.cuda.device(z.device):

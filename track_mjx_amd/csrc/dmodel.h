@@ -90,6 +90,11 @@ struct DModel {
   // per-dof packed words kept in LDS: [2i] = Madr | depth << 16 ; [2i+1] = chain_start | (jump + 1) << 8
   // (ancestors of dof i: i-1 .. chain_start, then jump, jump-1, .. 0 — checked on the host)
   int tdof[TM_MAXV * 2];
+  // lean (rodent chain) kernel: ONE packed word per dof, kept in two registers of the lane that owns dofs lane / lane + 64 (the table above took
+  // 146 words of LDS per env): Mend = Madr + depth (11 bits) | depth << 11 (6) | in-chain run i - chain_start << 17 (5) | (wrench subset + 1)
+  // << 22 (4); jump + 1 = depth - run, and the limit row of dof i is i - 6 (checked on the host: rodent_chains_match).  gpack[g] = last dof of paw
+  // group g (0xff: none) | its depth << 8 | its run << 16: what J v needs of the group's dof (one LDS word per group)
+  int tpack[TM_MAXV], gpack[TM_MAXG];
   int body_nsub[TM_MAXB];  // subtree size (bodies are numbered depth-first: subtree = [b, b + nsub))
   // subtree sums (wave kernel): a RUN is a maximal chain b, b+1, .. with parent[b+1] == b.  After the per-run suffix sums,
   // every branch body p (more than one child), taken in DESCENDING order, adds the finished sums of its non-first children

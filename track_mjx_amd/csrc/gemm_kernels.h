@@ -89,24 +89,27 @@ __device__ __forceinline__ float gemm_row16_sum(float x) {
 }
 
 template <int NIW> struct GemmCfg { static constexpr int NWAVE = NIW >= 2 ? 8 : 4, THREADS = 64 * NWAVE, NI = 4 * NIW / NWAVE; };
-template <int NIW, bool BT, bool AVEC, bool WVEC, int EPI = 0>
+// MT: 16-row tiles per workgroup tile — 5 (80 rows: one workgroup per CU at 20 480 rows) or 2 (32 rows: 5 120-row problems, one rank's share of the
+// 8-GPU configuration, are 160 workgroups instead of 64 on the 256 CUs; tmjx_hip.hip: gemm_mt)
+template <int NIW, bool BT, bool AVEC, bool WVEC, int EPI = 0, int MT = 5>
 __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
                                                   float *__restrict__ C, int ldc, int M, int N, int K, GemmLN ln = GemmLN{}) {
   constexpr int BN = 64 * NIW;
+  constexpr int BM = 16 * MT, A_ROWS = BM + 8;      // rows of the workgroup tile; LDS rows of the A image (the tile + 8 dump rows)
   constexpr int LDB_T = GEMM_LDA;            // BT: [n][k] image, 40 floats per row
   constexpr int LDB_N = BN + 4;              // !BT: [k][n] image, row stride 4 mod 8
   // (8 extra rows behind the A tile: the lanes of the partly empty last staging pass write THERE instead of sitting out a divergent
   // branch — a branch in the K step splits its basic block, which voids the sched_group_barrier interleave and costs a waitcnt)
-  constexpr int A_FLOATS = GEMM_A_ROWS * GEMM_LDA, B_FLOATS = BT ? BN * LDB_T : GEMM_BK * LDB_N, STAGE = A_FLOATS + B_FLOATS;
+  constexpr int A_FLOATS = A_ROWS * GEMM_LDA, B_FLOATS = BT ? BN * LDB_T : GEMM_BK * LDB_N, STAGE = A_FLOATS + B_FLOATS;
   extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
   // TWO waves per SIMD (8 per workgroup) once the tile is 128 columns or wider: with one wave per SIMD everything that is not an
   // MFMA (address arithmetic, masks, LDS traffic, the barrier) idles the matrix pipe — measured 52 % MFMA-busy; the second wave's
   // MFMAs fill those gaps.  The waves sit side by side along N: 16 NI columns each.
   constexpr int NT = GemmCfg<NIW>::THREADS, NI = GemmCfg<NIW>::NI;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * BN, nw = wave * 16 * NI;      // this wave's first column inside the tile
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, nw = wave * 16 * NI;      // this wave's first column inside the tile
   // ---- global -> register staging (float4 per thread): A 80 x 8 float4 (the last pass partly empty), B BN x 8 or 32 x BN / 4
-  constexpr int A_PASS = (GEMM_BM * 8 + NT - 1) / NT, B_PASS = BT ? (BN * 8) / NT : (GEMM_BK * (BN / 4)) / NT, NPASS = A_PASS + B_PASS;
+  constexpr int A_PASS = (BM * 8 + NT - 1) / NT, B_PASS = BT ? (BN * 8) / NT : (GEMM_BK * (BN / 4)) / NT, NPASS = A_PASS + B_PASS;
   // TWO register sets: tile j travels in set j & 1, loaded a whole K step before it is written to LDS (the write sits between the
   // MFMAs of the step in between, so nothing waits for memory)
   struct Stage { gf4 v[NPASS]; int m[NPASS]; };
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
       const int f = t + NT * p, r = f >> 3, c4 = f & 7;
-      const bool ok = f < GEMM_BM * 8 && m0 + r < M;
+      const bool ok = f < BM * 8 && m0 + r < M;
       R.v[p] = gemm_ld4<AVEC>(A, (long long)(m0 + (ok ? r : 0)) * lda, k0 + 4 * c4, K, ok, R.m[p]);
     }
 #pragma unroll
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
-      const int f = t + NT * p, r = f < GEMM_BM * 8 ? f >> 3 : GEMM_BM + ((f >> 3) & 7), c4 = f & 7;
+      const int f = t + NT * p, r = f < BM * 8 ? f >> 3 : BM + ((f >> 3) & 7), c4 = f & 7;
       *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = gemm_mask4(R.v[p], R.m[p]);
     }
 #pragma unroll
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
   const float *pa[A_PASS], *pb[B_PASS];
 #pragma unroll
   for (int p = 0; p < A_PASS; p++) {
-    const int f = t + NT * p, r = f < GEMM_BM * 8 ? f >> 3 : 0, c4 = f & 7;
+    const int f = t + NT * p, r = f < BM * 8 ? f >> 3 : 0, c4 = f & 7;
     pa[p] = A + (long long)min(m0 + r, M - 1) * lda + 4 * c4;
   }
 #pragma unroll
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
-      const int f = t + NT * p, r = f < GEMM_BM * 8 ? f >> 3 : GEMM_BM + ((f >> 3) & 7), c4 = f & 7;
+      const int f = t + NT * p, r = f < BM * 8 ? f >> 3 : BM + ((f >> 3) & 7), c4 = f & 7;
       *reinterpret_cast<gf4 *>(sa + r * GEMM_LDA + 4 * c4) = R.v[p];
     }
 #pragma unroll
@@ -185,11 +188,11 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       else { const int r = f / (BN / 4), c4 = f % (BN / 4); *reinterpret_cast<gf4 *>(sb + r * LDB_N + 4 * c4) = R.v[A_PASS + p]; }
     }
   };
-  struct Frag { gf4 a[5], b[NI]; };
+  struct Frag { gf4 a[MT], b[NI]; };
   auto fread = [&](Frag &F, int stage, int c) {
     const float *sa = gemm_lds + stage * STAGE, *sb = sa + A_FLOATS;
 #pragma unroll
-    for (int a = 0; a < 5; a++) F.a[a] = *reinterpret_cast<const gf4 *>(sa + (16 * a + li) * GEMM_LDA + 16 * c + 4 * kq);
+    for (int a = 0; a < MT; a++) F.a[a] = *reinterpret_cast<const gf4 *>(sa + (16 * a + li) * GEMM_LDA + 16 * c + 4 * kq);
     if (BT) {
 #pragma unroll
       for (int b = 0; b < NI; b++) F.b[b] = *reinterpret_cast<const gf4 *>(sb + (nw + 16 * b + li) * LDB_T + 16 * c + 4 * kq);
@@ -209,9 +212,9 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       }
     }
   };
-  gf4 acc[5][NI];
+  gf4 acc[MT][NI];
 #pragma unroll
-  for (int a = 0; a < 5; a++)
+  for (int a = 0; a < MT; a++)
 #pragma unroll
     for (int b = 0; b < NI; b++) acc[a][b] = gf4{0.f, 0.f, 0.f, 0.f};
   auto mma = [&](const Frag &F) {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
     for (int e = 0; e < 4; e++)
 #pragma unroll
-      for (int a = 0; a < 5; a++)
+      for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int b = 0; b < NI; b++) {
           // BT: the weight fragment goes in as the FIRST operand, i.e. the tile comes out transposed: register r of lane (li, kq) is
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
           else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[a][e], F.b[b][e], acc[a][b], 0, 0, 0);
         }
   };
-  constexpr int NMFMA = 20 * NI;                       // MFMAs per 16-deep chunk and wave
-  constexpr int NFR = 5 + (BT ? NI : 4 * NI);          // LDS reads per chunk
+  constexpr int NMFMA = 4 * MT * NI;                       // MFMAs per 16-deep chunk and wave
+  constexpr int NFR = MT + (BT ? NI : 4 * NI);          // LDS reads per chunk
   // One K step (32 deep = two chunks of 16) of tile k in stage s, ONE barrier in its middle and MFMAs on both sides of it:
   //   phase A: chunk 0's MFMAs, between them the fragment reads of chunk 1 and the LDS writes of tile k + 1 (register set RW, in
   //            flight since a step and a half) into the other stage — last read before the previous barrier;
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #ifndef GEMM_ABL
 #define GEMM_ABL 0          // timing ablations (wrong results): 1 no global loads, 2 no LDS writes, 4 no barrier, 8 no fragment reads
 #endif
+  constexpr int SPREAD = (NMFMA - NFR) / (NPASS + 1) > 0 ? (NMFMA - NFR) / (NPASS + 1) : 1;      // MFMAs between two pinned LDS writes / global loads
   auto kstep = [&](auto fast_tag, Frag &F0, Frag &F1, Stage &RW, int stage, int k_next3) {
     constexpr bool F = decltype(fast_tag)::value;
     if (!(GEMM_ABL & 8)) fread(F1, stage, 1);
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     }
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
-      GEMM_SGB(SG_MFMA, (NMFMA - NFR) / (NPASS + 1), 0);
+      GEMM_SGB(SG_MFMA, SPREAD, 0);
       if (!F) GEMM_SGB(SG_VALU, 12, 0);
       GEMM_SGB(SG_DS_WRITE, 1, 0);
     }
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     // i.e. behind the NEXT step's LDS writes — half a step before their data is needed instead of a step and a half
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
-      GEMM_SGB(SG_MFMA, (NMFMA - NFR) / (NPASS + 1), 0);
+      GEMM_SGB(SG_MFMA, SPREAD, 0);
       GEMM_SGB(SG_VALU, F ? 2 : GEMM_LOAD_VALU, 0);
       GEMM_SGB(SG_VMEM_READ, 1, 0);
     }
@@ -326,8 +330,8 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     // nw + 16 b + 4 kq + r.  Row sums: over r and b in registers, over kq by two cross-lane adds, over the waves through LDS (the K loop's
     // stages are dead).
     constexpr int NW = GemmCfg<NIW>::NWAVE;
-    static_assert(2 * GEMM_BM * NW <= 2 * STAGE, "reduction scratch must fit the K loop's LDS");
-    float *red1 = gemm_lds, *red2 = gemm_lds + GEMM_BM * NW;
+    static_assert(2 * BM * NW <= 2 * STAGE, "reduction scratch must fit the K loop's LDS");
+    float *red1 = gemm_lds, *red2 = gemm_lds + BM * NW;
     gf4 bv[NI], gv[NI], bev[NI];
 #pragma unroll
     for (int b = 0; b < NI; b++) {
@@ -335,9 +339,9 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       bv[b] = *reinterpret_cast<const gf4 *>(bias + col); gv[b] = *reinterpret_cast<const gf4 *>(ln.gamma + col); bev[b] = *reinterpret_cast<const gf4 *>(ln.beta + col);
     }
     // z first (straight from the accumulators), then the accumulators are overwritten by silu(z + bias)
-    float stat[5];
+    float stat[MT];
 #pragma unroll
-    for (int a = 0; a < 5; a++) {
+    for (int a = 0; a < MT; a++) {
       const int row = m0 + 16 * a + li;
       float p = 0.f;
 #pragma unroll
@@ -353,11 +357,11 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     auto exchange = [&](float *red) {  // stat[a] <- sum over the waves
       if (kq == 0) {
 #pragma unroll
-        for (int a = 0; a < 5; a++) red[(16 * a + li) * NW + wave] = stat[a];
+        for (int a = 0; a < MT; a++) red[(16 * a + li) * NW + wave] = stat[a];
       }
       __syncthreads();
 #pragma unroll
-      for (int a = 0; a < 5; a++) {
+      for (int a = 0; a < MT; a++) {
         const gf4 *q = reinterpret_cast<const gf4 *>(red + (16 * a + li) * NW);
         float m = 0.f;
 #pragma unroll
@@ -367,9 +371,9 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     };
     exchange(red1);
     const float inv_n = 1.f / (float)BN;
-    float mean[5];
+    float mean[MT];
 #pragma unroll
-    for (int a = 0; a < 5; a++) {
+    for (int a = 0; a < MT; a++) {
       mean[a] = stat[a] * inv_n;
       float q = 0.f;
 #pragma unroll
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     }
     exchange(red2);
 #pragma unroll
-    for (int a = 0; a < 5; a++) {
+    for (int a = 0; a < MT; a++) {
       const int row = m0 + 16 * a + li;
       const float rstd = rsqrtf(stat[a] * inv_n + ln.eps);
       if (row < M) {
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
   if constexpr (EPI == 2) {
     static_assert(!BT && NI == 2 && NIW == 4, "LayerNorm-backward epilogue: input-gradient kernel, 256-column tile");
     constexpr int NW = GemmCfg<NIW>::NWAVE;
-    static_assert(2 * GEMM_BM * NW <= 2 * STAGE, "reduction scratch must fit the K loop's LDS");
+    static_assert(2 * BM * NW <= 2 * STAGE, "reduction scratch must fit the K loop's LDS");
     float *red = gemm_lds;                                   // [80 rows][NW][2]
     const int c0 = nw + 8 * kq;                              // the lane's eight columns (of rows 16 a + li)
     float bv[8], gv[8];
@@ -406,11 +410,11 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
       for (int j = 0; j < 4; j++) { bv[j] = b0[j]; bv[4 + j] = b1[j]; gv[j] = g0[j]; gv[4 + j] = g1[j]; }
     }
-    float mean[5], rstd[5], m1[5], m2[5];      // (z is loaded twice, once per pass: keeping 40 more values live spilled registers)
+    float mean[MT], rstd[MT], m1[MT], m2[MT];      // (z is loaded twice, once per pass: keeping 40 more values live spilled registers)
 #define DY(a, j) acc[a][(j) & 1][(j) >> 1]      /* the tile entry of column c0 + j */
     const float inv_n = 1.f / (float)BN;
 #pragma unroll
-    for (int a = 0; a < 5; a++) {
+    for (int a = 0; a < MT; a++) {
       const int row = m0 + 16 * a + li;
       const bool ok = row < M;
       const long long rr = ok ? row : M - 1;
@@ -430,11 +434,11 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     __syncthreads();                   // every wave has read its last fragments
     if (kq == 0) {
 #pragma unroll
-      for (int a = 0; a < 5; a++) *reinterpret_cast<gf2 *>(red + ((16 * a + li) * NW + wave) * 2) = gf2{m1[a], m2[a]};
+      for (int a = 0; a < MT; a++) *reinterpret_cast<gf2 *>(red + ((16 * a + li) * NW + wave) * 2) = gf2{m1[a], m2[a]};
     }
     __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 5; a++) {
+    for (int a = 0; a < MT; a++) {
       const gf4 *q = reinterpret_cast<const gf4 *>(red + (16 * a + li) * NW * 2);
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
     for (int j = 0; j < 8; j++) { cg[j] = 0.f; cb[j] = 0.f; cz[j] = 0.f; }
 #pragma unroll
-    for (int a = 0; a < 5; a++) {
+    for (int a = 0; a < MT; a++) {
       const int row = m0 + 16 * a + li;
       const long long rr = row < M ? row : M - 1;
       const gf4 z0 = *reinterpret_cast<const gf4 *>(ln.z + rr * ldc + c0), z1 = *reinterpret_cast<const gf4 *>(ln.z + rr * ldc + c0 + 4);
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     const int col = n0 + nw + 8 * kq;
     const bool vec = !(ldc & 3) && !((uintptr_t)C & 15) && col + 7 < N, vec2 = !(ldc & 1) && !((uintptr_t)C & 7);
 #pragma unroll
-    for (int a = 0; a < 5; a++) {
+    for (int a = 0; a < MT; a++) {
       const int row = m0 + 16 * a + li;
       if (row < M) {
         float *o = C + (long long)row * ldc + col;
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       }
 #endif
 #pragma unroll
-      for (int a = 0; a < 5; a++) {
+      for (int a = 0; a < MT; a++) {
         const int row = m0 + 16 * a + li;
         if (row < M) {
           float *o = C + (long long)row * ldc + col;
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
     const float bv = (bias && col < N) ? bias[col] : 0.f;
 #endif
 #pragma unroll
-    for (int a = 0; a < 5; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = m0 + 16 * a + 4 * kq + r;

@@ -38,6 +38,13 @@ inline bool rodent_chains_match(const DModel &m) {
     for (int k = 0; k < 4; k++) if (m.con_g1_quat[cc][k] != m.con_g1_quat[0][k]) return false;
     if (m.con_mu[cc] != m.con_mu[0]) return false;      // ... and reads ONE friction coefficient (TMW_MU)
   }
+  // ... keeps the per-dof table as one packed word per dof in registers (dmodel.h: tpack) and takes the limit row of dof i as i - 6 (every hinge
+  // of the rodent is limited, rows in dof order; the free joint's six dofs have none)
+  for (int i = 0; i < m.nv; i++) {
+    if (m.tpack[i] == 0 && i > 0) return false;
+    if (m.dof_limrow[i] != (i >= 6 ? i - 6 : -1)) return false;
+  }
+  if (m.nv > 128 || m.nlim != m.nv - 6) return false;
   return adr == m.nnz;
 }
 inline WLayout make_wave_layout(const DModel &m, bool allow_chains = true) {
@@ -364,6 +371,16 @@ inline bool build_dmodel(const void *blob, size_t nbytes, DModel &m, std::string
       if (a != (int)m.anc_dof[m.dof_Madr[i] + q]) { err = "kinematic tree is not 'chains hanging off one trunk chain' (wave kernel limitation)"; return false; }
     }
     if (m.dof_depth[i] >= 64) { err = "dof depth exceeds the wavefront width"; return false; }
+    // packed word of the lean kernel (dmodel.h: tpack); a model whose fields do not fit keeps 0 here and never takes that kernel (rodent_chains_match)
+    const int mend = m.dof_Madr[i] + m.dof_depth[i], ws1 = m.dof_wsub[i] + 1;
+    m.tpack[i] = (mend < 2048 && m.dof_depth[i] < 64 && r < 32 && ws1 < 16 && jump + 1 == m.dof_depth[i] - r)
+                     ? (mend | (m.dof_depth[i] << 11) | (r << 17) | (ws1 << 22)) : 0;
+  }
+  for (int g = 0; g < m.ngroup; g++) {
+    const int ld = m.grp_lastdof[g];
+    int sgm = ld;
+    while (sgm > 0 && m.dof_parentid[sgm] == sgm - 1) sgm--;
+    m.gpack[g] = ld < 0 ? 0xff : (ld | (m.dof_depth[ld] << 8) | ((ld - sgm) << 16));
   }
   for (int b = 0; b < m.nbody; b++) {
     int nsub = 1;

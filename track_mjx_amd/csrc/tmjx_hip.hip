@@ -852,24 +852,38 @@ int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float 
 // vector (dwordx4) loads of a row-major operand: 16-byte aligned rows (pointer and leading dimension) — then ld >= cols rounded up to 4
 // holds by itself (ld is a multiple of 4 and >= cols), i.e. the last float4 of a row stays inside the row's allocation
 static bool aligned16(const void *p, long long ld) { return !((uintptr_t)p & 15) && !(ld & 3); }
-template <int NIW, bool BT, bool AVEC, bool WVEC>
+// Rows per workgroup tile (16 MT): 80 where that fills the chip (20 480 rows = 256 workgroups, one per CU), 32 where 80-row tiles would leave most
+// CUs idle — 5 120 rows (one rank's share of the 8-GPU configuration: batch_size 2048 / 8 x unroll_length 20) are 64 workgroups of 80 rows but
+// 160 of 32.  Cost model: rounds of 256 workgroups x the tile's MFMA time (a 32-row tile streams the same weight tile per K step as an 80-row one,
+// ~ 10 % over its 2 / 5 share).  TMJX_GEMM_MT=5 / 2 forces either (tuning, tests).
+static int gemm_mt(int M, int col_tiles) {
+  static const int forced = getenv("TMJX_GEMM_MT") ? atoi(getenv("TMJX_GEMM_MT")) : 0;
+  if (forced == 5 || forced == 2) return forced;
+  const long long w5 = (long long)((M + 79) / 80) * col_tiles, w2 = (long long)((M + 31) / 32) * col_tiles;
+  const double c5 = (double)((w5 + 255) / 256) * 5.0, c2 = (double)((w2 + 255) / 256) * 2.2;
+  return c2 < c5 ? 2 : 5;
+}
+template <int NIW, bool BT, bool AVEC, bool WVEC, int MT = 5>
 static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
-  constexpr int BN = 64 * NIW;
-  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + (BT ? BN * GEMM_LDA : GEMM_BK * (BN + 4)));
+  constexpr int BN = 64 * NIW, BM = 16 * MT;
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)((BM + 8) * GEMM_LDA + (BT ? BN * GEMM_LDA : GEMM_BK * (BN + 4)));
   static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT, AVEC, WVEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT, AVEC, WVEC, 0, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act): ") + hipGetErrorString(e));
     attr_set = true;
   }
-  dim3 grid((M + GEMM_BM - 1) / GEMM_BM, (N + BN - 1) / BN);
-  hipLaunchKernelGGL((k_gemm_act<NIW, BT, AVEC, WVEC>), grid, dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K, GemmLN{});
+  dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+  hipLaunchKernelGGL((k_gemm_act<NIW, BT, AVEC, WVEC, 0, MT>), grid, dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K, GemmLN{});
   return check_launch("k_gemm_act");
 }
 template <int NIW, bool BT>
 static int gemm_act_vec(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
   const bool av = aligned16(A, lda), wv = aligned16(W, ldw);
-  if (av && wv) return launch_gemm_act<NIW, BT, true, true>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  if (av && wv) {        // (the 32-row tile exists for the aligned form only: every operand of the learner is)
+    if (gemm_mt(M, (N + 64 * NIW - 1) / (64 * NIW)) == 2) return launch_gemm_act<NIW, BT, true, true, 2>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+    return launch_gemm_act<NIW, BT, true, true>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  }
   if (av) return launch_gemm_act<NIW, BT, true, false>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
   if (wv) return launch_gemm_act<NIW, BT, false, true>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
   return launch_gemm_act<NIW, BT, false, false>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
@@ -884,17 +898,17 @@ static int gemm_act(const float *A, int lda, const float *W, int ldw, const floa
   return gemm_act_vec<4, BT>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
 }
 // Dense -> SiLU -> LayerNorm forward in one launch (k_gemm_act<.., LN = true>): the layer must be exactly one tile wide
-template <int NIW>
+template <int NIW, int MT>
 static int launch_gemm_ln(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, int ldc, int M, int N, int K, GemmLN ln, hipStream_t s) {
-  constexpr int BN = 64 * NIW;
-  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + BN * GEMM_LDA);
+  constexpr int BN = 64 * NIW, BM = 16 * MT;
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)((BM + 8) * GEMM_LDA + BN * GEMM_LDA);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, 1, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act LN): ") + hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, 1>), dim3((M + GEMM_BM - 1) / GEMM_BM, 1), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
+  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, 1, MT>), dim3((M + BM - 1) / BM, 1), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
   return check_launch("k_gemm_act(LN)");
 }
 template <bool YVEC, bool XVEC>
@@ -910,18 +924,18 @@ static int launch_gemm_dw(const float *dY, int ldy, const float *X, int ldx, flo
   hipLaunchKernelGGL((k_gemm_dw<YVEC, XVEC>), grid, dim3(512), lds, s, dY, ldy, X, ldx, scratch, M, N, K, with_bias, rps, ld);
   return TMJX_OK;
 }
-template <int NIW>
+template <int NIW, int MT>
 static int launch_gemm_silu(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, float *Y, int ldc, int M, int N, int K, hipStream_t s) {
-  constexpr int BN = 64 * NIW;
-  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + BN * GEMM_LDA);
+  constexpr int BN = 64 * NIW, BM = 16 * MT;
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)((BM + 8) * GEMM_LDA + BN * GEMM_LDA);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, true, true, true, 3, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act SiLU): ") + hipGetErrorString(e));
     attr_set = true;
   }
   GemmLN ln{nullptr, nullptr, Y, nullptr, 0.f, nullptr, nullptr};
-  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, 3>), dim3((M + GEMM_BM - 1) / GEMM_BM, (N + BN - 1) / BN), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
+  hipLaunchKernelGGL((k_gemm_act<NIW, true, true, true, 3, MT>), dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, Z, ldc, M, N, K, ln);
   return check_launch("k_gemm_act(SiLU)");
 }
 extern "C" {
@@ -938,9 +952,14 @@ int tmjx_gemm_nt_silu_ln(const float *A, int lda, const float *W, int ldw, const
   if (!tmjx_gemm_nt_silu_ln_ok(A, lda, W, ldw, N)) return fail(TMJX_EINVAL, "tmjx_gemm_nt_silu_ln: N must be 64, 128 or 256 and the operands' rows 16-byte aligned");
   GemmLN ln{gamma, beta, Y, stats, eps, nullptr, nullptr};
   hipStream_t s = (hipStream_t)stream;
-  if (N == 64) return launch_gemm_ln<1>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
-  if (N == 128) return launch_gemm_ln<2>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
-  return launch_gemm_ln<4>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+  if (gemm_mt(M, 1) == 2) {
+    if (N == 64) return launch_gemm_ln<1, 2>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+    if (N == 128) return launch_gemm_ln<2, 2>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+    return launch_gemm_ln<4, 2>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+  }
+  if (N == 64) return launch_gemm_ln<1, 5>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+  if (N == 128) return launch_gemm_ln<2, 5>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
+  return launch_gemm_ln<4, 5>(A, lda, W, ldw, bias, Z, ldc, M, N, K, ln, s);
 }
 // Dense -> SiLU forward in one launch (k_gemm_act<.., EPI = 3>): Z = A W^T (without the bias), Y = silu(Z + bias); any N, 16-byte aligned operand rows
 int tmjx_gemm_nt_silu_ok(const float *A, int lda, const float *W, int ldw) { return aligned16(A, lda) && aligned16(W, ldw); }
@@ -949,9 +968,15 @@ int tmjx_gemm_nt_silu(const float *A, int lda, const float *W, int ldw, const fl
   if (M < 1 || N < 1 || K < 1 || lda < K || ldc < N || ldw < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
   if (!tmjx_gemm_nt_silu_ok(A, lda, W, ldw)) return fail(TMJX_EINVAL, "tmjx_gemm_nt_silu: the operands' rows must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (N <= 64) return launch_gemm_silu<1>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
-  if (N <= 128) return launch_gemm_silu<2>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
-  return launch_gemm_silu<4>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+  const int niw = N <= 64 ? 1 : N <= 128 ? 2 : 4;
+  if (gemm_mt(M, (N + 64 * niw - 1) / (64 * niw)) == 2) {
+    if (niw == 1) return launch_gemm_silu<1, 2>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+    if (niw == 2) return launch_gemm_silu<2, 2>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+    return launch_gemm_silu<4, 2>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+  }
+  if (niw == 1) return launch_gemm_silu<1, 5>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+  if (niw == 2) return launch_gemm_silu<2, 5>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
+  return launch_gemm_silu<4, 5>(A, lda, W, ldw, bias, Z, Y, ldc, M, N, K, s);
 }
 int tmjx_silu_fwd(const float *z, const float *bias, float *y, long long rows, int N, void *stream) {
   if (!z || !bias || !y) return fail(TMJX_EINVAL, "null argument");
@@ -967,34 +992,44 @@ int tmjx_silu_bwd(const float *dy, const float *z, const float *bias, float *dz,
   hipLaunchKernelGGL(k_silu_bwd_f32, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dy, z, bias, dz, total, N);
   return check_launch("k_silu_bwd_f32");
 }
+}  // extern "C"
+template <int MT>
+static int launch_gemm_ln_bwd(const float *dY, int ldy, const float *W, int ldw, const float *bias, float *dz, int M, int N, int K, GemmLN ln, hipStream_t s) {
+  constexpr int BM = 16 * MT;
+  constexpr size_t lds = 2 * sizeof(float) * (size_t)((BM + 8) * GEMM_LDA + GEMM_BK * (256 + 4));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<4, false, true, true, 2, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act LN bwd): ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemm_act<4, false, true, true, 2, MT>), dim3((M + BM - 1) / BM, 1), dim3(GemmCfg<4>::THREADS), lds, s, dY, ldy, W, ldw, bias, dz, N, M, N, K, ln);
+  return check_launch("k_gemm_act(LN bwd)");
+}
+extern "C" {
 int tmjx_gemm_nn_ln_bwd_ok(const float *dY, int ldy, const float *W, int ldw, int N) { return N == 256 && aligned16(dY, ldy) && aligned16(W, ldw); }
-long long tmjx_gemm_nn_ln_bwd_partial_floats(int M, int N) { return (long long)((M + GEMM_BM - 1) / GEMM_BM) * 3 * N; }
+// (one partial row of 3 N column sums per workgroup of the launch: the row tile is gemm_mt's)
+long long tmjx_gemm_nn_ln_bwd_partial_floats(int M, int N) { const int bm = 16 * gemm_mt(M, 1); return (long long)((M + bm - 1) / bm) * 3 * N; }
 int tmjx_gemm_nn_ln_bwd(const float *dY, int ldy, const float *W, int ldw, const float *z, const float *bias, const float *gamma, const float *stats,
                         float *dz, float *partial, int M, int N, int K, void *stream) {
   if (!dY || !W || !z || !bias || !gamma || !stats || !dz || !partial) return fail(TMJX_EINVAL, "null argument");
   if (M < 1 || K < 1 || ldy < K || ldw < N) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
   if (!tmjx_gemm_nn_ln_bwd_ok(dY, ldy, W, ldw, N)) return fail(TMJX_EINVAL, "tmjx_gemm_nn_ln_bwd: N must be 256 and the operands' rows 16-byte aligned");
-  constexpr size_t lds = 2 * sizeof(float) * (size_t)(GEMM_A_ROWS * GEMM_LDA + GEMM_BK * (256 + 4));
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<4, false, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act LN bwd): ") + hipGetErrorString(e));
-    attr_set = true;
-  }
   GemmLN ln{gamma, nullptr, nullptr, const_cast<float *>(stats), 0.f, z, partial};
   // (the kernel's contraction length is its "K" = the next layer's width; its "N" = this block's width = 256; z and dz are dense [M][256])
-  hipLaunchKernelGGL((k_gemm_act<4, false, true, true, 2>), dim3((M + GEMM_BM - 1) / GEMM_BM, 1), dim3(GemmCfg<4>::THREADS), lds, (hipStream_t)stream, dY, ldy, W, ldw, bias, dz, N,
-                     M, N, K, ln);
-  return check_launch("k_gemm_act(LN bwd)");
+  if (gemm_mt(M, 1) == 2) return launch_gemm_ln_bwd<2>(dY, ldy, W, ldw, bias, dz, M, N, K, ln, (hipStream_t)stream);
+  return launch_gemm_ln_bwd<5>(dY, ldy, W, ldw, bias, dz, M, N, K, ln, (hipStream_t)stream);
 }
 int tmjx_gemm_nn(const float *A, int lda, const float *W, int ldw, float *C, int ldc, int M, int N, int K, void *stream) {
   return gemm_act<false>(A, lda, W, ldw, nullptr, C, ldc, M, N, K, stream);
 }
-// rows of M per slab and number of slabs so that tiles x slabs is about the number of CUs (256)
-static void dw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab) {
+// rows of M per slab and number of slabs so that tiles x slabs is about the number of CUs (256); `max_slabs` > 0 caps the slab count (the
+// grouped launch shares the chip between its problems: tmjx_gemm_dw_grouped)
+static void dw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab, int max_slabs = 0) {
   const int tiles = ((N + DW_BT - 1) / DW_BT) * ((K + DW_BT - 1) / DW_BT);
   static const int target = getenv("TMJX_DW_WGS") ? atoi(getenv("TMJX_DW_WGS")) : 256;      // tuning knob
   int want = (target + tiles - 1) / tiles;      // one workgroup per CU: twice as many slabs (two per CU) ran the kernel no faster and doubled the reduction's traffic
+  if (max_slabs > 0 && want > max_slabs) want = max_slabs;
   if (want < 1) want = 1;
   int rps = (((M + want - 1) / want) + DW_BM - 1) / DW_BM * DW_BM;
   if (rps < DW_BM) rps = DW_BM;
@@ -1032,6 +1067,14 @@ int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
   DwGroup G;
   G.n = n;
   int wg = 0, red = 0;
+  // The problems of a group run side by side in ONE launch: together they should fill the chip about twice (TMJX_DW_GROUP_WGS workgroups, two
+  // 74 KB workgroups fit a CU), not once EACH — nine problems split for 256 workgroups apiece were 2 300 workgroups writing and re-reading
+  // 64 slabs per weight matrix (160 MB per backward pass at 20 480 rows, 130 MB at 5 120).  Never more slabs than the problem's own split
+  // (the caller sized the scratch by tmjx_gemm_dw_scratch_floats).
+  static const int group_target = getenv("TMJX_DW_GROUP_WGS") ? atoi(getenv("TMJX_DW_GROUP_WGS")) : 512;
+  int all_tiles = 0;
+  for (int i = 0; i < n; i++) all_tiles += ((probs[i].N + DW_BT - 1) / DW_BT) * ((probs[i].K + DW_BT - 1) / DW_BT);
+  const int max_slabs = group_target > 0 ? (group_target + all_tiles - 1) / (all_tiles > 0 ? all_tiles : 1) : 0;
   for (int i = 0; i < n; i++) {
     const tmjx_dw_problem_t &q = probs[i];
     if (!q.dY || !q.X || !q.dW || !q.scratch) return fail(TMJX_EINVAL, "null pointer in a problem");
@@ -1040,7 +1083,7 @@ int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
     DwProblem &P = G.p[i];
     P.dY = q.dY; P.X = q.X; P.dW = q.dW; P.db = q.db; P.slabs = q.scratch;
     P.ldy = q.ldy; P.ldx = q.ldx; P.lddw = q.lddw; P.M = q.M; P.N = q.N; P.K = q.K;
-    dw_split(q.M, q.N, q.K, &P.rows_per_split, &P.S, &P.ld_slab);
+    dw_split(q.M, q.N, q.K, &P.rows_per_split, &P.S, &P.ld_slab, max_slabs);
     P.tiles_n = (q.N + DW_BT - 1) / DW_BT; P.tiles_k = (q.K + DW_BT - 1) / DW_BT;
     P.wg_begin = wg; wg += P.tiles_n * P.tiles_k * P.S;
     P.red_begin = red; red += (int)(((long long)q.N * (q.K + (q.db ? 1 : 0)) + 255) / 256);

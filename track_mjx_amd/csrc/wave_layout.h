@@ -40,8 +40,11 @@ struct WLayout {
     l_qpos = l; l += nq; l_qvel = l; l += nv; l_act = l; l += lean ? 0 : nu;
     l_cdof = l; l += nv * 6; l_M = l; l += nnz; l_con_dist = l; l += ncon; l_con_off = l; l += ncon * 3;
     l_con_frame = l; l += lean ? 3 + ncon * 3 : ncon * 6; l_lim_sign = l; l += (nlim + 3) / 4; l_qfrc_smooth = l; l += lean ? 0 : nv;
-    l_com = l; l += 4; l_sv = l; l += ngroup * 6; l_tdof = l; l += nv * 2;
-    l_tgrp = l; l += (ngroup + 3) / 4;      // bytes: last dof of each paw group (-1 = none)
+    l_com = l; l += 4; l_sv = l; l += ngroup * 6;
+    // per-dof index table: two words per dof — or (lean) NOT in LDS: one packed word per dof in two registers of the lane that owns the dof (round 5;
+    // every read of the table in the chain kernels is lane-local: DModel::tpack, WCtx::tp0 / tp1)
+    l_tdof = l; l += lean ? 0 : nv * 2;
+    l_tgrp = l; l += lean ? ngroup : (ngroup + 3) / 4;      // bytes: last dof of each paw group (-1 = none); lean: one packed word per group (DModel::gpack)
     l_con_mu = l; l += lean ? 0 : ncon;  // friction coefficient of every contact slot: a model constant the products with J / J^T need on every call (lean: ONE
                                          // coefficient for all slots, a uniform read of the model — model_host.h checks it)
     // byte tables: compact row -> original row of the ACTIVE constraint rows (wave_physics.h: tmw_make_constraint); contact -> its first

@@ -88,6 +88,7 @@ struct WCtx {
   float qfs0[TMW_NL], qfs1[TMW_NL];   // lean layout: qfrc_smooth of dof lane / lane + 64 (tmw_velocity_inertia -> solver, Euler)
   float dg0[TMW_NL], dg1[TMW_NL];     // CG: D = 1 / Dinv of dof lane / lane + 64 (tmw_solve_cg; read lane-locally only)
   float wp0[TMW_NL], wp1[TMW_NL];     // CG: w = D^-1 ghat of the PREVIOUS gradient (Polak-Ribiere numerator)
+  int tp0[TMW_NL], tp1[TMW_NL];       // lean layout: packed index word of dof lane / lane + 64 (DModel::tpack; round 5: the table left LDS)
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
 // solver statistics of the last substep, kept in the spare LDS word behind the centre of mass (registers are what this kernel has none
@@ -203,11 +204,16 @@ TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     for (int i = lane; i < K.nq + K.nv + (K.lean ? 0 : K.nu); i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel (| act); the warm start stays in global memory
-    for (int i = lane; i < 2 * K.nv; i += 64) {   // index table of the sparse rows (+ the dof's limit row / wrench subset in the top bytes)
-      int dof = i >> 1, extra = (i & 1) ? m.dof_wsub[dof] + 1 : m.dof_limrow[dof] + 1;
-      L[K.l_tdof + i] = tm_i2f(m.tdof[i] | (extra << 24));
+    if (K.lean) {     // the dofs' packed index words: two registers per lane, one LDS word per paw group
+      c.tp0[TMW_LI] = m.tpack[lane < K.nv ? lane : 0]; c.tp1[TMW_LI] = m.tpack[lane + 64 < K.nv ? lane + 64 : 64];
+      for (int g = lane; g < K.ngroup; g += 64) L[K.l_tgrp + g] = tm_i2f(m.gpack[g]);
+    } else {
+      for (int i = lane; i < 2 * K.nv; i += 64) {   // index table of the sparse rows (+ the dof's limit row / wrench subset in the top bytes)
+        int dof = i >> 1, extra = (i & 1) ? m.dof_wsub[dof] + 1 : m.dof_limrow[dof] + 1;
+        L[K.l_tdof + i] = tm_i2f(m.tdof[i] | (extra << 24));
+      }
+      for (int g = lane; g < K.ngroup; g += 64) ((signed char *)(L + K.l_tgrp))[g] = (signed char)m.grp_lastdof[g];
     }
-    for (int g = lane; g < K.ngroup; g += 64) ((signed char *)(L + K.l_tgrp))[g] = (signed char)m.grp_lastdof[g];
     for (int cc = lane; cc < K.ncon; cc += 64) { if (!K.lean) L[K.l_con_mu + cc] = m.con_mu[cc]; TMW_CONGRP(K)[cc] = (unsigned char)m.con_grp[cc]; }
     {
       int su = lane / 6;
@@ -233,6 +239,20 @@ TM_DEV int tmw_anc(int i, int q, int w1) {
   int r = i - (w1 & 0xff);
   return q <= r ? i - q : ((w1 >> 8) & 0xff) + r - q;
 }
+// lean layout: the dof's ONE packed word (DModel::tpack) sits in a register of the lane that owns the dof (i = lane: tp0, i = lane + 64: tp1)
+// (read through an OPAQUE copy at every use: the words are launch constants, and whatever is decoded from a visible launch constant — depths, row
+// addresses, loop masks — is hoisted in front of the substep loop and kept in registers for the whole kernel: 131 -> 158 VGPRs without this)
+#ifdef TM_HOST_EMU
+TM_DEV int tmw_opaque_v(int x) { return x; }
+#else
+TM_DEV int tmw_opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+#endif
+#define TMW_TP(i) tmw_opaque_v((i) < 64 ? c.tp0[TMW_LI] : c.tp1[TMW_LI])
+#define TMW_TP_MEND(p) ((p) & 0x7ff)
+#define TMW_TP_DEPTH(p) (((p) >> 11) & 0x3f)
+#define TMW_TP_RUN(p) (((p) >> 17) & 0x1f)               /* i - chain_start;  jump + 1 = depth - run */
+#define TMW_TP_WSUB1(p) (((p) >> 22) & 0xf)
+TM_DEV int tmw_anc_r(int i, int q, int r, int jp1) { return q <= r ? i - q : jp1 + r - q; }
 TM_DEV void tmw_store_state(WCtx &c, const WLayout &K, float time) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
@@ -688,10 +708,12 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
       for (int k = 0; k < 10; k++) I[k] = L[K.l_cinert + b * 10 + k];
       for (int k = 0; k < 6; k++) cd[k] = L[K.l_cdof + i * 6 + k];
       tm_inert_mul(buf, I, cd);
-      int w0 = TMW_W0(i), w1 = TMW_W1(i), adr = TMW_ADR(w0), d = TMW_DEPTH(w0);
+      int adr, d, run, jp1;
+      if (K.lean) { const int tp = TMW_TP(i); d = TMW_TP_DEPTH(tp); adr = TMW_TP_MEND(tp) - d; run = TMW_TP_RUN(tp); jp1 = d - run; }
+      else { const int w0 = TMW_W0(i), w1 = TMW_W1(i); adr = TMW_ADR(w0); d = TMW_DEPTH(w0); run = i - (w1 & 0xff); jp1 = (w1 >> 8) & 0xff; }
 #pragma unroll 4
       for (int k = 0; k <= d; k++) {
-        const float *cj = L + K.l_cdof + tmw_anc(i, k, w1) * 6;
+        const float *cj = L + K.l_cdof + tmw_anc_r(i, k, run, jp1) * 6;
         float s = buf[0] * cj[0] + buf[1] * cj[1] + buf[2] * cj[2] + buf[3] * cj[3] + buf[4] * cj[4] + buf[5] * cj[5];
         if (k == 0) s += rc[1];          // armature
         L[K.l_M + adr + k] = s;
@@ -1294,7 +1316,7 @@ TM_DEV void tmw_rows_invert(WCtx &c, const WLayout &K, tmw_f2 (*n)[TMW_NL], tmw_
     TMW_FOR {
       float v = acc[TMW_LI].x + acc[TMW_LI].y;
       TMW_SET_ROW(n, k, v);
-      // (lane dk = the row's unit diagonal: stored too, so that the row products of wave_matvec.h can take N = L^-1 with its diagonal)
+      // (lane dk = the row's unit diagonal: stored too, kept: N = L^-1 with its diagonal)
       if (TMW_MASK(TMW_M_LT(dk + 1))) L[adr0 - lane + (off + dk)] = v;
     }
   }
@@ -1434,13 +1456,19 @@ TM_DEV int tmw_opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 #endif
 // both dof slots of a lane (i and i + 64) advance in the same loops, so that their loads share the LDS round trips
 template <int MAXR0, int MAXR1, int MAXT>
-TM_DEV void tmw_row_runs2(const float *L, const WLayout &K, int A, int x, int lane, bool diag, float &z0, float &z1) {
+TM_DEV void tmw_row_runs2(const float *L, const WLayout &K, int A, int x, int lane, bool diag, float &z0, float &z1, int tp0, int tp1) {
   const int i0 = lane, i1 = lane + 64 < K.nv ? lane + 64 : 64;
-  int w00 = tm_f2i(L[K.l_tdof + 2 * i0]), w01 = tm_f2i(L[K.l_tdof + 2 * i0 + 1]);
-  int w10 = tm_f2i(L[K.l_tdof + 2 * i1]), w11 = tm_f2i(L[K.l_tdof + 2 * i1 + 1]);
-  int d0 = TMW_DEPTH(w00), r0 = i0 - (w01 & 0xff), j0 = (w01 >> 8) & 0xff;
-  int d1 = TMW_DEPTH(w10), r1 = i1 - (w11 & 0xff), j1 = (w11 >> 8) & 0xff;
-  const float *A0 = L + A + TMW_ADR(w00), *x0 = L + x + i0, *A1 = L + A + TMW_ADR(w10), *x1 = L + x + i1;
+  int d0, r0, j0, d1, r1, j1, adr0, adr1;
+  if (K.lean) {       // the packed words come in registers (WCtx::tp0 / tp1)
+    d0 = TMW_TP_DEPTH(tp0); r0 = TMW_TP_RUN(tp0); j0 = d0 - r0; adr0 = TMW_TP_MEND(tp0) - d0;
+    d1 = TMW_TP_DEPTH(tp1); r1 = TMW_TP_RUN(tp1); j1 = d1 - r1; adr1 = TMW_TP_MEND(tp1) - d1;
+  } else {
+    int w00 = tm_f2i(L[K.l_tdof + 2 * i0]), w01 = tm_f2i(L[K.l_tdof + 2 * i0 + 1]);
+    int w10 = tm_f2i(L[K.l_tdof + 2 * i1]), w11 = tm_f2i(L[K.l_tdof + 2 * i1 + 1]);
+    d0 = TMW_DEPTH(w00); r0 = i0 - (w01 & 0xff); j0 = (w01 >> 8) & 0xff; adr0 = TMW_ADR(w00);
+    d1 = TMW_DEPTH(w10); r1 = i1 - (w11 & 0xff); j1 = (w11 >> 8) & 0xff; adr1 = TMW_ADR(w10);
+  }
+  const float *A0 = L + A + adr0, *x0 = L + x + i0, *A1 = L + A + adr1, *x1 = L + x + i1;
   float a0 = diag ? A0[0] * x0[0] : 0.f, a1 = diag ? A1[0] * x1[0] : 0.f;
   const int maxr0 = tmw_opaque_s(MAXR0), maxr1 = tmw_opaque_s(MAXR1), maxt = tmw_opaque_s(MAXT);
 #pragma unroll 4
@@ -1462,24 +1490,14 @@ TM_DEV void tmw_row_runs2(const float *L, const WLayout &K, int A, int x, int la
 // (A x)_i over the ancestors of i (+ diagonal) for every dof, kept in two lane registers
 TM_DEV void tmw_rowpart_chains(WCtx &c, const WLayout &K, int A, int x, bool diag, float *z0, float *z1) {
   float *L = c.L; TMW_LANE_DECL
-  TMW_FOR { tmw_row_runs2<tmw_chain_maxrun(0, 64), tmw_chain_maxrun(64, 73), TMW_RODENT_TRUNK>(L, K, A, x, lane, diag, z0[TMW_LI], z1[TMW_LI]); }
+  TMW_FOR { tmw_row_runs2<tmw_chain_maxrun(0, 64), tmw_chain_maxrun(64, 73), TMW_RODENT_TRUNK>(L, K, A, x, lane, diag, z0[TMW_LI], z1[TMW_LI], tmw_opaque_v(c.tp0[TMW_LI]), tmw_opaque_v(c.tp1[TMW_LI])); }
 }
-// (the same mat-vecs on the matrix cores: measured SLOWER than the vector-ALU versions below — see the header — and compiled only with
-// -DTMW_MFMA_MATVEC; tests/test_hostemu_parity.py keeps that build honest)
-#include "wave_matvec.h"
+// (the same mat-vecs on the matrix cores were measured SLOWER than the vector-ALU versions below in round 4 — DESIGN.md "K2 in detail"; that
+// experiment, csrc/wave_matvec.h, left the tree in round 5 with the LDS table it read: git history, commit a70fc19)
 // x <- M^-1 x using N = L^-1:  x = N D^-1 N^T x   (two sparse mat-vecs; `x` is an LDS vector offset, `tmp` a free one)
 TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x, int tmp) {
   float *L = c.L; TMW_LANE_DECL
   TMW_REG(float, z0); TMW_REG(float, z1);
-#ifdef TMW_MFMA_MATVEC
-  if (K.chains) {
-    TMW_TICK2(15);
-    tmw_colprod_mfma<1>(c, K, K.l_LD, x, tmp);
-    TMW_TICK2(26);
-    tmw_rowprod_mfma<true>(c, K, K.l_LD, tmp, x);
-    return;
-  }
-#endif
   if (K.chains) {
     TMW_TICK2(15);
     tmw_colpart_chains<true>(c, K, K.l_LD, x, x);
@@ -1519,15 +1537,6 @@ TM_DEV void tmw_solve(WCtx &c, const WLayout &K, int x, int tmp) {
 // y = M x
 TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
   float *L = c.L; TMW_LANE_DECL
-#ifdef TMW_MFMA_MATVEC
-  if (K.chains) {
-    TMW_TICK2(15);
-    tmw_rowprod_mfma<true>(c, K, K.l_M, x, y);
-    tmw_colprod_mfma<2>(c, K, K.l_M, x, y);
-    TMW_TICK2(24);
-    return;
-  }
-#endif
   if (K.chains) {
     TMW_REG(float, z0); TMW_REG(float, z1);
     TMW_TICK2(15);
@@ -1552,12 +1561,13 @@ TM_DEV void tmw_jmul_stage1(WCtx &c, const WLayout &K, int v) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   TMW_FOR {
     if (lane < K.ngroup * 6) {  // spatial velocity of each paw body, one lane per (group, component)
-      int g = lane / 6, k = lane - g * 6, ld = ((const signed char *)(L + K.l_tgrp))[g];
+      int g = lane / 6, k = lane - g * 6, ld, d, run, jp1;
+      if (K.lean) { const int gp = tm_f2i(L[K.l_tgrp + g]); ld = (gp & 0xff) == 0xff ? -1 : (gp & 0xff); d = (gp >> 8) & 0xff; run = (gp >> 16) & 0xff; jp1 = d - run; }
+      else { ld = ((const signed char *)(L + K.l_tgrp))[g]; const int w1 = TMW_W1(ld >= 0 ? ld : 0); d = TMW_DEPTH(TMW_W0(ld >= 0 ? ld : 0)); run = ld - (w1 & 0xff); jp1 = (w1 >> 8) & 0xff; }
       float s = 0.f;
       if (ld >= 0) {
-        int w1 = TMW_W1(ld), d = TMW_DEPTH(TMW_W0(ld));
 #pragma unroll 4
-        for (int q = 0; q <= d; q++) { int i = tmw_anc(ld, q, w1); s += L[K.l_cdof + i * 6 + k] * L[v + i]; }
+        for (int q = 0; q <= d; q++) { int i = tmw_anc_r(ld, q, run, jp1); s += L[K.l_cdof + i * 6 + k] * L[v + i]; }
       }
       L[K.l_sv + lane] = s;
     }
@@ -1659,7 +1669,8 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       float s = 0.f;
-      int lr = TMW_LIMROW1(TMW_W0(i)) - 1, su = TMW_WSUB1(TMW_W1(i)) - 1;
+      // (lean: the limit row of dof i is i - 6 and the wrench subset rides in the dof's packed register word — model_host.h: rodent_chains_match)
+      const int lr = K.lean ? (i >= 6 ? i - 6 : -1) : TMW_LIMROW1(TMW_W0(i)) - 1, su = K.lean ? TMW_TP_WSUB1(TMW_TP(i)) - 1 : TMW_WSUB1(TMW_W1(i)) - 1;
       {                  // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise (branch-free: see above)
         const int svb = TMW_LIMSIGN(K)[lr >= 0 ? lr : 0], sv = lr >= 0 ? svb : 0;
         const int kr = sv != 0 ? (sv < 0 ? -sv : sv) - 1 : 0;
@@ -1679,16 +1690,6 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
 TM_DEV void tmw_mul_m_jmul(WCtx &c, const WLayout &K, int x, int y, int out) {
   float *L = c.L; TMW_LANE_DECL
   if (!K.chains) { tmw_mul_m(c, K, x, y); tmw_jmul(c, K, x, out); return; }
-#ifdef TMW_MFMA_MATVEC
-  TMW_TICK2(15);
-  tmw_jmul_stage1(c, K, x);
-  tmw_rowprod_mfma<true>(c, K, K.l_M, x, y);
-  tmw_colprod_mfma<2>(c, K, K.l_M, x, y);       // ends with a barrier: l_sv is complete as well
-  tmw_jmul_stage2(c, K, x, out);
-  TMW_SYNC();
-  TMW_TICK2(24);
-  return;
-#endif
   TMW_REG(float, z0); TMW_REG(float, z1);
   TMW_TICK2(15);
   tmw_jmul_stage1(c, K, x);
@@ -1841,9 +1842,6 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool 
 // x -> out = D^-1 N^T x   (leaf -> root; out may alias x)
 TM_DEV void tmw_solve_up(WCtx &c, const WLayout &K, int x, int out) {
   float *L = c.L; TMW_LANE_DECL
-#ifdef TMW_MFMA_MATVEC
-  if (K.chains) { tmw_colprod_mfma<1>(c, K, K.l_LD, x, out); return; }
-#endif
   if (K.chains) { tmw_colpart_chains<true>(c, K, K.l_LD, x, out); return; }
   TMW_REG(float, z0); TMW_REG(float, z1);
   TMW_FOR {
@@ -1860,9 +1858,6 @@ TM_DEV void tmw_solve_up(WCtx &c, const WLayout &K, int x, int out) {
 // out = N x   (root -> leaf; out may NOT alias x)
 TM_DEV void tmw_solve_down(WCtx &c, const WLayout &K, int x, int out) {
   float *L = c.L; TMW_LANE_DECL
-#ifdef TMW_MFMA_MATVEC
-  if (K.chains) { tmw_rowprod_mfma<true>(c, K, K.l_LD, x, out); return; }
-#endif
   if (K.chains) {
     TMW_REG(float, z0); TMW_REG(float, z1);
     tmw_rowpart_chains(c, K, K.l_LD, x, false, z0, z1);
