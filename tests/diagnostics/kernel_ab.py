@@ -7,7 +7,9 @@ results.  Both arms are the host emulation of the real kernel body (tests/hostem
 three action scales of tests/test_gpu_parity_strict.py — and compared after every substep: every physics row (qpos, qvel, act, warm start,
 time), the outputs of the last forward pass (xpos, torso xmat, qfrc_actuator) and the solver statistics.  Prints the worst absolute
 difference (0 expected) and exits non-zero otherwise.
-usage: python tests/diagnostics/kernel_ab.py [rev = HEAD] [n_env = 48] [control steps = 4]"""
+TMJX_EMU_POISON=nan in the environment fills what a wave finds when it starts (LDS image; in the working tree's build also registers and scratch)
+with NaNs instead of zeros: a run under it must give the same bits as one without (no result may depend on words the kernel did not write).
+usage: [TMJX_EMU_POISON=nan] python tests/diagnostics/kernel_ab.py [rev = HEAD] [n_env = 48] [control steps = 4]"""
 import ctypes as C
 import subprocess
 import sys
@@ -28,8 +30,15 @@ nctl = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 tmp = Path(tempfile.mkdtemp())
 
 
+POISON_PATCH = ("    for (auto &v : lds) v = 0.f;\n", "    { const char *ps_ = getenv(\"TMJX_EMU_POISON\"); const float pz_ = ps_ ? (!strcmp(ps_, \"nan\") ? __builtin_nanf(\"\") : (float)atof(ps_)) : 0.f; for (auto &v : lds) v = pz_; }\n")
+
+
 def build(tag, tree: Path, defs=()):
     so = tmp / f"libhostemu_{tag}.so"
+    src = tree / "tests" / "hostemu" / "hostemu.cpp"
+    text = src.read_text()
+    if "TMJX_EMU_POISON" not in text and POISON_PATCH[0] in text and tree != ROOT:       # an older revision: give its LDS image the same poison switch
+        src.write_text(text.replace(POISON_PATCH[0], POISON_PATCH[1]))
     subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", *defs, "-o", str(so), str(tree / "tests" / "hostemu" / "hostemu.cpp")], check=True)
     return so
 

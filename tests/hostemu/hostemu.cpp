@@ -7,6 +7,7 @@
 // this library and the product path fails loudly without libtmjx_hip.so.
 #define TM_HOST_EMU 1
 #define TM_DEV static inline
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -84,10 +85,23 @@ void emu_physics(EmuModel *mm, float *st, const float *action, int nsub, int do_
 // wave-per-env kernel body (csrc/wave_physics.h): one emulated 64-lane wavefront + an LDS image per env
 void emu_physics_wave(EmuModel *mm, float *st, const float *action, int nsub, int do_euler, float *ws_dump, int n) {
   std::vector<float> lds(std::max(tmjx_host::make_wave_layout(mm->h, true).lds_floats, tmjx_host::make_wave_layout(mm->h, false).lds_floats) + 64);
+  // TMJX_EMU_POISON=nan (or a number): what a wave finds in LDS, in its registers and in its scratch when it starts is whatever the previous wave on
+  // that CU left there — NaNs, if that env had blown up.  The kernel body must not let such words reach a result (0 x NaN is NaN: a masked product
+  // needs the select on BOTH operands or on the product); the default image is zeros, under which such a read goes unnoticed.
+  const char *poison_s = getenv("TMJX_EMU_POISON");
+  const float poison = poison_s ? (!strcmp(poison_s, "nan") ? NAN : (float)atof(poison_s)) : 0.f;
   for (int e = 0; e < n; e++) {
-    for (auto &v : lds) v = 0.f;
+    for (auto &v : lds) v = poison;
     WCtx c{&mm->h, lds.data(), st, n, e, 0, nullptr, 0ull, ws_dump};
-    std::vector<float> spill(mm->h.nnz + mm->h.nv + 64, 0.f);
+    if (poison_s) {
+      for (int l = 0; l < TMW_NL; l++) {
+        c.qfs0[l] = c.qfs1[l] = c.dg0[l] = c.dg1[l] = c.wp0[l] = c.wp1[l] = poison;
+#ifdef TMW_EMU_HAS_QA
+        c.qa0[l] = c.qa1[l] = c.ma0[l] = c.ma1[l] = poison;
+#endif
+      }
+    }
+    std::vector<float> spill(mm->h.nnz + mm->h.nv + 64, poison);
     c.mspill = spill.data() + 64;
     c.action = action;
     const WLayout K = tmjx_host::make_wave_layout(mm->h, !getenv("TMJX_EMU_GENERIC"));

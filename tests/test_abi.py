@@ -42,9 +42,10 @@ def test_no_product_import_of_oracle_or_emulation():
         assert "liboracle" not in src and "libhostemu" not in src, p
 
 
-def test_chain_layout_fits_twelve_envs_per_cu():
-    """The rodent (chain) LDS map of the wave kernel must stay within 10 of the CU's 128 LDS granules of 1280 bytes (measured granule:
-    tools/micro/lds_occupancy.hip), i.e. twelve resident envs per CU (csrc/wave_layout.h; eleven until round 4)."""
+def test_chain_layout_fits_fourteen_envs_per_cu():
+    """The rodent (chain) LDS map of the wave kernel must stay within 9 of the CU's 128 LDS granules of 1280 bytes (measured granule:
+    tools/micro/lds_occupancy.hip): room for fourteen envs per CU (csrc/wave_layout.h; ten granules in round 4) — the register bound, not LDS, keeps
+    the product at twelve (csrc/tmjx_wave.hip says why)."""
     import subprocess, tempfile, textwrap
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
@@ -58,13 +59,14 @@ def test_chain_layout_fits_twelve_envs_per_cu():
         (Path(d) / "l.cpp").write_text(src)
         subprocess.run(["g++", "-std=c++17", "-o", f"{d}/l", f"{d}/l.cpp"], check=True)
         chain, generic = (int(v) for v in subprocess.run([f"{d}/l"], check=True, capture_output=True, text=True).stdout.split())
-    # LDS is granted in 1280-byte granules on gfx950 (tools/micro/lds_occupancy.hip): 10 granules = twelve resident envs per CU (128 // 10)
-    assert chain * 4 <= 10 * 1280 and generic * 4 <= 20 * 1024 + 2048
+    # LDS is granted in 1280-byte granules on gfx950 (tools/micro/lds_occupancy.hip): 9 granules = fourteen resident envs per CU (128 // 9)
+    assert chain * 4 <= 9 * 1280 and generic * 4 <= 20 * 1024 + 2048
 
 
 def test_physics_kernel_resources_allow_three_waves_per_simd(tmp_path):
-    """The rodent physics kernel in the built library must keep <= 168 VGPRs (three waves per SIMD: 3 x 168 <= 512) and no scratch:
-    172 registers once silently cut the pipelined roll-out back to 8 envs per CU.  Read from the code object's metadata."""
+    """The rodent physics kernel in the built library must keep <= 168 VGPRs (three waves per SIMD: 3 x 168 <= 512 = twelve envs per CU; it takes
+    about 130 — the four-wave build at 128 registers was measured slower, csrc/tmjx_wave.hip), no spills and no scratch: 172 registers once
+    silently cut the pipelined roll-out back to 8 envs per CU.  Read from the code object's metadata."""
     import shutil, subprocess
     from track_mjx_amd import hip
     bundler, readelf = "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-readelf"
@@ -87,7 +89,7 @@ def test_physics_kernel_resources_allow_three_waves_per_simd(tmp_path):
     vg = int(re.search(r"\.vgpr_count:\s+(\d+)", after).group(1))
     sp = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", after).group(1))
     scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", after).group(1))
-    assert vg <= 168 and sp == 0 and scratch == 0, (vg, sp, scratch)
+    assert vg <= 136 and sp == 0 and scratch == 0, (vg, sp, scratch)
 
 
 def test_argument_validation_of_the_learner_entry_points_without_gpu():

@@ -81,15 +81,29 @@ struct WLayout {
       l_LD = l_M;
       l_scanA = l_M; l_scanB = l_M + nbody * 8; l_dscanA = l_scanA; l_dscanB = l_scanB;
       l = l_alias0;
-      l_Dinv = l; l += nv; l_efc_D = l; l += nefc; l_efc_aref = l; l += nefc; l_Jaref = l; l += nefc;
+#ifdef TMW_NO_EFCD_PACK
+      l_Dinv = l; l += nv; l_efc_D = l; l += nefc;
+#else
+      l_Dinv = l; l += nv; l_efc_D = l; l += lean ? nlim + ncon : nefc;
+#endif
+      l_efc_aref = l; l += nefc; l_Jaref = l; l += nefc;      // (lean: efc_D per CONTACT, wave_physics.h TMW_DIDX)
       l_jv = l_efc_aref; l_wr = l_efc_aref;
       // Solver vectors (round 4: 3 520 -> 3 199 words = 12 796 bytes = TEN granules of 1 280 bytes -> TWELVE envs per CU).  What left LDS or
       // shares words: D = 1 / Dinv and the previous CG direction's w live in two registers per lane (WCtx::dg*, wp*: read lane-locally only);
       // qacc_smooth (dead once the CG's start point is chosen) and qfrc_constraint (written by the LAST J^T f of a CG pass, after that pass's
       // line search has consumed search_q; read by D^-1 N^T and, after the loop, by Euler's right-hand side before timestep * damping is
       // staged there) share the words of l_search; Euler's right-hand side rides in l_Mgrad; the friction coefficient is a model scalar.
+      // Round 5: the CG's iterate qacc and ut = y - y_s, which every pass of the loop updates lane-locally, live in two registers per lane each
+      // (WCtx::qa*, ma*); the LDS image a product needs across lanes at the START of the solve (J qacc, M qacc, D^-1 N^T ut) is staged through
+      // the search direction's and its gradient's words, dead until the first gradient: l_qacc = l_mv, l_Ma = l_Mgrad.
+#ifdef TMW_NO_QA_REGS
       l_qacc = l; l += nv; l_Ma = l; l += nv;
       l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv;
+#else
+      if (!lean) { l_qacc = l; l += nv; l_Ma = l; l += nv; }
+      l_Mgrad = l; l += nv; l_search = l; l += nv; l_hdamp = l_search; l_mv = l; l += nv;
+      if (lean) { l_qacc = l_mv; l_Ma = l_Mgrad; }
+#endif
       l_qacc_smooth = lean ? l_search : l; l += lean ? 0 : nv; l_qfrc_constraint = lean ? l_search : l; l += lean ? 0 : nv;
       l_dummy = l_mv;
       int eA = l;
@@ -99,7 +113,12 @@ struct WLayout {
       l = l_alias0;
       l_xipos = l; l += nbody * 3; l_jl_anchor = l; l += njnt * 3; l_jl_axis = l; l += njnt * 3;
       int eB1 = l;
+      // (lean, round 5: cinert overlays xipos too — the cinert step takes its bodies' origins into registers before the first row is written)
+#ifdef TMW_NO_XIPOS_OVERLAY
       l_cinert = l_alias0 + nbody * 3; l_cfrc = lean ? l_M + nv * 7 : l_cinert + nbody * 10;
+#else
+      l_cinert = lean ? l_alias0 : l_alias0 + nbody * 3; l_cfrc = lean ? l_M + nv * 7 : l_cinert + nbody * 10;
+#endif
       int eB2 = lean ? l_cinert + nbody * 10 : l_cfrc + nbody * 6;
       lds_floats = eA > eB1 ? eA : eB1;
       if (eB2 > lds_floats) lds_floats = eB2;

@@ -70,6 +70,7 @@ typedef const __attribute__((address_space(4))) DModel TmwModel;
 #endif
 // a small model array as a local (the vector helpers of tm_common.h take plain pointers)
 #define TMW_LOCAL(name, n, src) float name[n]; { _Pragma("unroll") for (int k_ = 0; k_ < (n); k_++) name[k_] = (src)[k_]; }
+#define TMW_EMU_HAS_QA 1      // (tests/hostemu: WCtx carries the qa* / ma* registers)
 struct WCtx {
   TmwModel *mp;
   float *L;          // LDS
@@ -88,6 +89,8 @@ struct WCtx {
   float qfs0[TMW_NL], qfs1[TMW_NL];   // lean layout: qfrc_smooth of dof lane / lane + 64 (tmw_velocity_inertia -> solver, Euler)
   float dg0[TMW_NL], dg1[TMW_NL];     // CG: D = 1 / Dinv of dof lane / lane + 64 (tmw_solve_cg; read lane-locally only)
   float wp0[TMW_NL], wp1[TMW_NL];     // CG: w = D^-1 ghat of the PREVIOUS gradient (Polak-Ribiere numerator)
+  float qa0[TMW_NL], qa1[TMW_NL];     // lean layout, CG: the iterate qacc of dof lane / lane + 64 (in LDS only while a product with J or M reads it: l_qacc = l_mv)
+  float ma0[TMW_NL], ma1[TMW_NL];     // lean layout, CG: ut = y - y_s (first M qacc; parked in / staged through l_Ma = l_Mgrad)
   int tp0[TMW_NL], tp1[TMW_NL];       // lean layout: packed index word of dof lane / lane + 64 (DModel::tpack; round 5: the table left LDS)
   float *mspill;              // chain layout (WLayout::m_spilled): this env's copy of M in global memory (nnz words, 64 readable words in front)
 };
@@ -113,11 +116,30 @@ struct WCtx {
 #define TMW_ACT(a) (*(K.lean ? &WST(m.s_act, (a)) : &L[K.l_act + (a)]))
 #define TMW_QFS(i) (K.lean ? ((i) < 64 ? c.qfs0[TMW_LI] : c.qfs1[TMW_LI]) : L[K.l_qfrc_smooth + (i)])
 #define TMW_QFS_SET(i, v) do { if (!K.lean) L[K.l_qfrc_smooth + (i)] = (v); else if ((i) < 64) c.qfs0[TMW_LI] = (v); else c.qfs1[TMW_LI] = (v); } while (0)
+// lean layout: the CG's iterate and ut = y - y_s are updated lane-locally by every pass of the loop — two registers per lane each (round 5); an
+// LDS image exists only where a product needs the vector across lanes (J qacc, M qacc, D^-1 N^T ut at the start of the solve), staged through
+// the words of the search direction / its gradient, which are dead then (wave_layout.h: l_qacc = l_mv, l_Ma = l_Mgrad)
+#ifdef TMW_NO_QA_REGS
+#define TMW_QAREG(K) 0
+#else
+#define TMW_QAREG(K) ((K).lean)
+#endif
+#define TMW_QA(i) (TMW_QAREG(K) ? ((i) < 64 ? c.qa0[TMW_LI] : c.qa1[TMW_LI]) : L[K.l_qacc + (i)])
+#define TMW_QA_SET(i, v) do { if (!TMW_QAREG(K)) L[K.l_qacc + (i)] = (v); else if ((i) < 64) c.qa0[TMW_LI] = (v); else c.qa1[TMW_LI] = (v); } while (0)
+#define TMW_MA(i) (TMW_QAREG(K) ? ((i) < 64 ? c.ma0[TMW_LI] : c.ma1[TMW_LI]) : L[K.l_Ma + (i)])
+#define TMW_MA_SET(i, v) do { if (!TMW_QAREG(K)) L[K.l_Ma + (i)] = (v); else if ((i) < 64) c.ma0[TMW_LI] = (v); else c.ma1[TMW_LI] = (v); } while (0)
 #define TMW_DG(i) ((i) < 64 ? c.dg0[TMW_LI] : c.dg1[TMW_LI])
 #define TMW_WP(i) ((i) < 64 ? c.wp0[TMW_LI] : c.wp1[TMW_LI])
 #define TMW_WP_SET(i, v) do { if ((i) < 64) c.wp0[TMW_LI] = (v); else c.wp1[TMW_LI] = (v); } while (0)
 // friction coefficient of contact slot cc: lean layout = ONE coefficient for all slots (a uniform model read; tmjx_host::rodent_chains_match)
 #define TMW_MU(cc) (K.lean ? m.con_mu[0] : L[K.l_con_mu + (cc)])
+// efc_D of compact row kr: the four pyramid rows of a contact share ONE value (same penetration, impedance and weight), so the lean layout keeps
+// it per contact — limits first (row = index), then one word per active contact (nlim + ncon words instead of nlim + 4 ncon; round 5)
+#ifdef TMW_NO_EFCD_PACK
+#define TMW_DIDX(kr) (kr)
+#else
+#define TMW_DIDX(kr) (K.lean ? ((kr) < c.nla ? (kr) : c.nla + (((kr) - c.nla) >> 2)) : (kr))
+#endif
 #define TMW_LIMSIGN(K) ((signed char *)(L + (K).l_lim_sign))      /* sign * (compact row + 1) of a violated limit, 0 otherwise */
 TM_DEV int tm_f2i(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 TM_DEV float tm_i2f(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
@@ -202,6 +224,14 @@ TM_DEV int tmw_prefix(const int *flag, int *excl) {
 // ------------------------------------------------------------------------------------------ state in / out
 TM_DEV float tmw_load_state(WCtx &c, const WLayout &K, const float *action) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  // The env's LDS image starts from ZEROS, not from what the previous wave on this CU left there.  The branch-free row products read a few
+  // words in front of / behind their vectors and cancel them by a zero FACTOR (tmw_row_runs2: select on the matrix entry only, one instruction
+  // per product fewer) — sound while those words are finite, and a wave that ran an env whose state had blown up leaves NaNs behind.  Until
+  // round 5 every such word happened to lie in an array the position stage rewrites; with cinert moved onto xipos the tail of region B is not
+  // (tests/diagnostics/kernel_ab.py under TMJX_EMU_POISON=nan found it; on the GPU it showed as a flaky twin test under full-scale actions).
+  // Once per launch (ten substeps): 45 stores per lane.
+  TMW_FOR { for (int i = lane; i < K.lds_floats; i += 64) L[i] = 0.f; }
+  TMW_SYNC();
   TMW_FOR {
     for (int i = lane; i < K.nq + K.nv + (K.lean ? 0 : K.nu); i += 64) L[K.l_qpos + i] = WST(m.s_qpos, i);      // qpos | qvel (| act); the warm start stays in global memory
     if (K.lean) {     // the dofs' packed index words: two registers per lane, one LDS word per paw group
@@ -462,7 +492,15 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
   }
   TMW_SYNC();
   TMW_TICK2(31);
-  // (6) cinert (overwrites the dead scanB / joint-frame scratch)
+  // (6) cinert (overwrites the dead scanB / joint-frame scratch — and, in the lean layout, xipos itself: every lane takes the inertial-frame
+  // origins of its two bodies into registers first; round 5, wave_layout.h: l_cinert = l_xipos)
+  TMW_REG(float, xo0); TMW_REG(float, xo1); TMW_REG(float, xo2); TMW_REG(float, xo3); TMW_REG(float, xo4); TMW_REG(float, xo5);
+  TMW_FOR {
+    const int b0 = lane < K.nbody ? lane : 0, b1 = lane + 64 < K.nbody ? lane + 64 : 0;
+    xo0[TMW_LI] = L[K.l_xipos + b0 * 3]; xo1[TMW_LI] = L[K.l_xipos + b0 * 3 + 1]; xo2[TMW_LI] = L[K.l_xipos + b0 * 3 + 2];
+    xo3[TMW_LI] = L[K.l_xipos + b1 * 3]; xo4[TMW_LI] = L[K.l_xipos + b1 * 3 + 1]; xo5[TMW_LI] = L[K.l_xipos + b1 * 3 + 2];
+  }
+  TMW_SYNC();
   TMW_FOR {
     for (int b = lane; b < K.nbody; b += 64) {
       float ci[10];
@@ -477,7 +515,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
         float q[4], X[9], off[3];
         tm_quat_mul(q, s + 3, iq_);
         tm_quat_to_mat(X, q);
-        for (int k = 0; k < 3; k++) off[k] = L[K.l_xipos + b * 3 + k] - com[k];
+        off[0] = (b < 64 ? xo0[TMW_LI] : xo3[TMW_LI]) - com[0]; off[1] = (b < 64 ? xo1[TMW_LI] : xo4[TMW_LI]) - com[1]; off[2] = (b < 64 ? xo2[TMW_LI] : xo5[TMW_LI]) - com[2];
         float oo = tm_dot3(off, off);
         ci[0] = X[0] * in[0] * X[0] + X[1] * in[1] * X[1] + X[2] * in[2] * X[2] + (oo - off[0] * off[0]) * mass;
         ci[1] = X[3] * in[0] * X[3] + X[4] * in[1] * X[4] + X[5] * in[2] * X[5] + (oo - off[1] * off[1]) * mass;
@@ -487,8 +525,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
         ci[5] = X[3] * in[0] * X[6] + X[4] * in[1] * X[7] + X[5] * in[2] * X[8] - off[1] * off[2] * mass;
         ci[6] = off[0] * mass; ci[7] = off[1] * mass; ci[8] = off[2] * mass; ci[9] = mass;
       }
-      // NOTE: written after every lane has read its xipos/xquat inputs above in this block only for its OWN body;
-      // cinert rows never overlap scanA or xipos (model_host.h LDS map), so no cross-lane hazard.
+      // cinert rows never overlap scanA (the matrix region in the lean layout); xipos, which they may overlay, is in registers since the barrier above
       for (int k = 0; k < 10; k++) L[K.l_cinert + b * 10 + k] = ci[k];
     }
   }
@@ -1618,7 +1655,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
       const int r0b = TMW_CCROW(K)[cc], r0 = on ? r0b : 0;      // first of the contact's four compact rows (255: none)
       float ja[4], D[4], f[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) { ja[e] = L[K.l_Jaref + r0 + e]; D[e] = L[K.l_efc_D + r0 + e]; }
+      for (int e = 0; e < 4; e++) { ja[e] = L[K.l_Jaref + r0 + e]; D[e] = L[K.l_efc_D + TMW_DIDX(r0 + e)]; }
       const float mu = TMW_MU(cc);
       const float *off = L + K.l_con_off + cc * 3;
       const float o0 = off[0], o1 = off[1], o2 = off[2];
@@ -1674,7 +1711,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
       {                  // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise (branch-free: see above)
         const int svb = TMW_LIMSIGN(K)[lr >= 0 ? lr : 0], sv = lr >= 0 ? svb : 0;
         const int kr = sv != 0 ? (sv < 0 ? -sv : sv) - 1 : 0;
-        const float ja = L[K.l_Jaref + kr], D = L[K.l_efc_D + kr];
+        const float ja = L[K.l_Jaref + kr], D = L[K.l_efc_D + TMW_DIDX(kr)];
         const float fl = -D * ja;
         s = (sv != 0 && ja < 0.f) ? (sv > 0 ? fl : -fl) : 0.f;
       }
@@ -1765,7 +1802,7 @@ TM_DEV void tmw_make_constraint(WCtx &c, const WLayout &K) {
       }
       tm_kbi(m.timestep, solref, solimp, pos, k, b, imp);
       float Rr = fmaxf(iw * (1.f - imp) / imp, TM_MINVAL);
-      L[K.l_efc_D + kr] = 1.f / Rr;
+      L[K.l_efc_D + TMW_DIDX(kr)] = 1.f / Rr;        // (lean: the four rows of a contact write the same word with the same value)
       L[K.l_efc_aref + kr] = -b * L[K.l_jv + kr] - k * imp * pos;
     }
   }
@@ -1821,9 +1858,10 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool 
     for (int e = lane; e < c.nact; e += 64) {
       float ja = L[K.l_Jaref + e] - L[K.l_efc_aref + e];
       L[K.l_Jaref + e] = ja;
-      if (ja < 0.f) sc += L[K.l_efc_D + e] * ja * ja;
+      if (ja < 0.f) sc += L[K.l_efc_D + TMW_DIDX(e)] * ja * ja;
     }
-    if (!jonly) for (int i = lane; i < K.nv; i += 64) sg += (L[K.l_Ma + i] - TMW_QFS(i)) * (L[q + i] - L[K.l_qacc_smooth + i]);
+    // (lean: the only evaluation with a Gauss term is the warm start's, q = l_qacc: iterate and M q come from their registers)
+    if (!jonly) for (int i = lane; i < K.nv; i += 64) sg += (TMW_MA(i) - TMW_QFS(i)) * ((TMW_QAREG(K) ? TMW_QA(i) : L[q + i]) - L[K.l_qacc_smooth + i]);
     pc[TMW_LI] = sc; pg[TMW_LI] = sg;
   }
   TMW_SYNC();
@@ -1882,7 +1920,7 @@ TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num, float im
   TMW_FOR {
     float sa = 0.f, sb = 0.f;
     for (int i = lane; i < K.nv; i += 64) {
-      float w = L[K.l_Ma + i] - L[K.l_Mgrad + i], dw = TMW_DG(i) * w;
+      float w = TMW_MA(i) - L[K.l_Mgrad + i], dw = TMW_DG(i) * w;
       L[K.l_Mgrad + i] = w;
       sa += dw * w; sb += dw * (w - TMW_WP(i));
     }
@@ -2063,7 +2101,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int i = lane; i < K.nv; i += 64) {
       float sq = L[K.l_search + i], ds = TMW_DG(i) * L[K.l_mv + i];
-      a0 += sq * sq; a1 += ds * L[K.l_Ma + i]; a2 += ds * L[K.l_mv + i];
+      a0 += sq * sq; a1 += ds * TMW_MA(i); a2 += ds * L[K.l_mv + i];
     }
     p0[TMW_LI] = a0; p1[TMW_LI] = a1; p2[TMW_LI] = a2;
   }
@@ -2079,7 +2117,7 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
       // nact <= 16: the rows sit in lanes 0-15 and are replicated in lanes 16-31 and 32-47 (tmw_ls_points16)
       int e = w16 ? (lane & 15) : lane + 64 * sl;
       bool ok = w16 ? (sl == 0 && lane < 48 && e < c.nact) : e < c.nact;
-      float ja = ok ? L[K.l_Jaref + (ok ? e : 0)] : 1.f, jv = ok ? L[K.l_jv + (ok ? e : 0)] : 0.f, D = ok ? L[K.l_efc_D + (ok ? e : 0)] : 0.f;   // padding rows: never active
+      float ja = ok ? L[K.l_Jaref + (ok ? e : 0)] : 1.f, jv = ok ? L[K.l_jv + (ok ? e : 0)] : 0.f, D = ok ? L[K.l_efc_D + (ok ? TMW_DIDX(e) : 0)] : 0.f;   // padding rows: never active
       R.ja[TMW_LI][sl] = ja; R.jv[TMW_LI][sl] = jv; R.D[TMW_LI][sl] = D;
       R.t0[TMW_LI][sl] = 0.5f * ja * ja * D; R.t1[TMW_LI][sl] = jv * ja * D; R.t2[TMW_LI][sl] = 0.5f * jv * jv * D;
     }
@@ -2095,8 +2133,8 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   TMW_FOR {
     float sc = 0.f, sg = 0.f;
     for (int i = lane; i < K.nv; i += 64) {
-      float qa = L[K.l_qacc + i] + L[K.l_search + i] * ia, ut = L[K.l_Ma + i] + L[K.l_mv + i] * ia;
-      L[K.l_qacc + i] = qa; L[K.l_Ma + i] = ut;
+      float qa = TMW_QA(i) + L[K.l_search + i] * ia, ut = TMW_MA(i) + L[K.l_mv + i] * ia;
+      TMW_QA_SET(i, qa); TMW_MA_SET(i, ut);
       sg += TMW_DG(i) * ut * ut;
     }
 #pragma unroll
@@ -2118,8 +2156,11 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
 #endif
   TMW_FOR {
     c.dg1[TMW_LI] = 0.f; c.wp1[TMW_LI] = 0.f;
+    if (TMW_QAREG(K)) { c.qa1[TMW_LI] = 0.f; c.ma1[TMW_LI] = 0.f; }
     for (int i = lane; i < K.nv; i += 64) {
-      L[K.l_qacc + i] = WST(m.s_warm, i);
+      const float wq = WST(m.s_warm, i);
+      L[K.l_qacc + i] = wq;                                           // (lean: the staging image J qacc reads below)
+      if (TMW_QAREG(K)) { TMW_QA_SET(i, wq); TMW_MA_SET(i, L[K.l_Ma + i]); }     // ... and M * warm start, parked in l_Ma = l_Mgrad since tmw_forward took it
       const float dgi = 1.f / L[K.l_Dinv + i];
       if (i < 64) { c.dg0[TMW_LI] = dgi; c.wp0[TMW_LI] = 0.f; } else { c.dg1[TMW_LI] = dgi; c.wp1[TMW_LI] = 0.f; }
     }
@@ -2131,13 +2172,14 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   float cw = tmw_eval_cost(c, K, K.l_qacc, gauss, false, K.m_spilled());
   float cost = cw;
   if (cw < cs) {     // ut = y - y_s = D^-1 N^T (M qacc - qfrc_smooth)
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Ma + i] -= TMW_QFS(i); }
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Ma + i] -= TMW_QFS(i); }      // (lean: on the parked image, still intact)
     TMW_SYNC();
     tmw_solve_up(c, K, K.l_Ma, K.l_Ma);
+    if (TMW_QAREG(K)) { TMW_FOR { for (int i = lane; i < K.nv; i += 64) TMW_MA_SET(i, L[K.l_Ma + i]); } }
   } else {
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) { L[K.l_qacc + i] = L[K.l_qacc_smooth + i]; L[K.l_Ma + i] = 0.f; } }
+    TMW_FOR { for (int i = lane; i < K.nv; i += 64) { const float qs = L[K.l_qacc_smooth + i]; if (TMW_QAREG(K)) { TMW_QA_SET(i, qs); TMW_MA_SET(i, 0.f); } else { L[K.l_qacc + i] = qs; L[K.l_Ma + i] = 0.f; } } }
     TMW_SYNC();
-    cost = tmw_eval_cost(c, K, K.l_qacc, gauss, true);
+    cost = tmw_eval_cost(c, K, TMW_QAREG(K) ? K.l_qacc_smooth : K.l_qacc, gauss, true);      // (J q only: the same vector, read where it lies)
   }
   float prev_cost = INFINITY, num;
   float gn = tmw_update_gradient(c, K, num);
@@ -2179,7 +2221,8 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     TMW_TICK(8);
   }
   TMW_STATS(K) += 64.f * (float)it;
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) WST(m.s_warm, i) = L[K.l_qacc + i]; }
+  TMW_FOR { for (int i = lane; i < K.nv; i += 64) WST(m.s_warm, i) = TMW_QA(i); }
+  if (c.dump) { TMW_FOR { for (int i = lane; i < K.nv; i += 64) c.dump[(size_t)(m.w_qacc + i) * (size_t)c.n + (size_t)c.e] = TMW_QA(i); } }
   // (tests: qfrc_constraint shares its words with l_search = l_hdamp in the lean layout — Euler overwrites them)
   if (c.dump) { TMW_FOR { for (int i = lane; i < K.nv; i += 64) c.dump[(size_t)(m.w_qfrc_constraint + i) * (size_t)c.n + (size_t)c.e] = L[K.l_qfrc_constraint + i]; } }
   TMW_SYNC();
@@ -2307,7 +2350,6 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
     for (int i = lane; i < K.nv * 6; i += 64) WDUMP(m.w_cdof, i) = L[K.l_cdof + i];
     for (int i = lane; i < K.nv; i += 64) {
       WDUMP(m.w_qfrc_smooth, i) = TMW_QFS(i);        // (qacc_smooth, qfrc_constraint: written where they arise — tmw_forward, tmw_solve_cg)
-      WDUMP(m.w_qacc, i) = L[K.l_qacc + i];
     }
     for (int i = lane; i < K.ncon; i += 64) WDUMP(m.w_con_dist, i) = L[K.l_con_dist + i];
     for (int cc = lane; cc < K.ncon; cc += 64) {
@@ -2321,7 +2363,7 @@ TM_DEV void tmw_dump(WCtx &c, const WLayout &K, float *ws) {
       if (r < K.nlim) { float sv = (float)TMW_LIMSIGN(K)[r]; if (sv != 0.f) kr = (int)fabsf(sv) - 1; }
       else if (TMW_CCROW(K)[(r - K.nlim) >> 2] != 255) kr = TMW_CCROW(K)[(r - K.nlim) >> 2] + ((r - K.nlim) & 3);
       float ja = kr >= 0 ? L[K.l_Jaref + kr] : 0.f;
-      WDUMP(m.w_efc_force, r) = ja < 0.f ? -L[K.l_efc_D + kr] * ja : 0.f;
+      WDUMP(m.w_efc_force, r) = ja < 0.f ? -L[K.l_efc_D + TMW_DIDX(kr)] * ja : 0.f;
     }
     if (lane < 3) WDUMP(m.w_com, lane) = L[K.l_com + lane];
     // solver statistics of the last substep: CG iterations, line-search iterations (summed), rows that entered the solver, of which limits
