@@ -52,7 +52,7 @@ CONFIGS = {
     "cfg4": dict(envs_per_gpu=4096, n_clips=64, nets=FULL_NETS, rows_per_gpu=1024, matmul_dtype=None, random_clips=False,
                  label="rodent-mc-intention nets (enc 1024-512x4, dec 512x3-256x2, critic 512x5-256), fp32"),
     "cfg5": dict(envs_per_gpu=8192, n_clips=1024, nets=FULL_NETS, rows_per_gpu=2048, matmul_dtype="bf16", random_clips=True,
-                 label="1024-clip table (per-env clip gather), rodent-mc-intention nets with bf16 GEMM inputs / fp32 accumulate"),
+                 label="1024-clip table (per-env clip gather), rodent-mc-intention nets as a bf16 MLP on MFMA: GEMM inputs, hidden activations AND the saved pre-activations z in bf16, fp32 accumulate, fp32 master weights / loss head / optimiser"),
 }
 
 
@@ -368,7 +368,9 @@ def main(argv=None, runner=None):
             "metric": "env-steps/sec (whole node), rodent task @ 4096 envs/GPU", "value": env_steps / elapsed,
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if bc["matmul_dtype"] is None else f"f32 (physics, reward, loss head, optimiser) + {bc['matmul_dtype']} MLP GEMM inputs with f32 accumulate",
+            # (bf16 mode goes beyond SURVEY a16's "bf16 only for GEMM inputs": the pre-activations the backward epilogues re-read are saved as bf16 too —
+            # BASELINE configs[4] says "bf16 MLP on MFMA"; the fp32-z form of the same kernels measured 3.94 against 3.79 ms per minibatch step)
+            "dtype": "f32" if bc["matmul_dtype"] is None else f"f32 (physics, reward, loss head, optimiser, master weights) + {bc['matmul_dtype']} MLP: GEMM inputs, hidden activations and saved pre-activations in {bc['matmul_dtype']}, f32 accumulate",
             "data": "synthetic", "so_build_id": so_build_id(), "mjx_cpu": mjx_cpu_probe(),
             "config": {"workload": f"rodent tracking PPO training step ({args.config}): {n_local} envs/GPU, {learner.env_steps_per_training_step // (n_local * learner.T * world)}x{learner.T}-step unrolls (10 physics substeps each) + {sgd_steps} minibatch updates, {bc['label']}",
                        "n_clips": bc["n_clips"], "mlp_gemm_inputs": bc["matmul_dtype"] or "f32",

@@ -26,6 +26,12 @@ typedef float bgf2 __attribute__((ext_vector_type(2)));
 typedef unsigned bgu4 __attribute__((ext_vector_type(4)));
 typedef unsigned bgu2 __attribute__((ext_vector_type(2)));
 typedef unsigned short bf16_t;
+// (the acting policy's layer raises its waves' priority over the physics waves it runs next to: csrc/tm_common.h, TM_PRIO_ACTING)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TMJX_NO_ACT_PRIO)
+#define TM_PRIO_ACTING_BF() __builtin_amdgcn_s_setprio(3)
+#else
+#define TM_PRIO_ACTING_BF() do { } while (0)
+#endif
 
 #define BG_LDS(p) ((__attribute__((address_space(3))) void *)(p))
 #define BG_GLB(p) ((const __attribute__((address_space(1))) void *)(p))
@@ -797,6 +803,7 @@ template <bool A_KMAJOR>
 __global__ __launch_bounds__(64) void k_linear_nolds_bf16(const float *__restrict__ A, long long sa_row, long long sa_k, const bf16_t *__restrict__ W, int ldw,
                                                           const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                                           const float *__restrict__ mean, const float *__restrict__ inv_std) {
+  TM_PRIO_ACTING_BF();
   const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
   int ar[2], wc[2];

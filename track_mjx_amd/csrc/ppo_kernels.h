@@ -385,6 +385,7 @@ template <int VPT, bool OUT16 = false>
 __global__ __launch_bounds__(256) void k_silu_ln_fwd(const float *__restrict__ z, const float *__restrict__ bias, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ stats, int rows,
                                                      float eps, unsigned short *__restrict__ y16 = nullptr, int ldy16 = 0) {
+  TM_PRIO_ACTING();
   constexpr int H = VPT * 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float b[VPT], g[VPT], be[VPT];
@@ -481,6 +482,7 @@ template <bool A_KMAJOR>
 __global__ __launch_bounds__(64) void k_linear_nolds_mfma(const float *__restrict__ A, long long sa_row, long long sa_k, const float *__restrict__ W,
                                                           const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                                           const float *__restrict__ mean = nullptr, const float *__restrict__ inv_std = nullptr) {
+  TM_PRIO_ACTING();
   // mean / inv_std (optional, [K]): the operand is (A - mean) * inv_std — the observation normaliser applied while the raw observation is
   // loaded (the first layer of the LDS-free inference: no element-wise launch in front of it)
   typedef float __attribute__((ext_vector_type(4))) f4;
@@ -686,6 +688,7 @@ __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__
                                                        float *__restrict__ x, int n, int Z, int obs_w, int ref_w, long long obs_s0, long long obs_s1,
                                                        const float *__restrict__ mean, const float *__restrict__ stdv, int x_stride,
                                                        unsigned long long seed, const long long *__restrict__ rng_state) {
+  TM_PRIO_ACTING();
   // eps == nullptr: the latent noise is drawn here, Philox stream 2 of (seed, draw counter rng_state[0]) — the acting policy's graph then
   // holds no torch generator (two state fills per replay) and no normal_ launch; the pad columns [W, x_stride) are written as zeros
   const int W = Z + obs_w - ref_w;
@@ -721,6 +724,7 @@ __global__ __launch_bounds__(256) void k_latent_concat_bwd(const float *__restri
 __global__ __launch_bounds__(PPO_BLOCK) void k_sample_action(const float *__restrict__ logits, const float *__restrict__ noise, float *__restrict__ raw,
                                                              float *__restrict__ action_t, float *__restrict__ logp, int n, int A,
                                                              unsigned long long seed, long long *__restrict__ rng_state) {
+  TM_PRIO_ACTING();
   // noise == nullptr: drawn here (Philox stream 3 of (seed, rng_state[0])); the workgroup that finishes last then advances the draw counter
   // for the next inference (every workgroup has read it by then; ticket in rng_state[1])
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, e = gid / PPO_G, sub = gid % PPO_G;
@@ -774,6 +778,7 @@ template <> __device__ __forceinline__ void nl_unpack<1>(const float &v, float *
 template <int V, bool A_KMAJOR>
 __global__ __launch_bounds__(128) void k_linear_nolds(const float *__restrict__ A, long long sa_row, long long sa_k, const float *__restrict__ W,
                                                       const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K) {
+  TM_PRIO_ACTING();
   typedef typename NlVec<V>::T VT;
   const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;                   // 16 x 8 threads: a 64-row x 32-column tile per workgroup
   const int row0 = blockIdx.x * 64 + ty * NL_TM, col0 = blockIdx.y * 32 + tx * NL_TN;
@@ -1038,6 +1043,7 @@ struct RolloutStore {
   float *obs_dst2;
 };
 __global__ __launch_bounds__(64) void k_rollout_store(const RolloutStore s) {
+  TM_PRIO_ACTING();
   const int e = blockIdx.x * 64 + threadIdx.x, ny = gridDim.y - 1;
   if ((int)blockIdx.y < ny) {
     if (e >= s.n || !s.obs) return;

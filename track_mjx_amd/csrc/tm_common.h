@@ -131,3 +131,12 @@ TM_DEV void tm_kbi(float timestep, const float *solref, const float *solimp, flo
 TM_DEV void tm_kbi(const DModel &m, const float *solref, const float *solimp, float pos, float &k, float &b, float &imp) {
   tm_kbi(m.timestep, solref, solimp, pos, k, b, imp);
 }
+
+// Kernels of an env group's SERIAL phase (K3, roll-out store, acting policy: between two physics launches of the group) run next to the other groups'
+// physics waves, which are older and therefore win the SIMD's issue arbitration at equal priority (MI355X_MICROARCH.md "priority, then age"): these
+// short, latency-critical waves raise their own priority for their whole life (round 5; -DTMJX_NO_ACT_PRIO builds without it for A/B runs).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TMJX_NO_ACT_PRIO)
+#define TM_PRIO_ACTING() __builtin_amdgcn_s_setprio(3)
+#else
+#define TM_PRIO_ACTING() do { } while (0)
+#endif

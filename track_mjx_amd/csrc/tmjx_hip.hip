@@ -102,6 +102,7 @@ __global__ void k_window(const DModel *__restrict__ mp, float *st, const int *is
 }
 __global__ void k_post(const DModel *__restrict__ mp, float *st, int *is, const float *action, float *obs, float *reward,
                        float *done, float *trunc, float *metrics, const float *win, int split, int rep, int n) {
+  TM_PRIO_ACTING();
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const DModel &m = *mp;
@@ -141,6 +142,7 @@ __global__ void k_obs(const DModel *__restrict__ mp, float *st, const int *is, f
 // such launches mostly waited for wave slots: no gain; re-measured in round 3 with three env groups and one-wave blocks everywhere.)
 __global__ __launch_bounds__(64) void k_step_parts(const DModel *__restrict__ mp, float *st, const int *is, const float *action, float *win,
                                                    float *__restrict__ obs, float *P, int n, int n_obs_parts) {
+  TM_PRIO_ACTING();
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const DModel &m = *mp;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(64) void k_step_parts(const DModel *__restrict__ mp
 // auto-reset of the envs that are done: physics state, observation and prev_ctrl <- the snapshot taken at reset
 // (wrappers.py:104-144), one lane per (env, block of 16 rows)
 __global__ void k_autoreset(const DModel *__restrict__ mp, float *st, float *obs, const float *done, int n) {
+  TM_PRIO_ACTING();
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n || done[e] == 0.f) return;
   const DModel &m = *mp;
@@ -186,6 +189,7 @@ __global__ void k_autoreset(const DModel *__restrict__ mp, float *st, float *obs
 #define REC_ROWS_PER_THREAD 16
 __global__ __launch_bounds__(64) void k_rec_in(const DModel *__restrict__ mp, const float *__restrict__ st, const float *__restrict__ action,
                                                float *__restrict__ rec, int n, int rs) {
+  TM_PRIO_ACTING();
   const DModel &m = *mp;
   const int e = blockIdx.x * 64 + threadIdx.x, r0 = blockIdx.y * REC_ROWS_PER_THREAD;     // rows: nphys state rows, then nu action rows
   const int nrow = m.nphys + m.nu;
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(64) void k_rec_in(const DModel *__restrict__ mp, co
   }
 }
 __global__ __launch_bounds__(64) void k_rec_out(const DModel *__restrict__ mp, float *__restrict__ st, const float *__restrict__ rec, int n, int rs) {
+  TM_PRIO_ACTING();
   const DModel &m = *mp;
   const int e = blockIdx.x * 64 + threadIdx.x, r0 = blockIdx.y * REC_ROWS_PER_THREAD;
   const int nrow = m.s_prev_ctrl - m.s_qpos;      // physics state + xpos / torso xmat / qfrc_actuator
@@ -1067,11 +1072,11 @@ int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
   DwGroup G;
   G.n = n;
   int wg = 0, red = 0;
-  // The problems of a group run side by side in ONE launch: together they should fill the chip about twice (TMJX_DW_GROUP_WGS workgroups, two
+  // The problems of a group run side by side in ONE launch: together they should fill the chip about four times (TMJX_DW_GROUP_WGS = 1024 workgroups: two
   // 74 KB workgroups fit a CU), not once EACH — nine problems split for 256 workgroups apiece were 2 300 workgroups writing and re-reading
   // 64 slabs per weight matrix (160 MB per backward pass at 20 480 rows, 130 MB at 5 120).  Never more slabs than the problem's own split
   // (the caller sized the scratch by tmjx_gemm_dw_scratch_floats).
-  static const int group_target = getenv("TMJX_DW_GROUP_WGS") ? atoi(getenv("TMJX_DW_GROUP_WGS")) : 512;
+  static const int group_target = getenv("TMJX_DW_GROUP_WGS") ? atoi(getenv("TMJX_DW_GROUP_WGS")) : 1024;
   int all_tiles = 0;
   for (int i = 0; i < n; i++) all_tiles += ((probs[i].N + DW_BT - 1) / DW_BT) * ((probs[i].K + DW_BT - 1) / DW_BT);
   const int max_slabs = group_target > 0 ? (group_target + all_tiles - 1) / (all_tiles > 0 ? all_tiles : 1) : 0;
