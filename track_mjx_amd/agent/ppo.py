@@ -170,7 +170,7 @@ class FlatAdam:
         return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
 
 
-RESIDENT_ENVS_PER_CU = 12      # csrc/wave_layout.h: 12 780 B of LDS per env = 10 of a CU's 128 granules of 1 280 B (round 4; 11 envs per CU before)
+RESIDENT_ENVS_PER_CU = 12      # three waves per SIMD (csrc/tmjx_wave.hip: the register bound; the LDS image, 9 granules of 1 280 B since round 5, would allow 14)
 
 
 def default_groups(n_envs: int, device=None, widest_layer: int = 256) -> int:
