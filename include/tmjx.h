@@ -300,6 +300,10 @@ typedef struct tmjx_dw_problem_t {
   int32_t ldy, ldx, lddw, M, N, K;
 } tmjx_dw_problem_t;
 int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *problems, int n, void *stream);
+/* The same with the group's workgroup budget stated by the caller (0 = the default, 1024): the slab count of every problem is capped so that the
+ * whole launch is about `target_wgs` workgroups — a group launched NEXT TO other kernels (the value network's weight gradients behind its own
+ * backward pass, while the policy's still runs: agent/ppo.py) asks for fewer. */
+int tmjx_gemm_dw_grouped_wgs(const tmjx_dw_problem_t *probs, int n, int target_wgs, void *stream);
 
 /* ---- bf16 GEMM-input mode (BASELINE config 5 "bf16 MLP on MFMA"; layers: track_mjx/agent/mlp_ppo/intention_network.py:14-142, sizes
  * track_mjx/config/rodent-full-clips.yaml:50-57): operands bf16, accumulation and results fp32, v_mfma_f32_16x16x32_bf16 (csrc/gemm_bf16.h).

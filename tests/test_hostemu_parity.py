@@ -223,3 +223,37 @@ def test_action_repeat_of_the_episode_wrapper(setup, R):
             print(f"action_repeat {R}: summed reward err {rew_err:.2e}, obs rel err {obs_err:.2e} against the float32 oracle")
             assert rew_err < 2e-5 * R and obs_err < 2e-4
     assert seen_trunc and seen_restart, (seen_trunc, seen_term, seen_restart)
+
+
+def test_wave_kernel_results_do_not_depend_on_what_a_wave_finds_when_it_starts(setup, monkeypatch):
+    """A wave starts on whatever the previous wave of its CU left in LDS, in the registers and in its scratch — NaNs, if that env had blown up.
+    TMJX_EMU_POISON=nan starts the emulated wave from NaNs instead of zeros: free-running through contact, every physics row and output must come
+    out bit for bit as from the zero image.  (Round 5: the branch-free row products cancel out-of-range words by a zero factor; with cinert moved
+    onto xipos some of those words were no longer rewritten every substep, and the GPU's `action_repeat` twin test turned flaky under full-scale
+    actions — tmw_load_state now zero-fills the env's LDS image.)"""
+    w, blob, clip = setup
+    n = 12
+    res = []
+    for poison in (False, True):
+        if poison:
+            monkeypatch.setenv("TMJX_EMU_POISON", "nan")
+        else:
+            monkeypatch.delenv("TMJX_EMU_POISON", raising=False)
+        E = Emu(blob, n)
+        rng = np.random.default_rng(11)
+        qpos, qvel = _states(clip, n, rng, 0.001)
+        E.rows("qpos")[:] = qpos.T; E.rows("qvel")[:] = qvel.T
+        E.physics_wave(None, 1, do_euler=False)
+        out, contact = [], 0
+        for ctl in range(2):
+            a = np.clip(rng.normal(size=(n, 38)) * (0.3 if ctl == 0 else 1.0), -1, 1).T.astype(np.float32).copy()
+            for sub in range(10):
+                E.physics_wave(a, 1, True, dump=True)
+                out.append({k: E.rows(k).copy() for k in ("qpos", "qvel", "act", "qacc_warmstart", "xpos", "qfrc_actuator", "solver_stats")})
+                contact += int((E.rows("con_dist") < 0).any(0).sum())
+        res.append(out)
+        assert contact > 20
+    for t, (x, y) in enumerate(zip(*res)):
+        for k in x:
+            same = (x[k] == y[k]) | (np.isnan(x[k]) & np.isnan(y[k]))
+            assert same.all(), (t, k, int((~same).sum()))

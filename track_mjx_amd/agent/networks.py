@@ -325,6 +325,14 @@ class deferred_weight_grads:
         self.problems.append((dy2, x2, gw, gb))
         return gw, gb
 
+    def launch_subset(self, pick, target_wgs: int = 0):
+        """The recorded problems whose gradient view `pick(gw)` selects, NOW (stream-ordered on the current stream), as a group of their own with
+        a workgroup budget of `target_wgs` (0: the default); the others stay recorded for launch().  PPOLearner uses it to run the value network's
+        weight gradients on the side stream right behind that network's backward pass, next to the policy's backward pass on the main stream."""
+        mine = [q for q in self.problems if pick(q[2])]
+        self.problems = [q for q in self.problems if not pick(q[2])]
+        self._launch_problems(mine, target_wgs)
+
     def launch(self):
         import ctypes as C
         from .. import hip as _hip
@@ -339,7 +347,7 @@ class deferred_weight_grads:
         self._launch_problems(self.problems)
         self.problems = []
 
-    def _launch_problems(self, problems):
+    def _launch_problems(self, problems, target_wgs: int = 0):
         import ctypes as C
         from .. import hip as _hip
         if not problems:
@@ -355,7 +363,7 @@ class deferred_weight_grads:
                                     scratch.data_ptr() + 4 * off, dy.stride(0), x.stride(0), gw.stride(0), dy.shape[0], dy.shape[1], x.shape[1])
             off += (sizes[i] + 3) // 4 * 4
         with torch.cuda.device(dev):
-            _hip.check(L.tmjx_gemm_dw_grouped(arr, len(problems), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_gemm_dw_grouped")
+            _hip.check(L.tmjx_gemm_dw_grouped_wgs(arr, len(problems), int(target_wgs), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_gemm_dw_grouped")
         self.keep += [scratch] + [t for q in problems for t in q[:2]]
 
 

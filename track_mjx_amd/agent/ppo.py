@@ -256,6 +256,11 @@ class PPOLearner:
         # C1 in TWO buckets (the flat buffer is [policy | value]): the value network's gradients are reduced while the policy's backward pass
         # still runs (update()).  The reference's pmean sits inside the jitted step where XLA overlaps it (ppo.py:621-623)
         self._bucket_split = self.grads.segs[self._n_policy_params][0]
+        # (the value network's gradient views, and the workgroup budget of an EARLY weight-gradient group for them on the side stream, behind that
+        # network's backward pass and next to the policy's: TMJX_VALUE_DW_WGS.  Default 0 = one group at the end of the step: measured in round 5 at
+        # budgets 256 / 384 / 512 / 768 — 0.99 – 1.02 ms per config-2 minibatch step against 0.97 – 1.00 for the single group; the chip is busy either way)
+        self._value_grad_ptrs = {p.grad.data_ptr() for p in self.grads.params[self._n_policy_params:]}
+        self._value_dw_wgs = int(os.environ.get("TMJX_VALUE_DW_WGS", "0"))
         # Used when the gradient buffer is large (>= 8 MB: the rodent-mc-intention nets' 17.2 MB, ~ 0.2 ms on a ring) — cutting the captured
         # step into three graphs and issuing two collectives costs ~ 0.15 ms per minibatch step (measured with a one-rank RCCL group,
         # profiles/r04_bench_selflaunch_one_rank_bucketed.json), more than the 2.49 MB buffer of the 2x256 nets takes to reduce.  TMJX_BUCKET_OVERLAP=1 / 0 forces it
@@ -656,8 +661,14 @@ class PPOLearner:
             with deferred_weight_grads() as dwg:
                 grads = torch.autograd.grad(o, params, grad_outputs=g)
             if which != "policy" and self._sgd_side is not None:
+                if which == "all" and self._value_dw_wgs > 0:
+                    # the value network's weight gradients as a group of their own on the side stream, right behind that network's backward pass (autograd
+                    # has queued it there): they run NEXT TO the policy's backward pass instead of behind it in the one launch at the end of the step
+                    vptr = self._value_grad_ptrs
+                    with torch.cuda.stream(self._sgd_side):
+                        dwg.launch_subset(lambda gw: gw.data_ptr() in vptr, self._value_dw_wgs)
                 torch.cuda.current_stream(self.dev).wait_stream(self._sgd_side)     # the value net's backward ran there
-            dwg.launch()             # every layer's (dW, db) in one grouped launch, straight into the flat gradient buffer
+            dwg.launch()             # every (remaining) layer's (dW, db) in one grouped launch, straight into the flat gradient buffer
         setattr(self, "_dwg_" + which, dwg)          # (keeps the slab scratch alive until the next step)
         if which == "all":
             self.grads.assign(grads)

@@ -1066,7 +1066,8 @@ int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, f
   return check_launch("k_gemm_dw");
 }
 
-int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
+int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) { return tmjx_gemm_dw_grouped_wgs(probs, n, 0, stream); }
+int tmjx_gemm_dw_grouped_wgs(const tmjx_dw_problem_t *probs, int n, int target_wgs, void *stream) {
   if (!probs) return fail(TMJX_EINVAL, "null argument");
   if (n < 1 || n > DW_GROUP_MAX) return fail(TMJX_EINVAL, "1 .. 16 problems per group");
   DwGroup G;
@@ -1076,7 +1077,8 @@ int tmjx_gemm_dw_grouped(const tmjx_dw_problem_t *probs, int n, void *stream) {
   // 74 KB workgroups fit a CU), not once EACH — nine problems split for 256 workgroups apiece were 2 300 workgroups writing and re-reading
   // 64 slabs per weight matrix (160 MB per backward pass at 20 480 rows, 130 MB at 5 120).  Never more slabs than the problem's own split
   // (the caller sized the scratch by tmjx_gemm_dw_scratch_floats).
-  static const int group_target = getenv("TMJX_DW_GROUP_WGS") ? atoi(getenv("TMJX_DW_GROUP_WGS")) : 1024;
+  static const int group_default = getenv("TMJX_DW_GROUP_WGS") ? atoi(getenv("TMJX_DW_GROUP_WGS")) : 1024;
+  const int group_target = target_wgs > 0 ? target_wgs : group_default;       // (a group that runs NEXT TO other kernels asks for fewer workgroups)
   int all_tiles = 0;
   for (int i = 0; i < n; i++) all_tiles += ((probs[i].N + DW_BT - 1) / DW_BT) * ((probs[i].K + DW_BT - 1) / DW_BT);
   const int max_slabs = group_target > 0 ? (group_target + all_tiles - 1) / (all_tiles > 0 ? all_tiles : 1) : 0;
