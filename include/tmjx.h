@@ -214,6 +214,13 @@ int tmjx_latent_concat(const float *fc2, const float *eps, const float *obs, flo
 int tmjx_sample_action(const float *logits, const float *noise, float *raw, float *action_t, float *logp, int n, int A, uint64_t seed,
                        int64_t *rng_state, void *stream);
 
+/* The acting policy's dense layer (brax acting.actor_step through make_inference_fn, track_mjx/agent/mlp_ppo/ppo_networks.py:46-96; layers of
+ * intention_network.py:32-44,68-76) through a 20 KB LDS tile — what the CUs have free next to twelve resident physics workgroups since round 5:
+ * C[M][N] = op(A) W^T (+ bias), A row-major [M][lda], W [N][ldw], op = identity or (A - mean[k]) * inv_std[k] (mean / inv_std: both or neither).
+ * tmjx_linear_act_ok: 1 when the operands qualify (K % 4 == 0, 16-byte aligned rows); otherwise use tmjx_linear_nolds. */
+int tmjx_linear_act_ok(const float *A, int64_t lda, const float *W, int ldw, int K);
+int tmjx_linear_act(const float *A, int64_t lda, const float *W, int ldw, const float *bias, float *C, int M, int N, int K,
+                    const float *mean, const float *inv_std, void *stream);
 /* LDS-free dense layer (policy inference next to the physics kernel, which owns every CU's LDS):
  * C[M][N] = A W^T + bias (bias may be NULL); W [N][K] row-major; A[i][k] at A[i * sa_row + k * sa_k] with either sa_k == 1
  * (row-major activations) or sa_row == 1 (the [obs][n_env] buffer; M % 4 == 0 and 16-byte aligned columns required). */

@@ -1074,6 +1074,40 @@ def test_lds_free_linear_matches_torch(M, N, K, kmajor, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,lda,norm", [(1368, 256, 472, 696, True), (1364, 256, 256, 256, False), (1365, 120, 256, 256, False), (1365, 256, 288, 288, False),
+                                            (1365, 76, 256, 256, False), (2732, 1024, 472, 696, True), (64, 64, 32, 32, False), (1, 1, 4, 4, False),
+                                            (130, 65, 36, 40, True), (63, 33, 8, 8, False)])
+def test_lds_tiled_acting_layer_matches_torch(M, N, K, lda, norm):
+    """tmjx_linear_act (round 5: the acting policy's dense layer through a 20 KB LDS tile — what a CU has free next to twelve resident physics
+    workgroups): C = op(A) W^T + b against a float64 product at the acting path's shapes (an env group's rows x the 2 x 256 / rodent-mc-intention
+    widths, the first layer reading 472 of the observation's 696 columns with the normaliser applied on the way) and ragged ones; without a bias;
+    operands the entry does not take are refused, not mangled."""
+    import ctypes as C
+    from track_mjx_amd import hip as _hip
+    L = _hip.lib()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    buf = torch.randn((M, lda), generator=g, device=DEV)
+    A = buf[:, :K]
+    W = torch.randn((N, K), generator=g, device=DEV) / K ** 0.5
+    b = torch.randn(N, generator=g, device=DEV)
+    mean = torch.randn(K, generator=g, device=DEV) * 0.3 if norm else None
+    istd = (torch.rand(K, generator=g, device=DEV) + 0.5) if norm else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.tmjx_linear_act_ok(p(A), lda, p(W), K, K) == 1
+    a64 = (A.double() - mean.double()) * istd.double() if norm else A.double()
+    for bias in (b, None):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        _hip.check(L.tmjx_linear_act(p(A), lda, p(W), K, p(bias), p(out), M, N, K, p(mean), p(istd), stream), "tmjx_linear_act")
+        torch.cuda.synchronize()
+        ref = a64 @ W.double().t() + (bias.double() if bias is not None else 0.0)
+        assert float((out.double() - ref).abs().max()) <= 5e-6 * max(float(ref.abs().max()), 1.0), (M, N, K, bias is None)
+    # K not a multiple of 4 / unaligned rows: refused (the caller falls back to tmjx_linear_nolds)
+    assert L.tmjx_linear_act_ok(p(A), lda, p(W), K, K - 1) == 0 and L.tmjx_linear_act_ok(p(buf[:, 1:]), lda, p(W), K, K) == 0
+    assert L.tmjx_linear_act(p(buf[:, 1:]), lda, p(W), K, p(b), p(out), M, N, K, None, None, stream) == -22
+
+
+@pytest.mark.gpu
 def test_philox_known_answers_and_self_advancing_minibatch():
     """The device-side noise of the SGD step: (1) Philox4x32-10 against the known-answer vectors of the Random123 distribution (kat_vectors:
     zero, all-ones and pi-digit inputs); (2) tmjx_minibatch_begin: rows = the slot's slice of the permutation, bit-identical to index_select,

@@ -418,6 +418,18 @@ class PPOLearner:
                                                     Kp, p(mean), p(inv_std), stream), "tmjx_linear_nolds_bf16")
                 return out
 
+            # round 5: the layer through a 20 KB LDS tile (tmjx_linear_act) where the operands allow — the physics kernel's env image leaves that
+            # much LDS free on every CU next to twelve resident envs; TMJX_ACT_LDS=0 keeps the LDS-free kernels (A/B runs)
+            act_lds = os.environ.get("TMJX_ACT_LDS", "1") != "0"
+
+            def linear_lds(a, sa_row, sa_k, w, bias_t, out, mean=None, inv_std=None):
+                """True if the layer went through tmjx_linear_act (row-major a with aligned rows, K % 4 == 0)."""
+                if not act_lds or sa_k != 1 or not L.tmjx_linear_act_ok(p(a), sa_row, p(w), w.stride(0), w.shape[1]):
+                    return False
+                _hip.check(L.tmjx_linear_act(p(a), sa_row, p(w), w.stride(0), p(bias_t), p(out), n, out.shape[1], w.shape[1], p(mean), p(inv_std), stream),
+                           "tmjx_linear_act")
+                return True
+
             def linear(a, sa_row, sa_k, K, lin, bias=True):
                 if bf is not None and lin in bf.w:
                     return linear_bf16(a, sa_row, sa_k, lin, bias)
@@ -425,6 +437,8 @@ class PPOLearner:
                 # every collect()): the kernel then takes its float4 path; the extra k read finite activations x 0
                 w = self._padded_weight(lin)
                 out = torch.empty((n, lin.out_features), **f32)
+                if linear_lds(a, sa_row, sa_k, w, lin.bias if bias else None, out):
+                    return out
                 _hip.check(L.tmjx_linear_nolds(p(a), sa_row, sa_k, p(w), p(lin.bias) if bias else None, p(out),
                                                n, lin.out_features, w.shape[1], stream), "tmjx_linear_nolds")
                 return out
@@ -435,8 +449,9 @@ class PPOLearner:
                 elif folded:      # the operand is normalised while it is loaded (mean / inv_std padded with 0 / 0 to the weight's padded K)
                     w = self._padded_weight(blk.dense)
                     z = torch.empty((n, blk.dense.out_features), **f32)
-                    _hip.check(L.tmjx_linear_nolds_norm(p(a), sa_row, sa_k, p(w), None, p(z), n, blk.dense.out_features, w.shape[1],
-                                                        p(self._fold[0]), p(self._fold[1]), stream), "tmjx_linear_nolds_norm")
+                    if not linear_lds(a, sa_row, sa_k, w, None, z, self._fold[0], self._fold[1]):
+                        _hip.check(L.tmjx_linear_nolds_norm(p(a), sa_row, sa_k, p(w), None, p(z), n, blk.dense.out_features, w.shape[1],
+                                                            p(self._fold[0]), p(self._fold[1]), stream), "tmjx_linear_nolds_norm")
                     bias_v = blk.dense.bias
                 else:
                     z, bias_v = linear(a, sa_row, sa_k, K, blk.dense, bias=False), blk.dense.bias

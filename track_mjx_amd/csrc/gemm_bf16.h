@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void k_bgemm_dw_reduce(const float *__restrict
 // One wave per 32 x 32 output tile; a lane's 8 consecutive k (k = 32 s + 8 (lane / 16) ..) feed one operand register of each of the 2 x 2 tiles.
 // `mean` / `inv_std` (optional, [K]): the operand is (A - mean) * inv_std (the observation normaliser, first layer).
 template <bool A_KMAJOR>
-__global__ __launch_bounds__(64) void k_linear_nolds_bf16(const float *__restrict__ A, long long sa_row, long long sa_k, const bf16_t *__restrict__ W, int ldw,
+__global__ __launch_bounds__(64, 5) void k_linear_nolds_bf16(const float *__restrict__ A, long long sa_row, long long sa_k, const bf16_t *__restrict__ W, int ldw,
                                                           const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                                           const float *__restrict__ mean, const float *__restrict__ inv_std) {
   TM_PRIO_ACTING_BF();
@@ -849,19 +849,17 @@ __global__ __launch_bounds__(64) void k_linear_nolds_bf16(const float *__restric
       for (int b = 0; b < 2; b++)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bgb8, f.a[a]), __builtin_bit_cast(bgb8, f.w[b]), acc[a][b], 0, 0, 0);
   };
-  // three K steps in flight (a step is ONE matrix instruction per tile: what bounds a wave is the latency of its operand loads)
-  Frag f0, f1, f2;
+  // TWO K steps in flight (a step is ONE matrix instruction per tile: what bounds a wave is the latency of its operand loads).  Round 4 kept three —
+  // at 144 VGPRs + 48 AGPRs, and three physics waves of 136 allocated registers leave 104 of a SIMD's 512: such a wave could only start where a
+  // physics wave had retired.  Two steps fit __launch_bounds__(64, 5)'s 96 registers without a spill; same instructions in the same k order.
+  Frag f0, f1;
   load(f0, 0);
-  if (32 < K) load(f1, 32);
-  for (int k0 = 0; k0 < K; k0 += 96) {
-    if (k0 + 64 < K) load(f2, k0 + 64);
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    if (k0 + 32 < K) load(f1, k0 + 32);
     mma(f0);
     if (k0 + 32 >= K) break;
-    if (k0 + 96 < K) load(f0, k0 + 96);
+    if (k0 + 64 < K) load(f0, k0 + 64);
     mma(f1);
-    if (k0 + 64 >= K) break;
-    if (k0 + 128 < K) load(f1, k0 + 128);
-    mma(f2);
   }
   // accumulator component r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile
 #pragma unroll

@@ -478,8 +478,10 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partia
 // (2 x 2 MFMA tiles, 16 accumulator registers), operands of the next K step in flight while the 16 MFMAs of this one issue.  Next
 // to the other env group's physics kernel this matters twice: the fp32 MFMA rate equals the vector FMA rate, but the matrix pipe
 // is idle there while the vector ALU is what the physics kernel is bound by; and a one-wave workgroup fits any free wave slot.
+// __launch_bounds__(64, 5) (round 5): at most 96 registers.  Left to itself the allocator took 108 VGPRs + 32 AGPRs = 140 — and three physics waves of 136
+// allocated registers leave 104 of a SIMD's 512: the layer's waves could only start where a physics wave had retired.  Capped, the kernel needs 77, no spill.
 template <bool A_KMAJOR>
-__global__ __launch_bounds__(64) void k_linear_nolds_mfma(const float *__restrict__ A, long long sa_row, long long sa_k, const float *__restrict__ W,
+__global__ __launch_bounds__(64, 5) void k_linear_nolds_mfma(const float *__restrict__ A, long long sa_row, long long sa_k, const float *__restrict__ W,
                                                           const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                                           const float *__restrict__ mean = nullptr, const float *__restrict__ inv_std = nullptr) {
   TM_PRIO_ACTING();
@@ -549,6 +551,94 @@ __global__ __launch_bounds__(64) void k_linear_nolds_mfma(const float *__restric
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = row0 + 16 * a + 4 * kq + r;
+        if (row < M && c < N) C[(size_t)row * N + c] = acc[a][b][r] + bv;
+      }
+    }
+}
+
+// The acting policy's dense layer with a SMALL LDS tile (round 5).  The physics kernel's env image fell to 9 of a CU's 128 LDS granules, so twelve
+// resident envs leave 20 granules = 25 600 bytes free on every CU, and at ~130 VGPRs three physics waves leave room for one more wave of <= 104
+// registers on every SIMD: a 4-wave workgroup with <= 20 480 bytes of LDS fits next to a full house of physics workgroups at any time.  Against
+// the LDS-free kernel above (one wave per 32 x 32 tile, every operand word fetched from L2 by the wave that uses it, the K loop a chain of
+// exposed L2 latencies): 64 x 64 tiles staged through LDS (operands re-read 4 x less), the next K step's global loads in flight in registers
+// while this step's 32 MFMAs per wave issue.  Row-major A with 16-byte aligned rows, K % 4 == 0, W [N][ldw] with 16-byte aligned rows.
+// NORM: the operand is (A - mean[k]) * inv_std[k] (the observation normaliser, first layer), applied when the staged registers go to LDS.
+#define ACT_BM 64
+#define ACT_BK 32
+// __launch_bounds__(256, 5): at most 96 registers (accumulators included) — three physics waves of 136 allocated registers leave 104 of a SIMD's 512
+#define ACT_LD 40          // floats per LDS row (32 + 8: b128 fragment reads of 16 consecutive rows hit 16 distinct slots, as in gemm_kernels.h)
+template <bool NORM>
+__global__ __launch_bounds__(256, 5) void k_linear_act(const float *__restrict__ A, long long lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
+                                                    float *__restrict__ C, int M, int N, int K, const float *__restrict__ mean, const float *__restrict__ inv_std) {
+  TM_PRIO_ACTING();
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  __shared__ __attribute__((aligned(16))) float sA[ACT_BM * ACT_LD], sW[ACT_BM * ACT_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * ACT_BM, col0 = blockIdx.y * ACT_BM, wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const float *pa[2], *pw[2];
+  int sr[2], sc[2];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int f = t + 256 * p, r = f >> 3, c4 = f & 7;
+    sr[p] = r; sc[p] = 4 * c4;
+    pa[p] = A + (long long)min(row0 + r, M - 1) * lda + 4 * c4;        // rows / columns outside the matrix: clamped (their products are never stored)
+    pw[p] = W + (size_t)min(col0 + r, N - 1) * ldw + 4 * c4;
+  }
+  f4 ra[2], rw[2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const bool ok = k0 + sc[p] < K;                // K % 4 == 0: a float4 lies inside or outside as a whole
+      const int kc = ok ? k0 : 0;
+      f4 a = *reinterpret_cast<const f4 *>(pa[p] + kc), w = *reinterpret_cast<const f4 *>(pw[p] + kc);
+      if (NORM) {
+        const f4 mu = *reinterpret_cast<const f4 *>(mean + kc + sc[p]), is = *reinterpret_cast<const f4 *>(inv_std + kc + sc[p]);
+        a = (a - mu) * is;
+      }
+      ra[p] = ok ? a : f4{0.f, 0.f, 0.f, 0.f};
+      rw[p] = ok ? w : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+  load(0);
+  for (int k0 = 0; k0 < K; k0 += ACT_BK) {
+    __syncthreads();                                  // every wave has read the previous step's fragments
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      *reinterpret_cast<f4 *>(sA + sr[p] * ACT_LD + sc[p]) = ra[p];
+      *reinterpret_cast<f4 *>(sW + sr[p] * ACT_LD + sc[p]) = rw[p];
+    }
+    __syncthreads();
+    if (k0 + ACT_BK < K) load(k0 + ACT_BK);           // in flight while this step's MFMAs issue
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      f4 fa[2], fw[2];
+#pragma unroll
+      for (int a = 0; a < 2; a++) fa[a] = *reinterpret_cast<const f4 *>(sA + (wr + 16 * a + li) * ACT_LD + 16 * c + 4 * kq);
+#pragma unroll
+      for (int b = 0; b < 2; b++) fw[b] = *reinterpret_cast<const f4 *>(sW + (wc + 16 * b + li) * ACT_LD + 16 * c + 4 * kq);
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][e], fw[b][e], acc[a][b], 0, 0, 0);
+    }
+  }
+  // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const int c = col0 + wc + 16 * b + li;
+      const float bv = (bias && c < N) ? bias[c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + wr + 16 * a + 4 * kq + r;
         if (row < M && c < N) C[(size_t)row * N + c] = acc[a][b][r] + bv;
       }
     }

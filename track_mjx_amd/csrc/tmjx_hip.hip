@@ -826,6 +826,23 @@ int tmjx_linear_nolds_norm(const float *A, int64_t sa_row, int64_t sa_k, const f
   else hipLaunchKernelGGL((k_linear_nolds_mfma<false>), g2, dim3(64), 0, s, A, (long long)sa_row, (long long)sa_k, W, bias, C, M, N, K, mean, inv_std);
   return check_launch("k_linear_nolds_mfma(norm)");
 }
+// The acting policy's layer through a 20 KB LDS tile (k_linear_act, csrc/ppo_kernels.h): C[M][N] = op(A)[M][K] W[N][ldw]^T (+ bias), op = identity or
+// (A - mean) * inv_std.  Returns TMJX_EINVAL for operands it does not take (the caller then uses tmjx_linear_nolds): tmjx_linear_act_ok says which.
+int tmjx_linear_act_ok(const float *A, int64_t lda, const float *W, int ldw, int K) {
+  return !(K & 3) && !((uintptr_t)A & 15) && !(lda & 3) && !((uintptr_t)W & 15) && !(ldw & 3) && lda >= K && ldw >= K;
+}
+int tmjx_linear_act(const float *A, int64_t lda, const float *W, int ldw, const float *bias, float *C, int M, int N, int K, const float *mean,
+                    const float *inv_std, void *stream) {
+  if (!A || !W || !C) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1) return fail(TMJX_EINVAL, "bad sizes");
+  if (!tmjx_linear_act_ok(A, lda, W, ldw, K)) return fail(TMJX_EINVAL, "tmjx_linear_act: K % 4 == 0, row-major operands with 16-byte aligned rows");
+  if ((mean || inv_std) && (!mean || !inv_std || (((uintptr_t)mean | (uintptr_t)inv_std) & 15))) return fail(TMJX_EINVAL, "tmjx_linear_act: mean and inv_std together, 16-byte aligned");
+  dim3 grid((M + ACT_BM - 1) / ACT_BM, (N + ACT_BM - 1) / ACT_BM);
+  hipStream_t s = (hipStream_t)stream;
+  if (mean) hipLaunchKernelGGL((k_linear_act<true>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, mean, inv_std);
+  else hipLaunchKernelGGL((k_linear_act<false>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, (const float *)nullptr, (const float *)nullptr);
+  return check_launch("k_linear_act");
+}
 int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
                       void *stream) {
   if (!A || !W || !C) return fail(TMJX_EINVAL, "null argument");
