@@ -369,7 +369,7 @@ def main(argv=None, runner=None):
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # (bf16 mode goes beyond SURVEY a16's "bf16 only for GEMM inputs": the pre-activations the backward epilogues re-read are saved as bf16 too —
-            # BASELINE configs[4] says "bf16 MLP on MFMA"; the fp32-z form of the same kernels measured 3.94 against 3.79 ms per minibatch step)
+            # BASELINE configs[4] says "bf16 MLP on MFMA"; the fp32-z form is a build switch of the same sources, -DTMJX_BF16_Z_F32: 4.01 against 3.79 ms per minibatch step, profiles/r05_cfg5_z_variants.txt)
             "dtype": "f32" if bc["matmul_dtype"] is None else f"f32 (physics, reward, loss head, optimiser, master weights) + {bc['matmul_dtype']} MLP: GEMM inputs, hidden activations and saved pre-activations in {bc['matmul_dtype']}, f32 accumulate",
             "data": "synthetic", "so_build_id": so_build_id(), "mjx_cpu": mjx_cpu_probe(),
             "config": {"workload": f"rodent tracking PPO training step ({args.config}): {n_local} envs/GPU, {learner.env_steps_per_training_step // (n_local * learner.T * world)}x{learner.T}-step unrolls (10 physics substeps each) + {sgd_steps} minibatch updates, {bc['label']}",

@@ -345,6 +345,10 @@ int tmjx_bgemm_nt(const void *A, int a_is_f32, int lda, const uint16_t *B, int l
  *                       of dZ (d bias).
  * tmjx_bgemm_partial_floats(M, N, sums): floats of `partial` for sums = 3 (ln) or 1 (silu). */
 int tmjx_bgemm_row_tile_ok(int N);
+/* Element size of the SAVED PRE-ACTIVATIONS these entries exchange (`Z16` / `z16` below): 2 = bf16 (the product build: BASELINE configs[4] is a
+ * "bf16 MLP on MFMA"), 4 = float (a library built with -DTMJX_BF16_Z_F32: SURVEY a16's narrower "bf16 only for GEMM inputs"; the pointers then
+ * point to floats, leading dimensions stay in elements). */
+int tmjx_bf16_z_bytes(void);
 long long tmjx_bgemm_partial_floats(int M, int N, int sums);
 int tmjx_bgemm_ln_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, int ldb, const float *bias, const float *gamma, const float *beta, uint16_t *Z16, int ldz,
                       uint16_t *Y16, int ldy16, float *stats, int M, int N, int K, float eps, void *stream);

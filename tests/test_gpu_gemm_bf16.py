@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from track_mjx_amd.agent import networks as nw
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 EPS = 2.0 ** -24
@@ -128,7 +130,7 @@ def test_bgemm_ln_forward_epilogue(M, N, K, lda, a_bf16):
     a64, w64 = _bf(x).double(), _bf(blk.dense.weight.detach()).double()
     ref = a64 @ w64.t()
     bound = (a64.abs() @ w64.abs().t()) * EPS * (K ** 0.5 + 4) * 2 + 1e-30
-    assert z.dtype == torch.bfloat16 and ((z.double() - ref).abs() <= bound + 2.0 ** -8 * ref.abs()).all()
+    assert z.dtype == nw.bf16_z_dtype() and ((z.double() - ref).abs() <= bound + 2.0 ** -8 * ref.abs()).all()      # (bf16, or fp32 under -DTMJX_BF16_Z_F32)
     yr, a = _ln_ref(ref, blk.dense.bias.detach().double(), blk.norm.weight.detach().double(), blk.norm.bias.detach().double(), 1e-6)
     assert y.dtype == torch.bfloat16 and ((y.double() - yr).abs() <= 2.0 ** -8 * yr.abs() + 3e-5).all(), float((y.double() - yr).abs().max())
     mean, var = a.mean(1), a.var(1, unbiased=False)
@@ -145,7 +147,7 @@ def test_bgemm_ln_backward_epilogue(M, N, K, ldy, dy_bf16):
     g = torch.Generator(device=DEV).manual_seed(M + N + 7 * K)
     cons = _dense(N, K).to(DEV)                       # the consumer layer: N (the block's width) -> K
     sh = Bf16Shadows([cons]); sh.refresh()
-    z = torch.randn((M, N), generator=g, device=DEV).to(torch.bfloat16)        # the saved pre-activation is bf16 (tmjx_bgemm_ln_fwd)
+    z = torch.randn((M, N), generator=g, device=DEV).to(nw.bf16_z_dtype())        # the saved pre-activation as tmjx_bgemm_ln_fwd stores it (bf16; fp32 under -DTMJX_BF16_Z_F32)
     b = torch.randn(N, generator=g, device=DEV) * 0.3
     gam = 1 + 0.2 * torch.randn(N, generator=g, device=DEV)
     a = torch.nn.functional.silu(z.float() + b)
@@ -181,7 +183,7 @@ def test_bgemm_silu_forward_and_backward_epilogues(M, N, K, lda, yf32):
     torch.cuda.synchronize()
     a64, w64 = _bf(x).double(), _bf(lin.weight.detach()).double()
     ref = a64 @ w64.t()
-    assert z.dtype == torch.bfloat16 and ((z.double() - ref).abs() <= (a64.abs() @ w64.abs().t()) * EPS * (K ** 0.5 + 4) * 2 + 2.0 ** -8 * ref.abs() + 1e-30).all()
+    assert z.dtype == nw.bf16_z_dtype() and ((z.double() - ref).abs() <= (a64.abs() @ w64.abs().t()) * EPS * (K ** 0.5 + 4) * 2 + 2.0 ** -8 * ref.abs() + 1e-30).all()
     yr = torch.nn.functional.silu(ref + lin.bias.detach().double())          # (y comes from the fp32 accumulators, not from the rounded z)
     tol = 2e-6 if yf32 else 2.0 ** -8
     assert y.dtype == (torch.float32 if yf32 else torch.bfloat16) and ((y.double() - yr).abs() <= tol * yr.abs() + 3e-6).all()
@@ -379,7 +381,7 @@ def test_bf_silu_bwd_rank1_is_the_outer_product_through_the_plain_kernel(M, N):
     lib = _hip.lib()
     g = torch.Generator(device=DEV).manual_seed(M + N)
     dy1, w1 = torch.randn(M, generator=g, device=DEV), torch.randn(N, generator=g, device=DEV) * 0.1
-    z, bias = torch.randn(M, N, generator=g, device=DEV).to(torch.bfloat16), 0.3 * torch.randn(N, generator=g, device=DEV)
+    z, bias = torch.randn(M, N, generator=g, device=DEV).to(nw.bf16_z_dtype()), 0.3 * torch.randn(N, generator=g, device=DEV)
     dy = (dy1[:, None] * w1[None, :]).contiguous()
     p = lambda t: C.c_void_p(t.data_ptr())
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -177,12 +177,19 @@ def bgemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool, out: torch.Tens
     return dw, db
 
 
+def bf16_z_dtype() -> torch.dtype:
+    """Element type of the pre-activations the bf16-mode block kernels save for their backward pass: bf16 in the product build (BASELINE configs[4]:
+    "bf16 MLP on MFMA"), fp32 in a library built with -DTMJX_BF16_Z_F32 (SURVEY a16's "bf16 only for GEMM inputs") — tmjx_bf16_z_bytes()."""
+    from .. import hip as _hip
+    return torch.float32 if int(_hip.lib().tmjx_bf16_z_bytes()) == 4 else torch.bfloat16
+
+
 def bgemm_ln_fwd(x, wb, N: int, K: int, bias, gamma, beta, eps: float):
     """Dense -> SiLU -> LayerNorm forward in one launch (tmjx_bgemm_ln_fwd; N = 128 / 256 / 512): returns (z bf16 [rows, N] without the bias,
     y bf16 [rows, N], stats fp32 [rows, 2] = (mean, 1 / std))."""
     x = _rows2d(x)
     M = x.shape[0]
-    z = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    z = torch.empty((M, N), dtype=bf16_z_dtype(), device=x.device)
     y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
     _launch("tmjx_bgemm_ln_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(gamma), _p(beta), _p(z), N, _p(y), N,
@@ -209,7 +216,7 @@ def bgemm_silu_fwd(x, wb, N: int, K: int, bias, y_f32: bool = False):
     x = _rows2d(x)
     M = x.shape[0]
     ld = (N + 7) // 8 * 8
-    z = torch.empty((M, ld), dtype=torch.bfloat16, device=x.device)[:, :N]
+    z = torch.empty((M, ld), dtype=bf16_z_dtype(), device=x.device)[:, :N]
     y = torch.empty((M, ld), dtype=torch.float32 if y_f32 else torch.bfloat16, device=x.device)
     _launch("tmjx_bgemm_silu_fwd", x.device, _p(x), int(x.dtype == torch.float32), _ld(x), _p(wb), wb.stride(0), _p(bias), _p(z), ld,
             None if y_f32 else _p(y), ld, _p(y) if y_f32 else None, ld, M, N, K)

@@ -46,6 +46,22 @@ __device__ __forceinline__ bgf4 bg_unpack4(bgu2 u) {
   return bgf4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u), __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
 }
 __device__ __forceinline__ bgu2 bg_pack4(bgf4 v) { return bgu2{bg_pack(v.x, v.y), bg_pack(v.z, v.w)}; }
+// The saved pre-activations z of a block (what the backward epilogues re-read): bf16 — BASELINE config 5 is a "bf16 MLP on MFMA" — or, with
+// -DTMJX_BF16_Z_F32, fp32 (SURVEY a16's narrower reading: "bf16 only for GEMM inputs"; round 3's form of these kernels).  One element type and
+// four accessors; the C-ABI's `Z16` / `z16` pointers then point to floats (tmjx_bf16_z_bytes() says which: 2 or 4).
+#ifdef TMJX_BF16_Z_F32
+typedef float bz_t;
+__device__ __forceinline__ bgf4 bz_load4(const bz_t *p) { return *reinterpret_cast<const bgf4 *>(p); }
+__device__ __forceinline__ void bz_store4(bz_t *p, bgf4 v) { *reinterpret_cast<bgf4 *>(p) = v; }
+__device__ __forceinline__ float bz_f32(bz_t h) { return h; }
+__device__ __forceinline__ bz_t bz_from(float v) { return v; }
+#else
+typedef bf16_t bz_t;
+__device__ __forceinline__ bgf4 bz_load4(const bz_t *p) { return bg_unpack4(*reinterpret_cast<const bgu2 *>(p)); }
+__device__ __forceinline__ void bz_store4(bz_t *p, bgf4 v) { *reinterpret_cast<bgu2 *>(p) = bg_pack4(v); }
+__device__ __forceinline__ float bz_f32(bz_t h) { return bg_f32(h); }
+__device__ __forceinline__ bz_t bz_from(float v) { return (bf16_t)(bg_pack(v, 0.f) & 0xffffu); }
+#endif
 
 // byte offset of 16-byte chunk c (0 .. 7) of row r in a [rows][64 bf16] LDS image (128-byte rows, chunks XOR-swizzled)
 __device__ __forceinline__ int bg_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -87,7 +103,7 @@ struct BgEpi {
   float *stats;                   // EPI 1 writes (mean, 1 / std) per row, EPI 2 reads them
   bf16_t *y16; int ldy16;         // EPI 1 / 3: the activation as bf16 (the next layer's operand);  EPI 2 / 4: d loss / d z as bf16
   float *yf; int ldyf;            // EPI 3: the activation as fp32 instead (the consumer is an fp32 kernel)
-  const bf16_t *z; int ldz;       // EPI 2 / 4: the block's saved pre-activation (bf16 as EPI 1 / 3 stored it, without the bias)
+  const bz_t *z; int ldz;         // EPI 2 / 4: the block's saved pre-activation (as EPI 1 / 3 stored it — bz_t: bf16 or, -DTMJX_BF16_Z_F32, fp32 — without the bias)
   float *partial;                 // EPI 2 / 4: per-row-tile column sums: [gridDim.x][3][N] (d gamma | d beta | d bias) resp. [gridDim.x][N] (d bias)
   float eps;
 };
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
       float p = 0.f;
 #pragma unroll
       for (int b = 0; b < NI; b++) {
-        if (row < M) *reinterpret_cast<bgu2 *>(reinterpret_cast<bf16_t *>(C) + (size_t)row * ldc + nw + 16 * b + 4 * kq) = bg_pack4(acc[a][b]);
+        if (row < M) bz_store4(reinterpret_cast<bz_t *>(C) + (size_t)row * ldc + nw + 16 * b + 4 * kq, acc[a][b]);
 #pragma unroll
         for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
       }
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
 #pragma unroll
       for (int b = 0; b < NI; b++) {
         const int col = nw + 16 * b + 4 * kq;
-        const bgf4 z4 = bg_unpack4(*reinterpret_cast<const bgu2 *>(epi.z + rr * epi.ldz + col));
+        const bgf4 z4 = bz_load4(epi.z + rr * epi.ldz + col);
         const bgf4 bv4 = *reinterpret_cast<const bgf4 *>(bias + col), gv4 = *reinterpret_cast<const bgf4 *>(epi.gamma + col);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
     // second pass column block by column block: the three column sums of ONE block are live at a time (all NI of them cost 12 NI registers).
     // z is RE-LOADED through an opaque pointer: otherwise the loads (and the sigmoid / ahat values computed from them) of the first pass are
     // kept live across the exchange for the second one — MI NI 12 registers, spilled at NI = 4
-    const bf16_t *z2 = epi.z;
+    const bz_t *z2 = epi.z;
     asm volatile("" : "+s"(z2));
     float *pp = epi.partial + (size_t)blockIdx.x * 3 * BN;
 #pragma unroll
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
         const int row = m0 + 16 * a + li;
         const bool ok = row < M;
         const size_t rr = ok ? row : M - 1;
-        const bgf4 z4 = bg_unpack4(*reinterpret_cast<const bgu2 *>(z2 + rr * epi.ldz + col));
+        const bgf4 z4 = bz_load4(z2 + rr * epi.ldz + col);
         const float mean_a = epi.stats[2 * rr], rstd_a = epi.stats[2 * rr + 1];
         bgf4 o;
 #pragma unroll
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
   }
   if constexpr (EPI == 3 || EPI == 4) {
     // element-wise on the tile (any N: columns beyond N are computed on clamped weight rows and never stored)
-    const bool vec = EPI == 3 ? (!(ldc & 3) && !((uintptr_t)C & 7)) : true;
+    const bool vec = EPI == 3 ? (!(ldc & 3) && !((uintptr_t)C & (4 * sizeof(bz_t) - 1))) : true;
 #pragma unroll
     for (int b = 0; b < NI; b++) {
       const int col = n0 + nw + 16 * b + 4 * kq;
@@ -485,20 +501,20 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
 #pragma unroll
           for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[r]; o[r] = v / (1.f + expf(-v)); }
           if (ok) {
-            bf16_t *zo = reinterpret_cast<bf16_t *>(C) + (size_t)row * ldc + col;
-            if (vec && col + 3 < N) *reinterpret_cast<bgu2 *>(zo) = bg_pack4(acc[a][b]);
+            bz_t *zo = reinterpret_cast<bz_t *>(C) + (size_t)row * ldc + col;
+            if (vec && col + 3 < N) bz_store4(zo, acc[a][b]);
             else {
 #pragma unroll
-              for (int r = 0; r < 4; r++) if (col + r < N) zo[r] = (bf16_t)(bg_pack(acc[a][b][r], 0.f) & 0xffffu);
+              for (int r = 0; r < 4; r++) if (col + r < N) zo[r] = bz_from(acc[a][b][r]);
             }
           }
         } else {
           const size_t rr = ok ? row : M - 1;
           bgf4 z4 = {0.f, 0.f, 0.f, 0.f};
-          if (!(epi.ldz & 3) && col + 3 < N) z4 = bg_unpack4(*reinterpret_cast<const bgu2 *>(epi.z + rr * epi.ldz + col));       // (z's base is 8-byte aligned: checked by the entry point)
+          if (!(epi.ldz & 3) && col + 3 < N) z4 = bz_load4(epi.z + rr * epi.ldz + col);       // (z's base is aligned for four elements: checked by the entry point)
           else {
 #pragma unroll
-            for (int r = 0; r < 4; r++) if (col + r < N) z4[r] = bg_f32(epi.z[rr * epi.ldz + col + r]);
+            for (int r = 0; r < 4; r++) if (col + r < N) z4[r] = bz_f32(epi.z[rr * epi.ldz + col + r]);
           }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
@@ -540,14 +556,14 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
 // Unfused backward of a Dense -> SiLU block whose output gradient does not come out of a bf16 GEMM (the value net's last hidden layer: its
 // consumer is the 1-wide head on the fp32 kernels): dz = dy silu'(z + bias) as bf16 + per-80-row-tile column sums.  One workgroup per row tile,
 // a thread per column (coalesced rows).
-__global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ dy, int ldy, const bf16_t *__restrict__ z, int ldz, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ dy, int ldy, const bz_t *__restrict__ z, int ldz, const float *__restrict__ bias,
                                                      bf16_t *__restrict__ dz, int lddz, float *__restrict__ partial, int M, int N) {
   const int r0 = blockIdx.x * 80, r1 = min(M, r0 + 80);
   for (int c = threadIdx.x; c < N; c += 256) {
     const float b = bias[c];
     float sum = 0.f;
     for (int r = r0; r < r1; r++) {
-      const float v = bg_f32(z[(size_t)r * ldz + c]) + b, sig = 1.f / (1.f + expf(-v));
+      const float v = bz_f32(z[(size_t)r * ldz + c]) + b, sig = 1.f / (1.f + expf(-v));
       const float o = dy[(size_t)r * ldy + c] * (sig * (1.f + v * (1.f - sig)));
       dz[(size_t)r * lddz + c] = (bf16_t)(bg_pack(o, 0.f) & 0xffffu);
       sum += o;
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ d
 // formed here instead of by an input-gradient GEMM with a contraction length of one that writes [M][N] floats for this kernel to read back.
 template <bool RANK1>
 __global__ __launch_bounds__(256) void k_bf_silu_bwd4(const float *__restrict__ dy, int ldy, const float *__restrict__ dy1, const float *__restrict__ w1,
-                                                      const bf16_t *__restrict__ z, int ldz, const float *__restrict__ bias, bf16_t *__restrict__ dz, int lddz,
+                                                      const bz_t *__restrict__ z, int ldz, const float *__restrict__ bias, bf16_t *__restrict__ dz, int lddz,
                                                       float *__restrict__ partial, int M, int N) {
   __shared__ float red[256 * 4];
   const int ncg = N >> 2, nph = 256 / ncg, t = threadIdx.x, cg = t % ncg, ph = t / ncg;
@@ -572,7 +588,7 @@ __global__ __launch_bounds__(256) void k_bf_silu_bwd4(const float *__restrict__ 
     bgf4 wv = {0.f, 0.f, 0.f, 0.f}, sum = {0.f, 0.f, 0.f, 0.f};
     if (RANK1) wv = *reinterpret_cast<const bgf4 *>(w1 + 4 * cg);
     for (int r = r0 + ph; r < r1; r += nph) {
-      const bgf4 zv = bg_unpack4(*reinterpret_cast<const bgu2 *>(z + (size_t)r * ldz + 4 * cg));
+      const bgf4 zv = bz_load4(z + (size_t)r * ldz + 4 * cg);
       bgf4 d;
       if (RANK1) { const float g = dy1[r]; d = bgf4{g * wv.x, g * wv.y, g * wv.z, g * wv.w}; }
       else d = *reinterpret_cast<const bgf4 *>(dy + (size_t)r * ldy + 4 * cg);

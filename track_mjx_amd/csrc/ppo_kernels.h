@@ -581,18 +581,18 @@ __global__ __launch_bounds__(256, 5) void k_linear_act(const float *__restrict__
   for (int p = 0; p < 2; p++) {
     const int f = t + 256 * p, r = f >> 3, c4 = f & 7;
     sr[p] = r; sc[p] = 4 * c4;
-    pa[p] = A + (long long)min(row0 + r, M - 1) * lda + 4 * c4;        // rows / columns outside the matrix: clamped (their products are never stored)
-    pw[p] = W + (size_t)min(col0 + r, N - 1) * ldw + 4 * c4;
+    pa[p] = A + (long long)min(row0 + r, M - 1) * lda;                 // rows / columns outside the matrix: clamped (their products are never stored)
+    pw[p] = W + (size_t)min(col0 + r, N - 1) * ldw;
   }
   f4 ra[2], rw[2];
   auto load = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       const bool ok = k0 + sc[p] < K;                // K % 4 == 0: a float4 lies inside or outside as a whole
-      const int kc = ok ? k0 : 0;
+      const int kc = ok ? k0 + sc[p] : 0;            // (outside: the row's FIRST float4, always readable — K >= 4 — and zeroed below)
       f4 a = *reinterpret_cast<const f4 *>(pa[p] + kc), w = *reinterpret_cast<const f4 *>(pw[p] + kc);
       if (NORM) {
-        const f4 mu = *reinterpret_cast<const f4 *>(mean + kc + sc[p]), is = *reinterpret_cast<const f4 *>(inv_std + kc + sc[p]);
+        const f4 mu = *reinterpret_cast<const f4 *>(mean + kc), is = *reinterpret_cast<const f4 *>(inv_std + kc);
         a = (a - mu) * is;
       }
       ra[p] = ok ? a : f4{0.f, 0.f, 0.f, 0.f};

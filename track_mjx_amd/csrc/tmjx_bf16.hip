@@ -11,6 +11,8 @@
 
 extern "C" int tmjx_internal_fail(int code, const char *msg);       // tmjx_hip.hip: records the calling thread's error message
 static int fail(int code, const std::string &msg) { return tmjx_internal_fail(code, msg.c_str()); }
+#define BZ_ALIGN (4 * sizeof(bz_t) - 1)      // a saved pre-activation row is accessed four elements at a time (bz_t: gemm_bf16.h)
+extern "C" int tmjx_bf16_z_bytes(void) { return (int)sizeof(bz_t); }
 static int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(TMJX_EHIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -116,7 +118,7 @@ int tmjx_bgemm_ln_fwd(const void *A, int a_is_f32, int lda, const uint16_t *B, i
                       uint16_t *Y16, int ldy16, float *stats, int M, int N, int K, float eps, void *stream) {
   if (int rc = check_operands("tmjx_bgemm_ln_fwd", A, a_is_f32, lda, B, ldb, M, N, K)) return rc;
   if (!bias || !gamma || !beta || !Z16 || !Y16 || !stats) return fail(TMJX_EINVAL, "tmjx_bgemm_ln_fwd: null argument");
-  if (!row_tile_width(N) || ldz < N || ldy16 < N || (ldz & 3) || (ldy16 & 3) || ((uintptr_t)Z16 & 7) || ((uintptr_t)Y16 & 7))
+  if (!row_tile_width(N) || ldz < N || ldy16 < N || (ldz & 3) || (ldy16 & 3) || ((uintptr_t)Z16 & BZ_ALIGN) || ((uintptr_t)Y16 & 7))
     return fail(TMJX_EINVAL, "tmjx_bgemm_ln_fwd: N must be 128, 256 or 512 and the outputs' rows aligned");
   BgEpi e{};
   e.gamma = gamma; e.beta = beta; e.stats = stats; e.y16 = Y16; e.ldy16 = ldy16; e.eps = eps;
@@ -127,10 +129,10 @@ int tmjx_bgemm_ln_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *Bt
                       const float *stats, uint16_t *dZ16, int lddz, float *partial, int M, int N, int K, void *stream) {
   if (int rc = check_operands("tmjx_bgemm_ln_bwd", dY, dy_is_f32, ldy, Bt, ldb, M, N, K)) return rc;
   if (!z || !bias || !gamma || !stats || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bgemm_ln_bwd: null argument");
-  if (!row_tile_width(N) || ldz < N || lddz < N || (ldz & 3) || (lddz & 3) || ((uintptr_t)z & 7) || ((uintptr_t)dZ16 & 7))
+  if (!row_tile_width(N) || ldz < N || lddz < N || (ldz & 3) || (lddz & 3) || ((uintptr_t)z & BZ_ALIGN) || ((uintptr_t)dZ16 & 7))
     return fail(TMJX_EINVAL, "tmjx_bgemm_ln_bwd: N must be 128, 256 or 512 and z / dZ rows aligned");
   BgEpi e{};
-  e.gamma = gamma; e.stats = const_cast<float *>(stats); e.y16 = dZ16; e.ldy16 = lddz; e.z = z; e.ldz = ldz; e.partial = partial;
+  e.gamma = gamma; e.stats = const_cast<float *>(stats); e.y16 = dZ16; e.ldy16 = lddz; e.z = reinterpret_cast<const bz_t *>(z); e.ldz = ldz; e.partial = partial;
   return bgemm_epi<2>(dY, dy_is_f32, ldy, Bt, ldb, bias, nullptr, N, M, N, K, e, stream);
 }
 
@@ -148,27 +150,27 @@ int tmjx_bgemm_silu_bwd(const void *dY, int dy_is_f32, int ldy, const uint16_t *
                         float *partial, int M, int N, int K, void *stream) {
   if (int rc = check_operands("tmjx_bgemm_silu_bwd", dY, dy_is_f32, ldy, Bt, ldb, M, N, K)) return rc;
   if (!z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: null argument");
-  if (ldz < N || lddz < N || (lddz & 3) || ((uintptr_t)dZ16 & 7) || ((uintptr_t)z & 7)) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: bad leading dimensions / alignment");
+  if (ldz < N || lddz < N || (lddz & 3) || ((uintptr_t)dZ16 & 7) || ((uintptr_t)z & BZ_ALIGN)) return fail(TMJX_EINVAL, "tmjx_bgemm_silu_bwd: bad leading dimensions / alignment");
   BgEpi e{};
-  e.y16 = dZ16; e.ldy16 = lddz; e.z = z; e.ldz = ldz; e.partial = partial;
+  e.y16 = dZ16; e.ldy16 = lddz; e.z = reinterpret_cast<const bz_t *>(z); e.ldz = ldz; e.partial = partial;
   return bgemm_epi<4>(dY, dy_is_f32, ldy, Bt, ldb, bias, nullptr, N, M, N, K, e, stream);
 }
 
 int tmjx_bf_silu_bwd(const float *dY, int ldy, const uint16_t *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream) {
   if (!dY || !z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd: null argument");
   if (M < 1 || N < 1 || ldy < N || ldz < N || lddz < N) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd: bad sizes / leading dimensions");
-  const bool v4 = !(N & 3) && N <= 1024 && !(ldy & 3) && !(ldz & 3) && !(lddz & 3) && !(((uintptr_t)dY | (uintptr_t)bias) & 15) && !(((uintptr_t)dZ16 | (uintptr_t)z) & 7);
-  if (v4) hipLaunchKernelGGL(k_bf_silu_bwd4<false>, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, (const float *)nullptr, (const float *)nullptr, z, ldz, bias,
+  const bool v4 = !(N & 3) && N <= 1024 && !(ldy & 3) && !(ldz & 3) && !(lddz & 3) && !(((uintptr_t)dY | (uintptr_t)bias) & 15) && !((uintptr_t)dZ16 & 7) && !((uintptr_t)z & BZ_ALIGN);
+  if (v4) hipLaunchKernelGGL(k_bf_silu_bwd4<false>, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, (const float *)nullptr, (const float *)nullptr, reinterpret_cast<const bz_t *>(z), ldz, bias,
                              dZ16, lddz, partial, M, N);
-  else hipLaunchKernelGGL(k_bf_silu_bwd, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, z, ldz, bias, dZ16, lddz, partial, M, N);
+  else hipLaunchKernelGGL(k_bf_silu_bwd, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, dY, ldy, reinterpret_cast<const bz_t *>(z), ldz, bias, dZ16, lddz, partial, M, N);
   return check_launch("k_bf_silu_bwd");
 }
 
 int tmjx_bf_silu_bwd_rank1(const float *dy1, const float *w1, const uint16_t *z, int ldz, const float *bias, uint16_t *dZ16, int lddz, float *partial, int M, int N, void *stream) {
   if (!dy1 || !w1 || !z || !bias || !dZ16 || !partial) return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd_rank1: null argument");
-  if (M < 1 || N < 4 || (N & 3) || N > 1024 || ldz < N || lddz < N || (ldz & 3) || (lddz & 3) || (((uintptr_t)w1 | (uintptr_t)bias) & 15) || (((uintptr_t)dZ16 | (uintptr_t)z) & 7))
+  if (M < 1 || N < 4 || (N & 3) || N > 1024 || ldz < N || lddz < N || (ldz & 3) || (lddz & 3) || (((uintptr_t)w1 | (uintptr_t)bias) & 15) || ((uintptr_t)dZ16 & 7) || ((uintptr_t)z & BZ_ALIGN))
     return fail(TMJX_EINVAL, "tmjx_bf_silu_bwd_rank1: N must be a multiple of 4 up to 1024, rows 16-byte aligned");
-  hipLaunchKernelGGL(k_bf_silu_bwd4<true>, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, 0, dy1, w1, z, ldz, bias, dZ16, lddz, partial, M, N);
+  hipLaunchKernelGGL(k_bf_silu_bwd4<true>, dim3((M + 79) / 80), dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, 0, dy1, w1, reinterpret_cast<const bz_t *>(z), ldz, bias, dZ16, lddz, partial, M, N);
   return check_launch("k_bf_silu_bwd_rank1");
 }
 
