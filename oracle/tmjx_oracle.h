@@ -96,6 +96,9 @@ typedef struct {
   /* auto-reset snapshot (wrappers.py:93-95) */
   real first_obs[O_OBS], first_prev_ctrl[O_MAXU];
   OData first_d;
+  /* the CALLER's reference frame for the reward terms (compute_tracking_rewards(data, reference_frame, ...), reward.py:359-366): when fo_pos is
+   * non-NULL the five leaves of ONE frame (3 | 4 | nq-7 | (nbody-1)*3 | 3 floats) replace the env's own gather from the clip table */
+  const float *fo_pos, *fo_quat, *fo_joints, *fo_bodypos, *fo_angvel;
 } OEnv;
 
 #ifdef __cplusplus

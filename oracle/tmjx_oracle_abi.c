@@ -149,8 +149,9 @@ int tmjx_reset(tmjx_model *m, float *state, int32_t *istate, const int32_t *clip
   free(ev);
   return TMJX_OK;
 }
+typedef struct { const float *pos, *quat, *joints, *bodypos, *angvel; } FrameLeaves;      /* per env row-major: [n][3 | 4 | nq-7 | (nbody-1)*3 | 3] */
 static int step_impl(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done, float *trunc,
-                     float *metrics, int n, int do_physics) {
+                     float *metrics, int n, int do_physics, const FrameLeaves *fo) {
   if (!m || !state || !istate || !action || !obs || !reward || !done || !trunc || !metrics) return fail(TMJX_EINVAL, "null argument");
   if (n < 1) return fail(TMJX_EINVAL, "n_env must be >= 1");
   OEnv *ev = (OEnv *)malloc(sizeof(OEnv));
@@ -158,6 +159,12 @@ static int step_impl(tmjx_model *m, float *state, int32_t *istate, const float *
   for (int e = 0; e < n; e++) {
     env_from_rows(m, ev, state, istate, n, e);
     for (int i = 0; i < m->o->nu; i++) a[i] = *ROW(action, i);
+    ev->fo_pos = NULL;
+    if (fo) {
+      const int nj = m->o->nq - 7, nb3 = (m->o->nbody - 1) * 3;
+      ev->fo_pos = fo->pos + (size_t)e * 3; ev->fo_quat = fo->quat + (size_t)e * 4; ev->fo_joints = fo->joints + (size_t)e * nj;
+      ev->fo_bodypos = fo->bodypos + (size_t)e * nb3; ev->fo_angvel = fo->angvel + (size_t)e * 3;
+    }
     oracle_env_step_ex(m->o, ev, a, do_physics);
     env_to_rows(m, ev, state, istate, n, e, 0);
     outputs_to_rows(m, ev, obs, reward, done, trunc, metrics, n, e);
@@ -168,12 +175,21 @@ static int step_impl(tmjx_model *m, float *state, int32_t *istate, const float *
 int tmjx_step(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done, float *truncation,
               float *metrics, float *workspace, int n_env, void *stream) {
   (void)workspace; (void)stream;
-  return step_impl(m, state, istate, action, obs, reward, done, truncation, metrics, n_env, 1);
+  return step_impl(m, state, istate, action, obs, reward, done, truncation, metrics, n_env, 1, NULL);
 }
 int tmjx_reward_obs(tmjx_model *m, float *state, int32_t *istate, const float *action, float *obs, float *reward, float *done, float *truncation,
                     float *metrics, float *workspace, int n_env, void *stream) {
   (void)workspace; (void)stream;
-  return step_impl(m, state, istate, action, obs, reward, done, truncation, metrics, n_env, 0);
+  return step_impl(m, state, istate, action, obs, reward, done, truncation, metrics, n_env, 0, NULL);
+}
+/* include/tmjx.h: K3's reward / termination part with the CALLER's reference frame per env (reward.py:359-366) */
+int tmjx_reward_frame(tmjx_model *m, float *state, int32_t *istate, const float *action, const float *frame_pos, const float *frame_quat,
+                      const float *frame_joints, const float *frame_bodypos, const float *frame_angvel, float *obs, float *reward, float *done,
+                      float *truncation, float *metrics, int n_env, void *stream) {
+  (void)stream;
+  if (!frame_pos || !frame_quat || !frame_joints || !frame_bodypos || !frame_angvel) return fail(TMJX_EINVAL, "null reference-frame leaf");
+  FrameLeaves fo = {frame_pos, frame_quat, frame_joints, frame_bodypos, frame_angvel};
+  return step_impl(m, state, istate, action, obs, reward, done, truncation, metrics, n_env, 0, &fo);
 }
 int tmjx_physics(tmjx_model *m, float *state, const float *action, int n_substeps, float *workspace, int n, void *stream) {
   (void)workspace; (void)stream;

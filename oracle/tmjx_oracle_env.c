@@ -180,6 +180,7 @@ static void env_inner_step(const OModel *m, OEnv *e, const real *a, int do_physi
   const float *rj = clip_row(m, m->clip_joints, nj, e->clip_idx, frame);
   const float *rb = clip_row(m, m->clip_bodypos, nbp * 3, e->clip_idx, frame);
   const float *rw = clip_row(m, m->clip_angvel, 3, e->clip_idx, frame);
+  if (e->fo_pos) { rp = e->fo_pos; rq = e->fo_quat; rj = e->fo_joints; rb = e->fo_bodypos; rw = e->fo_angvel; }      /* the caller's gathered frame */
   /* info updates happen BEFORE the reward call (single_clip_tracking.py:227-234): prev_ctrl == action there */
   for (int i = 0; i < nu; i++) e->prev_ctrl[i] = a[i];
   for (int i = 0; i < nu; i++) e->action_buffer[e->buffer_index][i] = a[i];

@@ -86,7 +86,7 @@ def test_abi_twin_exports_the_env_entry_points_and_matches_the_native_oracle():
     H = _np_harness(blob, clip, n)
     sym = subprocess.run(["nm", "-D", "--defined-only", str(ABI_SO)], capture_output=True, text=True, check=True).stdout
     for name in ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_set_wrappers", "tmjx_set_action_repeat", "tmjx_clips_upload", "tmjx_reset", "tmjx_step",
-                 "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_gae", "tmjx_last_error", "tmjx_version"):
+                 "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_reward_frame", "tmjx_gae", "tmjx_last_error", "tmjx_version"):
         assert f" T {name}" in sym, name
     ci, sf, qn, vn, acts = _inputs(n)
     H.reset(ci, sf, qn, vn)
@@ -108,6 +108,54 @@ def test_abi_twin_exports_the_env_entry_points_and_matches_the_native_oracle():
         assert np.abs(o["reward"] - np.array([O.env_get(envs, e, "reward")[0] for e in range(n)])).max() < 1e-5
         assert np.array_equal(o["done"], np.array([O.env_get(envs, e, "done")[0] for e in range(n)], dtype=np.float32))
         assert np.array_equal(o["istate"][y.i_buffer_index], np.array([O.env_get(envs, e, "buffer_index")[0] for e in range(n)], dtype=np.int32))
+    H.close()
+
+
+def test_reward_frame_entry_of_the_twin_against_golden_vectors():
+    """tmjx_reward_frame through the oracle's ABI twin, on the CPU: the 24 golden cases of the track_mjx-owned maths (tests/golden/task_golden.npz:
+    numpy restatement of reward.py / single_clip_tracking.py) through a handle whose RESIDENT clip table is a different one (seed 999) — the
+    terms equal the golden ones only if the entry computes them from the frame the caller passes (compute_tracking_rewards(data,
+    reference_frame, ...), reward.py:359-366; call site single_clip_tracking.py:223-225,239-246); tmjx_reward_obs on the same buffers does not.
+    The GPU twin of this test: tests/test_gpu_parity_strict.py::test_compute_tracking_rewards_uses_the_reference_frame_the_caller_passes."""
+    G = np.load(ROOT / "tests" / "golden" / "task_golden.npz")
+    n = G["in_qpos"].shape[0]
+    w, cfg = default_walker()
+    blob = default_blob(w, cfg)
+    golden_table = _clips.make_synthetic_clips(w.model, 3, seed=123)          # the table make_golden.py used
+    other_table = _clips.make_synthetic_clips(w.model, 3, seed=999)
+    H = _np_harness(blob, other_table, n)
+    y, L = H.lay, H.L
+    H.reset(G["in_clip_idx"].astype(np.int32), G["in_start_frame"].astype(np.int32), np.zeros((74, n), np.float32), np.zeros((73, n), np.float32))
+    st = H.state
+    for k, r0 in (("qpos", y.qpos), ("qvel", y.qvel), ("xpos", y.xpos), ("qfrc_actuator", y.qfrc_actuator), ("xmat_torso", y.xmat_torso)):
+        v = np.ascontiguousarray(G["in_" + k].T)
+        st[r0:r0 + v.shape[0]] = v
+    st[y.time] = G["in_time"]
+    st[y.action_buffer:y.action_buffer + 1900] = np.ascontiguousarray(G["in_action_buffer"].T)
+    H.istate[y.i_buffer_index] = G["in_buffer_index"].astype(np.int32)
+    # the caller's gather, as the reference does it: frame index floor(time * mocap_hz + start_frame) in float32, un-fused (single_clip_tracking.py:452-454)
+    frames = np.floor(G["in_time"].astype(np.float32) * np.float32(50.0) + G["in_start_frame"].astype(np.float32)).astype(np.int64)
+    frames = np.clip(frames, 0, golden_table.position.shape[1] - 1)
+    ci = G["in_clip_idx"].astype(np.int64)
+    leaves = [np.ascontiguousarray(getattr(golden_table, k)[ci, frames], dtype=np.float32) for k in ("position", "quaternion", "joints", "body_positions", "angular_velocity")]
+    action = np.ascontiguousarray(G["in_action"].T, dtype=np.float32)
+    p = H.ptr
+    before = (H.state.copy(), H.istate.copy())
+    st2, ist2 = H.state.copy(), H.istate.copy()
+    rc = L.tmjx_reward_frame(H.h, p(st2), p(ist2), p(action), *[p(v) for v in leaves], p(H.obs), p(H.reward), p(H.done), p(H.trunc), p(H.metrics), n, None)
+    assert rc == 0, L.tmjx_last_error()
+    assert np.array_equal(before[0], H.state) and np.array_equal(before[1], H.istate)       # (it ran on the copies)
+    alive = G["out_done"] == 0
+    np.testing.assert_allclose(H.metrics.T, G["out_metrics"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(H.reward, G["out_reward"], rtol=2e-5, atol=2e-6)
+    assert np.array_equal(H.done, G["out_done"]) and alive.sum() >= 3 and (~alive).sum() >= 3
+    met_frame = H.metrics.copy()
+    # the resident (different) table through tmjx_reward_obs: other joint / position terms
+    st3, ist3 = H.state.copy(), H.istate.copy()
+    assert L.tmjx_reward_obs(H.h, p(st3), p(ist3), p(action), p(H.obs), p(H.reward), p(H.done), p(H.trunc), p(H.metrics), None, n, None) == 0
+    assert not np.allclose(H.metrics[2], met_frame[2], rtol=1e-3, atol=1e-6) and not np.allclose(H.metrics[15], met_frame[15], rtol=1e-3, atol=1e-6)
+    assert L.tmjx_reward_frame(H.h, p(st3), p(ist3), p(action), None, p(leaves[1]), p(leaves[2]), p(leaves[3]), p(leaves[4]), p(H.obs), p(H.reward), p(H.done),
+                               p(H.trunc), p(H.metrics), n, None) == -22
     H.close()
 
 
