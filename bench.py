@@ -145,6 +145,61 @@ def other_configs(timeout_s: float = 150.0) -> dict:
     return res
 
 
+def live_pmc_traffic(timeout_s: float = 90.0):
+    """HBM traffic of the env.step kernels from the PMC counters, collected BY THIS RUN: two child `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE
+    cannot share a pass: MI355X_MICROARCH.md "rocprofv3 PMC slots") over tools/time_step.py (4096 envs in one launch, 4 steps), counters in KB per
+    dispatch, FETCH_SIZE doubled — the gfx950 correction that guide prescribes.  Exactly what tools/profile_gpu.sh + tools/pmc_summary.py stamp into
+    profiles/pmc_traffic.json (the fallback when rocprofv3 is missing or a pass fails: the line says which it carries).  Returns None on any failure."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    step_kernels = ("void k_physics_wave", "k_rec_in", "k_rec_out", "k_step_parts", "k_window", "k_obs", "k_post_parts", "k_post", "k_autoreset")
+    tmp = tempfile.mkdtemp(prefix="tmjx_pmc_", dir="/tmp")
+    out: dict = {}
+    try:
+        for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", f"{tmp}/{kind}", "--",
+                   sys.executable, str(ROOT / "tools" / "time_step.py"), "--steps", "4"]
+            p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, start_new_session=True)
+            _CHILDREN.append(p)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None
+            finally:
+                if p in _CHILDREN:
+                    _CHILDREN.remove(p)
+            files = glob.glob(f"{tmp}/{kind}/**/*_counter_collection.csv", recursive=True)
+            if p.returncode != 0 or not files:
+                return None
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(max(files, key=lambda f: os.path.getmtime(f)))):
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                if k.startswith(step_kernels):
+                    vv = v[3:] if len(v) > 4 else v           # steady-state env.step launches (the first ones belong to reset / warm-up)
+                    out.setdefault(k.replace("void ", ""), {})[kind] = sum(vv) / len(vv) * 1024.0
+        kern = {k: {"fetch_bytes_raw": v.get("fetch", 0.0), "fetch_bytes_corrected": 2 * v.get("fetch", 0.0), "write_bytes": v.get("write", 0.0)} for k, v in out.items()}
+        dom = "k_physics_wave<true>"
+        if dom not in kern or "fetch" not in out[dom] or "write" not in out[dom]:
+            return None
+        return {"kernels": kern, "envs_per_launch": ENVS_PER_GPU, "hbm_bytes_per_launch": kern[dom]["fetch_bytes_corrected"] + kern[dom]["write_bytes"],
+                "hbm_bytes_per_launch_all_step_kernels": sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in kern.values()),
+                "so_build_id": so_build_id(), "collected_by_this_run": True}
+    except Exception:  # noqa: BLE001 — a report beside the headline, never a reason to lose it
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def dry_run_ranks(args) -> None:
     """`--dry-run-ranks`: the launcher plumbing without a GPU — every rank joins a gloo group, all-reduces a one, rank 0 prints the
     line's skeleton (tests/test_launch.py drives `bench.py --gpus 2 --dry-run-ranks` through the self-launch branch)."""
@@ -184,6 +239,7 @@ def main(argv=None, runner=None):
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
                     help="BASELINE.json configs[1] (default, the headline line) / configs[2] (cfg3: one rank's share per GPU) / configs[3] / configs[4]; the others are extra measurements")
     ap.add_argument("--dry-run-ranks", action="store_true", help="launcher check on CPU: gloo ranks, no GPU work (tests)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the HBM-traffic counters with two child rocprofv3 passes (then the stamped profiles/pmc_traffic.json is what the line carries)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short cfg4 / cfg5 measurements the default N = 1 line carries under config.other_configs")
     args = ap.parse_args(argv)
     from track_mjx_amd import launch
@@ -349,6 +405,7 @@ def main(argv=None, runner=None):
         achieved = ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
         k2_achieved = K2_ALGO_BYTES_PER_ENV_STEP * per_launch / (kernel_ms * 1e-3) / 1e9
         pmc, sq, flc, mf = prof("pmc_traffic.json"), prof("sq_counters.json"), prof("oracle_flop_count.json"), prof("mfma_counters.json")
+        live = None           # (the counters collected by THIS run replace the stamped file's further down, once the headline is safe from a time-out)
         # counter bytes per launch, scaled to this launch's env count: K2 alone, and all kernels of one env.step (K2 + record transposes + K3)
         pscale = per_launch / pmc.get("envs_per_launch", ENVS_PER_GPU) if pmc else None
         k2_traffic = pmc.get("hbm_bytes_per_launch") * pscale if pmc else None
@@ -392,7 +449,8 @@ def main(argv=None, runner=None):
                          "traffic_over_algorithmic": (step_traffic / (ALGO_BYTES_PER_ENV_STEP * per_launch)) if step_traffic else None,
                          "traffic_build_id": pmc.get("so_build_id") if pmc else None,
                          "traffic_build_is_this_runs": bool(pmc and pmc.get("so_build_id") == so_build_id()),
-                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (FETCH_SIZE doubled, the gfx950 correction), NOT collected by this run; bytes per launch scaled to this launch's env count",
+                         "traffic_collected_by_this_run": False,
+                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh (FETCH_SIZE doubled, the gfx950 correction), NOT collected by this run (replaced below when this run's own rocprofv3 passes succeed); bytes per launch scaled to this launch's env count",
                          "kernel": "k_physics_wave (10 physics substeps of one control step, one workgroup per env)",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * per_launch,
                          "avg_launch_ms": kernel_ms, "avg_launch_ms_is": f"shared-GPU duration: {ngrp} launches of {' / '.join(str(x) for x in sizes)} envs run concurrently (plus the other group's K3 / inference); the HIP events also span the two record-transpose launches (< 1 %)",
@@ -450,6 +508,18 @@ def main(argv=None, runner=None):
                 signal.pthread_sigmask(signal.SIG_SETMASK, old)
         for _s in (signal.SIGTERM, signal.SIGINT):
             signal.signal(_s, emit)
+        # the HBM-traffic counters collected by THIS run (two child rocprofv3 --pmc passes, ~40 s; only the default N = 1 line): the stamped
+        # profiles/pmc_traffic.json stays in the line if rocprofv3 is missing or a pass fails
+        if world == 1 and args.config == "cfg2" and not args.no_live_pmc and not args.no_cpu_baseline:
+            live = live_pmc_traffic()
+            if live:
+                sc = per_launch / live["envs_per_launch"]
+                r, k2t, stt = out["roofline"], live["hbm_bytes_per_launch"] * sc, live["hbm_bytes_per_launch_all_step_kernels"] * sc
+                r.update({"traffic": stt, "traffic_over_algorithmic": stt / (ALGO_BYTES_PER_ENV_STEP * per_launch), "traffic_build_id": live["so_build_id"],
+                          "traffic_build_is_this_runs": True, "traffic_collected_by_this_run": True,
+                          "traffic_source": "two child `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS run over tools/time_step.py (4096 envs in one launch; KB per dispatch, FETCH_SIZE doubled: the gfx950 correction), bytes per launch scaled to this launch's env count",
+                          "traffic_kernels": {k: v["fetch_bytes_corrected"] + v["write_bytes"] for k, v in live["kernels"].items()}})
+                r["k2_only"].update({"traffic": k2t, "traffic_over_algorithmic": k2t / (K2_ALGO_BYTES_PER_ENV_STEP * per_launch)})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # same action regime as the roll-out-only leg (0.3 * N(0,1)); the full-scale regime of BASELINE config 1 beside it
