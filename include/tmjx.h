@@ -138,6 +138,19 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
                   const float *truncation, const float *fc2, float *dlogits, float *dbaseline, float *dfc2, float *scratch,
                   float *out, void *stream);
 
+/* The same loss head in phases, for a caller that runs the policy and the value network on two streams: A (log-prob, entropy, KL sums) reads the policy's
+ * outputs only, B (GAE, advantage statistics, value loss) the value network's only, C (surrogate + every gradient) both, D writes out[8].  Each call launches
+ * the phases of its mask on its stream; the caller orders them (A, B before C; C before D).  unroll_length T <= 24.  Gradients: the bits of tmjx_ppo_loss;
+ * the entropy / KL scalars are added up in another order. */
+#define TMJX_PPO_PHASE_A 1
+#define TMJX_PPO_PHASE_B 2
+#define TMJX_PPO_PHASE_C 4
+#define TMJX_PPO_PHASE_D 8
+int tmjx_ppo_loss_phases(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *raw_action, const float *behaviour_logp,
+                         const float *noise, const float *baseline, const float *bootstrap, const float *reward, const float *discount,
+                         const float *truncation, const float *fc2, float *dlogits, float *dbaseline, float *dfc2, float *scratch,
+                         float *out, int phases, void *stream);
+
 /* Dense -> SiLU -> LayerNorm epilogue of the intention network's hidden layers (intention_network.py:14-88):
  * y = LayerNorm_{gamma,beta,eps}(silu(z + bias)), z [rows][H] = the GEMM output, H in {64, 128, 256, 512, 1024}.
  * fwd also writes stats [rows][2] = mean, rstd; bwd returns dz and grads [3][H] = d_gamma | d_beta | d_bias;

@@ -487,6 +487,62 @@ def test_fused_ppo_loss_head_matches_torch_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,B", [(7, 96), (20, 1024), (3, 70)])
+def test_loss_head_in_phases_gives_the_one_call_forms_gradients(T, B):
+    """tmjx_ppo_loss_phases — A on the policy's stream, B on the value network's, C after both, D beside the backward pass — against tmjx_ppo_loss on the same
+    inputs: the three gradient arrays bit for bit, the eight scalars to 1e-6 (the entropy / KL sums are added up in D instead of B); a second pass with
+    cfg.accumulate adds to `out`; an unroll longer than 24 steps is refused."""
+    import ctypes as C
+    import torch
+    from track_mjx_amd import hip
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator(device=dev).manual_seed(T * 1000 + B)
+    A, Z = 38, 60
+    rnd = lambda *s: torch.randn(*s, generator=g, device=dev)
+    logits, raw, noise, fc2 = rnd(T, B, 2 * A) * 0.5, rnd(T, B, A) * 0.7, rnd(T, B, A), rnd(T, B, 2 * Z) * 0.3
+    blogp, baseline, bootstrap, reward = rnd(T, B) * 0.3 - 30.0, rnd(T, B), rnd(B), rnd(T, B).abs()
+    discount = (torch.rand(T, B, generator=g, device=dev) > 0.1).float()
+    trunc = (torch.rand(T, B, generator=g, device=dev) > 0.9).float()
+    ins = [logits, raw, blogp, noise, baseline, bootstrap, reward, discount, trunc, fc2]
+    cfg = hip.PpoCfg(T, B, A, Z, 1.0, 0.95, 0.95, 0.2, 1e-2, 0.1, 1, 0)
+
+    def run(phased: bool, accumulate: int = 0, out=None):
+        cfg.accumulate = accumulate
+        outs = [torch.empty_like(logits), torch.empty_like(baseline), torch.empty_like(fc2), torch.zeros(L.tmjx_ppo_scratch_floats(T, B), device=dev),
+                torch.zeros(8, device=dev) if out is None else out]
+        ptr = [C.c_void_p(a.data_ptr()) for a in ins + outs]
+        cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+        if not phased:
+            hip.check(L.tmjx_ppo_loss(C.byref(cfg), *ptr, C.c_void_p(cur.cuda_stream)), "tmjx_ppo_loss")
+        else:
+            side.wait_stream(cur)
+            hip.check(L.tmjx_ppo_loss_phases(C.byref(cfg), *ptr, 2, C.c_void_p(side.cuda_stream)), "B")
+            hip.check(L.tmjx_ppo_loss_phases(C.byref(cfg), *ptr, 1, C.c_void_p(cur.cuda_stream)), "A")
+            cur.wait_stream(side)
+            hip.check(L.tmjx_ppo_loss_phases(C.byref(cfg), *ptr, 4, C.c_void_p(cur.cuda_stream)), "C")
+            side.wait_stream(cur)
+            hip.check(L.tmjx_ppo_loss_phases(C.byref(cfg), *ptr, 8, C.c_void_p(side.cuda_stream)), "D")
+            cur.wait_stream(side)
+        torch.cuda.synchronize()
+        return outs
+    ref, got = run(False), run(True)
+    for k in range(3):
+        assert torch.equal(ref[k], got[k]), k
+    assert float((ref[4] - got[4]).abs().max()) <= 1e-6 * max(1.0, float(ref[4].abs().max())), (ref[4], got[4])
+    one = run(True, 0)[4]
+    twice = run(True, 1, out=one.clone())[4]
+    assert float((twice - 2 * one).abs().max()) <= 1e-6 * max(1.0, float(one.abs().max()))
+    all_in_one = [torch.empty_like(logits), torch.empty_like(baseline), torch.empty_like(fc2), torch.zeros(L.tmjx_ppo_scratch_floats(T, B), device=dev), torch.zeros(8, device=dev)]
+    cfg.accumulate = 0
+    hip.check(L.tmjx_ppo_loss_phases(C.byref(cfg), *[C.c_void_p(a.data_ptr()) for a in ins + all_in_one], 15, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ABCD")
+    torch.cuda.synchronize()
+    assert torch.equal(all_in_one[0], ref[0]) and torch.equal(all_in_one[4], got[4])
+    long = hip.PpoCfg(25, B, A, Z, 1.0, 0.95, 0.95, 0.2, 1e-2, 0.1, 1, 0)
+    assert L.tmjx_ppo_loss_phases(C.byref(long), *[C.c_void_p(a.data_ptr()) for a in ins + all_in_one], 15, None) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("H", [64, 256, 1024])
 def test_fused_silu_layernorm_block_matches_torch(H):
     """tmjx_silu_ln_fwd / _bwd against torch's linear -> silu -> layer_norm, outputs and all four gradients."""

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from .. import hip as _hip
@@ -136,24 +138,42 @@ class _FusedLossHead(torch.autograd.Function):
 
 def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_cost: float = 1e-4, kl_weight: float = 1e-3,
                               discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
-                              clipping_epsilon: float = 0.3, normalize_advantage: bool = True, side_stream=None, acc_out: torch.Tensor | None = None):
+                              clipping_epsilon: float = 0.3, normalize_advantage: bool = True, side_stream=None, acc_out: torch.Tensor | None = None,
+                              scalars_on_side: bool = False):
     """The learner's form of compute_ppo_loss_fused: network outputs with autograd, then tmjx_ppo_loss OUTSIDE autograd; returns
     (metrics, outputs, output_grads) so that the caller runs ONE torch.autograd.grad(outputs, params, grad_outputs=output_grads) —
     no autograd node for the loss head, no `grad * 1.0` passes over the three gradient arrays, no clone of the scalar."""
     obs = data["observation_normalized"] if "observation_normalized" in data else normalizer.normalize(data["observation"])
     nxt = data["next_observation_last_normalized"] if "next_observation_last_normalized" in data else normalizer.normalize(data["next_observation_last"])
+    T, B = data["reward"].shape
+    dev = obs.device
+    L = _hip.lib()
+    # the loss head in phases (tmjx_ppo_loss_phases) when the networks run on two streams: B — GAE, advantage statistics, value loss: the value network's
+    # outputs only — goes onto the value network's stream, D (the eight scalars, which the backward pass does not wait for) leaves the main stream
+    # too: the main stream runs policy forward, A, C, backward.  TMJX_PPO_PHASES=0: the one-call form
+    phased = side_stream is not None and T <= 24 and os.environ.get("TMJX_PPO_PHASES", "1") != "0"
+    cfg_of = lambda A_, Z_: _hip.PpoCfg(T, B, A_, Z_, reward_scaling, discounting, gae_lambda, clipping_epsilon, entropy_cost, kl_weight,  # noqa: E731
+                                        int(normalize_advantage), int(acc_out is not None))
+    f32 = lambda a: a.detach().contiguous().float()  # noqa: E731
     if side_stream is not None:
         # the value network is independent of the policy until the loss head: its forward — and, because autograd runs a node's
         # backward on the stream of its forward, its backward too — goes to a second stream (a parallel branch of the captured
         # graph): its GEMMs run next to the policy's epilogue / reduction kernels and vice versa
-        cur = torch.cuda.current_stream(obs.device)
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            scratch = torch.empty(L.tmjx_ppo_scratch_floats(T, B), dtype=torch.float32, device=dev)
+            out = torch.empty(8, dtype=torch.float32, device=dev) if acc_out is None else acc_out
+            row = [f32(data[k]) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")]
         side_stream.wait_stream(cur)
         with torch.cuda.stream(side_stream):
             baseline = value(obs)
             with torch.no_grad():
                 bootstrap = value(nxt)
+                if phased:
+                    bl, bs = f32(baseline), f32(bootstrap)
         logits, fc2 = policy(obs, eps=data.get("latent_eps"), return_fc2=True)
-        cur.wait_stream(side_stream)
+        if not phased:
+            cur.wait_stream(side_stream)
         baseline.record_stream(cur); bootstrap.record_stream(cur)
     else:
         logits, fc2 = policy(obs, eps=data.get("latent_eps"), return_fc2=True)
@@ -162,24 +182,47 @@ def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_
             bootstrap = value(nxt)
     with torch.no_grad():
         noise = data["entropy_noise"] if "entropy_noise" in data else torch.randn(data["raw_action"].shape, dtype=torch.float32, device=logits.device)   # entropy sample (randn_like(loc))
-        T, B = data["reward"].shape
-        dev = logits.device
-        args = [a.detach().contiguous().float() for a in (logits, data["raw_action"], data["log_prob"], noise, baseline, bootstrap, data["reward"],
-                                                          data["discount"], data["truncation"], fc2)]
-        dlogits, dbaseline, dfc2 = torch.empty_like(args[0]), torch.empty_like(args[4]), torch.empty_like(args[9])
-        L = _hip.lib()
-        scratch = torch.empty(L.tmjx_ppo_scratch_floats(T, B), dtype=torch.float32, device=dev)
-        # `acc_out`: the caller's running sums of the eight loss scalars (the kernel ADDS to them: no add launch per minibatch step)
-        out = torch.empty(8, dtype=torch.float32, device=dev) if acc_out is None else acc_out
-        c = _hip.PpoCfg(T, B, data["raw_action"].shape[-1], fc2.shape[-1] // 2, reward_scaling, discounting, gae_lambda, clipping_epsilon,
-                        entropy_cost, kl_weight, int(normalize_advantage), int(acc_out is not None))
-        with torch.cuda.device(dev):
-            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if phased:
+            lg, nz, f2 = f32(logits), f32(noise), f32(fc2)
+            dlogits, dbaseline, dfc2 = torch.empty_like(lg), torch.empty_like(bl), torch.empty_like(f2)
+            c = cfg_of(data["raw_action"].shape[-1], fc2.shape[-1] // 2)
+            args = [lg, row[0], row[1], nz, bl, bs, row[2], row[3], row[4], f2]
             ptr = [C.c_void_p(a.data_ptr()) for a in args + [dlogits, dbaseline, dfc2, scratch, out]]
-            _hip.check(L.tmjx_ppo_loss(C.byref(c), *ptr, stream), "tmjx_ppo_loss")
+            for t_ in (scratch, out, dbaseline, *row):
+                t_.record_stream(side_stream)
+            for t_ in (bl, bs):
+                t_.record_stream(cur)
+
+            def phase(mask, stream):
+                _hip.check(L.tmjx_ppo_loss_phases(C.byref(c), *ptr, mask, C.c_void_p(stream.cuda_stream)), "tmjx_ppo_loss_phases")
+            with torch.cuda.device(dev):
+                phase(2, side_stream)           # B: behind the value network's forward pass, on its stream
+                phase(1, cur)                   # A: behind the policy's
+                cur.wait_stream(side_stream)
+                phase(4, cur)                   # C: both
+                if scalars_on_side:             # (the caller joins `side_stream` into the current stream later: PPOLearner._mb_backward)
+                    side_stream.wait_stream(cur)
+                    phase(8, side_stream)       # D: the scalars — in front of the value network's backward pass on ITS stream, off the policy's path
+                else:
+                    phase(8, cur)
+            args9 = f2
+        else:
+            args = [f32(a) for a in (logits, data["raw_action"], data["log_prob"], noise, baseline, bootstrap, data["reward"],
+                                     data["discount"], data["truncation"], fc2)]
+            dlogits, dbaseline, dfc2 = torch.empty_like(args[0]), torch.empty_like(args[4]), torch.empty_like(args[9])
+            if side_stream is None:
+                scratch = torch.empty(L.tmjx_ppo_scratch_floats(T, B), dtype=torch.float32, device=dev)
+                # `acc_out`: the caller's running sums of the eight loss scalars (the kernel ADDS to them: no add launch per minibatch step)
+                out = torch.empty(8, dtype=torch.float32, device=dev) if acc_out is None else acc_out
+            c = cfg_of(data["raw_action"].shape[-1], fc2.shape[-1] // 2)
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                ptr = [C.c_void_p(a.data_ptr()) for a in args + [dlogits, dbaseline, dfc2, scratch, out]]
+                _hip.check(L.tmjx_ppo_loss(C.byref(c), *ptr, stream), "tmjx_ppo_loss")
+            args9 = args[9]
     metrics = {"total_loss": out[0], "policy_loss": out[1], "v_loss": out[2], "kl_latent_loss": out[4], "entropy_loss": out[3]}
     handle = getattr(policy, "latent_grad_handle", None)
-    if handle is not None and handle.matches(fc2) and args[9].data_ptr() == fc2.data_ptr():
+    if handle is not None and handle.matches(fc2) and args9.data_ptr() == fc2.data_ptr():
         # fc2 has two gradients, the KL term's (here) and the latent sample's (tmjx_latent_concat_bwd): hand this one to that kernel, which sums
         # them, instead of seeding autograd with it (autograd would add the two with an element-wise launch of its own; same sum, same bits).
         # It is parked on THIS forward pass's handle: a backward pass that does not run through this forward leaves it there, and the policy's

@@ -648,7 +648,7 @@ class PPOLearner:
             self.shadows.refresh()          # one launch: the optimiser step behind the previous replay changed the master weights
         return data
 
-    def _mb_forward(self, idx, kl_w):
+    def _mb_forward(self, idx, kl_w, scalars_on_side: bool = False):
         """GPU: gather + both networks' forward passes + the loss head (outside autograd).  Returns (network outputs, their gradients, the loss
         kernel's eight scalars) for _mb_backward."""
         data = self._mb_data(idx)
@@ -658,7 +658,8 @@ class PPOLearner:
             twins = {on.data_ptr(): (data["observation_normalized_bf16"], on.shape[-1])}
         with gemm_inputs(self.matmul_dtype, self.shadows, twins):
             m, outs, gouts, out8 = _losses.ppo_loss_and_output_grads(self.policy, self.value, self.normalizer, data, kl_weight=kl_w,
-                                                                     side_stream=self._sgd_side, acc_out=self._acc8 if idx is None else None, **self.hp)
+                                                                     side_stream=self._sgd_side, acc_out=self._acc8 if idx is None else None,
+                                                                     scalars_on_side=scalars_on_side and self._sgd_side is not None, **self.hp)
         return outs, gouts, out8
 
     def _mb_backward(self, outs, gouts, which: str = "all"):
@@ -696,7 +697,7 @@ class PPOLearner:
         to self._acc8: a captured graph of it replays with NO host input (no index copy, no torch generator state to refresh)."""
         if self.dev.type == "cuda":
             # loss head outside autograd: its kernels give d loss / d(network outputs), one backward pass from the outputs
-            outs, gouts, out8 = self._mb_forward(idx, kl_w)
+            outs, gouts, out8 = self._mb_forward(idx, kl_w, scalars_on_side=True)      # (_mb_backward("all") joins the side stream)
             self._mb_backward(outs, gouts, "all")
             if idx is None:
                 return self._acc8                    # (the loss kernel added this step's scalars; reordered to METRIC_KEYS once per update())

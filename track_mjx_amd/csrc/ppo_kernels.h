@@ -308,9 +308,10 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_ppo_c(PpoCfg c, const float *__re
   if (threadIdx.x == 0) scratch[(size_t)4 * N + (size_t)blockIdx.x * 4 + 3] = acc[0];
 }
 
-// D: final scalars
-__global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk, const float *rec = nullptr, int nrec = 0) {
-  __shared__ float lds[16];
+// D: final scalars.  sum_parts (tmjx_ppo_loss_phases): the records do not carry A's entropy / KL sums (B ran next to A, on the value network's
+// stream) — D adds A's per-block partials up itself
+__global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk, const float *rec = nullptr, int nrec = 0, int sum_parts = 0) {
+  __shared__ float lds[64];
   __shared__ float scal_s[8];
   const int N = c.T * c.B;
   const float *part = scratch + 4 * (size_t)N, *scal = part + (size_t)4 * nblk;
@@ -319,10 +320,20 @@ __global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk, co
     __syncthreads();
     scal = scal_s;
   }
-  float acc[1] = {0.f};
-  for (int k = threadIdx.x; k < nblk; k += blockDim.x) acc[0] += part[4 * k + 3];
-  ppo_block_sum<1>(acc, lds);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) {
+    acc[0] += part[4 * k + 3];
+    if (sum_parts) { acc[1] += part[4 * k]; acc[2] += part[4 * k + 1]; acc[3] += part[4 * k + 2]; }
+  }
+  ppo_block_sum<4>(acc, lds);
   if (threadIdx.x == 0) {
+    if (sum_parts) {      // (the arithmetic of ppo_combine_records on the three sums)
+      const float n = (float)N;
+      scal_s[3] = acc[1] / n;
+      float kl0 = -0.5f * acc[2] / (float)(c.B * c.Z), kl = kl0;
+      if (c.T > 1) { float klt = 0.5f * acc[3] / (float)((c.T - 1) * c.B * c.Z); kl = (kl0 + klt * (float)(c.T - 1)) / (float)c.T; }
+      scal_s[4] = c.kl_weight * kl;
+    }
     float policy = -acc[0] / (float)N, v = scal[2], entl = -c.entropy_cost * scal[3], kl = scal[4];
     const float o[8] = {policy + v + entl + kl, policy, v, entl, kl, scal[0], scal[1], scal[3]};
     // accumulate: `out` is a running sum over the minibatch steps of an update (the learner's metric accumulator: no add launch per step)

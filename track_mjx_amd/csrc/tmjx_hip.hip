@@ -610,6 +610,32 @@ int tmjx_ppo_loss(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *r
   return check_launch("k_ppo");
 }
 
+// The loss head in phases, for a caller that runs the two networks on two streams (agent/losses.py: ppo_loss_and_output_grads): A needs the policy's outputs only,
+// B the value network's only — it goes onto THAT network's stream, next to the policy's last layers — C needs both, D (the eight scalars) nothing the backward
+// pass waits for: it leaves the main stream too.  Same arithmetic as tmjx_ppo_loss; the entropy / KL scalars are summed in D instead of B (a different order
+// of the same additions); the gradients are the same bits.  unroll_length <= 24 only.
+int tmjx_ppo_loss_phases(const tmjx_ppo_cfg_t *cfg, const float *logits, const float *raw_action, const float *behaviour_logp,
+                         const float *noise, const float *baseline, const float *bootstrap, const float *reward, const float *discount,
+                         const float *truncation, const float *fc2, float *dlogits, float *dbaseline, float *dfc2, float *scratch,
+                         float *out, int phases, void *stream) {
+  if (!cfg || !logits || !raw_action || !behaviour_logp || !noise || !baseline || !bootstrap || !reward || !discount || !truncation ||
+      !fc2 || !dlogits || !dbaseline || !dfc2 || !scratch || !out) return fail(TMJX_EINVAL, "null argument");
+  if (cfg->T < 1 || cfg->B < 1 || cfg->A < 1 || cfg->Z < 1) return fail(TMJX_EINVAL, "bad T / B / A / Z");
+  if (cfg->T > PPO_TMAX) return fail(TMJX_EINVAL, "tmjx_ppo_loss_phases: unroll_length > 24 (use tmjx_ppo_loss)");
+  if (phases < 1 || phases > 15) return fail(TMJX_EINVAL, "phases: a mask of TMJX_PPO_PHASE_A | _B | _C | _D");
+  PpoCfg c{cfg->T, cfg->B, cfg->A, cfg->Z, cfg->reward_scaling, cfg->discounting, cfg->gae_lambda, cfg->clip_eps, cfg->entropy_cost,
+           cfg->kl_weight, cfg->normalize_advantage, cfg->accumulate};
+  const int N = c.T * c.B, nblk = (N * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK, nrec = (c.B + 63) / 64;
+  float *rec = scratch + 4 * (size_t)N + (size_t)4 * nblk + 16;
+  hipStream_t s = (hipStream_t)stream;
+  if (phases & TMJX_PPO_PHASE_A) hipLaunchKernelGGL(k_ppo_a, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, noise, fc2, scratch, nblk);
+  if (phases & TMJX_PPO_PHASE_B) hipLaunchKernelGGL(k_ppo_b2, dim3(nrec), dim3(64), 0, s, c, baseline, bootstrap, reward, discount, truncation, scratch, 0, rec);   // (nblk = 0: no slice of A's partials)
+  if (phases & TMJX_PPO_PHASE_C) hipLaunchKernelGGL(k_ppo_c, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, behaviour_logp, noise, baseline, fc2, dlogits, dbaseline,
+                                                    dfc2, scratch, nblk, (const float *)rec, nrec);
+  if (phases & TMJX_PPO_PHASE_D) hipLaunchKernelGGL(k_ppo_d, dim3(1), dim3(256), 0, s, c, (const float *)scratch, out, nblk, (const float *)rec, nrec, 1);
+  return check_launch("k_ppo (phases)");
+}
+
 int tmjx_silu_ln_partial_floats(int rows, int H) { return ((rows + BLK_ROWS_PER_BLOCK - 1) / BLK_ROWS_PER_BLOCK) * 3 * H; }
 
 static int silu_ln_fwd_any(const float *z, const float *bias, const float *gamma, const float *beta, float *y, uint16_t *y16, int ldy16, float *stats, int rows, int H,
