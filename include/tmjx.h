@@ -384,6 +384,16 @@ int tmjx_bf_silu_bwd_rank1(const float *dy1, const float *w1, const uint16_t *z1
 long long tmjx_bgemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is_f32, int ldx, float *dW, int lddw, float *db, float *scratch,
                   int M, int N, int K, void *stream);
+/* All weight (+ bias) gradients of one backward pass in bf16 GEMM-input mode as ONE launch + one reduction launch: up to 24 problems of tmjx_bgemm_dw, each
+ * with its own scratch (>= tmjx_bgemm_dw_scratch_floats(M, N, K) floats); the slab count of every problem is capped so that the whole launch is about
+ * `target_wgs` workgroups (0: the default, 2048), in multiples of eight slabs (one per XCD).  The reference computes every layer's weight gradient inside one jax.value_and_grad
+ * (track_mjx/agent/mlp_ppo/ppo.py:286-300); `problems` is a HOST array (copied into the launch). */
+typedef struct tmjx_bdw_problem_t {
+  const void *dY, *X;
+  float *dW, *db, *scratch;       /* db may be NULL */
+  int32_t y_is_f32, x_is_f32, ldy, ldx, lddw, M, N, K;
+} tmjx_bdw_problem_t;
+int tmjx_bgemm_dw_grouped(const tmjx_bdw_problem_t *problems, int n, int target_wgs, void *stream);
 
 /* The stores of one env-group step into the roll-out buffers in one launch (the Transition of brax acting.actor_step, as the learner of
  * track_mjx/agent/mlp_ppo/ppo.py:330-348 collects it): obs [W][n] (env-minor) -> up to three row-major [n][W] destinations; raw [n][A],

@@ -105,6 +105,49 @@ def test_bgemm_dw(M, N, K, ldx, bias, y_bf16, x_bf16):
         assert db is None
 
 
+def test_grouped_weight_gradients_equal_the_layer_by_layer_ones():
+    """deferred_weight_grads in bf16 GEMM-input mode: bgemm_dw calls with a destination view inside the block are recorded and computed by ONE
+    tmjx_bgemm_dw_grouped launch at launch(); every result within the rounding bound of the float64 product (the slab split differs from the
+    stand-alone call's, so the sums are taken in another order), pads of row-padded destinations untouched, a call WITHOUT a destination view
+    inside the block is computed on the spot, 26 problems go as two groups."""
+    from track_mjx_amd.agent.networks import bgemm_dw, deferred_weight_grads
+    g = torch.Generator(device=DEV).manual_seed(77)
+    shapes = [(8192, 512, 512, True, True, True), (8192, 1024, 470, True, False, True), (8192, 256, 512, False, True, True), (8192, 120, 512, True, True, False),
+              (8192, 76, 256, True, True, True), (8192, 512, 286, True, False, True)] + [(4096, 128, 64 + 8 * i, True, i % 2 == 0, True) for i in range(20)]
+    ops, outs = [], []
+    with deferred_weight_grads() as d:
+        for M, N, K, ybf, xbf, bias in shapes:
+            ldx, ldy = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+            x = torch.randn((M, ldx), generator=g, device=DEV).to(torch.bfloat16 if xbf else torch.float32)[:, :K]
+            dy = torch.randn((M, ldy), generator=g, device=DEV).to(torch.bfloat16 if ybf else torch.float32)[:, :N]
+            full = torch.full((N, (K + 3) // 4 * 4), 7.0, device=DEV)
+            dbv = torch.full((N,), 7.0, device=DEV) if bias else None
+            dw, db = bgemm_dw(dy, x, bias, out=full[:, :K], out_bias=dbv)
+            ops.append((dy, x, bias)); outs.append((full, dw, db))
+        assert len(d.bproblems) == len(shapes)
+        torch.cuda.synchronize()
+        assert all(bool((f == 7.0).all()) for f, _, _ in outs), "a recorded problem was computed before launch()"
+        # no destination view: computed on the spot
+        dy, x, _ = ops[0]
+        now, _ = bgemm_dw(dy, x, False)
+        assert len(d.bproblems) == len(shapes)
+        d.launch()
+        assert not d.bproblems
+    torch.cuda.synchronize()
+    for (dy, x, bias), (full, dw, db) in zip(ops, outs):
+        M, K = x.shape
+        d64, x64 = _bf(dy).double(), _bf(x).double()
+        ref = d64.t() @ x64
+        bound = (d64.abs().t() @ x64.abs()) * EPS * (M ** 0.5 + 4) * 2 + 1e-30
+        assert ((dw.double() - ref).abs() <= bound).all()
+        assert (full[:, K:] == 7.0).all()
+        if bias:
+            src = dy.double()
+            assert ((db.double() - src.sum(0)).abs() <= src.abs().sum(0) * EPS * (M ** 0.5 + 4) * 2 + 1e-30).all()
+    d64, x64 = _bf(ops[0][0]).double(), _bf(ops[0][1]).double()
+    assert ((now.double() - d64.t() @ x64).abs() <= (d64.abs().t() @ x64.abs()) * EPS * (8192 ** 0.5 + 4) * 2 + 1e-30).all()
+
+
 def _ln_ref(z64, b64, g64, be64, eps):
     a = torch.nn.functional.silu(z64 + b64)
     return torch.nn.functional.layer_norm(a, (z64.shape[1],), g64, be64, eps), a

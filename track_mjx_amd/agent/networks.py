@@ -171,6 +171,13 @@ def bgemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool, out: torch.Tens
     K = x.shape[1]
     dw = torch.empty((N, K), dtype=torch.float32, device=dy.device) if out is None else out
     db = (torch.empty(N, dtype=torch.float32, device=dy.device) if out_bias is None else out_bias) if with_bias else None
+    d = deferred_weight_grads.active
+    if d is not None and d.group_bf16 and N > 1 and out is not None:
+        # inside the learner's backward pass, into a flat-buffer view (the parameter's FIRST use in this pass: `dest` / deferred_weight_grads.seen — a second
+        # use's gradient is added to the first by autograd DURING the pass and must exist by then): recorded, computed with every other layer's by ONE
+        # grouped launch behind the pass (deferred_weight_grads.launch)
+        d.bproblems.append((dy, x, dw, db))
+        return dw, db
     scratch = torch.empty(int(_hip.lib().tmjx_bgemm_dw_scratch_floats(M, N, K)), dtype=torch.float32, device=dy.device)
     _launch("tmjx_bgemm_dw", dy.device, _p(dy), int(dy.dtype == torch.float32), _ld(dy), _p(x), int(x.dtype == torch.float32), _ld(x),
             _p(dw), dw.stride(0) if N > 1 else max(dw.stride(0), K), _p(db), _p(scratch), M, N, K)
@@ -302,6 +309,8 @@ class deferred_weight_grads:
 
     def __enter__(self):
         self.problems, self.keep, self.colsums = [], [], []
+        # bf16 GEMM-input mode: the layers' weight gradients (networks.bgemm_dw) as one grouped launch too (tmjx_bgemm_dw_grouped; TMJX_BDW_GROUPED=0: layer by layer)
+        self.bproblems, self.group_bf16 = [], os.environ.get("TMJX_BDW_GROUPED", "1") != "0"
         self.seen: set = set()       # ids of the parameters whose gradient views have been handed to autograd in this block
         deferred_weight_grads.active = self
         return self
@@ -353,6 +362,31 @@ class deferred_weight_grads:
             self.colsums = []
         self._launch_problems(self.problems)
         self.problems = []
+        self._launch_bproblems()
+
+    def _launch_bproblems(self):
+        import ctypes as C
+        from .. import hip as _hip
+        probs, self.bproblems = self.bproblems, []
+        if not probs:
+            return
+        L = _hip.lib()
+        dev = probs[0][0].device
+        for at in range(0, len(probs), 24):
+            grp = probs[at:at + 24]
+            sizes = [int(L.tmjx_bgemm_dw_scratch_floats(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _, _ in grp]
+            scratch = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), dtype=torch.float32, device=dev)
+            arr = (_hip.BdwProblem * len(grp))()
+            off = 0
+            for i, (dy, x, dw, db) in enumerate(grp):
+                N, K = dy.shape[1], x.shape[1]
+                arr[i] = _hip.BdwProblem(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, scratch.data_ptr() + 4 * off,
+                                         int(dy.dtype == torch.float32), int(x.dtype == torch.float32), _ld(dy), _ld(x), dw.stride(0) if N > 1 else max(dw.stride(0), K),
+                                         dy.shape[0], N, K)
+                off += (sizes[i] + 3) // 4 * 4
+            with torch.cuda.device(dev):
+                _hip.check(L.tmjx_bgemm_dw_grouped(arr, len(grp), 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tmjx_bgemm_dw_grouped")
+            self.keep += [scratch] + [t for q in grp for t in q[:2]]
 
     def _launch_problems(self, problems, target_wgs: int = 0):
         import ctypes as C

@@ -807,6 +807,54 @@ __global__ __launch_bounds__(256) void k_bgemm_dw_reduce(const float *__restrict
 }
 
 
+// ---- every weight gradient of a backward pass in ONE launch (+ one reduction launch): the grouped form of csrc/gemm_kernels.h (k_gemm_dw_grouped) for
+// the bf16 operands.  Launched layer by layer a weight gradient has to split its rows into ~32 slabs to fill the chip on its own — 32 fp32 copies of the
+// weight matrix written and read back per layer; side by side the problems of a backward pass fill it with 4 - 8 slabs each.  The table travels by value
+// (hipGraph-safe); a problem's workgroups keep the XCD-aware order of k_bgemm_dw (all tiles of one row slab in one residue class mod 8).
+#define BDW_GROUP_MAX 24
+struct BdwProblem {
+  const void *dY, *X;
+  float *dW, *db, *slabs;
+  int ldy, ldx, lddw, M, N, K, y_f32, x_f32, rows_per_split, S, ld_slab, tiles_n, tiles_k;
+  int wg_begin, red_begin;
+};
+struct BdwGroup { BdwProblem p[BDW_GROUP_MAX]; int n; };
+__global__ __launch_bounds__(256) void k_bgemm_dw_grouped(const BdwGroup G) {
+  int i = 0;
+  for (int j = 1; j < G.n; j++) if ((int)blockIdx.x >= G.p[j].wg_begin) i = j;       // uniform
+  const BdwProblem &P = G.p[i];
+  const int local = blockIdx.x - P.wg_begin, tiles = P.tiles_n * P.tiles_k, xcd = local & 7, q = local >> 3;
+  const int split = (q / tiles) * 8 + xcd, tl = q % tiles;
+  if (split >= P.S) return;
+  const int wb = P.db != nullptr;
+  if (P.y_f32 && P.x_f32) bgemm_dw_tile<true, true>(P.dY, P.ldy, P.X, P.ldx, P.slabs, P.M, P.N, P.K, wb, P.rows_per_split, P.ld_slab, tl / P.tiles_k, tl % P.tiles_k, split);
+  else if (P.y_f32) bgemm_dw_tile<true, false>(P.dY, P.ldy, P.X, P.ldx, P.slabs, P.M, P.N, P.K, wb, P.rows_per_split, P.ld_slab, tl / P.tiles_k, tl % P.tiles_k, split);
+  else if (P.x_f32) bgemm_dw_tile<false, true>(P.dY, P.ldy, P.X, P.ldx, P.slabs, P.M, P.N, P.K, wb, P.rows_per_split, P.ld_slab, tl / P.tiles_k, tl % P.tiles_k, split);
+  else bgemm_dw_tile<false, false>(P.dY, P.ldy, P.X, P.ldx, P.slabs, P.M, P.N, P.K, wb, P.rows_per_split, P.ld_slab, tl / P.tiles_k, tl % P.tiles_k, split);
+}
+__global__ __launch_bounds__(256) void k_bgemm_dw_reduce_grouped(const BdwGroup G) {
+  int i = 0;
+  for (int j = 1; j < G.n; j++) if ((int)blockIdx.x >= G.p[j].red_begin) i = j;
+  const BdwProblem &P = G.p[i];
+  const int wb = P.db != nullptr;
+  const long long e = (long long)(blockIdx.x - P.red_begin) * 256 + threadIdx.x;
+  const int Kx = P.K + wb;
+  if (e >= (long long)P.N * Kx) return;
+  const int n = (int)(e / Kx), k = (int)(e % Kx);
+  const float *p = P.slabs + (size_t)n * P.ld_slab + k;
+  const size_t step = (size_t)P.N * P.ld_slab;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= P.S; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] += p[(size_t)(s + u) * step];
+  }
+  for (; s < P.S; s++) a[0] += p[(size_t)s * step];
+  const float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (k < P.K) P.dW[(size_t)n * P.lddw + k] = v; else P.db[n] = v;
+}
+
+
 // ---- The ACTING policy's dense layer in bf16 GEMM-input mode, without LDS (the bf16 twin of csrc/ppo_kernels.h: k_linear_nolds_mfma; the acting
 // policy runs next to the other env groups' physics kernel, which owns every CU's LDS).  C[M][N] = A[M][K] W^T (+ bias): the fp32 activations are
 // rounded to bf16 in registers (v_cvt_pk_bf16_f32 — the rounding the learner's kernels apply when they stage a tile), W is the layer's resident

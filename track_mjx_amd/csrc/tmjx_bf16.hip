@@ -49,10 +49,11 @@ static int bgemm_by_width(const void *A, int lda, const bf16_t *B, int ldb, cons
 }
 
 // rows of M per slab and number of slabs: about two workgroups (four waves each) per CU
-static void bdw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab) {
+static void bdw_split(int M, int N, int K, int *rows_per_split, int *S, int *ld_slab, int max_slabs = 0) {
   const int tiles = ((N + BGDW_BT - 1) / BGDW_BT) * ((K + BGDW_BT - 1) / BGDW_BT);
   static const int target = getenv("TMJX_BDW_WGS") ? atoi(getenv("TMJX_BDW_WGS")) : 512;      // tuning knob
   int want = (target + tiles - 1) / tiles;
+  if (max_slabs > 0 && want > max_slabs) want = max_slabs;      // (a problem of a group: the group fills the chip, not the problem)
   if (want < 1) want = 1;
   int rps = (((M + want - 1) / want) + BGDW_BM - 1) / BGDW_BM * BGDW_BM;
   if (rps < BGDW_BM) rps = BGDW_BM;
@@ -201,6 +202,42 @@ int tmjx_bgemm_dw(const void *dY, int y_is_f32, int ldy, const void *X, int x_is
   const long long total = (long long)N * (K + wb);
   hipLaunchKernelGGL(k_bgemm_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)scratch, dW, db, S, N, K, wb, ld, lddw);
   return check_launch("k_bgemm_dw");
+}
+
+// Every weight gradient of a backward pass in one launch + one reduction launch (k_bgemm_dw_grouped): problems as tmjx_bgemm_dw takes them, each with a
+// scratch of tmjx_bgemm_dw_scratch_floats(M, N, K) floats.  target_wgs: workgroups the GROUP should bring (0: TMJX_BDW_GROUP_WGS, default 2048).
+int tmjx_bgemm_dw_grouped(const tmjx_bdw_problem_t *probs, int n, int target_wgs, void *stream) {
+  if (!probs) return fail(TMJX_EINVAL, "null argument");
+  if (n < 1 || n > BDW_GROUP_MAX) return fail(TMJX_EINVAL, "1 .. 24 problems per group");
+  static const int group_default = getenv("TMJX_BDW_GROUP_WGS") ? atoi(getenv("TMJX_BDW_GROUP_WGS")) : 2048;
+  const int group_target = target_wgs > 0 ? target_wgs : group_default;
+  int all_tiles = 0;
+  for (int i = 0; i < n; i++) all_tiles += ((probs[i].N + BGDW_BT - 1) / BGDW_BT) * ((probs[i].K + BGDW_BT - 1) / BGDW_BT);
+  // slabs in EIGHTS: a problem's slab s runs on XCD s % 8 (k_bgemm_dw's order: the tiles of one row slab share an L2), so 6 slabs leave two XCDs without
+  // work (measured on config 5's 17 layers: 6 slabs 4.05 ms per minibatch step, 7 -> 3.98 with a 16-slab grid, 8 -> 3.74; layer by layer 3.80)
+  int max_slabs = ((group_target + all_tiles / 2) / (all_tiles > 0 ? all_tiles : 1) + 4) / 8 * 8;
+  if (max_slabs < 8) max_slabs = 8;
+  BdwGroup G;
+  G.n = n;
+  int wg = 0, red = 0;
+  for (int i = 0; i < n; i++) {
+    const tmjx_bdw_problem_t &q = probs[i];
+    if (!q.dY || !q.X || !q.dW || !q.scratch) return fail(TMJX_EINVAL, "null pointer in a problem");
+    if (q.M < 1 || q.N < 1 || q.K < 1 || q.ldy < q.N || q.ldx < q.K || q.lddw < q.K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions in a problem");
+    if (((uintptr_t)q.dY & 15) || ((uintptr_t)q.X & 15) || (q.ldy & (q.y_is_f32 ? 3 : 7)) || (q.ldx & (q.x_is_f32 ? 3 : 7)))
+      return fail(TMJX_EINVAL, "tmjx_bgemm_dw_grouped: operand rows must be 16-byte aligned");
+    BdwProblem &P = G.p[i];
+    P.dY = q.dY; P.X = q.X; P.dW = q.dW; P.db = q.db; P.slabs = q.scratch;
+    P.ldy = q.ldy; P.ldx = q.ldx; P.lddw = q.lddw; P.M = q.M; P.N = q.N; P.K = q.K; P.y_f32 = q.y_is_f32 ? 1 : 0; P.x_f32 = q.x_is_f32 ? 1 : 0;
+    bdw_split(q.M, q.N, q.K, &P.rows_per_split, &P.S, &P.ld_slab, max_slabs);
+    P.tiles_n = (q.N + BGDW_BT - 1) / BGDW_BT; P.tiles_k = (q.K + BGDW_BT - 1) / BGDW_BT;
+    P.wg_begin = wg; wg += P.tiles_n * P.tiles_k * ((P.S + 7) / 8) * 8;
+    P.red_begin = red; red += (int)(((long long)q.N * (q.K + (q.db ? 1 : 0)) + 255) / 256);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bgemm_dw_grouped, dim3(wg), dim3(256), 2 * BGDW_STAGE, s, G);
+  hipLaunchKernelGGL(k_bgemm_dw_reduce_grouped, dim3(red), dim3(256), 0, s, G);
+  return check_launch("k_bgemm_dw_grouped");
 }
 
 }  // extern "C"

@@ -35,7 +35,7 @@ EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_reward_frame", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss", "tmjx_ppo_loss_phases",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_silu_ln_fwd_bf16", "tmjx_silu_ln_bwd_bf16", "tmjx_minibatch_begin_bf16", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_latent_concat_bwd_add", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_linear_act", "tmjx_linear_act_ok", "tmjx_linear_nolds_norm", "tmjx_linear_nolds_bf16", "tmjx_adam_clip", "tmjx_adam_clip_norm", "tmjx_adam_norm_floats", "tmjx_colsum_scratch_floats", "tmjx_colsum",
            "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_colsum_grouped", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_grouped_wgs", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_set_action_repeat", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
-           "tmjx_rollout_store", "tmjx_clips_share", "tmjx_gemm_nt_silu", "tmjx_gemm_nt_silu_ok", "tmjx_silu_fwd", "tmjx_silu_bwd", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bf16_z_bytes", "tmjx_bgemm_partial_floats",
+           "tmjx_rollout_store", "tmjx_clips_share", "tmjx_gemm_nt_silu", "tmjx_gemm_nt_silu_ok", "tmjx_silu_fwd", "tmjx_silu_bwd", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_grouped", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bf16_z_bytes", "tmjx_bgemm_partial_floats",
            "tmjx_bgemm_ln_fwd", "tmjx_bgemm_ln_bwd", "tmjx_bgemm_silu_fwd", "tmjx_bgemm_silu_bwd", "tmjx_bf_silu_bwd", "tmjx_bf_silu_bwd_rank1",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
@@ -56,6 +56,12 @@ class DwProblem(C.Structure):
     """tmjx_dw_problem_t (include/tmjx.h)."""
     _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("scratch", C.c_void_p),
                 ("ldy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
+
+
+class BdwProblem(C.Structure):
+    """tmjx_bdw_problem_t (include/tmjx.h)."""
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("scratch", C.c_void_p),
+                ("y_is_f32", C.c_int32), ("x_is_f32", C.c_int32), ("ldy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
 
 
 class RolloutStore(C.Structure):
@@ -249,6 +255,7 @@ def load(path: Path):
     sig.setdefault("tmjx_bgemm_dw_scratch_floats", [None, None])[0] = [C.c_int, C.c_int, C.c_int]
     sig.setdefault("tmjx_bgemm_dw_scratch_floats", [None, None])[1] = C.c_longlong
     sig.setdefault("tmjx_bgemm_dw", [None, None])[0] = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_bgemm_dw_grouped", [None, None])[0] = [C.POINTER(BdwProblem), C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_set_wrappers", [None, None])[0] = [vp, C.c_int, C.c_int]
     sig.setdefault("tmjx_set_action_repeat", [None, None])[0] = [vp, C.c_int]
     sig.setdefault("tmjx_stats_scratch_floats", [None, None])[0] = [C.c_int]
