@@ -29,6 +29,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# dmabuf IPC: RCCL across processes needs it on this driver (the launchers export it; a rank started some other way must have it before HIP initialises)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_ENV_STEP = 15644        # SURVEY.md §8 d4 / BASELINE.md §2: 3911 four-byte words per env step (K2+K3 together)
 # of which the physics kernel (K2) itself moves: reads qpos..time 259 + action 38, writes qpos..time 259 + xpos 204 +
