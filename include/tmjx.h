@@ -309,6 +309,16 @@ int tmjx_gemm_nt_silu_ok(const float *A, int lda, const float *W, int ldw);
 int tmjx_gemm_nt_silu(const float *A, int lda, const float *W, int ldw, const float *bias, float *Z, float *Y, int ldc, int M, int N, int K, void *stream);
 int tmjx_silu_fwd(const float *z, const float *bias, float *y, long long rows, int N, void *stream);
 int tmjx_silu_bwd(const float *dy, const float *z, const float *bias, float *dz, long long rows, int N, void *stream);
+/* The backward pass of the value MLP without an element-wise launch between its GEMMs (brax make_value_network, ppo_networks.py:180-184: Dense -> swish ... Dense(1)):
+ * tmjx_gemm_nn_silu_bwd: dZ[M][N] = (dY[M][K] W[K][N]) silu'(z + bias) — the input gradient of a hidden layer's consumer with THAT layer's SiLU backward on the
+ *   accumulators (z, dZ dense [M][N]; operand rows 16-byte aligned: tmjx_gemm_nn_silu_bwd_ok);
+ * tmjx_silu_bwd_rank1: dz[m][k] = (dy1[m] w1[k]) silu'(z[m][k] + bias[k]) — the same for the 1-wide head, whose input gradient is an outer product;
+ * tmjx_head_dw: the head's gradients dw[k] = sum_m dy1[m] x[m][k], db[0] = sum_m dy1[m] (a matrix-vector product; scratch >= tmjx_head_dw_scratch_floats). */
+int tmjx_gemm_nn_silu_bwd_ok(const float *dY, int ldy, const float *W, int ldw);
+int tmjx_gemm_nn_silu_bwd(const float *dY, int ldy, const float *W, int ldw, const float *z, const float *bias, float *dZ, int M, int N, int K, void *stream);
+int tmjx_silu_bwd_rank1(const float *dy1, const float *w1, const float *z, const float *bias, float *dz, long long rows, int N, void *stream);
+long long tmjx_head_dw_scratch_floats(int M, int K);
+int tmjx_head_dw(const float *dy1, const float *x, int ldx, float *dw, float *db, float *scratch, int M, int K, void *stream);
 long long tmjx_gemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream);
 /* All weight (+ bias) gradients of one backward pass as ONE launch + one reduction launch: up to 16 independent problems of tmjx_gemm_dw,

@@ -291,3 +291,101 @@ def test_value_net_silu_layers_without_torch_elementwise_kernels(M, widths):
         assert (a.double() - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, float((a.double() - b).abs().max() / b.abs().max())
     with torch.no_grad():
         assert torch.allclose(net(x), v, rtol=0, atol=0)          # the inference path runs the same kernels
+
+
+@pytest.mark.parametrize("M,N,K", [(20480, 256, 256), (5120, 256, 256), (2048, 512, 512), (2048, 256, 512), (333, 24, 8), (1000, 128, 64), (77, 64, 40), (81, 100, 36)])
+def test_input_gradient_with_silu_backward_epilogue_keeps_the_bits(M, N, K):
+    """tmjx_gemm_nn_silu_bwd (k_gemm_act<.., EPI = 4>): dZ = (dY W) silu'(z + bias) in one launch against tmjx_gemm_nn followed by tmjx_silu_bwd — the same
+    accumulators, the same expression: bit for bit; both tile heights (80 and 32 rows by M), ragged rows and widths."""
+    from track_mjx_amd.agent import networks as nw
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dy = torch.randn((M, K), generator=g, device=DEV)
+    w = torch.randn((K, N), generator=g, device=DEV) / K ** 0.5          # the consumer's weight [out = K][in = N]
+    z = torch.randn((M, N), generator=g, device=DEV)
+    b = 0.3 * torch.randn(N, generator=g, device=DEV)
+    dx = nw.gemm_nn(dy, w)
+    want = torch.empty_like(z)
+    nw._launch("tmjx_silu_bwd", DEV, nw._p(dx), nw._p(z), nw._p(b), nw._p(want), M, N)
+    got = torch.full_like(z, 7.0)
+    nw._launch("tmjx_gemm_nn_silu_bwd", DEV, nw._p(dy), dy.stride(0), nw._p(w), w.stride(0), nw._p(z), nw._p(b), nw._p(got), M, N, K)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), float((got - want).abs().max())
+    s = torch.sigmoid(z.double() + b.double())
+    ref = (dy.double() @ w.double()) * (s * (1 + (z.double() + b.double()) * (1 - s)))
+    assert (got.double() - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("M,N", [(20480, 256), (5117, 512), (333, 8), (1, 4)])
+def test_rank1_silu_backward_and_head_gradients(M, N):
+    """tmjx_silu_bwd_rank1 against the outer product through tmjx_gemm_nn + tmjx_silu_bwd (bit for bit: one product, the same expression) and tmjx_head_dw
+    against float64 (a sum over rows in another order than tmjx_gemm_dw's slabs: the fp32 dot-product bound)."""
+    from track_mjx_amd import hip
+    from track_mjx_amd.agent import networks as nw
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    dy1 = torch.randn(M, generator=g, device=DEV)
+    w1 = torch.randn((1, N), generator=g, device=DEV)
+    z = torch.randn((M, N), generator=g, device=DEV)
+    b = 0.3 * torch.randn(N, generator=g, device=DEV)
+    dx = nw.gemm_nn(dy1.view(M, 1), w1)
+    want = torch.empty_like(z)
+    nw._launch("tmjx_silu_bwd", DEV, nw._p(dx), nw._p(z), nw._p(b), nw._p(want), M, N)
+    got = torch.full_like(z, 7.0)
+    nw._launch("tmjx_silu_bwd_rank1", DEV, nw._p(dy1), nw._p(w1), nw._p(z), nw._p(b), nw._p(got), M, N)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # head gradients: x with a leading dimension
+    buf = torch.randn((M, N + 4), generator=g, device=DEV)
+    x = buf[:, :N]
+    dw, db = torch.full((1, N), 7.0, device=DEV), torch.full((1,), 7.0, device=DEV)
+    scratch = torch.empty(int(hip.lib().tmjx_head_dw_scratch_floats(M, N)), device=DEV)
+    nw._launch("tmjx_head_dw", DEV, nw._p(dy1), nw._p(x), x.stride(0), nw._p(dw), nw._p(db), nw._p(scratch), M, N)
+    torch.cuda.synchronize()
+    ref = dy1.double() @ x.double()
+    bound = (dy1.double().abs() @ x.double().abs()) * EPS * (M ** 0.5 + 4) * 2 + 1e-30
+    assert ((dw[0].double() - ref).abs() <= bound).all()
+    assert abs(float(db[0]) - float(dy1.double().sum())) <= float(dy1.double().abs().sum()) * EPS * (M ** 0.5 + 4) * 2 + 1e-30
+
+
+@pytest.mark.parametrize("M,widths", [(20480, (696, 256, 256, 1)), (2048, (696, 512, 512, 256, 1)), (333, (40, 24, 8, 1))])
+def test_value_chain_function_against_the_layer_by_layer_path(M, widths, monkeypatch):
+    """ValueNet's learner pass as ONE autograd function (_ValueChainFn) against the per-layer functions (TMJX_VALUE_CHAIN=0): value and the hidden layers'
+    gradients bit for bit (same kernels forward, same expressions backward), the 1-wide head's gradients to the dot-product bound; under
+    deferred_weight_grads with flat gradient views the hidden layers' weight gradients land in the views."""
+    from track_mjx_amd.agent import networks as nw
+    torch.manual_seed(M + 1)
+    net = nw.ValueNet(widths[0], widths[1:-1]).to(DEV)
+    with torch.no_grad():
+        for m in net.net:
+            if isinstance(m, torch.nn.Linear):
+                m.bias.copy_(0.3 * torch.randn_like(m.bias))
+    x = torch.randn((M, widths[0]), device=DEV)
+    cot = torch.randn(M, device=DEV)
+    params = list(net.parameters())
+    seen = []
+    orig = nw._ValueChainFn.forward
+    monkeypatch.setattr(nw._ValueChainFn, "forward", staticmethod(lambda *a: (seen.append(1), orig(*a))[1]))
+    v1 = net(x)
+    g1 = torch.autograd.grad(v1, params, cot)
+    assert seen, "the fused value chain did not run"
+    monkeypatch.setenv("TMJX_VALUE_CHAIN", "0")
+    n0 = len(seen)
+    v0 = net(x)
+    g0 = torch.autograd.grad(v0, params, cot)
+    assert len(seen) == n0
+    assert torch.equal(v0, v1)
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        if i < len(params) - 2:
+            assert torch.equal(a, b), (i, float((a - b).abs().max()))
+        else:
+            assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-6, (i, float((a - b).abs().max()))
+    monkeypatch.delenv("TMJX_VALUE_CHAIN")
+    # with flat gradient views: the deferred group writes the hidden layers' gradients there
+    for p in params:
+        p.grad = torch.full_like(p, 7.0)
+    with nw.deferred_weight_grads() as d:
+        g2 = torch.autograd.grad(net(x), params, cot)
+        d.launch()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(g2, g0)):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-6, (i, float((a - b).abs().max()))
+    assert g2[0].data_ptr() == params[0].grad.data_ptr()

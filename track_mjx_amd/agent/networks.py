@@ -737,6 +737,87 @@ class _HipSiluDenseFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _ValueChainFn(torch.autograd.Function):
+    """The whole fp32 value MLP (brax make_value_network, ppo_networks.py:180-184: Dense -> swish ... Dense(1)) as ONE autograd function: forward as the per-layer
+    functions do it (tmjx_gemm_nt_silu per hidden layer, tmjx_gemm_nt for the 1-wide head); backward WITHOUT an element-wise launch between the GEMMs and without a
+    GEMM for the head: tmjx_head_dw (the head's gradients: a matrix-vector product), tmjx_silu_bwd_rank1 (the last hidden layer's d loss / d z from the head's
+    outer-product input gradient), then per hidden layer tmjx_gemm_nn_silu_bwd (its input gradient with the PRODUCING layer's SiLU backward on the accumulators);
+    weight gradients of the hidden layers into the learner's grouped launch as before.  Same expressions as tmjx_silu_bwd / tmjx_gemm_nn: the hidden layers'
+    gradients keep their bits; the head's weight gradient is summed in another order than tmjx_gemm_dw's slabs."""
+
+    @staticmethod
+    def forward(ctx, x, lins, *params):
+        x2 = _rows2d(x)
+        M = x2.shape[0]
+        h, saved = x2, []
+        for lin in lins[:-1]:
+            N, K = lin.weight.shape
+            z = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+            y = torch.empty_like(z)
+            _launch("tmjx_gemm_nt_silu", x2.device, _p(h), h.stride(0), _p(lin.weight), lin.weight.stride(0), _p(lin.bias), _p(z), _p(y), N, M, N, K)
+            saved.append((h, z))
+            h = y
+        head = lins[-1]
+        out = gemm_nt(h, head.weight, head.bias)
+        ctx.lins, ctx.saved, ctx.h_last, ctx.x_shape = lins, saved, h, x.shape
+        return out.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .. import hip as _hip
+        lins, saved = ctx.lins, ctx.saved
+        L = _hip.lib()
+        dev = dout.device
+        dy1 = dout.reshape(-1)
+        dy1 = dy1 if dy1.is_contiguous() else dy1.contiguous()
+        M = dy1.shape[0]
+        head = lins[-1]
+        grads = {}
+        # the head: gradients as a matrix-vector product, its input gradient never materialised
+        K = head.in_features
+        dwh, dbh = torch.empty((1, K), dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(L.tmjx_head_dw_scratch_floats(M, K)), dtype=torch.float32, device=dev)
+        _launch("tmjx_head_dw", dev, _p(dy1), _p(ctx.h_last), ctx.h_last.stride(0), _p(dwh), _p(dbh), _p(scratch), M, K)
+        grads[id(head.weight)], grads[id(head.bias)] = dwh, dbh
+        last = lins[-2]
+        dz = torch.empty_like(saved[-1][1])
+        _launch("tmjx_silu_bwd_rank1", dev, _p(dy1), _p(head.weight), _p(saved[-1][1]), _p(last.bias), _p(dz), M, last.out_features)
+        d = deferred_weight_grads.active
+        dx = None
+        for i in range(len(lins) - 2, -1, -1):
+            lin = lins[i]
+            xin, _ = saved[i]
+            got = d.try_add(dz, xin, lin.weight, lin.bias) if d is not None else None
+            dw, db = got if got is not None else gemm_dw(dz, xin, True)
+            grads[id(lin.weight)], grads[id(lin.bias)] = dw, db
+            if i > 0:
+                prev, pz = lins[i - 1], saved[i - 1][1]
+                dzp = torch.empty_like(pz)
+                _launch("tmjx_gemm_nn_silu_bwd", dev, _p(dz), dz.stride(0), _p(lin.weight), lin.weight.stride(0), _p(pz), _p(prev.bias), _p(dzp), M, prev.out_features, lin.out_features)
+                dz = dzp
+            elif ctx.needs_input_grad[0]:
+                dx = gemm_nn(dz, lin.weight).view(ctx.x_shape)
+        ctx._keep = scratch
+        out = []
+        for lin in lins:
+            out += [grads[id(lin.weight)], grads[id(lin.bias)]]
+        return (dx, None, *out)
+
+
+def _value_chain_ok(x2, lins) -> bool:
+    """The fused fp32 value chain's preconditions: a 1-wide head behind at least one hidden layer, widths in fours, 16-byte aligned rows everywhere."""
+    from .. import hip as _hip
+    if os.environ.get("TMJX_VALUE_CHAIN", "1") == "0" or len(lins) < 2 or lins[-1].out_features != 1 or lins[-1].bias is None:
+        return False
+    L = _hip.lib()
+    if x2.data_ptr() % 16 or x2.stride(0) % 4 or x2.stride(1) != 1:
+        return False
+    for lin in lins[:-1]:
+        if lin.bias is None or lin.out_features % 4 or lin.in_features % 4 or lin.weight.data_ptr() % 16 or lin.weight.stride(0) % 4 or lin.bias.data_ptr() % 16:
+            return False
+    return lins[-1].in_features % 4 == 0 and lins[-1].weight.data_ptr() % 16 == 0 and bool(L.tmjx_gemm_nt_silu_ok(_p(x2), x2.stride(0), _p(lins[0].weight), lins[0].weight.stride(0)))
+
+
 class _BfDenseFn(torch.autograd.Function):
     """bf16 GEMM-input mode (BASELINE config 5): y = x W^T (+ b) with all three contractions on the library's bf16 MFMA kernels — forward
     tmjx_bgemm_nt against the weight's shadow, input gradient tmjx_bgemm_nt against the transposed shadow, weight + bias gradient
@@ -1116,6 +1197,9 @@ class ValueNet(nn.Module):
             # fp32 on the GPU: every hidden layer is ONE launch forward (GEMM + SiLU epilogue), no torch element-wise kernel in either direction
             h = obs
             dense = [m for m in self.net if isinstance(m, nn.Linear)]
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and _value_chain_ok(_rows2d(obs), dense):
+                # the learner's pass: the whole MLP as one autograd function (no element-wise launch between the backward GEMMs, the 1-wide head without a GEMM)
+                return _ValueChainFn.apply(obs, dense, *[p for lin in dense for p in (lin.weight, lin.bias)]).squeeze(-1)
             for lin in dense[:-1]:
                 if torch.is_grad_enabled() and (lin.weight.requires_grad or h.requires_grad):
                     h = _HipSiluDenseFn.apply(h, lin.weight, lin.bias)

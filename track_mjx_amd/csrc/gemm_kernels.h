@@ -76,6 +76,7 @@ struct GemmLN {
   const float *gamma, *beta; float *y, *stats; float eps;      // EPI 1 (forward);  EPI 2 reads gamma and stats
   const float *z; float *partial;                              // EPI 2: the block's saved pre-activation z; per-workgroup column sums [3][BN]
 };
+// EPI 4 (input-gradient kernel, any tile): the SiLU backward of the producing Dense -> SiLU layer on the accumulators (see the epilogue).
 // EPI 2 (input-gradient kernel, tile = whole rows, N == 256): the tile is d loss / d y of a Dense -> SiLU -> LayerNorm block (y its output);
 // the epilogue applies that block's LayerNorm + SiLU backward (the arithmetic of k_silu_ln_bwd) and stores d loss / d z instead, plus the
 // workgroup's column sums of (dy * ahat | dy | dz) = partial d gamma | d beta | d bias: the block's own backward launch disappears.
@@ -488,7 +489,14 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       const int row = m0 + 16 * a + li;
       if (row < M) {
         float *o = C + (long long)row * ldc + col;
-        const float v[8] = {acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1], acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
+        float v[8] = {acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1], acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
+        if constexpr (EPI == 4) {       // SiLU backward of the producing layer on the accumulators (see the generic path below): `bias` is that layer's
+          const float *zr = ln.z + (long long)row * ldc + col;
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            if (col + k < N) { const float x = zr[k] + bias[col + k], sig = 1.f / (1.f + expf(-x)); v[k] *= sig * (1.f + x * (1.f - sig)); }
+          }
+        }
         if (vec) { *reinterpret_cast<gf4 *>(o) = gf4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<gf4 *>(o + 4) = gf4{v[4], v[5], v[6], v[7]}; }
         else if (vec2) {                 // rows 8-byte aligned only (an odd multiple of 2 floats wide, e.g. 470 or 286)
 #pragma unroll
@@ -556,6 +564,15 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = m0 + 16 * a + 4 * kq + r;
+        if constexpr (EPI == 4) {
+          // the tile is d loss / d y of a Dense -> SiLU layer (this GEMM: its consumer's input gradient); `bias` is THAT layer's bias, ln.z its saved
+          // pre-activation (dense [M][ldc], without the bias): d loss / d z = dy silu'(z + bias) — the expression of k_silu_bwd_f32, whose launch and
+          // whose re-read of dy disappear
+          if (row < M && col < N) {
+            const float v = ln.z[(long long)row * ldc + col] + bv, sig = 1.f / (1.f + expf(-v));
+            C[(long long)row * ldc + col] = acc[a][b][r] * (sig * (1.f + v * (1.f - sig)));
+          }
+        } else
         if (row < M && col < N) C[(long long)row * ldc + col] = acc[a][b][r] + bv;
       }
   }

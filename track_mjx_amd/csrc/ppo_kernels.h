@@ -1127,6 +1127,55 @@ __global__ __launch_bounds__(256) void k_silu_bwd_f32(const float *__restrict__ 
   }
 }
 
+// The 1-wide head of the value MLP (brax make_value_network: MLP(hidden..., 1)) behind a Dense -> SiLU layer, backward:
+//   k_silu_bwd_rank1_f32: d loss / d z of that layer = (dy1[m] w1[k]) silu'(z[m][k] + bias[k]) — the head's input gradient is an outer product, formed here
+//     instead of by an input-gradient GEMM with a contraction length of one + k_silu_bwd_f32 (same expressions, same bits);
+//   k_head_dw / k_head_dw_reduce: the head's weight gradient dw[k] = sum_m dy1[m] x[m][k] and bias gradient sum_m dy1[m] — a matrix-vector product, which the
+//     128 x 128 tiles of k_gemm_dw run at 1 / 128 of their width.  Row slabs of 64 rows per workgroup, a thread per column (coalesced), fixed-order reduction.
+__global__ __launch_bounds__(256) void k_silu_bwd_rank1_f32(const float *__restrict__ dy1, const float *__restrict__ w1, const float *__restrict__ z, const float *__restrict__ bias,
+                                                            float *__restrict__ dz, long long total, int N) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;      // N % 4 == 0 (host check): the four elements share a row
+  if (i >= total) return;
+  const long long m = i / N;
+  const int k = (int)(i - m * N);
+  const float d = dy1[m];
+  const float4 zv = *reinterpret_cast<const float4 *>(z + i), bv = *reinterpret_cast<const float4 *>(bias + k), wv = *reinterpret_cast<const float4 *>(w1 + k);
+  const float v[4] = {zv.x + bv.x, zv.y + bv.y, zv.z + bv.z, zv.w + bv.w}, w[4] = {wv.x, wv.y, wv.z, wv.w};
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { const float sig = 1.f / (1.f + expf(-v[j])); o[j] = (d * w[j]) * (sig * (1.f + v[j] * (1.f - sig))); }
+  *reinterpret_cast<float4 *>(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
+}
+#define HEAD_DW_ROWS 64
+__global__ __launch_bounds__(256) void k_head_dw(const float *__restrict__ dy1, const float *__restrict__ x, int ldx, float *__restrict__ partial, int M, int K) {
+  const int r0 = blockIdx.x * HEAD_DW_ROWS, r1 = min(M, r0 + HEAD_DW_ROWS);
+  float *out = partial + (size_t)blockIdx.x * (K + 1);
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int m = r0;
+    for (; m + 4 <= r1; m += 4) {
+      a0 = fmaf(dy1[m], x[(size_t)m * ldx + k], a0); a1 = fmaf(dy1[m + 1], x[(size_t)(m + 1) * ldx + k], a1);
+      a2 = fmaf(dy1[m + 2], x[(size_t)(m + 2) * ldx + k], a2); a3 = fmaf(dy1[m + 3], x[(size_t)(m + 3) * ldx + k], a3);
+    }
+    for (; m < r1; m++) a0 = fmaf(dy1[m], x[(size_t)m * ldx + k], a0);
+    out[k] = (a0 + a1) + (a2 + a3);
+  }
+  if (threadIdx.x == 0) { float sb = 0.f; for (int m = r0; m < r1; m++) sb += dy1[m]; out[K] = sb; }
+}
+__global__ __launch_bounds__(256) void k_head_dw_reduce(const float *__restrict__ partial, float *__restrict__ dw, float *__restrict__ db, int slabs, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k > K) return;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= slabs; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) a[u] += partial[(size_t)(s + u) * (K + 1) + k];
+  }
+  for (; s < slabs; s++) a[0] += partial[(size_t)s * (K + 1) + k];
+  const float v = (a[0] + a[1]) + (a[2] + a[3]);
+  if (k < K) dw[k] = v; else if (db) db[0] = v;
+}
+
 // ---- roll-out buffer stores of one env-group step in ONE launch (agent/ppo.py: collect; brax acting.actor_step builds the Transition the
 // same way, track_mjx/agent/mlp_ppo/ppo.py:330-348): the env's observation [W][n] (env-minor, what the kernels and the LDS-free inference
 // read) transposed into the row-major roll-out buffer [n][W] (up to two destinations: row t + 1 of this unroll, or the unroll's

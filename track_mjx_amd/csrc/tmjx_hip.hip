@@ -911,19 +911,27 @@ static int gemm_mt(int M, int col_tiles) {
   const double c5 = (double)((w5 + 255) / 256) * 5.0, c2 = (double)((w2 + 255) / 256) * 2.2;
   return c2 < c5 ? 2 : 5;
 }
-template <int NIW, bool BT, bool AVEC, bool WVEC, int MT = 5>
-static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
+template <int NIW, bool BT, bool AVEC, bool WVEC, int MT = 5, int EPI = 0>
+static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s, GemmLN ln = GemmLN{}) {
   constexpr int BN = 64 * NIW, BM = 16 * MT;
   constexpr size_t lds = 2 * sizeof(float) * (size_t)((BM + 8) * GEMM_LDA + (BT ? BN * GEMM_LDA : GEMM_BK * (BN + 4)));
   static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT, AVEC, WVEC, 0, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_act<NIW, BT, AVEC, WVEC, EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_gemm_act): ") + hipGetErrorString(e));
     attr_set = true;
   }
   dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-  hipLaunchKernelGGL((k_gemm_act<NIW, BT, AVEC, WVEC, 0, MT>), grid, dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K, GemmLN{});
+  hipLaunchKernelGGL((k_gemm_act<NIW, BT, AVEC, WVEC, EPI, MT>), grid, dim3(GemmCfg<NIW>::THREADS), lds, s, A, lda, W, ldw, bias, C, ldc, M, N, K, ln);
   return check_launch("k_gemm_act");
+}
+// the input gradient of a Dense -> SiLU layer's consumer with that layer's SiLU backward in the epilogue (k_gemm_act<.., EPI = 4>; aligned operands only)
+template <int NIW>
+static int launch_gemm_nn_silu_bwd(const float *dY, int ldy, const float *W, int ldw, const float *bias, float *dZ, int M, int N, int K, const float *z, hipStream_t s) {
+  GemmLN ln{};
+  ln.z = z;
+  if (gemm_mt(M, (N + 64 * NIW - 1) / (64 * NIW)) == 2) return launch_gemm_act<NIW, false, true, true, 2, 4>(dY, ldy, W, ldw, bias, dZ, N, M, N, K, s, ln);
+  return launch_gemm_act<NIW, false, true, true, 5, 4>(dY, ldy, W, ldw, bias, dZ, N, M, N, K, s, ln);
 }
 template <int NIW, bool BT>
 static int gemm_act_vec(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s) {
@@ -1032,6 +1040,36 @@ int tmjx_silu_fwd(const float *z, const float *bias, float *y, long long rows, i
   const long long total = rows * N;
   hipLaunchKernelGGL(k_silu_fwd_f32, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, z, bias, y, total, N);
   return check_launch("k_silu_fwd_f32");
+}
+// dZ[M][N] = (dY[M][K] W[K][N]) silu'(z + bias): the consumer's input gradient and the producing Dense -> SiLU layer's backward in ONE launch; z, dZ dense [M][N]
+int tmjx_gemm_nn_silu_bwd_ok(const float *dY, int ldy, const float *W, int ldw) { return aligned16(dY, ldy) && aligned16(W, ldw); }
+int tmjx_gemm_nn_silu_bwd(const float *dY, int ldy, const float *W, int ldw, const float *z, const float *bias, float *dZ, int M, int N, int K, void *stream) {
+  if (!dY || !W || !z || !bias || !dZ) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || N < 1 || K < 1 || ldy < K || ldw < N) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  if (!tmjx_gemm_nn_silu_bwd_ok(dY, ldy, W, ldw)) return fail(TMJX_EINVAL, "tmjx_gemm_nn_silu_bwd: the operands' rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 64) return launch_gemm_nn_silu_bwd<1>(dY, ldy, W, ldw, bias, dZ, M, N, K, z, s);
+  if (N <= 128) return launch_gemm_nn_silu_bwd<2>(dY, ldy, W, ldw, bias, dZ, M, N, K, z, s);
+  return launch_gemm_nn_silu_bwd<4>(dY, ldy, W, ldw, bias, dZ, M, N, K, z, s);
+}
+// dz[m][k] = (dy1[m] w1[k]) silu'(z[m][k] + bias[k]): the SiLU backward of the last hidden layer of an MLP with a 1-wide head (N % 4 == 0, 16-byte aligned arrays)
+int tmjx_silu_bwd_rank1(const float *dy1, const float *w1, const float *z, const float *bias, float *dz, long long rows, int N, void *stream) {
+  if (!dy1 || !w1 || !z || !bias || !dz) return fail(TMJX_EINVAL, "null argument");
+  if (rows < 1 || N < 4 || (N & 3) || (((uintptr_t)w1 | (uintptr_t)z | (uintptr_t)bias | (uintptr_t)dz) & 15)) return fail(TMJX_EINVAL, "tmjx_silu_bwd_rank1: N % 4 == 0 and 16-byte aligned arrays");
+  const long long total = rows * N;
+  hipLaunchKernelGGL(k_silu_bwd_rank1_f32, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dy1, w1, z, bias, dz, total, N);
+  return check_launch("k_silu_bwd_rank1_f32");
+}
+// the 1-wide head's gradients: dw[k] = sum_m dy1[m] x[m][k], db[0] = sum_m dy1[m] (db may be NULL); scratch >= tmjx_head_dw_scratch_floats(M, K) floats
+long long tmjx_head_dw_scratch_floats(int M, int K) { return (M < 1 || K < 1) ? 0 : (long long)((M + HEAD_DW_ROWS - 1) / HEAD_DW_ROWS) * (K + 1); }
+int tmjx_head_dw(const float *dy1, const float *x, int ldx, float *dw, float *db, float *scratch, int M, int K, void *stream) {
+  if (!dy1 || !x || !dw || !scratch) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || K < 1 || ldx < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  const int slabs = (M + HEAD_DW_ROWS - 1) / HEAD_DW_ROWS;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_head_dw, dim3(slabs), dim3(256), 0, s, dy1, x, ldx, scratch, M, K);
+  hipLaunchKernelGGL(k_head_dw_reduce, dim3((K + 1 + 255) / 256), dim3(256), 0, s, (const float *)scratch, dw, db, slabs, K);
+  return check_launch("k_head_dw");
 }
 int tmjx_silu_bwd(const float *dy, const float *z, const float *bias, float *dz, long long rows, int N, void *stream) {
   if (!dy || !z || !bias || !dz) return fail(TMJX_EINVAL, "null argument");
