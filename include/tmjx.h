@@ -319,6 +319,9 @@ int tmjx_gemm_nn_silu_bwd(const float *dY, int ldy, const float *W, int ldw, con
 int tmjx_silu_bwd_rank1(const float *dy1, const float *w1, const float *z, const float *bias, float *dz, long long rows, int N, void *stream);
 long long tmjx_head_dw_scratch_floats(int M, int K);
 int tmjx_head_dw(const float *dy1, const float *x, int ldx, float *dw, float *db, float *scratch, int M, int K, void *stream);
+/* The 1-wide head's forward pass y[m] = x[m][:K] . w + bias[0] as a matrix-vector product (bias may be NULL; K % 4 == 0, 16-byte aligned rows: tmjx_head_fwd_ok). */
+int tmjx_head_fwd_ok(const float *x, int ldx, const float *w, int K);
+int tmjx_head_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int M, int K, void *stream);
 long long tmjx_gemm_dw_scratch_floats(int M, int N, int K);
 int tmjx_gemm_dw(const float *dY, int ldy, const float *X, int ldx, float *dW, float *db, float *scratch, int M, int N, int K, void *stream);
 /* All weight (+ bias) gradients of one backward pass as ONE launch + one reduction launch: up to 16 independent problems of tmjx_gemm_dw,

@@ -113,8 +113,17 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) 
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if N == 1 and _head_kernels() and K % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0:
+        # a 1-wide layer (the value MLP's head) is a matrix-vector product: a wave per row instead of a 16 x 64 MFMA tile at 1 / 64 of its width — in EVERY
+        # pass that computes it (learner, bootstrap value, evaluation), so that they agree to the bit
+        _launch("tmjx_head_fwd", x.device, _p(x), x.stride(0), _p(w), _p(bias), _p(y), M, K)
+        return y
     _launch("tmjx_gemm_nt", x.device, _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, K)
     return y
+
+
+def _head_kernels() -> bool:
+    return os.environ.get("TMJX_HEAD_KERNELS", "1") != "0"
 
 
 def gemm_nn(dy: torch.Tensor, w: torch.Tensor, cols: int | None = None) -> torch.Tensor:
@@ -137,6 +146,11 @@ def gemm_dw(dy: torch.Tensor, x: torch.Tensor, with_bias: bool):
     K = x.shape[1]
     dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     db = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias else None
+    if N == 1 and _head_kernels() and dy.stride(0) == 1:
+        # a 1-wide layer's gradients: a matrix-vector product (tmjx_head_dw) instead of a 128 x 128 tile at 1 / 128 of its width
+        scratch = torch.empty(int(_hip.lib().tmjx_head_dw_scratch_floats(M, K)), dtype=torch.float32, device=dy.device)
+        _launch("tmjx_head_dw", dy.device, _p(dy), _p(x), x.stride(0), _p(dw), _p(db), _p(scratch), M, K)
+        return dw, db
     scratch = torch.empty(int(_hip.lib().tmjx_gemm_dw_scratch_floats(M, N, K)), dtype=torch.float32, device=dy.device)
     _launch("tmjx_gemm_dw", dy.device, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(db), _p(scratch), M, N, K)
     return dw, db

@@ -1162,18 +1162,41 @@ __global__ __launch_bounds__(256) void k_head_dw(const float *__restrict__ dy1, 
   }
   if (threadIdx.x == 0) { float sb = 0.f; for (int m = r0; m < r1; m++) sb += dy1[m]; out[K] = sb; }
 }
+// 32 columns per workgroup, the slabs dealt to 8 groups of threads (a thread per column and group: 40 dependent loads at 320 slabs instead of 320), the groups'
+// sums added through LDS in a fixed order
 __global__ __launch_bounds__(256) void k_head_dw_reduce(const float *__restrict__ partial, float *__restrict__ dw, float *__restrict__ db, int slabs, int K) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k > K) return;
-  float a[4] = {0.f, 0.f, 0.f, 0.f};
-  int s = 0;
-  for (; s + 4 <= slabs; s += 4) {
-#pragma unroll
-    for (int u = 0; u < 4; u++) a[u] += partial[(size_t)(s + u) * (K + 1) + k];
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, sg = threadIdx.x >> 5, k = blockIdx.x * 32 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (k <= K) {
+    int s = sg;
+    for (; s + 8 < slabs; s += 16) { a0 += partial[(size_t)s * (K + 1) + k]; a1 += partial[(size_t)(s + 8) * (K + 1) + k]; }
+    if (s < slabs) a0 += partial[(size_t)s * (K + 1) + k];
   }
-  for (; s < slabs; s++) a[0] += partial[(size_t)s * (K + 1) + k];
-  const float v = (a[0] + a[1]) + (a[2] + a[3]);
-  if (k < K) dw[k] = v; else if (db) db[0] = v;
+  red[sg][c] = a0 + a1;
+  __syncthreads();
+  if (sg == 0 && k <= K) {
+    const float v = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+    if (k < K) dw[k] = v; else if (db) db[0] = v;
+  }
+}
+// y[m] = x[m][:] . w + b: the 1-wide head forward as a matrix-vector product — a wave per row (16 rows per workgroup of 4 waves), a float4 of the row per lane
+// and 256 columns per pass, the lane sums added by wave shuffles.  K % 4 == 0, rows of x 16-byte aligned (host check).
+__global__ __launch_bounds__(256) void k_head_fwd(const float *__restrict__ x, int ldx, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ y, int M, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float b = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int m = (blockIdx.x * 4 + wave) * 4 + j;
+    if (m >= M) break;
+    float a = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + (size_t)m * ldx + k), wv = *reinterpret_cast<const float4 *>(w + k);
+      a = fmaf(xv.x, wv.x, a); a = fmaf(xv.y, wv.y, a); a = fmaf(xv.z, wv.z, a); a = fmaf(xv.w, wv.w, a);
+    }
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) y[m] = a + b;
+  }
 }
 
 // ---- roll-out buffer stores of one env-group step in ONE launch (agent/ppo.py: collect; brax acting.actor_step builds the Transition the

@@ -1068,8 +1068,17 @@ int tmjx_head_dw(const float *dy1, const float *x, int ldx, float *dw, float *db
   const int slabs = (M + HEAD_DW_ROWS - 1) / HEAD_DW_ROWS;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_head_dw, dim3(slabs), dim3(256), 0, s, dy1, x, ldx, scratch, M, K);
-  hipLaunchKernelGGL(k_head_dw_reduce, dim3((K + 1 + 255) / 256), dim3(256), 0, s, (const float *)scratch, dw, db, slabs, K);
+  hipLaunchKernelGGL(k_head_dw_reduce, dim3((K + 1 + 31) / 32), dim3(256), 0, s, (const float *)scratch, dw, db, slabs, K);
   return check_launch("k_head_dw");
+}
+// y[m] = x[m][:K] . w[:K] + bias[0] (bias may be NULL): the 1-wide head's forward pass; K % 4 == 0, x rows and w 16-byte aligned
+int tmjx_head_fwd_ok(const float *x, int ldx, const float *w, int K) { return !(K & 3) && aligned16(x, ldx) && !((uintptr_t)w & 15); }
+int tmjx_head_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int M, int K, void *stream) {
+  if (!x || !w || !y) return fail(TMJX_EINVAL, "null argument");
+  if (M < 1 || K < 1 || ldx < K) return fail(TMJX_EINVAL, "bad sizes / leading dimensions");
+  if (!tmjx_head_fwd_ok(x, ldx, w, K)) return fail(TMJX_EINVAL, "tmjx_head_fwd: K % 4 == 0 and 16-byte aligned rows");
+  hipLaunchKernelGGL(k_head_fwd, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, y, M, K);
+  return check_launch("k_head_fwd");
 }
 int tmjx_silu_bwd(const float *dy, const float *z, const float *bias, float *dz, long long rows, int N, void *stream) {
   if (!dy || !z || !bias || !dz) return fail(TMJX_EINVAL, "null argument");

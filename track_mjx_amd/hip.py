@@ -35,7 +35,7 @@ EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips
            "tmjx_physics", "tmjx_physics_step", "tmjx_forward", "tmjx_reward_obs", "tmjx_reward_frame", "tmjx_gae", "tmjx_ppo_scratch_floats", "tmjx_ppo_loss", "tmjx_ppo_loss_phases",
            "tmjx_silu_ln_partial_floats", "tmjx_silu_ln_fwd", "tmjx_silu_ln_bwd", "tmjx_silu_ln_fwd_bf16", "tmjx_silu_ln_bwd_bf16", "tmjx_minibatch_begin_bf16", "tmjx_gather_normalize", "tmjx_latent_concat", "tmjx_latent_concat_bwd", "tmjx_latent_concat_bwd_add", "tmjx_sample_action", "tmjx_linear_nolds", "tmjx_linear_act", "tmjx_linear_act_ok", "tmjx_linear_nolds_norm", "tmjx_linear_nolds_bf16", "tmjx_adam_clip", "tmjx_adam_clip_norm", "tmjx_adam_norm_floats", "tmjx_colsum_scratch_floats", "tmjx_colsum",
            "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_colsum_grouped", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_grouped_wgs", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_set_action_repeat", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
-           "tmjx_rollout_store", "tmjx_clips_share", "tmjx_gemm_nt_silu", "tmjx_gemm_nt_silu_ok", "tmjx_silu_fwd", "tmjx_silu_bwd", "tmjx_gemm_nn_silu_bwd_ok", "tmjx_gemm_nn_silu_bwd", "tmjx_silu_bwd_rank1", "tmjx_head_dw_scratch_floats", "tmjx_head_dw", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_grouped", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bf16_z_bytes", "tmjx_bgemm_partial_floats",
+           "tmjx_rollout_store", "tmjx_clips_share", "tmjx_gemm_nt_silu", "tmjx_gemm_nt_silu_ok", "tmjx_silu_fwd", "tmjx_silu_bwd", "tmjx_gemm_nn_silu_bwd_ok", "tmjx_gemm_nn_silu_bwd", "tmjx_silu_bwd_rank1", "tmjx_head_dw_scratch_floats", "tmjx_head_dw", "tmjx_head_fwd_ok", "tmjx_head_fwd", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_grouped", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bf16_z_bytes", "tmjx_bgemm_partial_floats",
            "tmjx_bgemm_ln_fwd", "tmjx_bgemm_ln_bwd", "tmjx_bgemm_silu_fwd", "tmjx_bgemm_silu_bwd", "tmjx_bf_silu_bwd", "tmjx_bf_silu_bwd_rank1",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
@@ -245,6 +245,8 @@ def load(path: Path):
     sig.setdefault("tmjx_head_dw_scratch_floats", [None, None])[0] = [C.c_int, C.c_int]
     sig.setdefault("tmjx_head_dw_scratch_floats", [None, None])[1] = C.c_longlong
     sig.setdefault("tmjx_head_dw", [None, None])[0] = [fp, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, vp]
+    sig.setdefault("tmjx_head_fwd_ok", [None, None])[0] = [fp, C.c_int, fp, C.c_int]
+    sig.setdefault("tmjx_head_fwd", [None, None])[0] = [fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, vp]
     sig.setdefault("tmjx_rollout_store", [None, None])[0] = [C.POINTER(RolloutStore), vp]
     sig.setdefault("tmjx_clips_share", [None, None])[0] = [vp, vp]
     sig.setdefault("tmjx_bf16_shadow", [None, None])[0] = [C.POINTER(Bf16Shadow), C.c_int, vp]
