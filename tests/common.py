@@ -15,8 +15,9 @@ from track_mjx_amd import config as _config  # noqa: E402
 from track_mjx_amd import walker as _walker  # noqa: E402
 
 
-def default_walker():
-    cfg = _config.default_config()
+def default_walker(config: str = "rodent-full-clips"):
+    """Walker + one of the reference's two shipped rodent configurations (track_mjx_amd/config.py: NAMED_CONFIGS)."""
+    cfg = _config.named_config(config)
     return _walker.Rodent(**cfg["walker_config"]), cfg
 
 
@@ -29,7 +30,7 @@ def default_blob(w=None, cfg=None, *, episode_length=195, auto_reset=True, n_fra
     return _walker.build_blob(
         w, n_frames=n_frames or ea["physics_steps_per_control_step"], iterations=iterations or ea["iterations"],
         ls_iterations=iterations or ea["ls_iterations"], timestep=timestep or ea["mj_model_timestep"], mocap_hz=ea["mocap_hz"],
-        clip_length=rc["clip_length"], traj_length=rc["traj_length"], window=rw["var_window_size"],
+        clip_length=rc["clip_length"], traj_length=rc["traj_length"], window=rw.get("var_window_size", 50),
         episode_length=episode_length, reward_f=_config.reward_vector(rw), auto_reset=auto_reset)
 
 
@@ -41,9 +42,10 @@ def make_oracle(blob, clip=None, precision="f32"):
     return O
 
 
-def make_env_and_oracle(num_envs=64, n_clips=4, device="cuda:0", wrappers=True, seed=0, precision="f32", episode_length=195):
+def make_env_and_oracle(num_envs=64, n_clips=4, device="cuda:0", wrappers=True, seed=0, precision="f32", episode_length=195,
+                        config="rodent-full-clips"):
     from track_mjx_amd.environment import MultiClipTracking, RewardConfig, wrap
-    w, cfg = default_walker()
+    w, cfg = default_walker(config)
     cl = _clips.make_synthetic_clips(w.model, n_clips, seed=seed)
     ea = cfg["env_config"]["env_args"]
     env = MultiClipTracking(cl, w, RewardConfig(**cfg["env_config"]["reward_weights"]), **ea, **cfg["reference_config"],

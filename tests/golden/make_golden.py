@@ -10,7 +10,10 @@ both checked against these vectors.
   reward.py:219-260  ctrl / ctrl_diff / energy   reward.py:263-311 health + penalty terms
   reward.py:314-356  action variance / jerk      single_clip_tracking.py:322-454 obs + frame index
   walker/base.py:170-258 egocentric maths (brax.math.rotate / relative_quat)   losses.py:39-100 GAE
-Run: python tests/golden/make_golden.py   (deterministic; commit the .npz)
+Two fixture files, one per shipped rodent configuration (track_mjx_amd/config.py: NAMED_CONFIGS): task_golden.npz = rodent-full-clips.yaml,
+task_golden_sps.npz = rodent-sps-per-actor.yaml (5 substeps per control step => 0.01 s per step, penalty scale [1, 1, 0.2], RewardConfig's
+default var / jerk coefficients, energy term off).
+Run: python tests/golden/make_golden.py   (deterministic; commit the .npz files)
 """
 import sys
 from pathlib import Path
@@ -80,10 +83,10 @@ def step_terms(case, clip, w, cfg):
     fall = 1.0 - healthy
     spd = np.sum((pos_distance * np.array(rw["penalty_pos_distance_scale"], dtype=f32)) ** 2)
     too_far = float(spd > f32(rw["too_far_dist"])); bad_pose = float(joint_distance > f32(rw["bad_pose_dist"])); bad_quat = float(quat_distance > f32(rw["bad_quat_dist"]))
-    mean_act = buf.mean(0); var_cost = f32(rw["var_coeff"]) * np.sum(((buf - mean_act) ** 2).mean(0))
+    mean_act = buf.mean(0); var_cost = f32(rw.get("var_coeff", 5e-2)) * np.sum(((buf - mean_act) ** 2).mean(0))   # reward.py:52: default 5e-2
     ordered = np.concatenate([buf, buf], 0)[bidx:bidx + 50]
     jerks = ordered[2:] - 2 * ordered[1:-1] + ordered[:-2]
-    jerk_cost = f32(rw["jerk_coeff"]) * np.sum(jerks ** 2)
+    jerk_cost = f32(rw.get("jerk_coeff", 5e-4)) * np.sum(jerks ** 2)
     reward = (joint_reward + pos_reward + quat_reward + angvel_reward + bodypos_reward + endeff_reward - ctrl_cost - ctrl_diff_cost
               - energy_cost - var_cost - jerk_cost)
     done = max(fall, too_far, bad_pose, bad_quat)
@@ -124,11 +127,13 @@ def gae_numpy(trunc, term, rew, val, boot, lam, disc):
     return vs.astype(f32), adv.astype(f32)
 
 
-def main():
-    cfg = _config.default_config()
+def main(config="rodent-full-clips", fname="task_golden.npz", seed=2024):
+    cfg = _config.named_config(config)
+    ea = cfg["env_config"]["env_args"]
+    dt = f32(ea["mj_model_timestep"] * ea["physics_steps_per_control_step"])     # one control step
     w = _walker.Rodent(**cfg["walker_config"])
     clip = _clips.make_synthetic_clips(w.model, 3, seed=123)
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(seed)
     out = {}
     n = 24
     keys_in = ("qpos", "qvel", "xpos", "xmat_torso", "qfrc_actuator", "action", "action_buffer", "buffer_index", "clip_idx", "start_frame", "time")
@@ -137,7 +142,7 @@ def main():
         c = dict(qpos=(rng.normal(size=74) * 0.2).astype(f32), qvel=rng.normal(size=73).astype(f32), xpos=(rng.normal(size=204) * 0.1).astype(f32),
                  xmat_torso=rng.normal(size=9).astype(f32), qfrc_actuator=rng.normal(size=73).astype(f32), action=rng.uniform(-1, 1, 38).astype(f32),
                  action_buffer=rng.uniform(-1, 1, 1900).astype(f32), buffer_index=np.int32([0, 1, 49, 17][i % 4]), clip_idx=np.int32(i % 3),
-                 start_frame=np.int32(rng.integers(0, 44)), time=f32(rng.integers(0, 195)) * f32(0.02))
+                 start_frame=np.int32(rng.integers(0, 44)), time=f32(rng.integers(0, 195)) * dt)
         if i < 6:   # near-reference states: rewards away from 0, health inside the band, edge cases of the thresholds
             fr = cur_frame(c["time"], 50, c["start_frame"])
             c["qpos"] = np.concatenate([clip.position[c["clip_idx"], fr], clip.quaternion[c["clip_idx"], fr], clip.joints[c["clip_idx"], fr]]).astype(f32) + (rng.normal(size=74) * 0.01).astype(f32)
@@ -154,7 +159,7 @@ def main():
     # frame-index table: steps 1..195 x start 0..43, time accumulated by 10 fp32 adds of 0.002 per step (FMA-sensitive)
     t = f32(0); table = np.zeros((195, 44), dtype=np.int32); times = np.zeros(195, dtype=f32)
     for s in range(195):
-        for _ in range(10):
+        for _ in range(ea["physics_steps_per_control_step"]):
             t = f32(t + f32(0.002))
         times[s] = t
         table[s] = [cur_frame(t, 50, st) for st in range(44)]
@@ -169,9 +174,10 @@ def main():
     rew, val, boot = rng.normal(size=(T, B)).astype(f32), rng.normal(size=(T, B)).astype(f32), rng.normal(size=B).astype(f32)
     vs, adv = gae_numpy(trunc, term, rew, val, boot, f32(0.95), f32(0.98))
     out.update(gae_trunc=trunc, gae_term=term, gae_rew=rew, gae_val=val, gae_boot=boot, gae_vs=vs, gae_adv=adv)
-    np.savez_compressed(Path(__file__).with_name("task_golden.npz"), **out)
-    print("wrote task_golden.npz:", {k: v.shape for k, v in out.items() if k.startswith("out_")})
+    np.savez_compressed(Path(__file__).with_name(fname), **out)
+    print(f"wrote {fname}:", {k: v.shape for k, v in out.items() if k.startswith("out_")})
 
 
 if __name__ == "__main__":
     main()
+    main("rodent-sps-per-actor", "task_golden_sps.npz", seed=2025)

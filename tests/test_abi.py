@@ -89,7 +89,10 @@ def test_physics_kernel_resources_allow_three_waves_per_simd(tmp_path):
     vg = int(re.search(r"\.vgpr_count:\s+(\d+)", after).group(1))
     sp = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", after).group(1))
     scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", after).group(1))
-    assert vg <= 136 and sp == 0 and scratch == 0, (vg, sp, scratch)
+    # the occupancy-relevant bound: three waves per SIMD = floor(512 / 168) allocated VGPRs (__launch_bounds__(64, 3)); the kernel takes ~130 — reported,
+    # not pinned: a compiler that lands anywhere up to 168 changes nothing about the residency
+    print(f"k_physics_wave<true>: {vg} VGPRs (bound 168 = three waves per SIMD), {sp} spilled, {scratch} B scratch")
+    assert vg <= 168 and sp == 0 and scratch == 0, (vg, sp, scratch)
 
 
 def test_argument_validation_of_the_learner_entry_points_without_gpu():

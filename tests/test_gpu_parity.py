@@ -90,10 +90,13 @@ def test_forward_intermediates():
     assert act_ref.sum() > 0, "test state must exercise contacts"
 
 
-@pytest.mark.parametrize("variant", ["product", "generic-tree", "lane-per-env"])
-def test_substep_teacher_forced(variant, monkeypatch):
+@pytest.mark.parametrize("variant,config", [("product", "rodent-full-clips"), ("product", "rodent-sps-per-actor"), ("generic-tree", "rodent-full-clips"),
+                                            ("generic-tree", "rodent-sps-per-actor"), ("lane-per-env", "rodent-full-clips")])
+def test_substep_teacher_forced(variant, config, monkeypatch):
     """product: the static rodent kernel (register-resident chain path); generic-tree: TMJX_WAVE_DYNAMIC=1, the run-time-layout
-    wave kernel any other model gets (LDS-resident sparse factorisation); lane-per-env: TMJX_IMPL=lane (tests/lane/physics_core.h)."""
+    wave kernel any other model gets (LDS-resident sparse factorisation); lane-per-env: TMJX_IMPL=lane (tests/lane/physics_core.h).
+    config: the reference's two shipped rodent configurations — rodent-full-clips.yaml:12-14 (CG 5 / 5) and rodent-sps-per-actor.yaml:13-15
+    (CG 4 / 4 = the constructor defaults of multi_clip_tracking.py:24-25): the solver's iteration counts are run-time constants of the handle."""
     if variant == "generic-tree":
         monkeypatch.setenv("TMJX_WAVE_DYNAMIC", "1")
     elif variant == "lane-per-env":
@@ -105,7 +108,8 @@ def test_substep_teacher_forced(variant, monkeypatch):
         monkeypatch.setattr(hip, "_lib", hip.load(lane_so))
         monkeypatch.setenv("TMJX_IMPL", "lane")
     n = 64
-    env, O32, cl = make_env_and_oracle(num_envs=n, wrappers=False)
+    env, O32, cl = make_env_and_oracle(num_envs=n, wrappers=False, config=config)
+    assert env._opts["iterations"] == (5 if config == "rodent-full-clips" else 4)
     O64 = make_oracle(env._blob, cl, "f64")
     rng = np.random.default_rng(1)
     qpos, qvel = _init_states(cl, n, rng, sink=0.001)
@@ -137,9 +141,13 @@ def test_substep_teacher_forced(variant, monkeypatch):
     print("substep parity (median, max, f32-oracle max):", max(w[1] for w in worst), max(w[2] for w in worst), max(w[3] for w in worst))
 
 
-def test_env_reset_step_and_autoreset():
+@pytest.mark.parametrize("config", ["rodent-full-clips", "rodent-sps-per-actor"])
+def test_env_reset_step_and_autoreset(config):
+    """config rodent-sps-per-actor: 5 substeps per control step (0.01 s of clip time per step), CG 4 / 4, penalty scale [1, 1, 0.2] and
+    RewardConfig's default var / jerk coefficients (rodent-sps-per-actor.yaml:13-16,39; reward.py:51-53)."""
     n = 32
-    env, O, cl = make_env_and_oracle(num_envs=n, wrappers=True)
+    env, O, cl = make_env_and_oracle(num_envs=n, wrappers=True, config=config)
+    assert env._n_frames == (10 if config == "rodent-full-clips" else 5)
     g = torch.Generator().manual_seed(5)
     clip = torch.randint(0, 4, (n,), generator=g, dtype=torch.int32); start = torch.randint(0, 44, (n,), generator=g, dtype=torch.int32)
     qn = (torch.rand((74, n), generator=g) * 2 - 1) * 1e-3; vn = (torch.rand((73, n), generator=g) * 2 - 1) * 1e-3
@@ -226,14 +234,15 @@ def test_reward_obs_alone_random_states():
     assert keep.sum() >= 0 and frames_o.min() >= 0
 
 
-def test_frame_index_table_bit_exact():
-    """floor(time*50 + start) with time accumulated in fp32 by 10 adds of 0.002 per step: steps 1..195 x start 0..43.
+@pytest.mark.parametrize("config", ["rodent-full-clips", "rodent-sps-per-actor"])
+def test_frame_index_table_bit_exact(config):
+    """floor(time*50 + start) with time accumulated in fp32 by 10 (rodent-sps-per-actor: 5) adds of 0.002 per step: steps 1..195 x start 0..43.
     The clip's joint table is frame-coded (joints[c,f,:] = f) so the frame the KERNEL gathered is read back from the
     observation's joint rows (obs = ref_joints[frame+1+t] - qpos[7:], qpos joints = 0)."""
     from track_mjx_amd import clips as _clips
     from track_mjx_amd.environment import MultiClipTracking, RewardConfig
     n = 44
-    w, cfg = default_walker()
+    w, cfg = default_walker(config)
     cl = _clips.make_synthetic_clips(w.model, 1, seed=0)
     cl.joints[:] = np.arange(250, dtype=np.float32)[None, :, None]
     env = MultiClipTracking(cl, w, RewardConfig(**cfg["env_config"]["reward_weights"]), **cfg["env_config"]["env_args"],
@@ -244,7 +253,7 @@ def test_frame_index_table_bit_exact():
     env.state_buf[L.qpos + 7:L.qpos + 74].zero_()
     t = np.float32(0.0); a = torch.zeros((38, n), device=DEV)
     for step in range(1, 196):
-        for _ in range(10):
+        for _ in range(cfg["env_config"]["env_args"]["physics_steps_per_control_step"]):
             t = np.float32(t + np.float32(0.002))
         env.rows("time").fill_(float(t))
         prod = np.float32(t * np.float32(50.0))
@@ -398,15 +407,24 @@ def test_train_calls_policy_params_fn_after_every_eval(tmp_path):
         assert set(kw) == {"current_step", "jit_logging_inference_fn", "params", "policy_params_fn_key", "render_video"}
         obs = torch.randn((5, env.observation_size), generator=torch.Generator().manual_seed(kw["current_step"]))
         act, extra = kw["jit_logging_inference_fn"](kw["params"], obs, kw["policy_params_fn_key"])
-        act2, _ = kw["jit_logging_inference_fn"](kw["params"], obs, None)
-        assert act.shape == (5, 38) and torch.equal(act, act2) and (act.abs() <= 1).all()            # deterministic: the mode, tanh-squashed
+        act1, extra1 = kw["jit_logging_inference_fn"](kw["params"], obs, kw["policy_params_fn_key"])
+        act2, extra2 = kw["jit_logging_inference_fn"](kw["params"], obs, None)
+        # ppo_networks.py:116-130: the ACTION is the mode (tanh-squashed), the latent is still sampled from key_network: same key => same action,
+        # another key => another latent sample => another action; the latent statistics do not depend on the key
+        assert act.shape == (5, 38) and torch.equal(act, act1) and not torch.equal(act, act2) and (act.abs() <= 1).all()
+        assert torch.equal(extra["latent_mean"], extra2["latent_mean"]) and torch.equal(extra["latent_logvar"], extra2["latent_logvar"])
         assert extra["latent_mean"].shape == (5, 60) and extra["latent_logvar"].shape == (5, 60)
         calls.append((kw["current_step"], kw["render_video"], kw["policy_params_fn_key"], act.cpu(), {k: v.clone() for k, v in kw["params"][1].items()}))
+
+    def cb(it):          # a failing user callback must not end the run (ppo.py:713-717: try / except + warning)
+        saved.append(it)
+        if it == 1:
+            raise RuntimeError("user callback failed")
 
     mk, params, metrics = ppo.train(env, num_timesteps=3 * 64 * 4 * 5, episode_length=195, config_dict=cfg, num_evals=4, unroll_length=5, batch_size=64,
                                     num_minibatches=4, num_updates_per_batch=1, normalize_observations=True, encoder_hidden_layer_sizes=(64,),
                                     decoder_hidden_layer_sizes=(64,), value_hidden_layer_sizes=(64,), learning_rate=1e-3, seed=1,
-                                    policy_params_fn=f, checkpoint_callback=saved.append, checkpoint_path=str(tmp_path / "ck"))
+                                    policy_params_fn=f, checkpoint_callback=cb, checkpoint_path=str(tmp_path / "ck"))
     assert [c[0] for c in calls] == [1, 2, 3] and [c[1] for c in calls] == [False, True, False]
     assert len({c[2] for c in calls}) == 3, "a fresh key per call"
     assert saved == [0, 1, 2, 3]

@@ -226,14 +226,17 @@ def test_config1_single_env_full_episode_teacher_forced():
     assert max(obs_err) < 2e-5 and max(rew_err) < 1e-4
 
 
-def test_reward_obs_kernel_against_golden_vectors():
+@pytest.mark.parametrize("config,fixture", [("rodent-full-clips", "task_golden.npz"), ("rodent-sps-per-actor", "task_golden_sps.npz")])
+def test_reward_obs_kernel_against_golden_vectors(config, fixture):
     """tests/golden/task_golden.npz straight into tmjx_reward_obs (no oracle in between): the 24 known-answer cases of the
-    track_mjx-owned maths (tests/golden/make_golden.py: numpy float32 restatement of reward.py / single_clip_tracking.py / base.py)."""
+    track_mjx-owned maths (tests/golden/make_golden.py: numpy float32 restatement of reward.py / single_clip_tracking.py / base.py).
+    task_golden_sps.npz: the same for the reference's other shipped rodent configuration (rodent-sps-per-actor.yaml: penalty scale
+    [1, 1, 0.2], no var / jerk keys => RewardConfig's defaults of reward.py:51-53, 0.01 s per control step)."""
     from track_mjx_amd import clips as _clips
     from track_mjx_amd.environment import MultiClipTracking, RewardConfig, wrap
-    G = np.load(Path(__file__).parent / "golden" / "task_golden.npz")
+    G = np.load(Path(__file__).parent / "golden" / fixture)
     n = G["in_qpos"].shape[0]
-    w, cfg = default_walker()
+    w, cfg = default_walker(config)
     cl = _clips.make_synthetic_clips(w.model, 3, seed=123)          # the table make_golden.py used
     env = wrap(MultiClipTracking(cl, w, RewardConfig(**cfg["env_config"]["reward_weights"]), **cfg["env_config"]["env_args"],
                                  **cfg["reference_config"], num_envs=n, device=DEV), episode_length=195)

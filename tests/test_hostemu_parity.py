@@ -57,13 +57,18 @@ def test_forward_intermediates_sparse_vs_dense(setup, impl):
     assert np.array_equal(E.rows("con_dist") < 0, np.stack([O64.get(d, "con_dist") < 0 for d in ds], 1))
 
 
-@pytest.mark.parametrize("impl", ["lane", "wave", "wave-generic"])
+@pytest.mark.parametrize("impl", ["lane", "wave", "wave-generic", "wave-cg4"])
 def test_substeps_teacher_forced(setup, impl, monkeypatch):
     """wave: the rodent's register-resident chain path (what the static GPU kernel runs); wave-generic: TMJX_EMU_GENERIC=1, the
-    LDS-resident sparse path any other tree takes."""
+    LDS-resident sparse path any other tree takes; wave-cg4: the chain path with the solver options of the reference's other shipped
+    rodent configuration (rodent-sps-per-actor.yaml:13-14: CG 4 / 4 — run-time constants of the blob, not kernel constants)."""
     if impl == "wave-generic":
         monkeypatch.setenv("TMJX_EMU_GENERIC", "1")
     w, blob, clip = setup
+    if impl == "wave-cg4":
+        w4, cfg4 = default_walker("rodent-sps-per-actor")
+        blob = default_blob(w4, cfg4)
+        impl = "wave"
     n = 8
     E = Emu(blob, n); O32 = make_oracle(blob, clip, "f32"); O64 = make_oracle(blob, clip, "f64")
     rng = np.random.default_rng(1)

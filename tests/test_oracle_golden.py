@@ -8,6 +8,9 @@ from tests.common import default_blob, default_walker, make_oracle
 from track_mjx_amd import clips as _clips
 
 G = np.load(Path(__file__).parent / "golden" / "task_golden.npz")
+# the reference's other shipped rodent configuration (rodent-sps-per-actor.yaml: CG 4 / 4, 5 substeps per control step, penalty scale
+# [1, 1, 0.2], RewardConfig's default var / jerk coefficients): step cases + its own frame-index table (0.01 s per control step)
+G_SPS = np.load(Path(__file__).parent / "golden" / "task_golden_sps.npz")
 
 
 @pytest.fixture(scope="module")
@@ -17,7 +20,14 @@ def oracle():
     return make_oracle(default_blob(w, cfg), clip, "f32"), w
 
 
-def _run_case(O, envs, i):
+@pytest.fixture(scope="module")
+def oracle_sps():
+    w, cfg = default_walker("rodent-sps-per-actor")
+    clip = _clips.make_synthetic_clips(w.model, 3, seed=123)
+    return make_oracle(default_blob(w, cfg), clip, "f32"), w
+
+
+def _run_case(O, envs, i, G=G):
     z = np.zeros(74)
     O.env_reset(envs, 0, int(G["in_clip_idx"][i]), int(G["in_start_frame"][i]), z, z[:73])
     for k in ("qpos", "qvel", "xpos", "qfrc_actuator"):
@@ -29,11 +39,13 @@ def _run_case(O, envs, i):
     O.env_post(envs, 0, G["in_action"][i])
 
 
-def test_step_terms_match_golden(oracle):
-    O, w = oracle
+@pytest.mark.parametrize("which", ["rodent-full-clips", "rodent-sps-per-actor"])
+def test_step_terms_match_golden(which, request):
+    O, w = request.getfixturevalue("oracle" if which == "rodent-full-clips" else "oracle_sps")
+    G = globals()["G" if which == "rodent-full-clips" else "G_SPS"]
     envs = O.new_envs(1)
     for i in range(G["in_qpos"].shape[0]):
-        _run_case(O, envs, i)
+        _run_case(O, envs, i, G)
         assert int(O.env_get(envs, 0, "cur_frame")[0]) == int(G["out_frame"][i]) or G["out_done"][i] > 0
         m = O.env_get(envs, 0, "metrics")
         np.testing.assert_allclose(m, G["out_metrics"][i], rtol=2e-5, atol=2e-6, err_msg=f"case {i}")
@@ -46,8 +58,10 @@ def test_step_terms_match_golden(oracle):
     assert (G["out_done"] == 0).sum() >= 3 and (G["out_done"] > 0).sum() >= 3
 
 
-def test_frame_index_table_bit_exact(oracle):
-    O, w = oracle
+@pytest.mark.parametrize("which", ["rodent-full-clips", "rodent-sps-per-actor"])
+def test_frame_index_table_bit_exact(which, request):
+    O, w = request.getfixturevalue("oracle" if which == "rodent-full-clips" else "oracle_sps")
+    G = globals()["G" if which == "rodent-full-clips" else "G_SPS"]
     envs = O.new_envs(1)
     z = np.zeros(74)
     for start in range(44):
@@ -55,8 +69,11 @@ def test_frame_index_table_bit_exact(oracle):
         for s in range(195):
             O.env_set(envs, 0, "time", [G["frame_times"][s]])
             assert int(O.env_get(envs, 0, "cur_frame")[0]) == int(G["frame_table"][s, start])
-    # documented example: start 0, steps 4..8 land on frames 3..7 (t = 0.07999998 at step 4)
-    assert list(G["frame_table"][3:8, 0]) == [3, 4, 5, 6, 7]
+    if which == "rodent-full-clips":
+        # documented example: start 0, steps 4..8 land on frames 3..7 (t = 0.07999998 at step 4)
+        assert list(G["frame_table"][3:8, 0]) == [3, 4, 5, 6, 7]
+    else:
+        assert G["frame_table"][-1, 0] in (96, 97)      # 195 control steps of 0.01 s at 50 Hz
 
 
 def test_gae_matches_golden_and_closed_form(oracle):

@@ -10,10 +10,12 @@ normaliser statistics with three small sum all-reduces per training step (C2).
 """
 from __future__ import annotations
 
+import logging
 import math
 import time
 from typing import Callable
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -931,7 +933,10 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
             return None
         out = _ckpt.save_step_dir(checkpoint_path, it, learner, config=config_dict, env_steps=env_steps)
         if checkpoint_callback is not None:
-            checkpoint_callback(it)
+            try:        # ppo.py:713-717 and checkpointing.save: a failing user callback is logged, the training run goes on
+                checkpoint_callback(it)
+            except Exception as e:
+                logging.warning(f"checkpoint callback failed at step {it}: {e}")
         return out
     env_step_per_training_step = learner.env_steps_per_training_step * int(action_repeat)      # ppo.py:260-262
     num_evals_after_init = max(num_evals - 1, 1)
@@ -957,21 +962,45 @@ def train(environment, num_timesteps: int, episode_length: int, ckpt_mgr=None, c
     def current_policy_params():
         return ({k: v.clone() for k, v in learner.normalizer.state_dict().items()}, {k: v.clone() for k, v in learner.policy.state_dict().items()})
 
+    logging_scratch: dict = {}          # ONE scratch copy of the policy module for the logging policy, made at its first call
+
+    def _logging_key(key_sample):
+        """A threefry key from whatever the caller holds: a jax-style uint32[2] key, an int seed, the (seed, call) tuple this train() hands to
+        `policy_params_fn`, or None."""
+        from .. import jax_random as _jr
+        if key_sample is None:
+            return _jr.PRNGKey(0)
+        if isinstance(key_sample, (tuple, list)) and len(key_sample) == 2 and not hasattr(key_sample, "dtype"):
+            return _jr.fold_in(_jr.PRNGKey(int(key_sample[0])), int(key_sample[1]))
+        k = np.asarray(key_sample.cpu() if isinstance(key_sample, torch.Tensor) else key_sample)
+        if k.shape == (2,):
+            return k.astype(np.uint32)
+        return _jr.PRNGKey(int(k))
+
     @torch.no_grad()
     def logging_inference_fn(params, observations, key_sample=None):
-        """make_logging_inference_fn(ppo_network)(deterministic=True) (ppo_networks.py:103-149, jitted at ppo.py:514-515): the mode of the action
-        distribution and the latent statistics, computed with `params` = (normalizer state, policy state) — functionally: the live
-        learner's networks are left as they were."""
+        """make_logging_inference_fn(ppo_network)(deterministic=True) (ppo_networks.py:103-149, jitted at ppo.py:514-515) with `params` =
+        (normalizer state, policy state) — functionally: the live learner's networks are left as they were.  As in the reference, ONLY the
+        action is deterministic: `policy_network.apply(*params, observations, key_network)` is called without `deterministic=True`
+        (ppo_networks.py:117-119), so the latent is still SAMPLED — `key_sample -> split -> key_network` (:116), `-> split -> encoder_rng`
+        (intention_network.py:104), `eps = normal(encoder_rng, logvar.shape)` (:85-88), drawn here by the pinned threefry restatement
+        (track_mjx_amd/jax_random.py) — and the action is the mode of the distribution of the resulting logits (:124-130)."""
         import copy
+        from .. import jax_random as _jr
         norm_sd, pol_sd = params[0], params[1]
-        pol = copy.deepcopy(learner.policy)
+        pol = logging_scratch.get("policy")
+        if pol is None:
+            pol = logging_scratch["policy"] = copy.deepcopy(learner.policy)
         pol.load_state_dict(pol_sd)
         obs = torch.as_tensor(observations, dtype=torch.float32, device=learner.dev)
         lead = obs.shape[:-1]
         obs = obs.reshape(-1, obs.shape[-1])
         if learner.normalize_observations:
             obs = (obs - norm_sd["mean"].to(learner.dev)) / norm_sd["std"].to(learner.dev)
-        logits, mean, logvar = pol(obs, eps=torch.zeros((obs.shape[0], pol.latents), device=learner.dev), deterministic=True)
+        key_network = _jr.split(_logging_key(key_sample))[1]
+        encoder_rng = _jr.split(key_network)[1]
+        eps = torch.from_numpy(np.asarray(_jr.normal(encoder_rng, (*lead, pol.latents)), dtype=np.float32)).reshape(-1, pol.latents).to(learner.dev)
+        logits, mean, logvar = pol(obs, eps=eps, deterministic=False)
         return (NormalTanh.mode(logits.float()).reshape(*lead, -1), {"latent_mean": mean.reshape(*lead, -1), "latent_logvar": logvar.reshape(*lead, -1)})
     metrics: dict = {}
     total_steps, done_steps = int(restored.get("env_steps") or 0), 0       # TrainingState.env_steps continues across a resume

@@ -79,6 +79,38 @@ def default_config() -> dict[str, Any]:
     }
 
 
+def sps_per_actor_config() -> dict[str, Any]:
+    """The reference's other shipped rodent configuration (values: rodent-sps-per-actor.yaml:11-17,19-39,45-52,67-82): CG 4 / 4 — also
+    the constructor defaults of multi_clip_tracking.py:16-32 —, 5 physics substeps per control step, `penalty_pos_distance_scale`
+    [1, 1, 0.2], 512 x 3 nets, and NO `var_*` / `jerk_coeff` keys, i.e. RewardConfig's defaults (reward.py:51-53: window 50, var_coeff
+    5e-2, jerk_coeff 5e-4).  That file also omits `energy_cost_weight`, which the reference's dataclass requires (reward.py:27-28): it is
+    given as 0.0 here (term off).  The walker stays the shipped blob's (torque actuators, rescale 0.9): the file's position-actuator /
+    0.8 walker needs a recompile with tools/compile_model.py and the affine-bias actuator path, which is not built."""
+    cfg = default_config()
+    cfg["env_config"]["env_args"].update(iterations=4, ls_iterations=4, physics_steps_per_control_step=5)
+    rw = cfg["env_config"]["reward_weights"]
+    for k in ("var_window_size", "var_coeff", "jerk_coeff"):
+        del rw[k]
+    rw.update(energy_cost_weight=0.0, penalty_pos_distance_scale=[1.0, 1.0, 0.2])
+    cfg["network_config"].update(encoder_layer_sizes=[512, 512, 512], decoder_layer_sizes=[512, 512, 512], critic_layer_sizes=[512, 512, 512],
+                                 kl_weight=1e-3)
+    ts = cfg["train_setup"]
+    ts.update(train_subset_ratio=None, eval_every=2_000_000, reset_every=50_000_000)
+    ts["train_config"].update(num_envs=8192, num_timesteps=50_000_000, discounting=0.95, entropy_cost=5e-2)
+    return cfg
+
+
+NAMED_CONFIGS = {"rodent-full-clips": default_config, "rodent-sps-per-actor": sps_per_actor_config}
+
+
+def named_config(name: str) -> dict[str, Any]:
+    """`--config-name` of the reference's hydra CLI (train.py:56): one of the shipped rodent configurations by file stem."""
+    try:
+        return NAMED_CONFIGS[name]()
+    except KeyError:
+        raise KeyError(f"unknown configuration {name!r}: one of {sorted(NAMED_CONFIGS)}") from None
+
+
 def _deep_update(dst: dict, src: dict) -> dict:
     for k, v in src.items():
         if isinstance(v, dict) and isinstance(dst.get(k), dict):
@@ -88,8 +120,8 @@ def _deep_update(dst: dict, src: dict) -> dict:
     return dst
 
 
-def load_config(path: str | None = None, overrides: list[str] | None = None) -> dict[str, Any]:
-    cfg = default_config()
+def load_config(path: str | None = None, overrides: list[str] | None = None, name: str | None = None) -> dict[str, Any]:
+    cfg = named_config(name) if name else default_config()
     if path:
         with open(path) as f:
             _deep_update(cfg, yaml.safe_load(f) or {})
@@ -104,7 +136,8 @@ def load_config(path: str | None = None, overrides: list[str] | None = None) -> 
 
 
 def reward_vector(rw: dict[str, Any]) -> np.ndarray:
-    d = dict(rw)
+    d = dict(var_coeff=5e-2, jerk_coeff=5e-4)     # RewardConfig's defaults (reward.py:52-53) for reward_weights dicts without the keys
+    d.update(rw)
     d["healthy_z_lo"], d["healthy_z_hi"] = d["healthy_z_range"]
     d["pen0"], d["pen1"], d["pen2"] = d["penalty_pos_distance_scale"]
     return np.array([float(d[k]) for k in REWARD_F], dtype=np.float64)

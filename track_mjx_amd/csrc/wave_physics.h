@@ -1,9 +1,10 @@
 // csrc/wave_physics.h — K2, wave-per-env: one 64-lane wavefront integrates one env; every per-env array of a
-// substep lives in LDS (wave_layout.h: 14 080 bytes per env for the rodent's chain layout = 11 LDS granules => 11 envs per CU = 2-3 waves per SIMD; the
-// inertia matrix is additionally kept in a per-env global copy between its two factorisations), the 64 lanes split bodies /
+// substep lives in LDS (wave_layout.h: 11 276 bytes per env for the rodent's chain layout = 9 LDS granules of 1280 B; the residency is set by the
+// registers — ~130 VGPRs under __launch_bounds__(64, 3) => three waves per SIMD = 12 envs per CU; the inertia matrix, the warm start, qfrc_actuator
+// and the activation state are additionally kept in a per-env global record between their uses), the 64 lanes split bodies /
 // dofs / constraint rows / matrix columns between them.
 //
-// Same maths as physics_core.h (MJX `mjx.step`, reference call site
+// Same maths as tests/lane/physics_core.h, the lane-per-env cross-check build (MJX `mjx.step`, reference call site
 // track_mjx/environment/task/single_clip_tracking.py:219) re-organised for the wavefront:
 //   * kinematics and velocity/acceleration prefixes by POINTER JUMPING over the tree (log2(depth) = 6 rounds
 //     instead of a 39-level walk); composite inertias / body forces by one branch-free reverse sweep,

@@ -64,7 +64,13 @@ def main(argv=None, runner=None):
     cfg_path = None
     if argv and argv[0].endswith((".yaml", ".yml")):
         cfg_path = argv.pop(0)
-    cfg = _config.load_config(cfg_path, argv)
+    cfg_name = None      # hydra's `--config-name <stem>` / `--config-name=<stem>` (train.py:56): one of config.NAMED_CONFIGS
+    for i, a in enumerate(list(argv)):
+        if a == "--config-name" and i + 1 < len(argv):
+            cfg_name = argv[i + 1]; del argv[i:i + 2]; break
+        if a.startswith("--config-name="):
+            cfg_name = a.split("=", 1)[1]; del argv[i]; break
+    cfg = _config.load_config(cfg_path, argv, name=cfg_name)
     from . import launch
     num_gpus = int(cfg.get("num_gpus", 1))
     if launch.needs_spawn(num_gpus):        # before anything touches the GPU: the ranks are a child process, never an exec
