@@ -319,6 +319,46 @@ int tmjx_gemm_nn_silu_bwd(const float *dY, int ldy, const float *W, int ldw, con
 int tmjx_silu_bwd_rank1(const float *dy1, const float *w1, const float *z, const float *bias, float *dz, long long rows, int N, void *stream);
 long long tmjx_head_dw_scratch_floats(int M, int K);
 int tmjx_head_dw(const float *dy1, const float *x, int ldx, float *dw, float *db, float *scratch, int M, int K, void *stream);
+/* ---- whole-chain kernels (csrc/mlp_chain.h) for nets whose hidden layers are exactly 256 wide (BASELINE configs[1] / configs[2]: encoder, decoder and
+ * critic = [256, 256]).  ONE launch runs a whole chain of the reference's layers — the encoder's Dense -> silu -> LayerNorm blocks + fc2_mean | fc2_logvar,
+ * the decoder's blocks + the action head (track_mjx/agent/mlp_ppo/intention_network.py:32-44,68-76,128-139), or brax's value MLP
+ * (ppo_networks.py:180-184) — on one workgroup's row tile: a layer's output goes to global memory exactly as the layer-by-layer entry points
+ * leave it (tmjx_gemm_nt_silu_ln / tmjx_gemm_nt_silu: z without the bias, y, stats = (mean, 1 / std) per row) AND stays on the CU as the next layer's
+ * operand.  Results are bit-identical to tmjx_gemm_nt_silu_ln / tmjx_gemm_nt_silu / tmjx_gemm_nt / tmjx_head_fwd called layer by layer.
+ *   epi 1: hidden layers are Dense -> SiLU -> LayerNorm blocks;  epi 3: Dense -> SiLU layers (no gamma / beta / stats).
+ *   Wf != NULL: an un-activated last layer outf[M][Nf] = y_last Wf^T + bf with Nf <= 128 (fc2, the action head); Nf == 1 (epi 3): the value
+ *   head as a dot product (Wf = its weight row of 256 floats, outf[M]).  hidden[0].K = the input width (<= lda); hidden[l > 0].K = 256.
+ * All rows 16-byte aligned (tmjx_chain_fwd_ok says whether a call qualifies); z, y dense [M][256]. */
+#define TMJX_CHAIN_MAX_HIDDEN 4
+typedef struct { const float *W, *bias, *gamma, *beta; float *z, *y, *stats; int32_t K, ldw; } tmjx_chain_layer_t;
+typedef struct {
+  const float *A; int32_t lda, M, n_hidden, epi;
+  tmjx_chain_layer_t hidden[TMJX_CHAIN_MAX_HIDDEN];
+  const float *Wf, *bf; float *outf; int32_t Nf, ldwf, ldof;
+  float eps;
+  void *prof;     /* NULL; or 16 uint64 per workgroup ((M + rows per tile - 1) / rows per tile workgroups): in-kernel clock stamps (tools/chain_stamps.py) */
+} tmjx_chain_fwd_t;
+int tmjx_chain_fwd_ok(const tmjx_chain_fwd_t *chain);
+int tmjx_chain_fwd(const tmjx_chain_fwd_t *chain, void *stream);
+/* The backward pass of such a chain in ONE launch: the input-gradient GEMMs from the last layer's output gradient G[M][Kg] down to the first
+ * hidden layer, each with the PRODUCING block's backward in its epilogue (what tmjx_gemm_nn_ln_bwd / tmjx_gemm_nn_silu_bwd do layer by layer),
+ * d loss / d z of every hidden layer written to global memory (dz: the operand of the weight gradients, tmjx_gemm_dw_grouped) and kept on the CU as
+ * the next GEMM's operand.  stage[0]: W = the LAST layer's weight [Kg][256], (z, bias, gamma, stats) = the last hidden block's saved tensors;
+ * stage[s > 0]: W = the weight [256][256] of hidden layer (n - s), block = hidden layer (n - 1 - s).  epi 2: Dense -> SiLU -> LayerNorm blocks
+ * (partial: >= tmjx_gemm_nn_ln_bwd_partial_floats(M, 256) floats per stage, one row of [d gamma | d beta | d bias] per workgroup: reduce with
+ * tmjx_colsum_grouped);  epi 4: Dense -> SiLU layers.  Kg == 1 (epi 4): the value head — G = dy1[M], stage[0].W = the head's weight row, stage 0 has
+ * no GEMM (tmjx_silu_bwd_rank1's expression).  W0 != NULL: a trailing GEMM dx[M][dx_cols] = dz_first W0[256][:dx_cols] (the decoder's first block:
+ * d loss / d latent, dx_cols <= 128).  Bit-identical to the layer-by-layer entry points. */
+typedef struct { const float *W; int32_t ldw; const float *z, *bias, *gamma, *stats; float *dz, *partial; } tmjx_chain_bwd_stage_t;
+typedef struct {
+  const float *G; int32_t ldg, Kg, M, n_stages, epi;
+  tmjx_chain_bwd_stage_t stage[TMJX_CHAIN_MAX_HIDDEN];
+  const float *W0; int32_t ldw0, dx_cols; float *dx; int32_t lddx;
+  void *prof;
+} tmjx_chain_bwd_t;
+int tmjx_chain_bwd_ok(const tmjx_chain_bwd_t *chain);
+int tmjx_chain_bwd(const tmjx_chain_bwd_t *chain, void *stream);
+
 /* The 1-wide head's forward pass y[m] = x[m][:K] . w + bias[0] as a matrix-vector product (bias may be NULL; K % 4 == 0, 16-byte aligned rows: tmjx_head_fwd_ok). */
 int tmjx_head_fwd_ok(const float *x, int ldx, const float *w, int K);
 int tmjx_head_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int M, int K, void *stream);

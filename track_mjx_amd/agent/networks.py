@@ -422,6 +422,90 @@ class deferred_weight_grads:
         self.keep += [scratch] + [t for q in problems for t in q[:2]]
 
 
+# ---- whole-chain fp32 kernels (csrc/mlp_chain.h): nets whose hidden layers are exactly 256 wide -----------------------------------------
+def chain_fwd_desc(x2, hidden, final=None, kind="ln", eps=1e-6, out=None):
+    """The tmjx_chain_fwd_t of one forward chain and the tensors it writes.  x2: [M, >= K0] fp32 rows (a column prefix of a wider buffer is
+    fine); hidden: [(weight [256, K], bias, gamma, beta)] ("ln") or [(weight, bias)] ("silu"); final: (weight [Nf, 256], bias) or None.
+    Returns (desc, saved = [(z, y, stats)] per hidden layer, out [M, Nf] / [M] for a 1-wide head / None, keep-alive list)."""
+    from .. import hip as _hip
+    M, dev = x2.shape[0], x2.device
+    d = _hip.ChainFwd()
+    d.A, d.lda, d.M, d.n_hidden, d.epi, d.eps = x2.data_ptr(), x2.stride(0), M, len(hidden), 1 if kind == "ln" else 3, float(eps)
+    saved = []
+    for l, h in enumerate(hidden):
+        w, b = h[0], h[1]
+        z = torch.empty((M, 256), dtype=torch.float32, device=dev)
+        y = torch.empty_like(z)
+        st = torch.empty((M, 2), dtype=torch.float32, device=dev) if kind == "ln" else None
+        L = d.hidden[l]
+        L.W, L.bias, L.z, L.y, L.K, L.ldw = w.data_ptr(), b.data_ptr(), z.data_ptr(), y.data_ptr(), w.shape[1], w.stride(0)
+        if kind == "ln":
+            L.gamma, L.beta, L.stats = h[2].data_ptr(), h[3].data_ptr(), st.data_ptr()
+        saved.append((z, y, st))
+    if final is not None:
+        wf, bf = final
+        Nf = wf.shape[0]
+        if out is None:
+            out = torch.empty((M,) if Nf == 1 else (M, Nf), dtype=torch.float32, device=dev)
+        d.Wf, d.bf, d.outf, d.Nf, d.ldwf, d.ldof = wf.data_ptr(), (bf.data_ptr() if bf is not None else None), out.data_ptr(), Nf, wf.stride(0), (1 if Nf == 1 else out.stride(0))
+    return d, saved, out
+
+
+def chain_fwd(x2, hidden, final=None, kind="ln", eps=1e-6):
+    """One launch: the whole chain forward (tmjx_chain_fwd).  Raises TmjxError (EINVAL) when the chain does not qualify: ask chain_fwd_ok first."""
+    import ctypes as C
+    d, saved, out = chain_fwd_desc(x2, hidden, final, kind, eps)
+    _launch("tmjx_chain_fwd", x2.device, C.byref(d))
+    return saved, out
+
+
+def chain_fwd_ok(x2, hidden, final=None, kind="ln") -> bool:
+    import ctypes as C
+    from .. import hip as _hip
+    if os.environ.get("TMJX_NO_CHAIN") or not (x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(1) == 1):
+        return False
+    if any(h[0].shape[0] != 256 for h in hidden) or not (1 <= len(hidden) <= 4):
+        return False
+    return bool(_hip.lib().tmjx_chain_fwd_ok(C.byref(chain_fwd_desc(x2[:1], hidden, final, kind)[0])))
+
+
+def chain_bwd(g, final_w, blocks, kind="ln", w0=None, dx_cols=None, prof=None, dx_ld=None):
+    """One launch: the backward chain (tmjx_chain_bwd).  g: d loss / d (last layer's output) [M, Kg] (a 1-wide head: [M]); final_w: the last layer's
+    weight [Kg, 256]; blocks: the hidden layers LAST FIRST as (weight [256, K], z, bias, gamma, stats) ("ln") or (weight, z, bias) ("silu") — the
+    weight of blocks[i] is the operand of stage i + 1; w0 / dx_cols: the first hidden layer's weight and how many of its input columns need a gradient.
+    Returns (dz per block (last first), partials per block or None, dx [M, ceil4(dx_cols)] or None)."""
+    import ctypes as C
+    from .. import hip as _hip
+    L = _hip.lib()
+    M, dev = g.shape[0], g.device
+    d = _hip.ChainBwd()
+    head = g.dim() == 1
+    d.G, d.ldg, d.Kg, d.M, d.n_stages, d.epi = g.data_ptr(), (1 if head else g.stride(0)), (1 if head else g.shape[1]), M, len(blocks), 2 if kind == "ln" else 4
+    dzs, partials = [], []
+    nfl = int(L.tmjx_gemm_nn_ln_bwd_partial_floats(M, 256)) if kind == "ln" else 0
+    for i, blk in enumerate(blocks):
+        S = d.stage[i]
+        w = final_w if i == 0 else blocks[i - 1][0]
+        S.W, S.ldw = w.data_ptr(), (w.stride(0) if w.dim() == 2 and w.shape[0] > 1 else 256)
+        dz = torch.empty((M, 256), dtype=torch.float32, device=dev)
+        S.z, S.bias, S.dz = blk[1].data_ptr(), blk[2].data_ptr(), dz.data_ptr()
+        if kind == "ln":
+            pt = torch.empty(nfl, dtype=torch.float32, device=dev)
+            S.gamma, S.stats, S.partial = blk[3].data_ptr(), blk[4].data_ptr(), pt.data_ptr()
+            partials.append(pt)
+        dzs.append(dz)
+    dx = None
+    if w0 is not None:
+        cols = int(dx_cols)
+        # (dx_ld: a buffer of the input's own width, of which only the first `cols` columns are written — what autograd wants back for the input)
+        dx = torch.empty((M, (cols + 3) // 4 * 4 if dx_ld is None else int(dx_ld)), dtype=torch.float32, device=dev)
+        d.W0, d.ldw0, d.dx_cols, d.dx, d.lddx = w0.data_ptr(), w0.stride(0), cols, dx.data_ptr(), dx.stride(0)
+    if prof is not None:
+        d.prof = prof.data_ptr()
+    _launch("tmjx_chain_bwd", dev, C.byref(d))
+    return dzs, (partials if kind == "ln" else None), dx
+
+
 # ---- a whole MLP chain as ONE autograd function (bf16 GEMM-input mode) -------------------------------------------------------------------
 class _Layer:
     """One layer of a chain: kind "ln" (Dense -> SiLU -> LayerNorm block), "silu" (Dense -> SiLU, brax value MLP), "dense" (un-activated) or
@@ -613,6 +697,111 @@ def _bf16_chain_ok(x) -> bool:
     sh = gemm_inputs.shadows
     return gemm_inputs.dtype == torch.bfloat16 and sh is not None and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not os.environ.get("TMJX_NO_BF16_CHAIN")
 
+
+
+class _F32ChainFn(torch.autograd.Function):
+    """y = chain(x) for an fp32 chain whose hidden layers are all 256 wide, forward AND backward ONE launch each (tmjx_chain_fwd / tmjx_chain_bwd,
+    csrc/mlp_chain.h): the encoder's blocks + fc2, the decoder's blocks + the action head (intention_network.py:32-44,68-76,128-139), brax's value MLP
+    with its 1-wide head (ppo_networks.py:180-184).  Bit-identical to the layer-by-layer functions (_HipBlockFn / _HipDenseFn / _ValueChainFn): same
+    saved tensors, same expressions; weight gradients go to the learner's grouped launch (deferred_weight_grads) as before, the LayerNorm blocks'
+    (d gamma | d beta | d bias) column-sum partials to its grouped reduction, the 1-wide head's gradients through tmjx_head_dw.  `layers`: _Layer list,
+    hidden layers ("ln" or "silu", all of one kind) then the last layer ("dense" / "head"); `dx_cols`: the input's leading columns that need a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, layers, dx_cols, *params):
+        x2 = _rows2d(x)
+        hid, last = layers[:-1], layers[-1]
+        kind = hid[0].kind
+        hidden = [(L.lin.weight, L.lin.bias, L.norm.weight, L.norm.bias) if kind == "ln" else (L.lin.weight, L.lin.bias) for L in hid]
+        eps = float(hid[0].norm.eps) if kind == "ln" else 0.0
+        saved, out = chain_fwd(x2, hidden, (last.lin.weight, last.lin.bias), kind, eps)
+        flat = [t for z, y, st in saved for t in ((z, y, st) if kind == "ln" else (z, y))]
+        ctx.save_for_backward(x2, *flat, *params)
+        ctx.layers, ctx.dx_cols, ctx.x_shape, ctx.kind, ctx.nflat = layers, dx_cols, x.shape, kind, len(flat)
+        return out.view(*x.shape[:-1], last.lin.out_features) if last.kind == "dense" else out.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .. import hip as _hip
+        layers, kind = ctx.layers, ctx.kind
+        hid, last = layers[:-1], layers[-1]
+        st_ = ctx.saved_tensors
+        x2, flat, params = st_[0], st_[1:1 + ctx.nflat], st_[1 + ctx.nflat:]
+        per = 3 if kind == "ln" else 2
+        saved = [flat[per * i:per * i + per] for i in range(len(hid))]
+        # the parameters as they were at forward time (saved tensors; version-checked by autograd), in _Layer.params() order
+        pit = iter(params)
+        P = [[next(pit) for _ in L.params()] for L in layers]
+        Lh = _hip.lib()
+        dev = dout.device
+        M = x2.shape[0]
+        d = deferred_weight_grads.active
+        grads: dict = {}
+        wf, bf = P[-1][0], P[-1][1]
+        y_last = saved[-1][1]
+        if last.kind == "head":
+            g = dout.reshape(-1)
+            g = g if g.is_contiguous() else g.contiguous()
+            K = wf.shape[1]
+            dwh, dbh = torch.empty((1, K), dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
+            scratch = torch.empty(int(Lh.tmjx_head_dw_scratch_floats(M, K)), dtype=torch.float32, device=dev)
+            _launch("tmjx_head_dw", dev, _p(g), _p(y_last), y_last.stride(0), _p(dwh), _p(dbh), _p(scratch), M, K)
+            grads[(len(layers) - 1, 0)], grads[(len(layers) - 1, 1)] = dwh, dbh
+            ctx._keep = scratch
+        else:
+            g = _rows2d(dout)
+            if g.data_ptr() % 16 or g.stride(0) % 4:
+                g = g.contiguous()
+            got = d.try_add(g, y_last, last.lin.weight, last.lin.bias) if d is not None else None
+            dw, db = got if got is not None else gemm_dw(g, y_last, True)
+            grads[(len(layers) - 1, 0)], grads[(len(layers) - 1, 1)] = dw, db
+        if kind == "ln":
+            blocks = [(P[l][0], saved[l][0], P[l][1], P[l][2], saved[l][2]) for l in range(len(hid) - 1, -1, -1)]
+        else:
+            blocks = [(P[l][0], saved[l][0], P[l][1]) for l in range(len(hid) - 1, -1, -1)]
+        want_dx = ctx.needs_input_grad[0]
+        cols = (x2.shape[1] if ctx.dx_cols is None else int(ctx.dx_cols)) if want_dx else None
+        dzs, partials, dx = chain_bwd(g, wf, blocks, kind, P[0][0] if want_dx else None, cols, dx_ld=x2.shape[1] if want_dx else None)
+        for i, dz in enumerate(dzs):
+            l = len(hid) - 1 - i
+            L = hid[l]
+            xin = x2 if l == 0 else saved[l - 1][1]
+            if kind == "ln":
+                got = d.try_add(dz, xin, L.lin.weight, None) if d is not None else None
+                grads[(l, 0)] = got[0] if got is not None else gemm_dw(dz, xin, False)[0]
+                g3 = torch.empty((3, 256), dtype=torch.float32, device=dev)
+                nblk = partials[i].numel() // 768
+                if d is not None and len(d.colsums) < 16:
+                    d.colsums.append((partials[i], g3, nblk, 768))      # reduced with the others in ONE launch behind the backward pass (launch())
+                else:
+                    one = (_hip.ColsumProblem * 1)(_hip.ColsumProblem(partials[i].data_ptr(), g3.data_ptr(), nblk, 768))
+                    _launch("tmjx_colsum_grouped", dev, one, 1)
+                grads[(l, 2)], grads[(l, 3)], grads[(l, 1)] = g3[0], g3[1], g3[2]
+            else:
+                got = d.try_add(dz, xin, L.lin.weight, L.lin.bias) if d is not None else None
+                grads[(l, 0)], grads[(l, 1)] = got if got is not None else gemm_dw(dz, xin, True)
+        out = [grads.get((l, j)) for l, L in enumerate(layers) for j in range(len(L.params()))]
+        return (dx.view(ctx.x_shape) if dx is not None else None, None, None, *out)
+
+
+def f32_chain(x, layers, dx_cols=None):
+    params = [p for L in layers for p in L.params()]
+    return _F32ChainFn.apply(x, layers, dx_cols, *params)
+
+
+def _f32_chain_ok(x, layers, dx_cols=None) -> bool:
+    """The whole-chain fp32 kernels take it: fp32 mode on the GPU, every hidden layer 256 wide, a last layer of at most 128 columns, aligned rows,
+    and the chain's input gradient (if any) limited to at most 128 leading columns."""
+    if gemm_inputs.dtype is not None or torch.is_autocast_enabled() or os.environ.get("TMJX_NO_CHAIN") or not (x.is_cuda and x.dtype == torch.float32):
+        return False
+    if x.requires_grad and torch.is_grad_enabled() and (x.shape[-1] if dx_cols is None else int(dx_cols)) > 128:
+        return False
+    hid, last = layers[:-1], layers[-1]
+    if not hid or any(L.lin.out_features != 256 or L.lin.bias is None for L in hid) or last.lin.bias is None or last.lin.in_features != 256:
+        return False
+    kind = hid[0].kind
+    hidden = [(L.lin.weight, L.lin.bias, L.norm.weight, L.norm.bias) if kind == "ln" else (L.lin.weight, L.lin.bias) for L in hid]
+    return chain_fwd_ok(_rows2d(x), hidden, (last.lin.weight, last.lin.bias), kind)
 
 
 class _BlockLink:
@@ -1142,9 +1331,15 @@ class IntentionPolicy(nn.Module):
                 self._dec_chain = [_Layer("ln", b.dense, b.norm) for b in self.decoder] + [_Layer("dense", self.head)]
             fc2 = bf16_chain(traj, self._enc_chain)
         else:
-            with ln_bwd_links():       # encoder and decoder are chains: each block's output feeds exactly one dense layer
-                h = self.encoder(traj)
-                fc2 = self.fc2(h)
+            if getattr(self, "_enc_f32", None) is None and obs.is_cuda:
+                self._enc_f32 = [_Layer("ln", b.dense, b.norm) for b in self.encoder] + [_Layer("dense", self.fc2)]
+                self._dec_f32 = [_Layer("ln", b.dense, b.norm) for b in self.decoder] + [_Layer("dense", self.head)]
+            if obs.is_cuda and _f32_chain_ok(traj, self._enc_f32):
+                fc2 = f32_chain(traj, self._enc_f32)          # 2 x 256 nets: the encoder + fc2 as ONE launch forward, one backward (csrc/mlp_chain.h)
+            else:
+                with ln_bwd_links():       # encoder and decoder are chains: each block's output feeds exactly one dense layer
+                    h = self.encoder(traj)
+                    fc2 = self.fc2(h)
         mean, logvar = torch.chunk(fc2, 2, dim=-1)
         if (not deterministic and fc2.is_cuda and fc2.dtype == torch.float32 and obs.dtype == torch.float32 and not torch.is_autocast_enabled()
                 and fc2.numel() >= 2 * self.latents * 1024):
@@ -1158,6 +1353,8 @@ class IntentionPolicy(nn.Module):
             x = x.view(*lead, x.shape[-1])
             if chains:
                 logits = bf16_chain(x, self._dec_chain, dx_cols=self.latents)
+            elif _f32_chain_ok(x, self._dec_f32, self.latents):
+                logits = f32_chain(x, self._dec_f32, dx_cols=self.latents)
             else:
                 with ln_bwd_links():
                     logits = self.head(self.decoder(x))
@@ -1211,6 +1408,13 @@ class ValueNet(nn.Module):
             # fp32 on the GPU: every hidden layer is ONE launch forward (GEMM + SiLU epilogue), no torch element-wise kernel in either direction
             h = obs
             dense = [m for m in self.net if isinstance(m, nn.Linear)]
+            if len(dense) > 1 and dense[-1].out_features == 1:
+                if getattr(self, "_f32_chain", None) is None:
+                    self._f32_chain = [_Layer("silu", m) for m in dense[:-1]] + [_Layer("head", dense[-1])]
+                if _f32_chain_ok(obs, self._f32_chain):
+                    # 256-wide critic: the whole MLP incl. its 1-wide head as ONE launch forward, one backward (csrc/mlp_chain.h) — in the learner's pass
+                    # and in the bootstrap value's alike (bit-identical to the layer-by-layer functions below)
+                    return f32_chain(obs, self._f32_chain).squeeze(-1)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and _value_chain_ok(_rows2d(obs), dense):
                 # the learner's pass: the whole MLP as one autograd function (no element-wise launch between the backward GEMMs, the 1-wide head without a GEMM)
                 return _ValueChainFn.apply(obs, dense, *[p for lin in dense for p in (lin.weight, lin.bias)]).squeeze(-1)

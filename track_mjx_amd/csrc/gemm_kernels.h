@@ -586,6 +586,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #endif
 }
 
+#ifndef GEMM_ACT_ONLY      // (csrc/mlp_chain.h shares this header's helpers from a translation unit of its own: the kernels below live in tmjx_hip.hip only)
 // ---- dW = dY^T X (+ db as the column of ones): slabs over row ranges
 #define DW_BT 128            // output tile: 128 (n) x 128 (k)
 #define DW_BM 32             // rows of M per LDS stage
@@ -818,3 +819,4 @@ __global__ __launch_bounds__(256) void k_dw_reduce_grouped(const DwGroup G) {
   const DwProblem &P = G.p[i];
   dw_reduce_elem(P.slabs, P.dW, P.db, P.S, P.N, P.K, P.db != nullptr, P.ld_slab, P.lddw, (long long)(blockIdx.x - P.red_begin) * 256 + threadIdx.x);
 }
+#endif  // GEMM_ACT_ONLY

@@ -911,6 +911,7 @@ static int gemm_mt(int M, int col_tiles) {
   const double c5 = (double)((w5 + 255) / 256) * 5.0, c2 = (double)((w2 + 255) / 256) * 2.2;
   return c2 < c5 ? 2 : 5;
 }
+extern "C" int tmjx_internal_gemm_mt(int M, int col_tiles) { return gemm_mt(M, col_tiles); }      // (tmjx_chain.hip: the chain kernels take the same row tile)
 template <int NIW, bool BT, bool AVEC, bool WVEC, int MT = 5, int EPI = 0>
 static int launch_gemm_act(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc, int M, int N, int K, hipStream_t s, GemmLN ln = GemmLN{}) {
   constexpr int BN = 64 * NIW, BM = 16 * MT;

@@ -14,7 +14,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 SO_PATH = Path(os.environ.get("TMJX_SO", str(_PKG / "libtmjx_hip.so")))  # TMJX_SO: alternative build (profiling)
 CSRC = _PKG / "csrc"
-SOURCES = (CSRC / "tmjx_hip.hip", CSRC / "tmjx_bf16.hip", CSRC / "tmjx_wave.hip")
+SOURCES = (CSRC / "tmjx_hip.hip", CSRC / "tmjx_bf16.hip", CSRC / "tmjx_wave.hip", CSRC / "tmjx_chain.hip")
 # per-source compiler flags: the physics kernel's unit is built without machine LICM (csrc/tmjx_wave.hip says why)
 SOURCE_FLAGS = {"tmjx_wave.hip": ("-mllvm", "-disable-machine-licm")}
 
@@ -37,6 +37,7 @@ EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips
            "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_colsum_grouped", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_grouped_wgs", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_set_action_repeat", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
            "tmjx_rollout_store", "tmjx_clips_share", "tmjx_gemm_nt_silu", "tmjx_gemm_nt_silu_ok", "tmjx_silu_fwd", "tmjx_silu_bwd", "tmjx_gemm_nn_silu_bwd_ok", "tmjx_gemm_nn_silu_bwd", "tmjx_silu_bwd_rank1", "tmjx_head_dw_scratch_floats", "tmjx_head_dw", "tmjx_head_fwd_ok", "tmjx_head_fwd", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_grouped", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bf16_z_bytes", "tmjx_bgemm_partial_floats",
            "tmjx_bgemm_ln_fwd", "tmjx_bgemm_ln_bwd", "tmjx_bgemm_silu_fwd", "tmjx_bgemm_silu_bwd", "tmjx_bf_silu_bwd", "tmjx_bf_silu_bwd_rank1",
+           "tmjx_chain_fwd_ok", "tmjx_chain_fwd", "tmjx_chain_bwd_ok", "tmjx_chain_bwd",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
 
@@ -74,6 +75,28 @@ class Bf16Shadow(C.Structure):
     """tmjx_bf16_shadow_t (include/tmjx.h)."""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("ld_src", C.c_int32),
                 ("ld_dst", C.c_int32), ("ld_dst_t", C.c_int32)]
+
+
+class ChainLayer(C.Structure):
+    """tmjx_chain_layer_t (include/tmjx.h)."""
+    _fields_ = [(k, C.c_void_p) for k in ("W", "bias", "gamma", "beta", "z", "y", "stats")] + [("K", C.c_int32), ("ldw", C.c_int32)]
+
+
+class ChainFwd(C.Structure):
+    """tmjx_chain_fwd_t (include/tmjx.h)."""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("M", C.c_int32), ("n_hidden", C.c_int32), ("epi", C.c_int32), ("hidden", ChainLayer * 4),
+                ("Wf", C.c_void_p), ("bf", C.c_void_p), ("outf", C.c_void_p), ("Nf", C.c_int32), ("ldwf", C.c_int32), ("ldof", C.c_int32), ("eps", C.c_float), ("prof", C.c_void_p)]
+
+
+class ChainBwdStage(C.Structure):
+    """tmjx_chain_bwd_stage_t (include/tmjx.h)."""
+    _fields_ = [("W", C.c_void_p), ("ldw", C.c_int32)] + [(k, C.c_void_p) for k in ("z", "bias", "gamma", "stats", "dz", "partial")]
+
+
+class ChainBwd(C.Structure):
+    """tmjx_chain_bwd_t (include/tmjx.h)."""
+    _fields_ = [("G", C.c_void_p), ("ldg", C.c_int32), ("Kg", C.c_int32), ("M", C.c_int32), ("n_stages", C.c_int32), ("epi", C.c_int32), ("stage", ChainBwdStage * 4),
+                ("W0", C.c_void_p), ("ldw0", C.c_int32), ("dx_cols", C.c_int32), ("dx", C.c_void_p), ("lddx", C.c_int32), ("prof", C.c_void_p)]
 
 
 class PpoCfg(C.Structure):
@@ -269,6 +292,10 @@ def load(path: Path):
     sig.setdefault("tmjx_stats_scratch_floats", [None, None])[0] = [C.c_int]
     sig.setdefault("tmjx_stats_sums", [None, None])[0] = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]
     sig.setdefault("tmjx_stats_apply", [None, None])[0] = [fp, C.c_float, fp, fp, fp, fp, C.c_int, C.c_float, C.c_float, vp]
+    sig.setdefault("tmjx_chain_fwd_ok", [None, None])[0] = [C.POINTER(ChainFwd)]
+    sig.setdefault("tmjx_chain_fwd", [None, None])[0] = [C.POINTER(ChainFwd), vp]
+    sig.setdefault("tmjx_chain_bwd_ok", [None, None])[0] = [C.POINTER(ChainBwd)]
+    sig.setdefault("tmjx_chain_bwd", [None, None])[0] = [C.POINTER(ChainBwd), vp]
     sig.setdefault("tmjx_debug_rows", [None, None])[0] = [vp, C.c_char_p, ip, ip]
     sig.setdefault("tmjx_last_error", [None, None])[1] = C.c_char_p
     sig.setdefault("tmjx_version", [None, None])[1] = C.c_char_p
