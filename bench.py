@@ -147,11 +147,9 @@ def other_configs(timeout_s: float = 150.0) -> dict:
     return res
 
 
-def live_pmc_traffic(timeout_s: float = 90.0):
-    """HBM traffic of the env.step kernels from the PMC counters, collected BY THIS RUN: two child `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE
-    cannot share a pass: MI355X_MICROARCH.md "rocprofv3 PMC slots") over tools/time_step.py (4096 envs in one launch, 4 steps), counters in KB per
-    dispatch, FETCH_SIZE doubled — the gfx950 correction that guide prescribes.  Exactly what tools/profile_gpu.sh + tools/pmc_summary.py stamp into
-    profiles/pmc_traffic.json (the fallback when rocprofv3 is missing or a pass fails: the line says which it carries).  Returns None on any failure."""
+def _pmc_pass(counters: list[str], script_args: list[str], timeout_s: float = 90.0):
+    """ONE child `rocprofv3 --pmc <counters> --kernel-trace` pass over `python <script_args>` (the interpreter directly behind `--`, a process group of its
+    own, killed on time-out): {kernel name up to '(': {counter: [value per dispatch, in dispatch order]}} or None on any failure."""
     import collections
     import csv
     import glob
@@ -161,45 +159,125 @@ def live_pmc_traffic(timeout_s: float = 90.0):
     import tempfile
     if not shutil.which("rocprofv3"):
         return None
-    step_kernels = ("void k_physics_wave", "k_rec_in", "k_rec_out", "k_step_parts", "k_window", "k_obs", "k_post_parts", "k_post", "k_autoreset")
     tmp = tempfile.mkdtemp(prefix="tmjx_pmc_", dir="/tmp")
-    out: dict = {}
     try:
-        for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", f"{tmp}/{kind}", "--",
-                   sys.executable, str(ROOT / "tools" / "time_step.py"), "--steps", "4"]
-            p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, start_new_session=True)
-            _CHILDREN.append(p)
-            try:
-                p.wait(timeout=timeout_s)
-            except subprocess.TimeoutExpired:
-                os.killpg(p.pid, signal.SIGKILL)
-                p.wait()
-                return None
-            finally:
-                if p in _CHILDREN:
-                    _CHILDREN.remove(p)
-            files = glob.glob(f"{tmp}/{kind}/**/*_counter_collection.csv", recursive=True)
-            if p.returncode != 0 or not files:
-                return None
-            agg = collections.defaultdict(list)
-            for r in csv.DictReader(open(max(files, key=lambda f: os.path.getmtime(f)))):
-                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-            for k, v in agg.items():
-                if k.startswith(step_kernels):
-                    vv = v[3:] if len(v) > 4 else v           # steady-state env.step launches (the first ones belong to reset / warm-up)
+        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", f"{tmp}/p", "--", sys.executable, *script_args]
+        p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, start_new_session=True)
+        _CHILDREN.append(p)
+        try:
+            p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            return None
+        finally:
+            if p in _CHILDREN:
+                _CHILDREN.remove(p)
+        files = glob.glob(f"{tmp}/p/**/*_counter_collection.csv", recursive=True)
+        if p.returncode != 0 or not files:
+            return None
+        per = collections.defaultdict(lambda: collections.defaultdict(dict))
+        for r in csv.DictReader(open(max(files, key=lambda f: os.path.getmtime(f)))):
+            d = per[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]
+            d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])     # (one row per XCD / SE instance: summed per dispatch)
+        return {k: {c: [v[i] for i in sorted(v)] for c, v in cs.items()} for k, cs in per.items()}
+    except Exception:  # noqa: BLE001 — a report beside the headline, never a reason to lose it
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+SQ_K2_COUNTERS = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES"]
+
+
+def live_pmc_traffic(timeout_s: float = 90.0):
+    """HBM traffic of the env.step kernels AND the vector-pipe counters of K2 from the PMC counters, collected BY THIS RUN: two child `rocprofv3 --pmc` passes
+    (FETCH_SIZE and WRITE_SIZE cannot share a pass — 3 + 2 of the 4 TCC slots: MI355X_MICROARCH.md "rocprofv3 PMC slots"; the four SQ counters ride with the
+    FETCH_SIZE pass, the SQ block has 8 slots of its own) over tools/time_step.py (4096 envs in one launch, 4 steps), traffic counters in KB per dispatch,
+    FETCH_SIZE doubled — the gfx950 correction that guide prescribes.  Exactly what tools/profile_gpu.sh + tools/pmc_summary.py / tools/sq_counters.sh +
+    tools/sq_summary.py stamp into profiles/pmc_traffic.json / sq_counters.json (the fallback when rocprofv3 is missing or a pass fails: the line says
+    which it carries).  Returns None on any failure."""
+    step_kernels = ("void k_physics_wave", "k_rec_in", "k_rec_out", "k_step_parts", "k_window", "k_obs", "k_post_parts", "k_post", "k_autoreset")
+    script = [str(ROOT / "tools" / "time_step.py"), "--steps", "4", "--scale", "0.3"]
+    try:
+        first = _pmc_pass(["FETCH_SIZE", *SQ_K2_COUNTERS], script, timeout_s)
+        sq_rode_along = first is not None
+        if first is None:
+            first = _pmc_pass(["FETCH_SIZE"], script, timeout_s)          # (should the two blocks' counters not combine on some driver: the traffic pass alone)
+        second = _pmc_pass(["WRITE_SIZE"], script, timeout_s) if first is not None else None
+        if first is None or second is None:
+            return None
+
+        def steady(v):            # steady-state env.step launches (the first ones belong to reset / warm-up)
+            return v[3:] if len(v) > 4 else v
+        out: dict = {}
+        for kind, res, ctr in (("fetch", first, "FETCH_SIZE"), ("write", second, "WRITE_SIZE")):
+            for k, cs in res.items():
+                if k.startswith(step_kernels) and ctr in cs:
+                    vv = steady(cs[ctr])
                     out.setdefault(k.replace("void ", ""), {})[kind] = sum(vv) / len(vv) * 1024.0
         kern = {k: {"fetch_bytes_raw": v.get("fetch", 0.0), "fetch_bytes_corrected": 2 * v.get("fetch", 0.0), "write_bytes": v.get("write", 0.0)} for k, v in out.items()}
         dom = "k_physics_wave<true>"
         if dom not in kern or "fetch" not in out[dom] or "write" not in out[dom]:
             return None
-        return {"kernels": kern, "envs_per_launch": ENVS_PER_GPU, "hbm_bytes_per_launch": kern[dom]["fetch_bytes_corrected"] + kern[dom]["write_bytes"],
-                "hbm_bytes_per_launch_all_step_kernels": sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in kern.values()),
-                "so_build_id": so_build_id(), "collected_by_this_run": True}
+        ret = {"kernels": kern, "envs_per_launch": ENVS_PER_GPU, "hbm_bytes_per_launch": kern[dom]["fetch_bytes_corrected"] + kern[dom]["write_bytes"],
+               "hbm_bytes_per_launch_all_step_kernels": sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in kern.values()),
+               "so_build_id": so_build_id(), "collected_by_this_run": True, "sq": None}
+        k2 = first.get("void k_physics_wave<true>") if sq_rode_along else None
+        if k2 and all(c in k2 for c in SQ_K2_COUNTERS):
+            # per wave (= env) and substep, as tools/sq_summary.py: pipe busy = SQ_INSTS_VALU x 2 cycles x waves per SIMD / resident cycles (SQ_WAVE_CYCLES ticks every
+            # 4 clocks); lane occupancy = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)
+            c = {n: sum(steady(k2[n])) / len(steady(k2[n])) / (ENVS_PER_GPU * 10) for n in SQ_K2_COUNTERS}
+            from track_mjx_amd.agent import ppo as _ppo
+            wps = _ppo.RESIDENT_ENVS_PER_CU / 4.0
+            ret["sq"] = {"valu_insts_per_wave_substep": c["SQ_INSTS_VALU"], "valu_pipe_busy": 2.0 * c["SQ_INSTS_VALU"] * wps / (4.0 * c["SQ_WAVE_CYCLES"]),
+                         "lane_occupancy": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0), "waves_per_simd": wps}
+        return ret
     except Exception:  # noqa: BLE001 — a report beside the headline, never a reason to lose it
         return None
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_mfma_util(timeout_s: float = 90.0):
+    """Matrix-pipe utilisation inside the learner's GEMM / chain kernels over the SGD half of a cfg2 training step (tools/sgd_step.py, eager launches), collected
+    BY THIS RUN with one child `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES` pass: utilisation = MFMA busy cycles / (4 SIMDs x CU busy cycles),
+    summed per kernel family (tools/mfma_summary.py's formula; fallback: the stamped profiles/mfma_counters.json)."""
+    res = _pmc_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"], [str(ROOT / "tools" / "sgd_step.py"), "--config", "cfg2"], timeout_s)
+    if not res:
+        return None
+    fam: dict = {}
+    for k, cs in res.items():
+        name = ("chain kernels (k_chain_fwd / k_chain_bwd)" if "k_chain_" in k else "k_gemm_dw (weight gradient)" if "k_gemm_dw" in k else
+                "k_gemm_act (forward / input gradient)" if "k_gemm_act" in k else None)
+        if name and "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "SQ_BUSY_CU_CYCLES" in cs:
+            f = fam.setdefault(name, [0.0, 0.0])
+            f[0] += sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]); f[1] += sum(cs["SQ_BUSY_CU_CYCLES"])
+    if not fam:
+        return None
+    tot = [sum(f[0] for f in fam.values()), sum(f[1] for f in fam.values())]
+    return {"families": {k: round(f[0] / max(4 * f[1], 1.0), 4) for k, f in fam.items()}, "all": round(tot[0] / max(4 * tot[1], 1.0), 4), "so_build_id": so_build_id()}
+
+
+def parity_summary():
+    """What the north_star's "qpos / qvel within 1e-5 rel" means for this build, read from the newest profiles/r*_parity_strict.log (the printed summary of
+    tests/test_gpu_parity_strict.py: 64 envs x 40 teacher-forced substeps per action regime against the float64 oracle)."""
+    import re
+    logs = sorted((ROOT / "profiles").glob("r*_parity_strict.log"))
+    out = {"oracle": "unpinned (own restatement of mujoco-mjx 3.3.2: the reference ships no fixtures and jax / mujoco cannot be imported here)",
+           "contract": "median over env-substeps <= 1e-5 relative to a float64 run of the oracle, one substep from an identical state; NOT every env-substep "
+                       "(a 5-iteration non-converged CG amplifies fp32 rounding: the float32 restatement of MJX's own dense path does no better)"}
+    if not logs:
+        return out
+    txt = logs[-1].read_text()
+    fr, fo, med = [], [], []
+    for blk in re.split(r"\[scale ", txt)[1:4]:
+        m = re.search(r"qvel: HIP against the FLOAT32 oracle.*?float64 oracle: HIP ([0-9.]+), float32 oracle ([0-9.]+)", blk)
+        q = re.search(r"qvel: HIP worst env \S+ \(float32 oracle \S+\); 99th pct \S+ \(\S+\); median (\S+) \((\S+)\)", blk)
+        if m:
+            fr.append(float(m.group(1))); fo.append(float(m.group(2)))
+        if q:
+            med.append(float(q.group(1)))
+    out.update({"action_scales": [0.03, 0.3, 1.0], "qvel_within_1e-5": fr, "qvel_within_1e-5_float32_oracle": fo, "qvel_median_rel_err": med, "source": f"profiles/{logs[-1].name}"})
+    return out
 
 
 def dry_run_ranks(args) -> None:
@@ -253,6 +331,8 @@ def main(argv=None, runner=None):
     bc = CONFIGS[args.config]
     if args.envs_per_gpu is None:
         args.envs_per_gpu = bc["envs_per_gpu"]
+    if os.environ.get("TMJX_PIN_CORES"):        # host-starvation stress (tools/gpu_lab.sh starve): this rank's threads on the named cores, before its first GPU call
+        os.sched_setaffinity(0, {int(c) for c in os.environ["TMJX_PIN_CORES"].split(",")})
 
     import torch
     import torch.distributed as dist
@@ -478,12 +558,23 @@ def main(argv=None, runner=None):
                               "valu_insts_per_wave_substep": sq.get("SQ_INSTS_VALU_per_wave_substep") if sq else None,
                               "counters_source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes, tools/sq_counters.sh), not collected by this run",
                               "counters_build_id": sq.get("so_build_id") if sq else None,
-                              "counters_build_is_this_runs": bool(sq and sq.get("so_build_id") == so_build_id())},
+                              "counters_build_is_this_runs": bool(sq and sq.get("so_build_id") == so_build_id()), "counters_collected_by_this_run": False},
             "roofline_mfma": {"bound": "mfma", "unit": "TFLOP/s", "peak": mfma_peak, "achieved": mfma_ach, "frac": mfma_ach / mfma_peak,
                               "what": f"{sgd_steps} minibatch SGD steps of {rows_mb} rows: GEMM flops (forward + d input + d weight, policy + value nets) / the whole SGD half's time incl. gathers, epilogues, loss head and optimiser (HIP events around update())",
                               "gemm_flops_per_minibatch_step": gemm_flops_step, "sgd_ms_per_minibatch_step": sgd_ms / sgd_steps,
-                              "mfma_util_inside_gemm_kernels": mf.get("mfma_util") if mf else None},
+                              "mfma_util_inside_gemm_kernels": mf.get("mfma_util") if mf else None, "mfma_util_collected_by_this_run": False,
+                              "mfma_util_source": "profiles/mfma_counters.json (tools/mfma_counters.sh), not collected by this run"},
+            "parity": parity_summary(),
         }
+        # the finished measurement is on disk before any extra runs: a hard kill (SIGKILL, a driver time-out) during the minute of extras below cannot lose it
+        # (stdout still carries exactly ONE line, the enriched one, printed by emit())
+        for side in (ROOT / "gpurun_out", Path("/tmp")):
+            try:
+                side.mkdir(exist_ok=True)
+                (side / "bench_headline.json").write_text(json.dumps(out) + "\n")
+                break
+            except OSError:
+                continue
         # the extras below (CPU baselines, child runs of cfg4 / cfg5) take a minute: if the caller's time-out ends this process during them
         # (SIGTERM / SIGINT), the headline measured above is printed as it stands instead of being lost — still exactly one JSON line
         import signal
@@ -514,6 +605,15 @@ def main(argv=None, runner=None):
         # profiles/pmc_traffic.json stays in the line if rocprofv3 is missing or a pass fails
         if world == 1 and args.config == "cfg2" and not args.no_live_pmc and not args.no_cpu_baseline:
             live = live_pmc_traffic()
+            if live and live.get("sq"):      # the vector-pipe counters of K2 rode along with the FETCH_SIZE pass: they replace the stamped file's
+                out["roofline_valu"].update({"valu_pipe_busy": live["sq"]["valu_pipe_busy"], "lane_occupancy": live["sq"]["lane_occupancy"],
+                                             "valu_insts_per_wave_substep": live["sq"]["valu_insts_per_wave_substep"], "counters_build_id": live["so_build_id"],
+                                             "counters_build_is_this_runs": True, "counters_collected_by_this_run": True,
+                                             "counters_source": "child `rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES` pass of THIS run over tools/time_step.py (4096 envs in one launch, 0.3-scaled actions)"})
+            mfl = live_mfma_util()
+            if mfl:
+                out["roofline_mfma"].update({"mfma_util_inside_gemm_kernels": mfl["all"], "mfma_util_by_kernel_family": mfl["families"], "mfma_util_collected_by_this_run": True,
+                                             "mfma_util_source": "child `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES` pass of THIS run over tools/sgd_step.py --config cfg2"})
             if live:
                 sc = per_launch / live["envs_per_launch"]
                 r, k2t, stt = out["roofline"], live["hbm_bytes_per_launch"] * sc, live["hbm_bytes_per_launch_all_step_kernels"] * sc

@@ -362,8 +362,10 @@ def test_value_chain_function_against_the_layer_by_layer_path(M, widths, monkeyp
     cot = torch.randn(M, device=DEV)
     params = list(net.parameters())
     seen = []
-    orig = nw._ValueChainFn.forward
+    orig, orig_f32 = nw._ValueChainFn.forward, nw._F32ChainFn.forward
     monkeypatch.setattr(nw._ValueChainFn, "forward", staticmethod(lambda *a: (seen.append(1), orig(*a))[1]))
+    # (a critic whose hidden layers are all 256 wide takes the whole-chain kernels, csrc/mlp_chain.h — one launch each way, bit-identical too: tests/test_gpu_chain.py)
+    monkeypatch.setattr(nw._F32ChainFn, "forward", staticmethod(lambda *a: (seen.append(1), orig_f32(*a))[1]))
     v1 = net(x)
     g1 = torch.autograd.grad(v1, params, cot)
     assert seen, "the fused value chain did not run"

@@ -4,6 +4,7 @@
 #   bash tools/gpu_lab.sh cfgstats            rocprofv3 kernel stats of the config-4 and config-5 bench commands (+ the count of library-GEMM rows)
 #   bash tools/gpu_lab.sh timeline [cfgN]     rocprofv3 kernel trace (rocpd) of the bench -> one SGD minibatch step (tools/step_timeline.py) and,
 #                                             for cfg2, one env group's serial roll-out phase (tools/rollout_timeline.py)
+#   bash tools/gpu_lab.sh starve              the rehearsal's 4 ranks with every rank pinned to the same two host cores against unpinned: what host starvation does to the roll-out
 #   bash tools/gpu_lab.sh rehearse            2 / 4 ranks of bench.py, tools/two_rank_sync_check.py and `python -m track_mjx_amd.train num_gpus=2`
 #                                             on ONE GPU over gloo (TMJX_REHEARSE_ON_ONE_GPU=1): plumbing of the N > 1 path, never a measurement
 set -u
@@ -47,5 +48,17 @@ o=json.loads(sys.stdin.read()); c=o['config']; print(o['n_gpus'], round(o['value
     train_setup.train_config.num_timesteps=100000 train_setup.eval_every=50000 train_setup.reset_every=50000 max_training_steps=3 n_synthetic_clips=4 num_gpus=2 \
     checkpoint_path=/tmp/tmjx_rehearse_ckpt > $OUT/train2.txt 2> $OUT/train2.err
   echo "train 2 ranks rc=$?"; grep "^\[train\]" $OUT/train2.txt | cut -c1-200 | tail -2;;
-*) echo "usage: bash tools/gpu_lab.sh cfgstats | timeline [cfgN] | rehearse"; exit 2;;
+starve)
+  # host-starvation stress of the roll-out: 4 ranks of bench.py sharing ONE GPU over gloo (the rehearsal mode: plumbing, never a measurement), once with the
+  # ranks free to use every host core, once with all four pinned to the SAME two cores (TMJX_PIN_CORES: os.sched_setaffinity before the first GPU call) —
+  # 4 ranks x 3 group streams x ~10 launches per group step from two cores.  What is compared: rollout_ms_per_step of the two runs
+  for PIN in free 0,1; do
+    [ "$PIN" = free ] && unset TMJX_PIN_CORES || export TMJX_PIN_CORES=$PIN
+    TMJX_REHEARSE_ON_ONE_GPU=1 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29561 \
+      bench.py --gpus 4 --envs-per-gpu 1024 --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --no-rollout-only > $OUT/pin_$PIN.json 2> $OUT/pin_$PIN.err
+    echo "pinned to cores: $PIN  rc=$?"; grep '^{' $OUT/pin_$PIN.json | tail -1 | python3 -c "
+import json,sys
+o=json.loads(sys.stdin.read()); c=o['config']; print('  ranks', c['ranks_seen'], ' roll-out ms per step', round(c['rollout_ms_per_step'], 2), ' sgd ms per step', round(c['sgd_ms_per_step'], 2), ' env-steps/s (all ranks on one GPU)', round(o['value']))"
+  done;;
+*) echo "usage: bash tools/gpu_lab.sh cfgstats | timeline [cfgN] | rehearse | starve"; exit 2;;
 esac

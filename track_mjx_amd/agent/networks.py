@@ -946,29 +946,38 @@ class _ValueChainFn(torch.autograd.Function):
     GEMM for the head: tmjx_head_dw (the head's gradients: a matrix-vector product), tmjx_silu_bwd_rank1 (the last hidden layer's d loss / d z from the head's
     outer-product input gradient), then per hidden layer tmjx_gemm_nn_silu_bwd (its input gradient with the PRODUCING layer's SiLU backward on the accumulators);
     weight gradients of the hidden layers into the learner's grouped launch as before.  Same expressions as tmjx_silu_bwd / tmjx_gemm_nn: the hidden layers'
-    gradients keep their bits; the head's weight gradient is summed in another order than tmjx_gemm_dw's slabs."""
+    gradients keep their bits; the head's weight gradient is summed in another order than tmjx_gemm_dw's slabs.  (Critics whose hidden layers are all 256 wide
+    take _F32ChainFn — one launch each way — instead.)  Activations, pre-activations and the parameters as they were at forward time travel through
+    ctx.save_for_backward (version-checked, visible to saved-tensor hooks); `lins` only names the Parameter objects whose .grad views the deferred
+    weight gradients land in."""
 
     @staticmethod
     def forward(ctx, x, lins, *params):
         x2 = _rows2d(x)
         M = x2.shape[0]
-        h, saved = x2, []
+        h, flat = x2, []
         for lin in lins[:-1]:
             N, K = lin.weight.shape
             z = torch.empty((M, N), dtype=torch.float32, device=x2.device)
             y = torch.empty_like(z)
             _launch("tmjx_gemm_nt_silu", x2.device, _p(h), h.stride(0), _p(lin.weight), lin.weight.stride(0), _p(lin.bias), _p(z), _p(y), N, M, N, K)
-            saved.append((h, z))
+            flat += [h, z]
             h = y
         head = lins[-1]
         out = gemm_nt(h, head.weight, head.bias)
-        ctx.lins, ctx.saved, ctx.h_last, ctx.x_shape = lins, saved, h, x.shape
+        ctx.save_for_backward(*flat, h, *params)
+        ctx.lins, ctx.x_shape = lins, x.shape
         return out.view(*x.shape[:-1], 1)
 
     @staticmethod
     def backward(ctx, dout):
         from .. import hip as _hip
-        lins, saved = ctx.lins, ctx.saved
+        lins = ctx.lins
+        nl = len(lins)
+        st = ctx.saved_tensors
+        saved = [(st[2 * i], st[2 * i + 1]) for i in range(nl - 1)]
+        h_last = st[2 * (nl - 1)]
+        W = [(st[2 * (nl - 1) + 1 + 2 * i], st[2 * (nl - 1) + 2 + 2 * i]) for i in range(nl)]      # (weight, bias) as saved at forward time
         L = _hip.lib()
         dev = dout.device
         dy1 = dout.reshape(-1)
@@ -980,15 +989,16 @@ class _ValueChainFn(torch.autograd.Function):
         K = head.in_features
         dwh, dbh = torch.empty((1, K), dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
         scratch = torch.empty(int(L.tmjx_head_dw_scratch_floats(M, K)), dtype=torch.float32, device=dev)
-        _launch("tmjx_head_dw", dev, _p(dy1), _p(ctx.h_last), ctx.h_last.stride(0), _p(dwh), _p(dbh), _p(scratch), M, K)
+        _launch("tmjx_head_dw", dev, _p(dy1), _p(h_last), h_last.stride(0), _p(dwh), _p(dbh), _p(scratch), M, K)
         grads[id(head.weight)], grads[id(head.bias)] = dwh, dbh
         last = lins[-2]
         dz = torch.empty_like(saved[-1][1])
-        _launch("tmjx_silu_bwd_rank1", dev, _p(dy1), _p(head.weight), _p(saved[-1][1]), _p(last.bias), _p(dz), M, last.out_features)
+        _launch("tmjx_silu_bwd_rank1", dev, _p(dy1), _p(W[-1][0]), _p(saved[-1][1]), _p(W[-2][1]), _p(dz), M, last.out_features)
         d = deferred_weight_grads.active
         dx = None
-        for i in range(len(lins) - 2, -1, -1):
+        for i in range(nl - 2, -1, -1):
             lin = lins[i]
+            w_i = W[i][0]
             xin, _ = saved[i]
             got = d.try_add(dz, xin, lin.weight, lin.bias) if d is not None else None
             dw, db = got if got is not None else gemm_dw(dz, xin, True)
@@ -996,10 +1006,10 @@ class _ValueChainFn(torch.autograd.Function):
             if i > 0:
                 prev, pz = lins[i - 1], saved[i - 1][1]
                 dzp = torch.empty_like(pz)
-                _launch("tmjx_gemm_nn_silu_bwd", dev, _p(dz), dz.stride(0), _p(lin.weight), lin.weight.stride(0), _p(pz), _p(prev.bias), _p(dzp), M, prev.out_features, lin.out_features)
+                _launch("tmjx_gemm_nn_silu_bwd", dev, _p(dz), dz.stride(0), _p(w_i), w_i.stride(0), _p(pz), _p(W[i - 1][1]), _p(dzp), M, prev.out_features, lin.out_features)
                 dz = dzp
             elif ctx.needs_input_grad[0]:
-                dx = gemm_nn(dz, lin.weight).view(ctx.x_shape)
+                dx = gemm_nn(dz, w_i).view(ctx.x_shape)
         ctx._keep = scratch
         out = []
         for lin in lins:
@@ -1018,7 +1028,11 @@ def _value_chain_ok(x2, lins) -> bool:
     for lin in lins[:-1]:
         if lin.bias is None or lin.out_features % 4 or lin.in_features % 4 or lin.weight.data_ptr() % 16 or lin.weight.stride(0) % 4 or lin.bias.data_ptr() % 16:
             return False
-    return lins[-1].in_features % 4 == 0 and lins[-1].weight.data_ptr() % 16 == 0 and bool(L.tmjx_gemm_nt_silu_ok(_p(x2), x2.stride(0), _p(lins[0].weight), lins[0].weight.stride(0)))
+    if not (lins[-1].in_features % 4 == 0 and lins[-1].weight.data_ptr() % 16 == 0 and bool(L.tmjx_gemm_nt_silu_ok(_p(x2), x2.stride(0), _p(lins[0].weight), lins[0].weight.stride(0)))):
+        return False
+    # the backward pass's fused input-gradient launches (tmjx_gemm_nn_silu_bwd: dY = a fresh dense [M][out] gradient — aligned whenever `out` is a multiple
+    # of four —, W = that layer's weight): asked here, so that a weight view with an unaligned stride takes the per-layer path instead of failing in backward
+    return all(bool(L.tmjx_gemm_nn_silu_bwd_ok(None, lin.out_features, _p(lin.weight), lin.weight.stride(0))) for lin in lins[1:-1])
 
 
 class _BfDenseFn(torch.autograd.Function):
@@ -1411,7 +1425,7 @@ class ValueNet(nn.Module):
             if len(dense) > 1 and dense[-1].out_features == 1:
                 if getattr(self, "_f32_chain", None) is None:
                     self._f32_chain = [_Layer("silu", m) for m in dense[:-1]] + [_Layer("head", dense[-1])]
-                if _f32_chain_ok(obs, self._f32_chain):
+                if os.environ.get("TMJX_VALUE_CHAIN", "1") != "0" and _f32_chain_ok(obs, self._f32_chain):
                     # 256-wide critic: the whole MLP incl. its 1-wide head as ONE launch forward, one backward (csrc/mlp_chain.h) — in the learner's pass
                     # and in the bootstrap value's alike (bit-identical to the layer-by-layer functions below)
                     return f32_chain(obs, self._f32_chain).squeeze(-1)
