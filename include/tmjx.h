@@ -336,8 +336,10 @@ typedef struct {
   tmjx_chain_layer_t hidden[TMJX_CHAIN_MAX_HIDDEN];
   const float *Wf, *bf; float *outf; int32_t Nf, ldwf, ldof;
   float eps;
+  int32_t rows_alloc;   /* rows every y buffer holds: >= tmjx_chain_rows(M) (a y that feeds the next layer of the launch is stored as whole row tiles) */
   void *prof;     /* NULL; or 16 uint64 per workgroup ((M + rows per tile - 1) / rows per tile workgroups): in-kernel clock stamps (tools/chain_stamps.py) */
 } tmjx_chain_fwd_t;
+int tmjx_chain_rows(int M);      /* M rounded up to the row tile (80 or 32 rows) the chain kernels take for M rows */
 int tmjx_chain_fwd_ok(const tmjx_chain_fwd_t *chain);
 int tmjx_chain_fwd(const tmjx_chain_fwd_t *chain, void *stream);
 /* The backward pass of such a chain in ONE launch: the input-gradient GEMMs from the last layer's output gradient G[M][Kg] down to the first
@@ -354,6 +356,7 @@ typedef struct {
   const float *G; int32_t ldg, Kg, M, n_stages, epi;
   tmjx_chain_bwd_stage_t stage[TMJX_CHAIN_MAX_HIDDEN];
   const float *W0; int32_t ldw0, dx_cols; float *dx; int32_t lddx;
+  int32_t rows_alloc;   /* rows every dz buffer holds: >= tmjx_chain_rows(M) */
   void *prof;
 } tmjx_chain_bwd_t;
 int tmjx_chain_bwd_ok(const tmjx_chain_bwd_t *chain);

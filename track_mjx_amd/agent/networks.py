@@ -432,10 +432,11 @@ def chain_fwd_desc(x2, hidden, final=None, kind="ln", eps=1e-6, out=None):
     d = _hip.ChainFwd()
     d.A, d.lda, d.M, d.n_hidden, d.epi, d.eps = x2.data_ptr(), x2.stride(0), M, len(hidden), 1 if kind == "ln" else 3, float(eps)
     saved = []
+    d.rows_alloc = rows = int(_hip.lib().tmjx_chain_rows(M))       # (a y that feeds the next layer of the launch leaves the CU as whole row tiles: padding rows)
     for l, h in enumerate(hidden):
         w, b = h[0], h[1]
         z = torch.empty((M, 256), dtype=torch.float32, device=dev)
-        y = torch.empty_like(z)
+        y = torch.empty((rows, 256), dtype=torch.float32, device=dev)[:M]
         st = torch.empty((M, 2), dtype=torch.float32, device=dev) if kind == "ln" else None
         L = d.hidden[l]
         L.W, L.bias, L.z, L.y, L.K, L.ldw = w.data_ptr(), b.data_ptr(), z.data_ptr(), y.data_ptr(), w.shape[1], w.stride(0)
@@ -483,11 +484,12 @@ def chain_bwd(g, final_w, blocks, kind="ln", w0=None, dx_cols=None, prof=None, d
     d.G, d.ldg, d.Kg, d.M, d.n_stages, d.epi = g.data_ptr(), (1 if head else g.stride(0)), (1 if head else g.shape[1]), M, len(blocks), 2 if kind == "ln" else 4
     dzs, partials = [], []
     nfl = int(L.tmjx_gemm_nn_ln_bwd_partial_floats(M, 256)) if kind == "ln" else 0
+    d.rows_alloc = rows = int(L.tmjx_chain_rows(M))
     for i, blk in enumerate(blocks):
         S = d.stage[i]
         w = final_w if i == 0 else blocks[i - 1][0]
         S.W, S.ldw = w.data_ptr(), (w.stride(0) if w.dim() == 2 and w.shape[0] > 1 else 256)
-        dz = torch.empty((M, 256), dtype=torch.float32, device=dev)
+        dz = torch.empty((rows, 256), dtype=torch.float32, device=dev)[:M]
         S.z, S.bias, S.dz = blk[1].data_ptr(), blk[2].data_ptr(), dz.data_ptr()
         if kind == "ln":
             pt = torch.empty(nfl, dtype=torch.float32, device=dev)

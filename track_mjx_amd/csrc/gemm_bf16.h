@@ -16,6 +16,7 @@
 //     memory and read TRANSPOSED by ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major): no transposed copy
 //     of any activation exists anywhere.  Slabs over row ranges + csrc/gemm_kernels.h's k_dw_reduce, the bias gradient rides along.
 #pragma once
+#include "silu_math.h"
 
 typedef short bgs8 __attribute__((ext_vector_type(8)));
 typedef short bgs4 __attribute__((ext_vector_type(4)));
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
       for (int b = 0; b < NI; b++) {
         if (row < M) bz_store4(reinterpret_cast<bz_t *>(C) + (size_t)row * ldc + nw + 16 * b + 4 * kq, acc[a][b]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
+        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = tm_silu(v); p += acc[a][b][r]; }
       }
       p += __shfl_xor(p, 16);
       stat[a] = p + __shfl_xor(p, 32);
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
           // passes: zeroing the accumulator in place made the compiler keep the masked AND the unmasked copy of some elements across the whole
           // epilogue — 8 spilled registers at NI = 4)
           const float v = z4[r] + bv4[r], dy = ok ? acc[a][b][r] : 0.f;
-          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean_a) * rstd_a, da = dy * gv4[r];
+          const float sig = tm_sigmoid(v), ah = (v * sig - mean_a) * rstd_a, da = dy * gv4[r];
           s1 += da; s2 += da * ah;
         }
       }
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const float v = z4[r] + bv4[r], dy = ok ? acc[a][b][r] : 0.f;
-          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean_a) * rstd_a, da = dy * gv4[r];
+          const float sig = tm_sigmoid(v), ah = (v * sig - mean_a) * rstd_a, da = dy * gv4[r];
           const float dact = rstd_a * (da - m1[a] - ah * m2[a]);
           o[r] = ok ? dact * (sig * (1.f + v * (1.f - sig))) : 0.f;
           cg[r] += dy * ah; cb[r] += dy; cz[r] += o[r];
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
         bgf4 o;
         if constexpr (EPI == 3) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[r]; o[r] = v / (1.f + expf(-v)); }
+          for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[r]; o[r] = tm_silu(v); }
           if (ok) {
             bz_t *zo = reinterpret_cast<bz_t *>(C) + (size_t)row * ldc + col;
             if (vec && col + 3 < N) bz_store4(zo, acc[a][b]);
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(512) void k_bgemm_nt(const void *__restrict__ Av, i
           }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float v = z4[r] + bv[r], sig = 1.f / (1.f + expf(-v));
+            const float v = z4[r] + bv[r], sig = tm_sigmoid(v);
             o[r] = ok ? acc[a][b][r] * (sig * (1.f + v * (1.f - sig))) : 0.f;
             cz[r] += o[r];
           }
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256) void k_bf_silu_bwd(const float *__restrict__ d
     const float b = bias[c];
     float sum = 0.f;
     for (int r = r0; r < r1; r++) {
-      const float v = bz_f32(z[(size_t)r * ldz + c]) + b, sig = 1.f / (1.f + expf(-v));
+      const float v = bz_f32(z[(size_t)r * ldz + c]) + b, sig = tm_sigmoid(v);
       const float o = dy[(size_t)r * ldy + c] * (sig * (1.f + v * (1.f - sig)));
       dz[(size_t)r * lddz + c] = (bf16_t)(bg_pack(o, 0.f) & 0xffffu);
       sum += o;
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void k_bf_silu_bwd4(const float *__restrict__ 
       bgf4 o;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float v = zv[j] + b[j], sig = 1.f / (1.f + expf(-v));
+        const float v = zv[j] + b[j], sig = tm_sigmoid(v);
         o[j] = d[j] * (sig * (1.f + v * (1.f - sig)));
       }
       *reinterpret_cast<bgu2 *>(dz + (size_t)r * lddz + 4 * cg) = bgu2{bg_pack(o.x, o.y), bg_pack(o.z, o.w)};

@@ -21,6 +21,7 @@
 //       values it stages (its four columns, all its rows), the eight partial sums per column meet in LDS after the loop and land in
 //       column K of the slab: no separate column-sum launches.
 #pragma once
+#include "silu_math.h"
 #include <type_traits>
 
 typedef float __attribute__((ext_vector_type(4))) gf4;
@@ -66,6 +67,7 @@ __device__ __forceinline__ gf4 gemm_mask4(gf4 v, int mask) {
 #define SG_VALU 0x2
 #define SG_MFMA 0x8
 #define SG_VMEM_READ 0x20
+#define SG_VMEM_WRITE 0x40
 #define SG_DS_READ 0x100
 #define SG_DS_WRITE 0x200
 
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       for (int b = 0; b < NI; b++) {
         if (row < M) *reinterpret_cast<gf4 *>(C + (long long)row * ldc + nw + 16 * b + 4 * kq) = acc[a][b];
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
+        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = tm_silu(v); p += acc[a][b][r]; }
       }
       p += __shfl_xor(p, 16);
       stat[a] = p + __shfl_xor(p, 32);
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
       for (int j = 0; j < 8; j++) {
         if (!ok) DY(a, j) = 0.f;                            // (rows past M contribute nothing to the column sums)
         const float v = (j < 4 ? z0[j] : z1[j - 4]) + bv[j];
-        const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
+        const float sig = tm_sigmoid(v), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
         s1 += da; s2 += da * ah;
       }
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const float v = (j < 4 ? z0[j] : z1[j - 4]) + bv[j];
-        const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
+        const float sig = tm_sigmoid(v), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
         const float dact = rstd[a] * (da - m1[a] - ah * m2[a]);
         o[j] = dact * (sig * (1.f + v * (1.f - sig)));
         cg[j] += DY(a, j) * ah; cb[j] += DY(a, j); cz[j] += row < M ? o[j] : 0.f;
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
           const float *zr = ln.z + (long long)row * ldc + col;
 #pragma unroll
           for (int k = 0; k < 8; k++) {
-            if (col + k < N) { const float x = zr[k] + bias[col + k], sig = 1.f / (1.f + expf(-x)); v[k] *= sig * (1.f + x * (1.f - sig)); }
+            if (col + k < N) { const float x = zr[k] + bias[col + k], sig = tm_sigmoid(x); v[k] *= sig * (1.f + x * (1.f - sig)); }
           }
         }
         if (vec) { *reinterpret_cast<gf4 *>(o) = gf4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<gf4 *>(o + 4) = gf4{v[4], v[5], v[6], v[7]}; }
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
             float *yo = ln.y + (long long)row * ldc + col;
             gf4 y;
 #pragma unroll
-            for (int r = 0; r < 4; r++) y[r] = v[r] / (1.f + expf(-v[r]));
+            for (int r = 0; r < 4; r++) y[r] = tm_silu(v[r]);
             if (vec && col + 3 < N) { *reinterpret_cast<gf4 *>(o) = acc[a][b]; *reinterpret_cast<gf4 *>(yo) = y; }
             else {
 #pragma unroll
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(GemmCfg<NIW>::THREADS) void k_gemm_act(const float 
           // pre-activation (dense [M][ldc], without the bias): d loss / d z = dy silu'(z + bias) — the expression of k_silu_bwd_f32, whose launch and
           // whose re-read of dy disappear
           if (row < M && col < N) {
-            const float v = ln.z[(long long)row * ldc + col] + bv, sig = 1.f / (1.f + expf(-v));
+            const float v = ln.z[(long long)row * ldc + col] + bv, sig = tm_sigmoid(v);
             C[(long long)row * ldc + col] = acc[a][b][r] * (sig * (1.f + v * (1.f - sig)));
           }
         } else

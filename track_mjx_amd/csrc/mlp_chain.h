@@ -42,15 +42,20 @@ struct ChainGemm {
   static constexpr int SPREAD = (NMFMA - NFR) / (NPASS + 1) > 0 ? (NMFMA - NFR) / (NPASS + 1) : 1;
   struct Stage { gf4 v[NPASS]; int m[NPASS]; };
   struct Frag { gf4 a[MT], b[NI]; };
+  // (A_LDS) the Y image this GEMM reads is ALSO what has to reach global memory (a hidden layer's y, a stage's d loss / d z): the producing epilogue
+  // leaves that store to THIS K loop — T4 = BM / 8 float4 per thread, TRK of them per K step, read back from the image (a wave per row: 1 KB
+  // contiguous) — so that the 80 KB do not leave the CU as one burst with the matrix pipe idle, but under the MFMAs of the next GEMM
+  static constexpr int T4 = A_LDS ? BM / 8 : 0, TRK = MT >= 4 ? 2 : 1;
   const float *A, *W;
-  float *ast, *yimg, *wst;
+  float *ast, *yimg, *wst, *tr_dst;
   int lda, ldw, M, N, K, m0, t, li, kq, nw;
   const float *pa[A_PASS > 0 ? A_PASS : 1], *pb[B_PASS];
   Stage R0, R1;
   Frag F0, F1;
 
-  __device__ __forceinline__ void init(const float *A_, int lda_, int M_, int m0_, const float *W_, int ldw_, int N_, int K_, float *yimg_, float *wst_) {
+  __device__ __forceinline__ void init(const float *A_, int lda_, int M_, int m0_, const float *W_, int ldw_, int N_, int K_, float *yimg_, float *wst_, float *tr_ = nullptr) {
     A = A_; lda = lda_; M = M_; m0 = m0_; W = W_; ldw = ldw_; N = N_; K = K_; yimg = yimg_; ast = yimg_; wst = wst_;
+    tr_dst = tr_ ? tr_ + (long long)m0_ * 256 : nullptr;
     t = threadIdx.x; li = t & 15; kq = (t & 63) >> 4; nw = (t >> 6) * 16 * NI;
 #pragma unroll
     for (int p = 0; p < A_PASS; p++) {
@@ -147,8 +152,9 @@ struct ChainGemm {
         }
   }
   // one K step of tile kt in stage s: k_gemm_act's kstep (one barrier in the middle, MFMAs on both sides, pinned interleave)
-  template <bool FASTS>
+  template <bool FASTS, int TR = 0>
   __device__ __forceinline__ void kstep(gf4 (&acc)[MT][NI], Stage &RW, int stage, int kt) {
+    gf4 trv[TR > 0 ? TR : 1];
     fread(F1, stage, 1, kt);
     swrite<!FASTS>(RW, stage ^ 1);
     mma(F0, acc);
@@ -159,12 +165,28 @@ struct ChainGemm {
     GEMM_SGB(SG_MFMA, NMFMA, 0);
     __syncthreads();
     fread(F0, stage ^ 1, 0, kt + 1);
+    if constexpr (TR > 0) {            // this step's share of the image -> registers (float4 f of the tile: row f / 64 — the wave's own —, chunk f % 64)
+#pragma unroll
+      for (int j = 0; j < TR; j++) {
+        const int f = t + CH_NT * min(kt * TRK + j, T4 - 1), row = f >> 6, c4 = f & 63;
+        trv[j] = *reinterpret_cast<const gf4 *>(yimg + row * 256 + ((c4 ^ (row & 15)) << 2));
+      }
+    }
     if (FASTS) gload_fast(RW, (kt + 3) * GEMM_BK); else gload(RW, (kt + 3) * GEMM_BK);
     mma(F1, acc);
+    if constexpr (TR > 0) {            // ... and on to global memory (rows past M land in the buffer's padding rows: no predicate, no branch in the step)
 #pragma unroll
-    for (int i = 0; i < NFR; i++) { GEMM_SGB(SG_MFMA, 1, 0); GEMM_SGB(SG_DS_READ, 1, 0); }
+      for (int j = 0; j < TR; j++) {
+        const int f = t + CH_NT * min(kt * TRK + j, T4 - 1);
+        *reinterpret_cast<gf4 *>(tr_dst + (long long)(f >> 6) * 256 + 4 * (f & 63)) = trv[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NFR + TR; i++) { GEMM_SGB(SG_MFMA, 1, 0); GEMM_SGB(SG_DS_READ, 1, 0); }
 #pragma unroll
     for (int i = 0; i < NPASS; i++) { GEMM_SGB(SG_MFMA, SPREAD, 0); GEMM_SGB(SG_VALU, FASTS ? 2 : GEMM_LOAD_VALU, 0); GEMM_SGB(SG_VMEM_READ, 1, 0); }
+#pragma unroll
+    for (int i = 0; i < TR; i++) { GEMM_SGB(SG_MFMA, 1, 0); GEMM_SGB(SG_VALU, 4, 0); GEMM_SGB(SG_VMEM_WRITE, 1, 0); }
     GEMM_SGB(SG_MFMA, NMFMA, 0);
   }
   // The first two weight (and A) tiles are requested EARLY — in a chain: before the previous layer's epilogue, so that their latency and that
@@ -181,6 +203,15 @@ struct ChainGemm {
     fread(F0, 0, 0, 0);
   }
   __device__ __forceinline__ void loop(gf4 (&acc)[MT][NI]) {
+    if constexpr (A_LDS) {
+      // K = 256: eight unmasked steps; the first NTRS of them (an even number: the steps come in pairs, one per register set) also carry the image
+      // to global memory, TRK float4 per thread and step (slots past T4 repeat the last one: the same bytes to the same address)
+      constexpr int NTRS = 2 * (((T4 + TRK - 1) / TRK + 1) / 2);
+      int kt = 0;
+      for (; kt < NTRS; kt += 2) { kstep<true, TRK>(acc, R1, 0, kt); kstep<true, TRK>(acc, R0, 1, kt + 1); }
+      for (; kt < 8; kt += 2) { kstep<true, 0>(acc, R1, 0, kt); kstep<true, 0>(acc, R0, 1, kt + 1); }
+      return;
+    }
     const int nk = (K + GEMM_BK - 1) / GEMM_BK;
     int kt = 0;
     const int nfast = (A_LDS || (K % GEMM_BK) == 0) ? nk : max(0, (nk - 4) & ~1);
@@ -246,8 +277,8 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwd P) {
   for (int l = 0;; l++) {
     const ChainHidden &H = P.h[l];
     const bool more = l + 1 < P.nh;         // (uniform)
-    if (more) { G.init(nullptr, 0, M, m0, P.h[l + 1].W, P.h[l + 1].ldw, 256, 256, yimg, wst); G.early(); }
-    else if (FIN == 1) { Gf.init(nullptr, 0, M, m0, P.Wf, P.ldwf, P.Nf, 256, yimg, wst); Gf.early(); }
+    if (more) { G.init(nullptr, 0, M, m0, P.h[l + 1].W, P.h[l + 1].ldw, 256, 256, yimg, wst, H.y); G.early(); }
+    else if (FIN == 1) { Gf.init(nullptr, 0, M, m0, P.Wf, P.ldwf, P.Nf, 256, yimg, wst, H.y); Gf.early(); }
     // ---- epilogue of hidden layer l (the expressions of k_gemm_act's EPI 1 / EPI 3, in their order)
     gf4 bv[2], gv[2], bev[2];
 #pragma unroll
@@ -265,7 +296,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwd P) {
       for (int b = 0; b < 2; b++) {
         if (row < M) *reinterpret_cast<gf4 *>(H.z + (long long)row * 256 + nw + 16 * b + 4 * kq) = acc[a][b];
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = v / (1.f + expf(-v)); p += acc[a][b][r]; }
+        for (int r = 0; r < 4; r++) { const float v = acc[a][b][r] + bv[b][r]; acc[a][b][r] = tm_silu(v); p += acc[a][b][r]; }
       }
       if (EPI == 1) { p += __shfl_xor(p, 16); stat[a] = p + __shfl_xor(p, 32); }
     }
@@ -310,16 +341,19 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwd P) {
         if (row < M && wave == 0 && kq == 0) { H.stats[2 * (long long)row] = mean[a]; H.stats[2 * (long long)row + 1] = rstd; }
       }
     }
-    // y: to global memory (what the backward pass and the weight gradients read) and to the Y image (the next layer's A operand)
+    // y: to the Y image (the next layer's A operand) — the next GEMM's K loop also carries it to global memory (what the backward pass and the weight
+    // gradients read), ChainGemm::kstep — or, behind the chain's last GEMM, to global memory from here
+    if (more || FIN == 1) chain_y_to_lds<MT>(yimg, acc, li, kq, nw);
+    else {
 #pragma unroll
-    for (int a = 0; a < MT; a++) {
-      const int row = m0 + 16 * a + li;
-      if (row < M) {
+      for (int a = 0; a < MT; a++) {
+        const int row = m0 + 16 * a + li;
+        if (row < M) {
 #pragma unroll
-        for (int b = 0; b < 2; b++) *reinterpret_cast<gf4 *>(H.y + (long long)row * 256 + nw + 16 * b + 4 * kq) = acc[a][b];
+          for (int b = 0; b < 2; b++) *reinterpret_cast<gf4 *>(H.y + (long long)row * 256 + nw + 16 * b + 4 * kq) = acc[a][b];
+        }
       }
     }
-    if (more || FIN == 1) chain_y_to_lds<MT>(yimg, acc, li, kq, nw);
     CHAIN_STAMP(stamp++);
     if (!more) break;
     zero();
@@ -453,8 +487,8 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwd P) {
     // the next GEMM's first weight tiles are requested in front of the epilogue — except where the epilogue has no registers to carry them through
     // (the 80-row tile's LayerNorm backward: 79 spilled registers with them), there behind it
     constexpr bool PRE = !(MT == 5 && (EPI == 2 || HEAD));
-    if (more) { G.init(nullptr, 0, M, m0, P.s[st + 1].W, P.s[st + 1].ldw, 256, 256, yimg, wst); if (PRE) G.early(); }
-    else if (DX) { Gx.init(nullptr, 0, M, m0, P.W0, P.ldw0, P.dx_cols, 256, yimg, wst); if (PRE) Gx.early(); }
+    if (more) { G.init(nullptr, 0, M, m0, P.s[st + 1].W, P.s[st + 1].ldw, 256, 256, yimg, wst, S.dz); if (PRE) G.early(); }
+    else if (DX) { Gx.init(nullptr, 0, M, m0, P.W0, P.ldw0, P.dx_cols, 256, yimg, wst, S.dz); if (PRE) Gx.early(); }
     const bool keep = more || DX;           // d loss / d z also feeds a GEMM of this launch
     float bv[8], gv[8];
     {
@@ -483,7 +517,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwd P) {
         for (int j = 0; j < 8; j++) {
           if (!ok) DY(a, j) = 0.f;
           const float v = (j < 4 ? z0[j] : z1[j - 4]) + bv[j];
-          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
+          const float sig = tm_sigmoid(v), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
           s1 += da; s2 += da * ah;
         }
         s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -515,16 +549,16 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwd P) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           const float v = (j < 4 ? z0[j] : z1[j - 4]) + bv[j];
-          const float sig = 1.f / (1.f + expf(-v)), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
+          const float sig = tm_sigmoid(v), ah = (v * sig - mean[a]) * rstd[a], da = DY(a, j) * gv[j];
           const float dact = rstd[a] * (da - m1[a] - ah * m2[a]);
           o[j] = dact * (sig * (1.f + v * (1.f - sig)));
           cg[j] += DY(a, j) * ah; cb[j] += DY(a, j); cz[j] += row < M ? o[j] : 0.f;
         }
-        if (row < M) {
+        if (keep) chain_o_to_lds(yimg, o, a, li, c0);        // (the consuming GEMM's K loop carries it on to global memory)
+        else if (row < M) {
           float *dst = S.dz + (long long)row * 256 + c0;
           *reinterpret_cast<gf4 *>(dst) = gf4{o[0], o[1], o[2], o[3]}; *reinterpret_cast<gf4 *>(dst + 4) = gf4{o[4], o[5], o[6], o[7]};
         }
-        if (keep) chain_o_to_lds(yimg, o, a, li, c0);
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) { cg[j] = gemm_row16_sum(cg[j]); cb[j] = gemm_row16_sum(cb[j]); cz[j] = gemm_row16_sum(cz[j]); }
@@ -545,14 +579,14 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwd P) {
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const float x = (j < 4 ? z0[j] : z1[j - 4]) + bv[j], sig = 1.f / (1.f + expf(-x));
+          const float x = (j < 4 ? z0[j] : z1[j - 4]) + bv[j], sig = tm_sigmoid(x);
           o[j] = DY(a, j) * (sig * (1.f + x * (1.f - sig)));
         }
-        if (row < M) {
+        if (keep) chain_o_to_lds(yimg, o, a, li, c0);        // (the consuming GEMM's K loop carries it on to global memory)
+        else if (row < M) {
           float *dst = S.dz + (long long)row * 256 + c0;
           *reinterpret_cast<gf4 *>(dst) = gf4{o[0], o[1], o[2], o[3]}; *reinterpret_cast<gf4 *>(dst + 4) = gf4{o[4], o[5], o[6], o[7]};
         }
-        if (keep) chain_o_to_lds(yimg, o, a, li, c0);
       }
     }
     CHAIN_STAMP(stamp++);

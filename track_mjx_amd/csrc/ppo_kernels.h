@@ -9,6 +9,7 @@
 //   scratch [4 T B + 4 nblk + 16] floats, nblk = ceil(8 T B / 256)
 //   out     [8]: total, policy_loss, v_loss, entropy_loss, kl_latent_loss, adv_mean, adv_std, entropy
 #pragma once
+#include "silu_math.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void k_silu_ln_fwd(const float *__restrict__ z
     float a[VPT], s = 0.f;
     silu_ln_load<VPT>(a, z + (size_t)r * H, lane);
 #pragma unroll
-    for (int k = 0; k < VPT; k++) { float v = a[k] + b[k]; a[k] = v / (1.f + expf(-v)); s += a[k]; }
+    for (int k = 0; k < VPT; k++) { float v = a[k] + b[k]; a[k] = tm_silu(v); s += a[k]; }
     float mean = wave_sum(s) / (float)H, q = 0.f;
 #pragma unroll
     for (int k = 0; k < VPT; k++) { float d = a[k] - mean; q += d * d; }
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void k_silu_ln_bwd(const float *__restrict__ d
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
       v[k] += b[k];
-      sig[k] = 1.f / (1.f + expf(-v[k]));
+      sig[k] = tm_sigmoid(v[k]);
       ah[k] = (v[k] * sig[k] - mean) * rstd;
       const float d = da[k];
       sg[k] += d * ah[k]; sb[k] += d;
@@ -1106,9 +1107,9 @@ __global__ __launch_bounds__(256) void k_silu_fwd_f32(const float *__restrict__ 
   if (!(N & 3)) {
     const float4 zv = *reinterpret_cast<const float4 *>(z + i), bv = *reinterpret_cast<const float4 *>(bias + (int)(i % N));
     float v[4] = {zv.x + bv.x, zv.y + bv.y, zv.z + bv.z, zv.w + bv.w};
-    *reinterpret_cast<float4 *>(y + i) = make_float4(v[0] / (1.f + expf(-v[0])), v[1] / (1.f + expf(-v[1])), v[2] / (1.f + expf(-v[2])), v[3] / (1.f + expf(-v[3])));
+    *reinterpret_cast<float4 *>(y + i) = make_float4(tm_silu(v[0]), tm_silu(v[1]), tm_silu(v[2]), tm_silu(v[3]));
   } else {
-    for (long long j = i; j < i + 4 && j < total; j++) { const float v = z[j] + bias[(int)(j % N)]; y[j] = v / (1.f + expf(-v)); }
+    for (long long j = i; j < i + 4 && j < total; j++) { const float v = z[j] + bias[(int)(j % N)]; y[j] = tm_silu(v); }
   }
 }
 __global__ __launch_bounds__(256) void k_silu_bwd_f32(const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ bias, float *__restrict__ dz,
@@ -1120,10 +1121,10 @@ __global__ __launch_bounds__(256) void k_silu_bwd_f32(const float *__restrict__ 
     const float v[4] = {zv.x + bv.x, zv.y + bv.y, zv.z + bv.z, zv.w + bv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
     float o[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const float sig = 1.f / (1.f + expf(-v[k])); o[k] = d[k] * (sig * (1.f + v[k] * (1.f - sig))); }
+    for (int k = 0; k < 4; k++) { const float sig = tm_sigmoid(v[k]); o[k] = d[k] * (sig * (1.f + v[k] * (1.f - sig))); }
     *reinterpret_cast<float4 *>(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
   } else {
-    for (long long j = i; j < i + 4 && j < total; j++) { const float v = z[j] + bias[(int)(j % N)], sig = 1.f / (1.f + expf(-v)); dz[j] = dy[j] * (sig * (1.f + v * (1.f - sig))); }
+    for (long long j = i; j < i + 4 && j < total; j++) { const float v = z[j] + bias[(int)(j % N)], sig = tm_sigmoid(v); dz[j] = dy[j] * (sig * (1.f + v * (1.f - sig))); }
   }
 }
 
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_silu_bwd_rank1_f32(const float *__restr
   const float v[4] = {zv.x + bv.x, zv.y + bv.y, zv.z + bv.z, zv.w + bv.w}, w[4] = {wv.x, wv.y, wv.z, wv.w};
   float o[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) { const float sig = 1.f / (1.f + expf(-v[j])); o[j] = (d * w[j]) * (sig * (1.f + v[j] * (1.f - sig))); }
+  for (int j = 0; j < 4; j++) { const float sig = tm_sigmoid(v[j]); o[j] = (d * w[j]) * (sig * (1.f + v[j] * (1.f - sig))); }
   *reinterpret_cast<float4 *>(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
 }
 #define HEAD_DW_ROWS 64

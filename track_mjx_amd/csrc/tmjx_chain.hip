@@ -38,8 +38,10 @@ static int chain_fwd_mt(const ChainFwd &P, hipStream_t s) {
   return launch_chain_fwd<5, EPI, FIN>(P, s);
 }
 
+static int chain_rows(int M) { const int bm = 16 * tmjx_internal_gemm_mt(M, 1); return (M + bm - 1) / bm * bm; }
 static const char *chain_fwd_why(const tmjx_chain_fwd_t *c) {
   if (!c || !c->A) return "null argument";
+  if (c->M >= 1 && c->rows_alloc < chain_rows(c->M)) return "rows_alloc: the y buffers must hold tmjx_chain_rows(M) rows (whole row tiles are stored)";
   if (c->epi != 1 && c->epi != 3) return "epi must be 1 (Dense -> SiLU -> LayerNorm blocks) or 3 (Dense -> SiLU layers)";
   if (c->n_hidden < 1 || c->n_hidden > TMJX_CHAIN_MAX_HIDDEN) return "1 .. 4 hidden layers";
   if (c->M < 1 || !rows16(c->A, c->lda)) return "M >= 1 and 16-byte aligned input rows";
@@ -79,6 +81,7 @@ static int chain_bwd_mt(const ChainBwd &P, hipStream_t s) {
 
 static const char *chain_bwd_why(const tmjx_chain_bwd_t *c) {
   if (!c || !c->G) return "null argument";
+  if (c->M >= 1 && c->rows_alloc < chain_rows(c->M)) return "rows_alloc: the dz buffers must hold tmjx_chain_rows(M) rows (whole row tiles are stored)";
   if (c->epi != 2 && c->epi != 4) return "epi must be 2 (Dense -> SiLU -> LayerNorm blocks) or 4 (Dense -> SiLU layers)";
   if (c->n_stages < 1 || c->n_stages > TMJX_CHAIN_MAX_HIDDEN) return "1 .. 4 stages (one per hidden layer)";
   if (c->M < 1 || c->Kg < 1 || c->Kg > 128) return "M >= 1 and a last layer of 1 .. 128 columns";
@@ -99,6 +102,7 @@ static const char *chain_bwd_why(const tmjx_chain_bwd_t *c) {
 }
 
 extern "C" {
+int tmjx_chain_rows(int M) { return M < 1 ? 0 : chain_rows(M); }
 int tmjx_chain_bwd_ok(const tmjx_chain_bwd_t *c) { return chain_bwd_why(c) == nullptr; }
 int tmjx_chain_bwd(const tmjx_chain_bwd_t *c, void *stream) {
   if (const char *why = chain_bwd_why(c)) return fail(TMJX_EINVAL, std::string("tmjx_chain_bwd: ") + why);

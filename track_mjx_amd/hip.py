@@ -37,7 +37,7 @@ EXPORTS = ("tmjx_model_create", "tmjx_model_destroy", "tmjx_layout", "tmjx_clips
            "tmjx_gather_minibatch", "tmjx_minibatch_begin", "tmjx_philox4x32_10", "tmjx_gemm_nt", "tmjx_gemm_nt_silu_ln", "tmjx_gemm_nt_silu_ln_ok", "tmjx_gemm_nn", "tmjx_colsum_grouped", "tmjx_gemm_nn_ln_bwd", "tmjx_gemm_nn_ln_bwd_ok", "tmjx_gemm_nn_ln_bwd_partial_floats", "tmjx_gemm_dw", "tmjx_gemm_dw_grouped", "tmjx_gemm_dw_grouped_wgs", "tmjx_gemm_dw_scratch_floats", "tmjx_set_wrappers", "tmjx_set_action_repeat", "tmjx_stats_scratch_floats", "tmjx_stats_sums", "tmjx_stats_apply",
            "tmjx_rollout_store", "tmjx_clips_share", "tmjx_gemm_nt_silu", "tmjx_gemm_nt_silu_ok", "tmjx_silu_fwd", "tmjx_silu_bwd", "tmjx_gemm_nn_silu_bwd_ok", "tmjx_gemm_nn_silu_bwd", "tmjx_silu_bwd_rank1", "tmjx_head_dw_scratch_floats", "tmjx_head_dw", "tmjx_head_fwd_ok", "tmjx_head_fwd", "tmjx_bf16_shadow", "tmjx_bgemm_nt", "tmjx_bgemm_dw", "tmjx_bgemm_dw_grouped", "tmjx_bgemm_dw_scratch_floats", "tmjx_bgemm_row_tile_ok", "tmjx_bf16_z_bytes", "tmjx_bgemm_partial_floats",
            "tmjx_bgemm_ln_fwd", "tmjx_bgemm_ln_bwd", "tmjx_bgemm_silu_fwd", "tmjx_bgemm_silu_bwd", "tmjx_bf_silu_bwd", "tmjx_bf_silu_bwd_rank1",
-           "tmjx_chain_fwd_ok", "tmjx_chain_fwd", "tmjx_chain_bwd_ok", "tmjx_chain_bwd",
+           "tmjx_chain_rows", "tmjx_chain_fwd_ok", "tmjx_chain_fwd", "tmjx_chain_bwd_ok", "tmjx_chain_bwd",
            "tmjx_debug_rows", "tmjx_last_error", "tmjx_version")
 
 
@@ -85,7 +85,7 @@ class ChainLayer(C.Structure):
 class ChainFwd(C.Structure):
     """tmjx_chain_fwd_t (include/tmjx.h)."""
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("M", C.c_int32), ("n_hidden", C.c_int32), ("epi", C.c_int32), ("hidden", ChainLayer * 4),
-                ("Wf", C.c_void_p), ("bf", C.c_void_p), ("outf", C.c_void_p), ("Nf", C.c_int32), ("ldwf", C.c_int32), ("ldof", C.c_int32), ("eps", C.c_float), ("prof", C.c_void_p)]
+                ("Wf", C.c_void_p), ("bf", C.c_void_p), ("outf", C.c_void_p), ("Nf", C.c_int32), ("ldwf", C.c_int32), ("ldof", C.c_int32), ("eps", C.c_float), ("rows_alloc", C.c_int32), ("prof", C.c_void_p)]
 
 
 class ChainBwdStage(C.Structure):
@@ -96,7 +96,7 @@ class ChainBwdStage(C.Structure):
 class ChainBwd(C.Structure):
     """tmjx_chain_bwd_t (include/tmjx.h)."""
     _fields_ = [("G", C.c_void_p), ("ldg", C.c_int32), ("Kg", C.c_int32), ("M", C.c_int32), ("n_stages", C.c_int32), ("epi", C.c_int32), ("stage", ChainBwdStage * 4),
-                ("W0", C.c_void_p), ("ldw0", C.c_int32), ("dx_cols", C.c_int32), ("dx", C.c_void_p), ("lddx", C.c_int32), ("prof", C.c_void_p)]
+                ("W0", C.c_void_p), ("ldw0", C.c_int32), ("dx_cols", C.c_int32), ("dx", C.c_void_p), ("lddx", C.c_int32), ("rows_alloc", C.c_int32), ("prof", C.c_void_p)]
 
 
 class PpoCfg(C.Structure):
@@ -292,6 +292,7 @@ def load(path: Path):
     sig.setdefault("tmjx_stats_scratch_floats", [None, None])[0] = [C.c_int]
     sig.setdefault("tmjx_stats_sums", [None, None])[0] = [fp, fp, fp, fp, C.c_longlong, C.c_int, vp]
     sig.setdefault("tmjx_stats_apply", [None, None])[0] = [fp, C.c_float, fp, fp, fp, fp, C.c_int, C.c_float, C.c_float, vp]
+    sig.setdefault("tmjx_chain_rows", [None, None])[0] = [C.c_int]
     sig.setdefault("tmjx_chain_fwd_ok", [None, None])[0] = [C.POINTER(ChainFwd)]
     sig.setdefault("tmjx_chain_fwd", [None, None])[0] = [C.POINTER(ChainFwd), vp]
     sig.setdefault("tmjx_chain_bwd_ok", [None, None])[0] = [C.POINTER(ChainBwd)]
