@@ -547,6 +547,16 @@ def test_loss_head_in_phases_gives_the_one_call_forms_gradients(T, B):
     ref, got = run(False), run(True)
     for k in range(3):
         assert torch.equal(ref[k], got[k]), k
+    # A and C in one call = ONE launch (k_ppo_ac: the two bodies back to back; what the learner issues behind B): the same bits again, scalars included
+    cfg.accumulate = 0
+    ac = [torch.empty_like(logits), torch.empty_like(baseline), torch.empty_like(fc2), torch.zeros(L.tmjx_ppo_scratch_floats(T, B), device=dev), torch.zeros(8, device=dev)]
+    pac = [C.c_void_p(a.data_ptr()) for a in ins + ac]
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for mask in (2, 1 | 4, 8):
+        hip.check(L.tmjx_ppo_loss_phases(C.byref(cfg), *pac, mask, st), "B | AC | D")
+    torch.cuda.synchronize()
+    for k in (0, 1, 2, 4):
+        assert torch.equal(ac[k], got[k]), k
     assert float((ref[4] - got[4]).abs().max()) <= 1e-6 * max(1.0, float(ref[4].abs().max())), (ref[4], got[4])
     one = run(True, 0)[4]
     twice = run(True, 1, out=one.clone())[4]

@@ -197,9 +197,8 @@ def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_
                 _hip.check(L.tmjx_ppo_loss_phases(C.byref(c), *ptr, mask, C.c_void_p(stream.cuda_stream)), "tmjx_ppo_loss_phases")
             with torch.cuda.device(dev):
                 phase(2, side_stream)           # B: behind the value network's forward pass, on its stream
-                phase(1, cur)                   # A: behind the policy's
                 cur.wait_stream(side_stream)
-                phase(4, cur)                   # C: both
+                phase(1 | 4, cur)               # A and C behind the policy's forward pass, ONE launch (k_ppo_ac; C's half needs B's records)
                 if scalars_on_side:             # (the caller joins `side_stream` into the current stream later: PPOLearner._mb_backward)
                     side_stream.wait_stream(cur)
                     phase(8, side_stream)       # D: the scalars — in front of the value network's backward pass on ITS stream, off the policy's path

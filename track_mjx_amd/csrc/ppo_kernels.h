@@ -309,6 +309,83 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_ppo_c(PpoCfg c, const float *__re
   if (threadIdx.x == 0) scratch[(size_t)4 * N + (size_t)blockIdx.x * 4 + 3] = acc[0];
 }
 
+// A and C in ONE launch (tmjx_ppo_loss_phases with both phases in the mask; round 6): the learner's main stream ran A (18 us), waited for B's records and ran
+// C (22 us) — two latency-bound launches of the same (t, b) x PPO_G lane groups over the same logits / actions / fc2 rows between the policy's forward
+// and backward chains, with the chip otherwise idle.  The bodies of k_ppo_a and k_ppo_c back to back, expression for expression (the log-prob stays in
+// its lane group's registers; it is still written to scratch[i]); the four per-block partial sums land where A and C put them.
+__global__ __launch_bounds__(PPO_BLOCK) void k_ppo_ac(PpoCfg c, const float *__restrict__ logits, const float *__restrict__ raw_action,
+                                                      const float *__restrict__ behaviour_logp, const float *__restrict__ noise,
+                                                      const float *__restrict__ baseline, const float *__restrict__ fc2, float *dlogits,
+                                                      float *dbaseline, float *dfc2, float *scratch, int nblk, const float *rec, int nrec) {
+  __shared__ float lds[64];
+  __shared__ float scal_s[8];
+  const int N = c.T * c.B, gid = blockIdx.x * PPO_BLOCK + threadIdx.x, i = gid / PPO_G, sub = gid % PPO_G;
+  const float *vs = scratch + N, *adv = scratch + 2 * (size_t)N;
+  if (threadIdx.x == 0) ppo_combine_records(c, rec, nrec, scal_s);
+  __syncthreads();
+  const float *scal = scal_s;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // entropy, kl0 inner sum, klt inner sum | surrogate
+  if (i < N) {
+    const int t = i / c.B;
+    const float *lg = logits + (size_t)i * 2 * c.A, *xa = raw_action + (size_t)i * c.A, *nz = noise + (size_t)i * c.A;
+    // ---- A
+    float logp = 0.f, ent = 0.f;
+    for (int a = sub; a < c.A; a += PPO_G) {
+      float loc = lg[a], scale = ppo_softplus(lg[c.A + a]) + 0.001f, x = xa[a], d = (x - loc) / scale;
+      logp += -0.5f * d * d - logf(scale) - 0.91893853320467274f - ppo_fldj(x);
+      float xs = loc + scale * nz[a];
+      ent += 0.5f + 0.91893853320467274f + logf(scale) + ppo_fldj(xs);
+    }
+    logp = ppo_group_sum(logp);
+    if (sub == 0) scratch[i] = logp;
+    acc[0] = ent;
+    const float *f = fc2 + (size_t)i * 2 * c.Z;
+    const float pv = 1.f - PPO_ALPHA * PPO_ALPHA;
+    {
+      float s = 0.f;
+      if (t == 0) {
+        for (int z = sub; z < c.Z; z += PPO_G) { float m = f[z], lv = f[c.Z + z]; s += 1.f + lv - m * m - expf(lv); }
+        acc[1] = s;
+      } else {
+        const float *fp = f - (size_t)c.B * 2 * c.Z;
+        for (int z = sub; z < c.Z; z += PPO_G) { float m = f[z], lv = f[c.Z + z], e = PPO_ALPHA * fp[z] - m; s += expf(lv) / pv + e * e / pv - 1.f + logf(pv) - lv; }
+        acc[2] = s;
+      }
+    }
+    // ---- C
+    const float Nf = (float)N;
+    float ad = adv[i];
+    if (c.normalize_advantage) ad = (ad - scal[0]) / (scal[1] + 1e-8f);
+    float rho = expf(logp - behaviour_logp[i]), lo = 1.f - c.clip_eps, hi = 1.f + c.clip_eps;
+    float rc = fminf(fmaxf(rho, lo), hi), s1 = rho * ad, s2 = rc * ad;
+    if (sub == 0) acc[3] = fminf(s1, s2);
+    float glp = (s1 <= s2 || (rho >= lo && rho <= hi)) ? -ad * rho / Nf : 0.f;
+    const float ce = -c.entropy_cost / Nf;
+    float *dl = dlogits + (size_t)i * 2 * c.A;
+    for (int a = sub; a < c.A; a += PPO_G) {
+      float loc = lg[a], raw = lg[c.A + a], scale = ppo_softplus(raw) + 0.001f, sig = ppo_sigmoid(raw), x = xa[a], d = x - loc;
+      float inv = 1.f / scale, dlp_loc = d * inv * inv, dlp_scale = d * d * inv * inv * inv - inv;
+      float n = nz[a], th = tanhf(loc + scale * n), de_loc = -2.f * th, de_scale = inv - 2.f * th * n;
+      dl[a] = glp * dlp_loc + ce * de_loc;
+      dl[c.A + a] = (glp * dlp_scale + ce * de_scale) * sig;
+    }
+    if (sub == 0) dbaseline[i] = -0.5f * (vs[i] - baseline[i]) / Nf;
+    const float kw = c.kl_weight;
+    const float c0 = kw / (float)c.T / (float)(c.B * c.Z), c1 = c.T > 1 ? kw * (float)(c.T - 1) / (float)c.T / (float)((c.T - 1) * c.B * c.Z) : 0.f;
+    const float *fp = f - (size_t)c.B * 2 * c.Z, *fn = f + (size_t)c.B * 2 * c.Z;
+    float *df = dfc2 + (size_t)i * 2 * c.Z;
+    for (int z = sub; z < c.Z; z += PPO_G) {
+      float m = f[z], lv = f[c.Z + z], dm, dlv;
+      if (t == 0) { dm = c0 * m; dlv = -0.5f * c0 * (1.f - expf(lv)); }
+      else { float e = PPO_ALPHA * fp[z] - m; dm = -c1 * e / pv; dlv = 0.5f * c1 * (expf(lv) / pv - 1.f); }
+      if (t + 1 < c.T) { float e2 = PPO_ALPHA * m - fn[z]; dm += c1 * PPO_ALPHA * e2 / pv; }
+      df[z] = dm; df[c.Z + z] = dlv;
+    }
+  }
+  ppo_block_sum<4>(acc, lds);
+  if (threadIdx.x == 0) { float *p = scratch + (size_t)4 * N + (size_t)blockIdx.x * 4; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = acc[3]; }
+}
+
 // D: final scalars.  sum_parts (tmjx_ppo_loss_phases): the records do not carry A's entropy / KL sums (B ran next to A, on the value network's
 // stream) — D adds A's per-block partials up itself
 __global__ void k_ppo_d(PpoCfg c, const float *scratch, float *out, int nblk, const float *rec = nullptr, int nrec = 0, int sum_parts = 0) {

@@ -628,6 +628,16 @@ int tmjx_ppo_loss_phases(const tmjx_ppo_cfg_t *cfg, const float *logits, const f
   const int N = c.T * c.B, nblk = (N * PPO_G + PPO_BLOCK - 1) / PPO_BLOCK, nrec = (c.B + 63) / 64;
   float *rec = scratch + 4 * (size_t)N + (size_t)4 * nblk + 16;
   hipStream_t s = (hipStream_t)stream;
+  // A and C in the same call: one launch (k_ppo_ac; TMJX_PPO_AC=0: two)
+  static const bool no_ac = getenv("TMJX_PPO_AC") && atoi(getenv("TMJX_PPO_AC")) == 0;
+  if ((phases & TMJX_PPO_PHASE_A) && (phases & TMJX_PPO_PHASE_C) && !no_ac) {
+    if (phases & TMJX_PPO_PHASE_B) {       // (B's records first: C's half reads them; A's half does not depend on B)
+      hipLaunchKernelGGL(k_ppo_b2, dim3(nrec), dim3(64), 0, s, c, baseline, bootstrap, reward, discount, truncation, scratch, 0, rec);
+      phases &= ~TMJX_PPO_PHASE_B;
+    }
+    hipLaunchKernelGGL(k_ppo_ac, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, behaviour_logp, noise, baseline, fc2, dlogits, dbaseline, dfc2, scratch, nblk, (const float *)rec, nrec);
+    phases &= ~(TMJX_PPO_PHASE_A | TMJX_PPO_PHASE_C);
+  }
   if (phases & TMJX_PPO_PHASE_A) hipLaunchKernelGGL(k_ppo_a, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, noise, fc2, scratch, nblk);
   if (phases & TMJX_PPO_PHASE_B) hipLaunchKernelGGL(k_ppo_b2, dim3(nrec), dim3(64), 0, s, c, baseline, bootstrap, reward, discount, truncation, scratch, 0, rec);   // (nblk = 0: no slice of A's partials)
   if (phases & TMJX_PPO_PHASE_C) hipLaunchKernelGGL(k_ppo_c, dim3(nblk), dim3(PPO_BLOCK), 0, s, c, logits, raw_action, behaviour_logp, noise, baseline, fc2, dlogits, dbaseline,
