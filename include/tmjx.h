@@ -337,6 +337,10 @@ typedef struct {
   const float *Wf, *bf; float *outf; int32_t Nf, ldwf, ldof;
   float eps;
   int32_t rows_alloc;   /* rows every y buffer holds: >= tmjx_chain_rows(M) (a y that feeds the next layer of the launch is stored as whole row tiles) */
+  /* latent tail (lat_out != NULL; epi 1, Nf = 2 lat_Z: the encoder + fc2_mean | fc2_logvar): the launch also writes the decoder's input,
+   * lat_out[M][lat_ld] = [ mean + lat_eps * exp(logvar / 2) (lat_Z columns) | prop[M][prop_w] (row stride prop_ld) ] — reparameterize + the decoder-input
+   * concat of intention_network.py:84-88,128-139, what tmjx_latent_concat computes as a launch of its own (same bits) */
+  const float *lat_eps; float *lat_out; const float *prop; int32_t lat_Z, lat_ld, prop_w, prop_ld;
   void *prof;     /* NULL; or 16 uint64 per workgroup ((M + rows per tile - 1) / rows per tile workgroups): in-kernel clock stamps (tools/chain_stamps.py) */
 } tmjx_chain_fwd_t;
 int tmjx_chain_rows(int M);      /* M rounded up to the row tile (80 or 32 rows) the chain kernels take for M rows */

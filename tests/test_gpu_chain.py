@@ -213,8 +213,8 @@ def _learner_2x256(rows_per_minibatch, seed_env=0):
     return L
 
 
-@pytest.mark.parametrize("rows", [128, 64])
-def test_training_with_the_chain_kernels_is_bit_identical_to_the_layer_by_layer_learner(rows, monkeypatch):
+@pytest.mark.parametrize("rows,latent_tail", [(128, False), (64, False), (128, True)])
+def test_training_with_the_chain_kernels_is_bit_identical_to_the_layer_by_layer_learner(rows, latent_tail, monkeypatch):
     """Two training steps (roll-out, normaliser, 2 x (256 / rows) minibatch SGD steps each, captured as hipGraphs) of the 2 x 256 nets with the whole-chain
     kernels and with TMJX_NO_CHAIN=1: same parameters, Adam moments and metrics to the bit — and the chain path really ran (k_chain_* entry points counted)."""
     from track_mjx_amd.agent import networks
@@ -230,6 +230,8 @@ def test_training_with_the_chain_kernels_is_bit_identical_to_the_layer_by_layer_
         return real_bwd(*a, **k)
     monkeypatch.setattr(networks, "chain_fwd", cf)
     monkeypatch.setattr(networks, "chain_bwd", cb)
+    if latent_tail:        # the encoder launch also samples the latent and writes the decoder's input (off by default: measured slower, networks.py)
+        monkeypatch.setenv("TMJX_CHAIN_LATENT", "1")
     L = _learner_2x256(rows)
     ms = [L.training_step(it) for it in range(2)]
     torch.cuda.synchronize()
@@ -244,3 +246,24 @@ def test_training_with_the_chain_kernels_is_bit_identical_to_the_layer_by_layer_
     assert torch.equal(got[0], R.opt.flat) and torch.equal(got[1], R.opt.exp_avg) and torch.equal(got[2], R.opt.exp_avg_sq)
     for a, b in zip(ms, mr):
         assert a.keys() == b.keys() and all(torch.equal(torch.as_tensor(a[k]), torch.as_tensor(b[k])) for k in a), (a, b)
+
+
+@pytest.mark.parametrize("M", [20480, 5120, 1365, 77])
+def test_latent_tail_of_the_encoder_chain_equals_tmjx_latent_concat(M):
+    """tmjx_chain_fwd with lat_out: the encoder launch also samples the latent and writes the decoder's input [mean + eps exp(logvar / 2) | obs[:, 470:]]
+    (reparameterize + concat, intention_network.py:84-88,128-139) — bit for bit what the separate tmjx_latent_concat launch writes from the same fc2."""
+    from track_mjx_amd.agent.networks import _launch, _p, chain_fwd
+    g = torch.Generator(device=DEV).manual_seed(M)
+    obs = torch.randn((M, 696), generator=g, device=DEV)
+    hidden, final = _net(g, 470, 2, 120, "ln")
+    eps = torch.randn((M, 60), generator=g, device=DEV)
+    dec_in = torch.full((M, 288), 7.0, device=DEV)
+    saved, fc2 = chain_fwd(obs[:, :470], hidden, final, "ln", latent=(eps, dec_in, obs[:, 470:]))
+    saved_r, fc2_r = chain_fwd(obs[:, :470], hidden, final, "ln")
+    ref = torch.full((M, 288), 7.0, device=DEV)
+    _launch("tmjx_latent_concat", DEV, _p(fc2_r), _p(eps), _p(obs), _p(ref), M, 60, 696, 470, 696, 1, None, None, 288, 0, None)
+    torch.cuda.synchronize()
+    assert torch.equal(fc2, fc2_r) and all(torch.equal(a[1], b[1]) for a, b in zip(saved, saved_r))
+    assert torch.equal(dec_in[:, :286], ref[:, :286]), float((dec_in[:, :286] - ref[:, :286]).abs().max())
+    want = fc2_r[:, :60].double() + eps.double() * torch.exp(0.5 * fc2_r[:, 60:].double())
+    assert (dec_in[:, :60].double() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))

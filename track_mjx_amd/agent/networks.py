@@ -423,7 +423,7 @@ class deferred_weight_grads:
 
 
 # ---- whole-chain fp32 kernels (csrc/mlp_chain.h): nets whose hidden layers are exactly 256 wide -----------------------------------------
-def chain_fwd_desc(x2, hidden, final=None, kind="ln", eps=1e-6, out=None):
+def chain_fwd_desc(x2, hidden, final=None, kind="ln", eps=1e-6, out=None, latent=None):
     """The tmjx_chain_fwd_t of one forward chain and the tensors it writes.  x2: [M, >= K0] fp32 rows (a column prefix of a wider buffer is
     fine); hidden: [(weight [256, K], bias, gamma, beta)] ("ln") or [(weight, bias)] ("silu"); final: (weight [Nf, 256], bias) or None.
     Returns (desc, saved = [(z, y, stats)] per hidden layer, out [M, Nf] / [M] for a 1-wide head / None, keep-alive list)."""
@@ -449,13 +449,18 @@ def chain_fwd_desc(x2, hidden, final=None, kind="ln", eps=1e-6, out=None):
         if out is None:
             out = torch.empty((M,) if Nf == 1 else (M, Nf), dtype=torch.float32, device=dev)
         d.Wf, d.bf, d.outf, d.Nf, d.ldwf, d.ldof = wf.data_ptr(), (bf.data_ptr() if bf is not None else None), out.data_ptr(), Nf, wf.stride(0), (1 if Nf == 1 else out.stride(0))
+    if latent is not None:
+        # the encoder chain's latent tail: (eps [M, Z], dec_in [M, ld] to write, prop = the proprioceptive columns [M, W] as a view with its own row stride)
+        leps, dec_in, prop = latent
+        d.lat_eps, d.lat_out, d.prop = leps.data_ptr(), dec_in.data_ptr(), prop.data_ptr()
+        d.lat_Z, d.lat_ld, d.prop_w, d.prop_ld = leps.shape[1], dec_in.stride(0), prop.shape[1], prop.stride(0)
     return d, saved, out
 
 
-def chain_fwd(x2, hidden, final=None, kind="ln", eps=1e-6):
+def chain_fwd(x2, hidden, final=None, kind="ln", eps=1e-6, latent=None):
     """One launch: the whole chain forward (tmjx_chain_fwd).  Raises TmjxError (EINVAL) when the chain does not qualify: ask chain_fwd_ok first."""
     import ctypes as C
-    d, saved, out = chain_fwd_desc(x2, hidden, final, kind, eps)
+    d, saved, out = chain_fwd_desc(x2, hidden, final, kind, eps, latent=latent)
     _launch("tmjx_chain_fwd", x2.device, C.byref(d))
     return saved, out
 
@@ -710,20 +715,33 @@ class _F32ChainFn(torch.autograd.Function):
     hidden layers ("ln" or "silu", all of one kind) then the last layer ("dense" / "head"); `dx_cols`: the input's leading columns that need a gradient."""
 
     @staticmethod
-    def forward(ctx, x, layers, dx_cols, *params):
+    def forward(ctx, x, layers, dx_cols, latent, *params):
         x2 = _rows2d(x)
         hid, last = layers[:-1], layers[-1]
         kind = hid[0].kind
         hidden = [(L.lin.weight, L.lin.bias, L.norm.weight, L.norm.bias) if kind == "ln" else (L.lin.weight, L.lin.bias) for L in hid]
         eps = float(hid[0].norm.eps) if kind == "ln" else 0.0
-        saved, out = chain_fwd(x2, hidden, (last.lin.weight, last.lin.bias), kind, eps)
+        dec_in = None
+        if latent is not None:
+            # the encoder: the launch also writes the decoder's input [latent sample | proprioception] (the kernel's latent tail); handed out as a second,
+            # non-differentiable output — _LatentViewFn ties it to fc2 for the backward pass
+            leps, prop = latent
+            wd = leps.shape[1] + prop.shape[1]
+            dec_in = torch.empty((x2.shape[0], (wd + 3) // 4 * 4), dtype=torch.float32, device=x2.device)
+            latent = (leps, dec_in, prop)
+        saved, out = chain_fwd(x2, hidden, (last.lin.weight, last.lin.bias), kind, eps, latent=latent)
         flat = [t for z, y, st in saved for t in ((z, y, st) if kind == "ln" else (z, y))]
         ctx.save_for_backward(x2, *flat, *params)
         ctx.layers, ctx.dx_cols, ctx.x_shape, ctx.kind, ctx.nflat = layers, dx_cols, x.shape, kind, len(flat)
-        return out.view(*x.shape[:-1], last.lin.out_features) if last.kind == "dense" else out.view(*x.shape[:-1], 1)
+        res = out.view(*x.shape[:-1], last.lin.out_features) if last.kind == "dense" else out.view(*x.shape[:-1], 1)
+        if dec_in is None:
+            return res
+        xd = dec_in[:, :wd]
+        ctx.mark_non_differentiable(xd)
+        return res, xd
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         from .. import hip as _hip
         layers, kind = ctx.layers, ctx.kind
         hid, last = layers[:-1], layers[-1]
@@ -783,12 +801,12 @@ class _F32ChainFn(torch.autograd.Function):
                 got = d.try_add(dz, xin, L.lin.weight, L.lin.bias) if d is not None else None
                 grads[(l, 0)], grads[(l, 1)] = got if got is not None else gemm_dw(dz, xin, True)
         out = [grads.get((l, j)) for l, L in enumerate(layers) for j in range(len(L.params()))]
-        return (dx.view(ctx.x_shape) if dx is not None else None, None, None, *out)
+        return (dx.view(ctx.x_shape) if dx is not None else None, None, None, None, *out)
 
 
-def f32_chain(x, layers, dx_cols=None):
+def f32_chain(x, layers, dx_cols=None, latent=None):
     params = [p for L in layers for p in L.params()]
-    return _F32ChainFn.apply(x, layers, dx_cols, *params)
+    return _F32ChainFn.apply(x, layers, dx_cols, latent, *params)
 
 
 def _f32_chain_ok(x, layers, dx_cols=None) -> bool:
@@ -1287,6 +1305,21 @@ class _LatentConcatFn(torch.autograd.Function):
         return dfc2, None, None, None, None
 
 
+class _LatentViewFn(torch.autograd.Function):
+    """The decoder input x = [mean + eps * exp(logvar / 2) | proprioception] when the encoder chain's launch has ALREADY written it (tmjx_chain_fwd's latent
+    tail): forward hands x on (no launch), backward is _LatentConcatFn's — d fc2 from d x through tmjx_latent_concat_bwd(_add)."""
+
+    @staticmethod
+    def forward(ctx, fc2, eps, x, handle=None):
+        ctx.handle = handle
+        ctx.save_for_backward(fc2.contiguous(), eps.contiguous())
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dx):
+        return (_LatentConcatFn.backward(ctx, dx)[0], None, None, None)
+
+
 class LatentGradHandle:
     """One policy forward pass's slot for a second gradient of its fc2 output (the KL term's): `policy.latent_grad_handle` after a forward that
     went through the fused latent kernel, else None.  `add(g)` parks the gradient, the backward of THAT forward's _LatentConcatFn node takes
@@ -1350,8 +1383,22 @@ class IntentionPolicy(nn.Module):
             if getattr(self, "_enc_f32", None) is None and obs.is_cuda:
                 self._enc_f32 = [_Layer("ln", b.dense, b.norm) for b in self.encoder] + [_Layer("dense", self.fc2)]
                 self._dec_f32 = [_Layer("ln", b.dense, b.norm) for b in self.decoder] + [_Layer("dense", self.head)]
+            xlat = None
             if obs.is_cuda and _f32_chain_ok(traj, self._enc_f32):
-                fc2 = f32_chain(traj, self._enc_f32)          # 2 x 256 nets: the encoder + fc2 as ONE launch forward, one backward (csrc/mlp_chain.h)
+                # 2 x 256 nets: the encoder + fc2 as ONE launch forward, one backward (csrc/mlp_chain.h).  The same launch CAN also sample the latent and write
+                # the decoder's input (its latent tail, TMJX_CHAIN_LATENT=1; bit-identical) — measured 13 us per minibatch step SLOWER than the separate
+                # tmjx_latent_concat launch (0.887 against 0.874 ms, two alternating pairs): that 25 us kernel runs next to the critic's chain on the other
+                # stream, whereas the tail lengthens a kernel that holds every CU.  Off by default
+                obs2 = obs.reshape(-1, obs.shape[-1])
+                if (not deterministic and obs.dtype == torch.float32 and obs2.shape[0] * 2 * self.latents >= 2 * self.latents * 1024 and self.latents % 4 == 0
+                        and (obs.shape[-1] - self.reference_obs_size) % 2 == 0 and obs2.stride(1) == 1 and obs2.stride(0) % 2 == 0 and self.reference_obs_size % 2 == 0
+                        and os.environ.get("TMJX_CHAIN_LATENT") == "1"):
+                    if eps is None:
+                        eps = torch.randn(obs.shape[:-1] + (self.latents,), dtype=torch.float32, device=obs.device)
+                    eps2 = eps.reshape(-1, self.latents).contiguous()
+                    fc2, xlat = f32_chain(traj, self._enc_f32, latent=(eps2, obs2[:, self.reference_obs_size:]))
+                else:
+                    fc2 = f32_chain(traj, self._enc_f32)
             else:
                 with ln_bwd_links():       # encoder and decoder are chains: each block's output feeds exactly one dense layer
                     h = self.encoder(traj)
@@ -1364,7 +1411,10 @@ class IntentionPolicy(nn.Module):
             if eps is None:
                 eps = torch.randn_like(mean)
             handle = LatentGradHandle(fc2.reshape(-1, fc2.shape[-1])) if (fc2.requires_grad and fc2.is_contiguous()) else None
-            x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size, handle)
+            if not chains and xlat is not None:
+                x = _LatentViewFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), xlat, handle)
+            else:
+                x = _LatentConcatFn.apply(fc2.reshape(-1, fc2.shape[-1]), eps.reshape(-1, self.latents), obs.reshape(-1, obs.shape[-1]), self.reference_obs_size, handle)
             self.latent_grad_handle = handle
             x = x.view(*lead, x.shape[-1])
             if chains:

@@ -232,6 +232,9 @@ struct ChainFwd {
   ChainHidden h[CHAIN_MAX_HIDDEN];
   const float *Wf, *bf; float *outf; int Nf, ldwf, ldof;      // FIN 1: un-activated last layer (Nf <= 128); FIN 2: the 1-wide head (Wf = its weight row)
   float eps;
+  // LAT (FIN 1, the encoder): behind fc2 = [mean | logvar] the latent sample z = mean + lat_eps * exp(logvar / 2) (reparameterize,
+  // intention_network.py:84-88) and the decoder's input [z | proprioception] (:128-139) — lat_out[M][lat_ld] <- [z (lat_Z) | prop[M][prop_w] (row stride prop_ld)]
+  const float *lat_eps; float *lat_out; const float *prop; int lat_Z, lat_ld, prop_w, prop_ld;
   unsigned long long *prof;      // NULL, or 16 shader-clock stamps per workgroup (tools/chain_stamps.py): kernel start, then behind every K loop and every epilogue
 };
 #define CHAIN_STAMP(i) do { if (P.prof && threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -248,7 +251,7 @@ __device__ __forceinline__ void chain_y_to_lds(float *yimg, const gf4 (&y)[MT][2
 // EPI 1: hidden layers are Dense -> SiLU -> LayerNorm blocks (k_gemm_act<.., EPI = 1>'s epilogue);  EPI 3: Dense -> SiLU (brax value MLP, EPI = 3)
 // FIN 0: the chain ends with its last hidden layer;  1: + an un-activated layer of at most 128 columns (fc2 / the policy head);
 //     2: + the value MLP's 1-wide head as a dot product, summed in k_head_fwd's order (lane groups of four columns by fmaf, then its xor butterfly)
-template <int MT, int EPI, int FIN>
+template <int MT, int EPI, int FIN, bool LAT = false>
 __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwd P) {
   using LD = ChainLds<MT>;
   constexpr int BM = LD::BM, NW = 8;
@@ -376,14 +379,43 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwd P) {
 #pragma unroll
     for (int a = 0; a < MT; a++) {
       const int row = m0 + 16 * a + li;
+      const gf4 v = accf[a][0] + bvf;
       if (row < M) {
         float *o = P.outf + (long long)row * P.ldof + col;
-        const gf4 v = accf[a][0] + bvf;
         if (vec && col + 3 < P.Nf) *reinterpret_cast<gf4 *>(o) = v;
         else {
 #pragma unroll
           for (int r = 0; r < 4; r++) if (col + r < P.Nf) o[r] = v[r];
         }
+      }
+      if (LAT) accf[a][0] = v;
+    }
+    if (LAT) {
+      // the fc2 tile through LDS (mean column j and logvar column Z + j sit in different waves), then the decoder input of the tile's rows:
+      // k_latent_concat's expression, fmaf(eps, expf(logvar / 2), mean), and the proprioceptive columns copied next to it
+      float *ft = yimg;                        // [BM][128]
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < MT; a++) *reinterpret_cast<gf4 *>(ft + (16 * a + li) * 128 + col) = accf[a][0];
+      __syncthreads();
+      const int Z = P.lat_Z, zq = Z >> 2;
+      for (int it = t; it < BM * zq; it += CH_NT) {
+        const int row = it / zq, q = it - row * zq;
+        const long long gr = m0 + row;
+        if (gr < M) {
+          const gf4 mu = *reinterpret_cast<const gf4 *>(ft + row * 128 + 4 * q), lv = *reinterpret_cast<const gf4 *>(ft + row * 128 + Z + 4 * q);
+          const gf4 ep = *reinterpret_cast<const gf4 *>(P.lat_eps + gr * Z + 4 * q);
+          gf4 z;
+#pragma unroll
+          for (int r = 0; r < 4; r++) z[r] = fmaf(ep[r], expf(0.5f * lv[r]), mu[r]);
+          *reinterpret_cast<gf4 *>(P.lat_out + gr * P.lat_ld + 4 * q) = z;
+        }
+      }
+      const int ph = P.prop_w >> 1;
+      for (int it = t; it < BM * ph; it += CH_NT) {
+        const int row = it / ph, q = it - row * ph;
+        const long long gr = m0 + row;
+        if (gr < M) *reinterpret_cast<gf2 *>(P.lat_out + gr * P.lat_ld + Z + 2 * q) = *reinterpret_cast<const gf2 *>(P.prop + gr * P.prop_ld + 2 * q);
       }
     }
   }

@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_latent_concat(const float *__restrict__
       float ep;
       if (eps) ep = eps[e * Z + c];
       else { float v4[4]; const size_t idx = e * Z + c; tm_normal4(seed, ctr, 2u, (unsigned)(idx >> 2), v4); ep = v4[idx & 3]; }
-      v = fc2[e * 2 * Z + c] + ep * expf(0.5f * fc2[e * 2 * Z + Z + c]);
+      v = fmaf(ep, expf(0.5f * fc2[e * 2 * Z + Z + c]), fc2[e * 2 * Z + c]);       // (written as the fused multiply-add it compiles to: the encoder chain's latent tail, csrc/mlp_chain.h, forms the same)
     } else if (c < W) { int k = ref_w + c - Z; v = obs[(long long)e * obs_s0 + (long long)k * obs_s1]; if (mean) v = (v - mean[k]) / stdv[k]; }
     x[e * (size_t)x_stride + c] = v;
   }

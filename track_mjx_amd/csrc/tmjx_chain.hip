@@ -20,22 +20,22 @@ static int check_launch(const char *what) {
 static bool al16(const void *p) { return !((uintptr_t)p & 15); }
 static bool rows16(const void *p, long long ld) { return al16(p) && !(ld & 3); }
 
-template <int MT, int EPI, int FIN>
+template <int MT, int EPI, int FIN, bool LAT = false>
 static int launch_chain_fwd(const ChainFwd &P, hipStream_t s) {
   constexpr size_t lds = sizeof(float) * (size_t)ChainLds<MT>::TOTAL;
   static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_chain_fwd<MT, EPI, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_chain_fwd<MT, EPI, FIN, LAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(TMJX_EHIP, std::string("hipFuncSetAttribute(k_chain_fwd): ") + hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_chain_fwd<MT, EPI, FIN>), dim3((P.M + 16 * MT - 1) / (16 * MT)), dim3(CH_NT), lds, s, P);
+  hipLaunchKernelGGL((k_chain_fwd<MT, EPI, FIN, LAT>), dim3((P.M + 16 * MT - 1) / (16 * MT)), dim3(CH_NT), lds, s, P);
   return check_launch("k_chain_fwd");
 }
-template <int EPI, int FIN>
+template <int EPI, int FIN, bool LAT = false>
 static int chain_fwd_mt(const ChainFwd &P, hipStream_t s) {
-  if (tmjx_internal_gemm_mt(P.M, 1) == 2) return launch_chain_fwd<2, EPI, FIN>(P, s);
-  return launch_chain_fwd<5, EPI, FIN>(P, s);
+  if (tmjx_internal_gemm_mt(P.M, 1) == 2) return launch_chain_fwd<2, EPI, FIN, LAT>(P, s);
+  return launch_chain_fwd<5, EPI, FIN, LAT>(P, s);
 }
 
 static int chain_rows(int M) { const int bm = 16 * tmjx_internal_gemm_mt(M, 1); return (M + bm - 1) / bm * bm; }
@@ -57,6 +57,12 @@ static const char *chain_fwd_why(const tmjx_chain_fwd_t *c) {
     if (!c->outf || c->Nf < 1 || c->Nf > 128) return "the last layer has 1 .. 128 columns";
     if (c->Nf == 1) { if (!al16(c->Wf)) return "the head's weight row must be 16-byte aligned"; }
     else if (c->ldwf < 256 || !rows16(c->Wf, c->ldwf) || c->ldof < c->Nf) return "the last layer's weight rows must be 16-byte aligned, ldwf >= 256, ldof >= Nf";
+  }
+  if (c->lat_out) {
+    if (c->epi != 1 || !c->Wf || c->Nf != 2 * c->lat_Z || !c->lat_eps || !c->prop) return "the latent tail follows a LayerNorm-block chain whose last layer is [mean | logvar] (Nf = 2 lat_Z)";
+    if (c->lat_Z < 4 || (c->lat_Z & 3) || c->prop_w < 0 || (c->prop_w & 1) || c->lat_ld < c->lat_Z + c->prop_w || (c->lat_ld & 3) || (c->prop_ld & 1) || c->prop_ld < c->prop_w)
+      return "latent tail: lat_Z % 4 == 0, prop_w and prop_ld even, lat_ld % 4 == 0 and >= lat_Z + prop_w";
+    if (!al16(c->lat_eps) || !al16(c->lat_out) || ((uintptr_t)c->prop & 7)) return "latent tail: lat_eps / lat_out 16-byte aligned, prop 8-byte aligned";
   }
   return nullptr;
 }
@@ -130,10 +136,12 @@ int tmjx_chain_fwd(const tmjx_chain_fwd_t *c, void *stream) {
   }
   P.Wf = c->Wf; P.bf = c->bf; P.outf = c->outf; P.Nf = c->Nf; P.ldwf = c->ldwf; P.ldof = c->ldof;
   P.prof = (unsigned long long *)c->prof;
+  P.lat_eps = c->lat_eps; P.lat_out = c->lat_out; P.prop = c->prop; P.lat_Z = c->lat_Z; P.lat_ld = c->lat_ld; P.prop_w = c->prop_w; P.prop_ld = c->prop_ld;
   hipStream_t s = (hipStream_t)stream;
   const int fin = !c->Wf ? 0 : (c->Nf == 1 ? 2 : 1);
   if (c->epi == 1) {
     if (fin == 0) return chain_fwd_mt<1, 0>(P, s);
+    if (fin == 1 && c->lat_out) return chain_fwd_mt<1, 1, true>(P, s);
     if (fin == 1) return chain_fwd_mt<1, 1>(P, s);
     return fail(TMJX_EINVAL, "tmjx_chain_fwd: a 1-wide last layer follows Dense -> SiLU layers (epi 3) only");
   }

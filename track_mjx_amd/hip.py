@@ -85,7 +85,9 @@ class ChainLayer(C.Structure):
 class ChainFwd(C.Structure):
     """tmjx_chain_fwd_t (include/tmjx.h)."""
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("M", C.c_int32), ("n_hidden", C.c_int32), ("epi", C.c_int32), ("hidden", ChainLayer * 4),
-                ("Wf", C.c_void_p), ("bf", C.c_void_p), ("outf", C.c_void_p), ("Nf", C.c_int32), ("ldwf", C.c_int32), ("ldof", C.c_int32), ("eps", C.c_float), ("rows_alloc", C.c_int32), ("prof", C.c_void_p)]
+                ("Wf", C.c_void_p), ("bf", C.c_void_p), ("outf", C.c_void_p), ("Nf", C.c_int32), ("ldwf", C.c_int32), ("ldof", C.c_int32), ("eps", C.c_float), ("rows_alloc", C.c_int32),
+                ("lat_eps", C.c_void_p), ("lat_out", C.c_void_p), ("prop", C.c_void_p), ("lat_Z", C.c_int32), ("lat_ld", C.c_int32), ("prop_w", C.c_int32), ("prop_ld", C.c_int32),
+                ("prof", C.c_void_p)]
 
 
 class ChainBwdStage(C.Structure):
