@@ -166,9 +166,15 @@ def ppo_loss_and_output_grads(policy, value, normalizer, data: dict, *, entropy_
             row = [f32(data[k]) for k in ("raw_action", "log_prob", "reward", "discount", "truncation")]
         side_stream.wait_stream(cur)
         with torch.cuda.stream(side_stream):
+            # the bootstrap value FIRST: its 1 024-row launch is latency-bound (32 workgroups, 44 us) — queued behind the critic's 20 480-row pass it ran next to
+            # the DECODER's pass at the end of the forward phase and held 32 CUs back from it (decoder chain 100 us against 78 alone); in front, it hides
+            # under the two large passes' first round
+            with torch.no_grad():
+                bootstrap = value(nxt) if os.environ.get("TMJX_BOOTSTRAP_LAST") != "1" else None
             baseline = value(obs)
             with torch.no_grad():
-                bootstrap = value(nxt)
+                if bootstrap is None:
+                    bootstrap = value(nxt)
                 if phased:
                     bl, bs = f32(baseline), f32(bootstrap)
         logits, fc2 = policy(obs, eps=data.get("latent_eps"), return_fc2=True)

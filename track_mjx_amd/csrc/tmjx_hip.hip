@@ -1178,11 +1178,18 @@ int tmjx_gemm_dw_grouped_wgs(const tmjx_dw_problem_t *probs, int n, int target_w
   // 74 KB workgroups fit a CU), not once EACH — nine problems split for 256 workgroups apiece were 2 300 workgroups writing and re-reading
   // 64 slabs per weight matrix (160 MB per backward pass at 20 480 rows, 130 MB at 5 120).  Never more slabs than the problem's own split
   // (the caller sized the scratch by tmjx_gemm_dw_scratch_floats).
-  static const int group_default = getenv("TMJX_DW_GROUP_WGS") ? atoi(getenv("TMJX_DW_GROUP_WGS")) : 1024;
-  const int group_target = target_wgs > 0 ? target_wgs : group_default;       // (a group that runs NEXT TO other kernels asks for fewer workgroups)
+  static const int group_env = getenv("TMJX_DW_GROUP_WGS") ? atoi(getenv("TMJX_DW_GROUP_WGS")) : 0;
+  const int group_target = target_wgs > 0 ? target_wgs : group_env;           // (a group that runs NEXT TO other kernels asks for fewer workgroups)
   int all_tiles = 0;
   for (int i = 0; i < n; i++) all_tiles += ((probs[i].N + DW_BT - 1) / DW_BT) * ((probs[i].K + DW_BT - 1) / DW_BT);
-  const int max_slabs = group_target > 0 ? (group_target + all_tiles - 1) / (all_tiles > 0 ? all_tiles : 1) : 0;
+  if (all_tiles < 1) all_tiles = 1;
+  // Round 6: the workgroup count has to land just UNDER a multiple of the 256 CUs.  The 2 x 256 nets' group is 42 tiles; per minibatch step at 20 480 /
+  // 5 120 rows (cfg2 / cfg3, ms): 6 slabs = 252 workgroups 0.842 / 0.381, 12 = 504 0.846 / 0.391, 10 = 420 0.882 / 0.395, 8 = 336 0.942 / 0.405,
+  // 25 = 1 050 (the old "about 1 024") 0.865 / 0.408 — a count like 336 puts a second workgroup on 80 of the CUs, which then run both at half speed while
+  // the rest wait; 1 050 is two full rounds of two per CU plus 26 stragglers.  So: as many slabs as keep tiles x slabs within ONE workgroup per CU (fewest
+  // slabs = least slab traffic and reduction work among the good counts).  Groups of more than 256 tiles (the rodent-mc-intention nets) are flat in
+  // this knob (5.06 - 5.09 ms): about 1 024 workgroups as before.  TMJX_DW_GROUP_WGS / target_wgs: an explicit workgroup budget instead.
+  const int max_slabs = group_target > 0 ? (group_target + all_tiles - 1) / all_tiles : (all_tiles <= 256 ? 256 / all_tiles : (1024 + all_tiles - 1) / all_tiles);
   for (int i = 0; i < n; i++) {
     const tmjx_dw_problem_t &q = probs[i];
     if (!q.dY || !q.X || !q.dW || !q.scratch) return fail(TMJX_EINVAL, "null pointer in a problem");
