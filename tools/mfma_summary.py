@@ -22,7 +22,8 @@ for cfg in ("cfg2", "cfg4", "cfg5"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"]
-        fam = ("k_gemm_act (forward / input gradient)" if "k_gemm_act" in k else "k_gemm_dw (weight gradient)" if "k_gemm_dw" in k else
+        fam = ("k_chain_fwd / k_chain_bwd (whole chains, 256-wide nets)" if "k_chain_" in k else
+               "k_gemm_act (forward / input gradient)" if "k_gemm_act" in k else "k_gemm_dw (weight gradient)" if "k_gemm_dw" in k else
                "k_bgemm_nt (bf16 forward / input gradient, fused epilogues)" if "k_bgemm_nt" in k else "k_bgemm_dw (bf16 weight gradient)" if "k_bgemm_dw<" in k else
                ("library GEMM" if k.startswith("Cijk") else None))
         if fam:
