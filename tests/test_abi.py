@@ -118,3 +118,51 @@ def test_argument_validation_of_the_learner_entry_points_without_gpu():
     assert L.tmjx_set_wrappers(None, 195, 1) == -22
     assert L.tmjx_set_action_repeat(None, 2) == -22
     assert L.tmjx_last_error()
+
+
+def test_argument_validation_of_the_chain_entry_points_without_gpu():
+    """tmjx_chain_fwd / tmjx_chain_bwd (csrc/mlp_chain.h) validate before they launch: what a chain kernel cannot run — null pointers, hidden layers that are not 256
+    wide, unaligned rows, a last layer wider than 128, y / dz buffers without the row-tile padding — is TMJX_EINVAL with a message, and the `_ok` twins say so
+    without an error.  No compute call is made (GPU-less build container)."""
+    L = hip.lib()
+    a = 1 << 20                                                    # a non-null, 16-byte aligned dummy address that is never dereferenced
+
+    def fwd(M=20480, K0=472, lda=696, n=2, Nf=120, rows=None, **over):
+        d = hip.ChainFwd()
+        d.A, d.lda, d.M, d.n_hidden, d.epi, d.eps = a, lda, M, n, 1, 1e-6
+        for l in range(min(n, 4)):
+            h = d.hidden[l]
+            h.W, h.bias, h.gamma, h.beta, h.z, h.y, h.stats, h.K, h.ldw = a, a, a, a, a, a, a, (K0 if l == 0 else 256), (K0 if l == 0 else 256)
+        d.Wf, d.bf, d.outf, d.Nf, d.ldwf, d.ldof = a, a, a, Nf, 256, Nf
+        d.rows_alloc = L.tmjx_chain_rows(M) if rows is None else rows
+        for k, v in over.items():
+            setattr(d, k, v)
+        return d
+    assert L.tmjx_chain_rows(20480) == 20480 and L.tmjx_chain_rows(5120) == 5120 and L.tmjx_chain_rows(1365) % 32 == 0 and L.tmjx_chain_rows(1365) >= 1365
+    assert L.tmjx_chain_rows(0) == 0
+    assert L.tmjx_chain_fwd_ok(ctypes.byref(fwd())) == 1
+    for bad, word in ((fwd(Nf=130), b"128"), (fwd(lda=695), b"aligned"), (fwd(rows=20479), b"rows_alloc"), (fwd(n=5), b"hidden"), (fwd(n=0), b"hidden"), (fwd(A=None), b"null"),
+                      (fwd(epi=2), b"epi"), (fwd(M=0), b"M >= 1"), (fwd(lat_out=a, lat_Z=60, lat_ld=288, prop_w=226, prop_ld=696), b"latent")):
+        assert L.tmjx_chain_fwd_ok(ctypes.byref(bad)) == 0
+        assert L.tmjx_chain_fwd(ctypes.byref(bad), None) == -22 and word in L.tmjx_last_error(), (word, L.tmjx_last_error())
+    wide = fwd()
+    wide.hidden[1].K, wide.hidden[1].ldw = 512, 512                # a hidden layer whose input is not 256 wide
+    assert L.tmjx_chain_fwd(ctypes.byref(wide), None) == -22 and b"256" in L.tmjx_last_error()
+    assert L.tmjx_chain_fwd(None, None) == -22
+
+    def bwd(M=20480, Kg=76, n=2, epi=2, **over):
+        d = hip.ChainBwd()
+        d.G, d.ldg, d.Kg, d.M, d.n_stages, d.epi, d.rows_alloc = a, Kg, Kg, M, n, epi, L.tmjx_chain_rows(M)
+        for i in range(min(n, 4)):
+            s = d.stage[i]
+            s.W, s.ldw, s.z, s.bias, s.gamma, s.stats, s.dz, s.partial = a, 256, a, a, a, a, a, a
+        for k, v in over.items():
+            setattr(d, k, v)
+        return d
+    assert L.tmjx_chain_bwd_ok(ctypes.byref(bwd())) == 1
+    assert L.tmjx_chain_bwd_ok(ctypes.byref(bwd(W0=a, ldw0=288, dx_cols=60, dx=a, lddx=286))) == 1
+    assert L.tmjx_chain_bwd_ok(ctypes.byref(bwd(Kg=1, epi=4, ldg=1))) == 1                     # the value head
+    for bad, word in ((bwd(Kg=130), b"128"), (bwd(Kg=1), b"1-wide"), (bwd(epi=3), b"epi"), (bwd(rows_alloc=100), b"rows_alloc"), (bwd(n=0), b"stages"),
+                      (bwd(Kg=78), b"aligned"), (bwd(W0=a, ldw0=288, dx_cols=200, dx=a, lddx=286), b"trailing"), (bwd(G=None), b"null")):
+        assert L.tmjx_chain_bwd_ok(ctypes.byref(bad)) == 0
+        assert L.tmjx_chain_bwd(ctypes.byref(bad), None) == -22 and word in L.tmjx_last_error(), (word, L.tmjx_last_error())
