@@ -45,6 +45,15 @@ inline bool rodent_chains_match(const DModel &m) {
     if (m.dof_limrow[i] != (i >= 6 ? i - 6 : -1)) return false;
   }
   if (m.nv > 128 || m.nlim != m.nv - 6) return false;
+  // ... and runs the kinematics with ONE body slot (wave_physics.h: tmw_position, "head-4 body tree"): body 0 the world at the origin, body 1 a
+  // jointless child of the world, body 2 the free-joint root (a child of the world: absolute by its qpos), body 3 welded to body 2, at most 64
+  // bodies behind them and no other free joint
+  if (m.nbody < 5 || m.nbody - 4 > 64 || m.nround_body < 1) return false;
+  if (m.body_jntnum[0] || m.body_jntnum[1] || m.body_jntnum[2] != 1 || m.body_jntnum[3]) return false;
+  if (m.jnt_type[m.body_jntadr[2]] != 0 || m.body_parentid[1] != 0 || m.body_parentid[2] != 0 || m.body_parentid[3] != 2) return false;
+  if (m.scan_parent[0] != -1 || m.scan_parent[1] != -1 || m.scan_parent[2] != -1 || m.scan_parent[3] != 2) return false;
+  for (int b = 4; b < m.nbody; b++)
+    for (int jj = 0; jj < m.body_jntnum[b]; jj++) if (m.jnt_type[m.body_jntadr[b] + jj] == 0) return false;
   return adr == m.nnz;
 }
 inline WLayout make_wave_layout(const DModel &m, bool allow_chains = true) {

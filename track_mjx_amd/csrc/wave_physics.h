@@ -310,17 +310,23 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
   // (1) local transform of every body relative to its parent (absolute for the free-joint body).  Everything the lane needs of the model for
   // its bodies comes from ONE flat record per body (DModel::body_kin), both bodies' records loaded up front: the chain body -> joint ->
   // joint fields -> qpos0[qposadr] was three dependent model reads per body, each about a thousand cycles next to eleven other waves
+  // Head-4 body tree (K.lean; model_host.h: rodent_chains_match checks it): body 0 = world (identity), 1 = a static child of the world, 2 = the
+  // free-joint root (absolute by its qpos), 3 = welded to it; the other nbody - 4 <= 64 bodies take ONE lane each — a second body slot for
+  // bodies 64 .. 67 cost every instruction of steps (1) and (2) a second time for four live lanes.  The four head bodies are finished by lanes
+  // 0 .. 3 right here: their entries never change during the rounds, except body 3's, which is its local frame in round 0 and root o local
+  // from round 1 on — the same numbers the two-slot form produced (bit-identical: tests/diagnostics/kernel_ab.py).
+  const int HB = K.lean ? 4 : 0;
   TMW_FOR {
     float rec[2][16];
 #pragma unroll
-    for (int slot = 0; slot < 2; slot++) {
-      const int b = lane + 64 * slot < K.nbody ? lane + 64 * slot : K.nbody - 1;
+    for (int slot = 0; slot < (K.lean ? 1 : 2); slot++) {
+      const int b = lane + HB + 64 * slot < K.nbody ? lane + HB + 64 * slot : K.nbody - 1;
 #pragma unroll
       for (int k = 0; k < 16; k++) rec[slot][k] = m.body_kin[b][k];
     }
 #pragma unroll
-    for (int slot = 0; slot < 2; slot++) {
-      const int b = lane + 64 * slot;
+    for (int slot = 0; slot < (K.lean ? 1 : 2); slot++) {
+      const int b = lane + HB + 64 * slot;
       if (b >= K.nbody) continue;
       const float *rc = rec[slot];
       float t[3] = {rc[0], rc[1], rc[2]};
@@ -335,7 +341,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
           jtype = m.jnt_type[j]; qa = m.jnt_qposadr[j]; q0 = m.qpos0[qa];
           for (int k = 0; k < 3; k++) { jpos[k] = m.jnt_pos[j][k]; jaxis[k] = m.jnt_axis[j][k]; }
         }
-        if (jtype == 0) {
+        if (!K.lean && jtype == 0) {
           for (int k = 0; k < 3; k++) t[k] = L[K.l_qpos + qa + k];
           for (int k = 0; k < 4; k++) q[k] = L[K.l_qpos + qa + 3 + k];
           tm_normalize4(q);
@@ -358,8 +364,35 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
       float *o = L + K.l_scanA + b * 8;
       o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3]; o[7] = tm_i2f(m.scan_parent[b]);
     }
+    if (K.lean && lane < 4) {
+      const int b = lane, jr = m.body_jntadr[2], qr = tm_f2i(m.body_kin[2][8]);
+      float t[3], q[4], tr[3], qq[4];       // the root's frame, by every one of the four lanes (lane 3 composes with it)
+      for (int k = 0; k < 3; k++) tr[k] = L[K.l_qpos + qr + k];
+      for (int k = 0; k < 4; k++) qq[k] = L[K.l_qpos + qr + 3 + k];
+      tm_normalize4(qq);
+      for (int k = 0; k < 3; k++) t[k] = m.body_kin[b][k];
+      for (int k = 0; k < 4; k++) q[k] = m.body_kin[b][3 + k];
+      if (b == 2) {
+        for (int k = 0; k < 3; k++) t[k] = tr[k];
+        for (int k = 0; k < 4; k++) q[k] = qq[k];
+        for (int k = 0; k < 3; k++) { L[K.l_jl_anchor + jr * 3 + k] = tr[k]; L[K.l_jl_axis + jr * 3 + k] = (k == 2) ? 1.f : 0.f; }
+      }
+      float *o = L + K.l_scanA + b * 8;
+      o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3]; o[7] = tm_i2f(b == 3 ? 2 : -1);
+      if (b == 3) {
+        float rt[3], q2[4];
+        tm_rotate(rt, t, qq);
+        for (int k = 0; k < 3; k++) t[k] = tr[k] + rt[k];
+        tm_quat_mul(q2, qq, q);
+        for (int k = 0; k < 4; k++) q[k] = q2[k];
+      }
+      o = L + K.l_scanB + b * 8;
+      o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3]; o[7] = tm_i2f(-1);
+    }
   }
   TMW_SYNC();
+  // (the root's normalised quaternion back into qpos, as the free-joint branch does: behind the barrier — every head lane has read the raw one)
+  if (K.lean) { TMW_FOR { if (lane < 4) L[K.l_qpos + tm_f2i(m.body_kin[2][8]) + 3 + lane] = L[K.l_scanA + 2 * 8 + 3 + lane]; } }
   TMW_TICK2(27);
   // (2) pointer jumping: T_b <- T_anc(b) o T_b ; anc(b) <- anc(anc(b)).  Even round count => result in scanA.
   int R = K.nround_body + (K.nround_body & 1);
@@ -367,7 +400,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
     const float *cur = L + ((r & 1) ? K.l_scanB : K.l_scanA);
     float *nxt = L + ((r & 1) ? K.l_scanA : K.l_scanB);
     TMW_FOR {
-      for (int b = lane; b < K.nbody; b += 64) {
+      for (int b = lane + HB; b < K.nbody; b += 64) {
         const float *s = cur + b * 8;
         float t[3] = {s[0], s[1], s[2]}, q[4] = {s[3], s[4], s[5], s[6]};
         int a = tm_f2i(s[7]);
@@ -383,6 +416,7 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
         float *o = nxt + b * 8;
         o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3]; o[7] = tm_i2f(a);
       }
+      if (K.lean && r == 1 && lane < 8) nxt[3 * 8 + lane] = cur[3 * 8 + lane];      // body 3's finished frame into scanA as well (the other head entries are in both buffers)
     }
     TMW_SYNC();
   }
