@@ -1631,6 +1631,8 @@ TM_DEV void tmw_mul_m(WCtx &c, const WLayout &K, int x, int y) {
 //   stage 1: spatial velocity of each paw body -> l_sv;   stage 2 (after a barrier): one lane per active row
 TM_DEV void tmw_jmul_stage1(WCtx &c, const WLayout &K, int v) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
+  // no penetrating contact (a wave-uniform fact of the env's substep, ~ 2 of 3 substeps): stage 2 reads l_sv for contact rows only
+  if (c.nact == c.nla) return;
   TMW_FOR {
     if (lane < K.ngroup * 6) {  // spatial velocity of each paw body, one lane per (group, component)
       int g = lane / 6, k = lane - g * 6, ld, d, run, jp1;
@@ -1684,6 +1686,10 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
   // (branch-free on purpose: written with `if (penetrating) { .. if (ja < 0) .. }` the compiler emitted a chain of ten dependent LDS round
   // trips, each behind its own exec-mask branch and lgkmcnt(0) wait; here every load of a contact is issued up front — inactive slots read
   // row 0 / their stale frame and select zero at the end)
+  // No penetrating contact at all (wave-uniform; ~ 2 of 3 substeps): every wrench and every subset sum is zero — the three passes over the
+  // contacts and, below, the dofs' wrench products (which would add exact zeros) are skipped
+  const bool anycon = c.nact > c.nla;
+  if (anycon) {
   TMW_FOR {
     for (int cc = lane; cc < K.ncon; cc += 64) {
       const bool on = L[K.l_con_dist + cc] < 0.f;
@@ -1738,6 +1744,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
     if (lane + 64 < m.n_wsub * 6) L[K.l_wr + lane + 64] = W1[TMW_LI];
   }
   TMW_SYNC();
+  }
   TMW_FOR {
     for (int i = lane; i < K.nv; i += 64) {
       float s = 0.f;
@@ -1750,7 +1757,7 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
         const float fl = -D * ja;
         s = (sv != 0 && ja < 0.f) ? (sv > 0 ? fl : -fl) : 0.f;
       }
-      if (su >= 0) { const float *w = L + K.l_wr + su * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
+      if (anycon && su >= 0) { const float *w = L + K.l_wr + su * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
       L[out + i] = s;
     }
   }
