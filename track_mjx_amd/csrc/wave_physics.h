@@ -573,11 +573,15 @@ TM_DEV void tmw_position(WCtx &c, const WLayout &K, bool emit) {
 // dofs x two dof slots with a barrier each (the loads do not depend on the running sum, the stores are fire-and-forget).
 TM_DEV void tmw_chain_scan(WCtx &c, const WLayout &K, int base) {
   float *L = c.L; TMW_LANE_DECL
+  // (round 6: the loads of a block of steps are issued TOGETHER, then the dependent adds and the stores — one load / wait / add / store per
+  // trip made every step a whole LDS round trip next to eleven other waves: ~ 200 cycles x 36 steps x two scans per substep)
   TMW_FOR {
     if (lane < 6) {
-      float acc = 0.f;
-#pragma unroll 1
-      for (int t = 0; t < TMW_RODENT_TRUNK; t++) { float *p = L + base + t * TMW_DS + lane; acc += *p; *p = acc; }
+      float *p = L + base + lane, v[TMW_RODENT_TRUNK], acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < TMW_RODENT_TRUNK; t++) v[t] = p[t * TMW_DS];
+#pragma unroll
+      for (int t = 0; t < TMW_RODENT_TRUNK; t++) { acc += v[t]; p[t * TMW_DS] = acc; }
     }
   }
   TMW_SYNC();
@@ -590,12 +594,15 @@ TM_DEV void tmw_chain_scan(WCtx &c, const WLayout &K, int base) {
 #undef TMW_X
       float acc = L[base + (d0 - 1) * TMW_DS + k];
       float *p = L + base + first * TMW_DS + k;
-      constexpr int MAXN = tmw_chain_maxrun(TMW_RODENT_TRUNK, 73) + 1;        // longest leaf chain (TMW_RODENT_DIMS: nv = 73)
+      constexpr int MAXN = tmw_chain_maxrun(TMW_RODENT_TRUNK, 73) + 1, UB = 8;        // longest leaf chain (TMW_RODENT_DIMS: nv = 73)
+      float keep = 0.f;
 #pragma unroll 1
-      for (int t = 0; t < MAXN; t++) {       // t >= n: re-reads the chain's first entry, no store
-        float v = p[(t < n ? t : 0) * TMW_DS];
-        acc += v;
-        if (t < n) p[t * TMW_DS] = acc;
+      for (int t0 = 0; t0 < MAXN; t0 += UB) {       // branch-free: a step t >= n re-reads the chain's LAST entry and stores the finished last sum there again
+        float v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) v[u] = p[(t0 + u < n ? t0 + u : n - 1) * TMW_DS];
+#pragma unroll
+        for (int u = 0; u < UB; u++) { acc += v[u]; keep = t0 + u < n ? acc : keep; p[(t0 + u < n ? t0 + u : n - 1) * TMW_DS] = keep; }
       }
     }
   }
