@@ -129,6 +129,14 @@ struct WCtx {
 #define TMW_QA_SET(i, v) do { if (!TMW_QAREG(K)) L[K.l_qacc + (i)] = (v); else if ((i) < 64) c.qa0[TMW_LI] = (v); else c.qa1[TMW_LI] = (v); } while (0)
 #define TMW_MA(i) (TMW_QAREG(K) ? ((i) < 64 ? c.ma0[TMW_LI] : c.ma1[TMW_LI]) : L[K.l_Ma + (i)])
 #define TMW_MA_SET(i, v) do { if (!TMW_QAREG(K)) L[K.l_Ma + (i)] = (v); else if ((i) < 64) c.ma0[TMW_LI] = (v); else c.ma1[TMW_LI] = (v); } while (0)
+// Both dof slots of a lane (dofs lane and lane + 64) in ONE straight-line pass (round 6).  `for (i = lane; i < nv; i += 64)` compiles to a
+// divergent two-trip loop: load, wait, use, branch, load, wait, use — two LDS round trips where the slots' loads can share one.  TMW_I1: an
+// in-range LDS index for slot 1's loads (a lane without a second dof re-reads its slot-0 words; the results are selected away, never multiplied
+// away: the words may hold anything).  Sums keep the loop's order and expressions (s += (ok ? a : 0) * b: the same contraction as the loop's s += a * b).
+#define TMW_OK1(K) (lane + 64 < (K).nv)
+#define TMW_I1(K) (TMW_OK1(K) ? lane + 64 : lane)
+#define TMW_MA1(K, i1) (TMW_QAREG(K) ? c.ma1[TMW_LI] : L[(K).l_Ma + (i1)])
+#define TMW_QA1(K, i1) (TMW_QAREG(K) ? c.qa1[TMW_LI] : L[(K).l_qacc + (i1)])
 #define TMW_DG(i) ((i) < 64 ? c.dg0[TMW_LI] : c.dg1[TMW_LI])
 #define TMW_WP(i) ((i) < 64 ? c.wp0[TMW_LI] : c.wp1[TMW_LI])
 #define TMW_WP_SET(i, v) do { if ((i) < 64) c.wp0[TMW_LI] = (v); else c.wp1[TMW_LI] = (v); } while (0)
@@ -1968,11 +1976,12 @@ TM_DEV float tmw_update_gradient(WCtx &c, const WLayout &K, float &num, float im
   TMW_REG(float, pa); TMW_REG(float, pb);
   TMW_FOR {
     float sa = 0.f, sb = 0.f;
-    for (int i = lane; i < K.nv; i += 64) {
-      float w = TMW_MA(i) - L[K.l_Mgrad + i], dw = TMW_DG(i) * w;
-      L[K.l_Mgrad + i] = w;
-      sa += dw * w; sb += dw * (w - TMW_WP(i));
-    }
+    const bool ok1 = TMW_OK1(K); const int i1 = TMW_I1(K);
+    const float g0 = L[K.l_Mgrad + lane], g1 = L[K.l_Mgrad + i1];
+    const float w0 = TMW_MA(lane) - g0, dw0 = c.dg0[TMW_LI] * w0, w1 = TMW_MA1(K, i1) - g1, dw1 = c.dg1[TMW_LI] * w1;
+    L[K.l_Mgrad + lane] = w0; if (ok1) L[K.l_Mgrad + i1] = w1;
+    sa += dw0 * w0; sb += dw0 * (w0 - c.wp0[TMW_LI]);
+    sa += (ok1 ? dw1 : 0.f) * w1; sb += (ok1 ? dw1 : 0.f) * (w1 - c.wp1[TMW_LI]);
     pa[TMW_LI] = sa; pb[TMW_LI] = sb;
   }
   TMW_SYNC();
@@ -2148,10 +2157,11 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   TMW_REG(float, p0); TMW_REG(float, p1); TMW_REG(float, p2);
   TMW_FOR {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int i = lane; i < K.nv; i += 64) {
-      float sq = L[K.l_search + i], ds = TMW_DG(i) * L[K.l_mv + i];
-      a0 += sq * sq; a1 += ds * TMW_MA(i); a2 += ds * L[K.l_mv + i];
-    }
+    const bool ok1 = TMW_OK1(K); const int i1 = TMW_I1(K);
+    const float sq0 = L[K.l_search + lane], sq1 = L[K.l_search + i1], m0 = L[K.l_mv + lane], m1 = L[K.l_mv + i1];
+    const float ds0 = c.dg0[TMW_LI] * m0, ds1 = ok1 ? c.dg1[TMW_LI] * m1 : 0.f;
+    a0 += sq0 * sq0; a1 += ds0 * TMW_MA(lane); a2 += ds0 * m0;
+    a0 += (ok1 ? sq1 : 0.f) * sq1; a1 += ds1 * TMW_MA1(K, i1); a2 += ds1 * m1;
     p0[TMW_LI] = a0; p1[TMW_LI] = a1; p2[TMW_LI] = a2;
   }
   float smag = sqrtf(tmw_sum(p0)) * scale;
@@ -2181,10 +2191,15 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   TMW_REG(float, pc); TMW_REG(float, pg);
   TMW_FOR {
     float sc = 0.f, sg = 0.f;
-    for (int i = lane; i < K.nv; i += 64) {
-      float qa = TMW_QA(i) + L[K.l_search + i] * ia, ut = TMW_MA(i) + L[K.l_mv + i] * ia;
-      TMW_QA_SET(i, qa); TMW_MA_SET(i, ut);
-      sg += TMW_DG(i) * ut * ut;
+    {
+      const bool ok1 = TMW_OK1(K); const int i1 = TMW_I1(K);
+      const float sq0 = L[K.l_search + lane], sq1 = L[K.l_search + i1], m0 = L[K.l_mv + lane], m1 = L[K.l_mv + i1];
+      const float qa0 = TMW_QA(lane) + sq0 * ia, ut0 = TMW_MA(lane) + m0 * ia;
+      const float qa1 = TMW_QA1(K, i1) + sq1 * ia, ut1 = TMW_MA1(K, i1) + m1 * ia;
+      TMW_QA_SET(lane, qa0); TMW_MA_SET(lane, ut0);
+      if (ok1) { TMW_QA_SET(lane + 64, qa1); TMW_MA_SET(lane + 64, ut1); }
+      sg += c.dg0[TMW_LI] * ut0 * ut0;
+      sg += (ok1 ? c.dg1[TMW_LI] * ut1 : 0.f) * ut1;
     }
 #pragma unroll
     for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
@@ -2232,7 +2247,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   }
   float prev_cost = INFINITY, num;
   float gn = tmw_update_gradient(c, K, num);
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_mv + i] = -L[K.l_Mgrad + i]; }
+  TMW_FOR { const int i1 = TMW_I1(K); const float g0 = L[K.l_Mgrad + lane], g1 = L[K.l_Mgrad + i1]; L[K.l_mv + lane] = -g0; if (TMW_OK1(K)) L[K.l_mv + i1] = -g1; }
   TMW_SYNC();
   TMW_TICK(6);
   TMW_STATS(K) = 0.f;
@@ -2248,7 +2263,7 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     float cost_new = tmw_linesearch(c, K, gauss);
     TMW_TICK(7);
     TMW_COUNT(36, 1000);
-    TMW_FOR { for (int i = lane; i < K.nv; i += 64) TMW_WP_SET(i, L[K.l_Mgrad + i]); }      // (lane-local: the lane that wrote w_i reads it back)
+    TMW_FOR { const float g0 = L[K.l_Mgrad + lane], g1 = L[K.l_Mgrad + TMW_I1(K)]; c.wp0[TMW_LI] = g0; if (TMW_OK1(K)) c.wp1[TMW_LI] = g1; }      // (lane-local: the lane that wrote w_i reads it back)
     prev_cost = cost;
     cost = cost_new;
     float den = gn;
@@ -2264,7 +2279,11 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
     gn = tmw_update_gradient(c, K, num, (prev_cost - cost) / scale, last_if);
     if (gn >= 0.f) {
       float beta = fmaxf(0.f, num / fmaxf(TM_MINVAL, den));
-      TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_mv + i] = -L[K.l_Mgrad + i] + beta * L[K.l_mv + i]; }
+      TMW_FOR {
+        const int i1 = TMW_I1(K);
+        const float g0 = L[K.l_Mgrad + lane], g1 = L[K.l_Mgrad + i1], s0 = L[K.l_mv + lane], s1 = L[K.l_mv + i1];
+        L[K.l_mv + lane] = -g0 + beta * s0; if (TMW_OK1(K)) L[K.l_mv + i1] = -g1 + beta * s1;
+      }
       TMW_SYNC();
     }
     TMW_TICK(8);
@@ -2299,7 +2318,16 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
     TmwModel &m = *c.mp;
     TMW_REG(float, w0); TMW_REG(float, w1);
     TMW_FOR { w0[TMW_LI] = WST(m.s_warm, lane); w1[TMW_LI] = lane + 64 < K.nv ? WST(m.s_warm, lane + 64) : 0.f; }
-    TMW_FOR { for (int i = lane; i < K.nnz; i += 64) c.mspill[i] = L[K.l_M + i]; }
+    TMW_FOR {      // (blocks of six LDS loads in flight: one load / wait / store per trip was 18 serial LDS round trips)
+      constexpr int NB = 6;
+      for (int i0 = lane; i0 < K.nnz; i0 += 64 * NB) {
+        float v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; u++) { const int i = i0 + 64 * u; v[u] = L[K.l_M + (i < K.nnz ? i : K.nnz - 1)]; }
+#pragma unroll
+        for (int u = 0; u < NB; u++) { const int i = i0 + 64 * u; if (i < K.nnz) c.mspill[i] = v[u]; }
+      }
+    }
     TMW_FOR { L[K.l_qacc + lane] = w0[TMW_LI]; if (lane + 64 < K.nv) L[K.l_qacc + lane + 64] = w1[TMW_LI]; }
     TMW_SYNC();
     tmw_mul_m(c, K, K.l_qacc, K.l_Ma);
