@@ -623,13 +623,15 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
   TmwModel &m = *c.mp; float *L = c.L; TMW_LANE_DECL
   int R = K.nround_dof + (K.nround_dof & 1);
   // inclusive prefix P_i = sum over ancestors-or-self of cdof * qvel
-  TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) {
-      float qv = L[K.l_qvel + i];
-      float *o = L + K.l_dscanA + i * TMW_DS;
-      for (int k = 0; k < 6; k++) o[k] = L[K.l_cdof + i * 6 + k] * qv;
-      if (!K.chains) o[6] = tm_i2f(m.dof_parentid[i]);
-    }
+  TMW_FOR {      // (both dof slots' loads first: TMW_I1)
+    const bool ok1 = TMW_OK1(K); const int i1 = TMW_I1(K);
+    const float qv0 = L[K.l_qvel + lane], qv1 = L[K.l_qvel + i1];
+    float cd0[6], cd1[6];
+    for (int k = 0; k < 6; k++) { cd0[k] = L[K.l_cdof + lane * 6 + k]; cd1[k] = L[K.l_cdof + i1 * 6 + k]; }
+    float *o0 = L + K.l_dscanA + lane * TMW_DS, *o1 = L + K.l_dscanA + i1 * TMW_DS;
+    for (int k = 0; k < 6; k++) o0[k] = cd0[k] * qv0;
+    if (!K.chains) o0[6] = tm_i2f(m.dof_parentid[lane]);
+    if (ok1) { for (int k = 0; k < 6; k++) o1[k] = cd1[k] * qv1; if (!K.chains) o1[6] = tm_i2f(m.dof_parentid[i1]); }
   }
   TMW_SYNC();
   if (K.chains) tmw_chain_scan(c, K, K.l_dscanA);
@@ -769,12 +771,12 @@ TM_DEV void tmw_velocity_inertia(WCtx &c, const WLayout &K) {
   // forces sit INSIDE the matrix region (wave_layout.h), which the rows of M are about to overwrite
   TMW_REG(float, bias0); TMW_REG(float, bias1);
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) {
-      const int b = m.dof_bodyid[i];
-      float bias = 0.f;
-      for (int k = 0; k < 6; k++) bias += L[K.l_cdof + i * 6 + k] * L[K.l_cfrc + b * 6 + k];
-      if (i < 64) bias0[TMW_LI] = bias; else bias1[TMW_LI] = bias;
-    }
+    const int i1 = TMW_I1(K), b0 = m.dof_bodyid[lane], b1 = m.dof_bodyid[i1];      // (one level for both slots' model reads, then both slots' LDS reads)
+    float cd0[6], cd1[6], cf0[6], cf1[6], s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < 6; k++) { cd0[k] = L[K.l_cdof + lane * 6 + k]; cd1[k] = L[K.l_cdof + i1 * 6 + k]; cf0[k] = L[K.l_cfrc + b0 * 6 + k]; cf1[k] = L[K.l_cfrc + b1 * 6 + k]; }
+    for (int k = 0; k < 6; k++) s0 += cd0[k] * cf0[k];
+    for (int k = 0; k < 6; k++) s1 += cd1[k] * cf1[k];
+    bias0[TMW_LI] = s0; if (TMW_OK1(K)) bias1[TMW_LI] = s1;
   }
   TMW_SYNC();
   TMW_FOR {
@@ -1760,21 +1762,32 @@ TM_DEV void tmw_jt_force(WCtx &c, const WLayout &K, int out) {
   }
   TMW_SYNC();
   }
-  TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) {
-      float s = 0.f;
+  TMW_FOR {      // both dof slots level by level (TMW_I1): limit-sign bytes, then the rows' Jaref / D, then the wrench products
+    const bool ok1 = TMW_OK1(K);
+    const int ii[2] = {lane, TMW_I1(K)};
+    int sv[2], su[2], kr[2]; float s[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int i = ii[t];
       // (lean: the limit row of dof i is i - 6 and the wrench subset rides in the dof's packed register word — model_host.h: rodent_chains_match)
-      const int lr = K.lean ? (i >= 6 ? i - 6 : -1) : TMW_LIMROW1(TMW_W0(i)) - 1, su = K.lean ? TMW_TP_WSUB1(TMW_TP(i)) - 1 : TMW_WSUB1(TMW_W1(i)) - 1;
-      {                  // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise (branch-free: see above)
-        const int svb = TMW_LIMSIGN(K)[lr >= 0 ? lr : 0], sv = lr >= 0 ? svb : 0;
-        const int kr = sv != 0 ? (sv < 0 ? -sv : sv) - 1 : 0;
-        const float ja = L[K.l_Jaref + kr], D = L[K.l_efc_D + TMW_DIDX(kr)];
-        const float fl = -D * ja;
-        s = (sv != 0 && ja < 0.f) ? (sv > 0 ? fl : -fl) : 0.f;
-      }
-      if (anycon && su >= 0) { const float *w = L + K.l_wr + su * 6; for (int k = 0; k < 6; k++) s += L[K.l_cdof + i * 6 + k] * w[k]; }
-      L[out + i] = s;
+      const int lr = K.lean ? (i >= 6 ? i - 6 : -1) : TMW_LIMROW1(TMW_W0(i)) - 1;
+      su[t] = K.lean ? TMW_TP_WSUB1(TMW_TP(lane + 64 * t)) - 1 : TMW_WSUB1(TMW_W1(i)) - 1;
+      const int svb = TMW_LIMSIGN(K)[lr >= 0 ? lr : 0];      // lim_sign packs sign * (compact row + 1) of a violated limit, 0 otherwise (branch-free: see above)
+      sv[t] = lr >= 0 ? svb : 0;
     }
+#pragma unroll
+    for (int t = 0; t < 2; t++) kr[t] = sv[t] != 0 ? (sv[t] < 0 ? -sv[t] : sv[t]) - 1 : 0;
+    const float ja0 = L[K.l_Jaref + kr[0]], D0 = L[K.l_efc_D + TMW_DIDX(kr[0])], ja1 = L[K.l_Jaref + kr[1]], D1 = L[K.l_efc_D + TMW_DIDX(kr[1])];
+    { const float fl = -D0 * ja0; s[0] = (sv[0] != 0 && ja0 < 0.f) ? (sv[0] > 0 ? fl : -fl) : 0.f; }
+    { const float fl = -D1 * ja1; s[1] = (sv[1] != 0 && ja1 < 0.f) ? (sv[1] > 0 ? fl : -fl) : 0.f; }
+    if (anycon) {
+      float cd[2][6], w[2][6];
+#pragma unroll
+      for (int t = 0; t < 2; t++) { const int sw = su[t] >= 0 ? su[t] : 0; for (int k = 0; k < 6; k++) { cd[t][k] = L[K.l_cdof + ii[t] * 6 + k]; w[t][k] = L[K.l_wr + sw * 6 + k]; } }
+#pragma unroll
+      for (int t = 0; t < 2; t++) { float a = s[t]; for (int k = 0; k < 6; k++) a += cd[t][k] * w[t][k]; s[t] = su[t] >= 0 ? a : s[t]; }
+    }
+    L[out + lane] = s[0]; if (ok1) L[out + ii[1]] = s[1];
   }
   TMW_SYNC();
 }
@@ -1918,7 +1931,13 @@ TM_DEV float tmw_eval_cost(WCtx &c, const WLayout &K, int q, float &gauss, bool 
       if (ja < 0.f) sc += L[K.l_efc_D + TMW_DIDX(e)] * ja * ja;
     }
     // (lean: the only evaluation with a Gauss term is the warm start's, q = l_qacc: iterate and M q come from their registers)
-    if (!jonly) for (int i = lane; i < K.nv; i += 64) sg += (TMW_MA(i) - TMW_QFS(i)) * ((TMW_QAREG(K) ? TMW_QA(i) : L[q + i]) - L[K.l_qacc_smooth + i]);
+    if (!jonly) {
+      const bool ok1 = TMW_OK1(K); const int i1 = TMW_I1(K);
+      const float qs0 = L[K.l_qacc_smooth + lane], qs1 = L[K.l_qacc_smooth + i1];
+      const float q0 = TMW_QAREG(K) ? c.qa0[TMW_LI] : L[q + lane], q1 = TMW_QAREG(K) ? c.qa1[TMW_LI] : L[q + i1];
+      sg += (TMW_MA(lane) - TMW_QFS(lane)) * (q0 - qs0);
+      sg += (ok1 ? TMW_MA1(K, i1) - (K.lean ? c.qfs1[TMW_LI] : L[K.l_qfrc_smooth + i1]) : 0.f) * (q1 - qs1);
+    }
     pc[TMW_LI] = sc; pg[TMW_LI] = sg;
   }
   TMW_SYNC();
@@ -2221,12 +2240,15 @@ TM_DEV void tmw_solve_cg(WCtx &c, const WLayout &K) {
   TMW_FOR {
     c.dg1[TMW_LI] = 0.f; c.wp1[TMW_LI] = 0.f;
     if (TMW_QAREG(K)) { c.qa1[TMW_LI] = 0.f; c.ma1[TMW_LI] = 0.f; }
-    for (int i = lane; i < K.nv; i += 64) {
-      const float wq = WST(m.s_warm, i);
-      L[K.l_qacc + i] = wq;                                           // (lean: the staging image J qacc reads below)
-      if (TMW_QAREG(K)) { TMW_QA_SET(i, wq); TMW_MA_SET(i, L[K.l_Ma + i]); }     // ... and M * warm start, parked in l_Ma = l_Mgrad since tmw_forward took it
-      const float dgi = 1.f / L[K.l_Dinv + i];
-      if (i < 64) { c.dg0[TMW_LI] = dgi; c.wp0[TMW_LI] = 0.f; } else { c.dg1[TMW_LI] = dgi; c.wp1[TMW_LI] = 0.f; }
+    {      // (both slots' global and LDS loads first: the warm start's global round trip once, not once per slot)
+      const bool ok1 = TMW_OK1(K); const int i1 = TMW_I1(K);
+      const float wq0 = WST(m.s_warm, lane), wq1 = WST(m.s_warm, i1);
+      const float ma0 = L[K.l_Ma + lane], ma1 = L[K.l_Ma + i1], di0 = L[K.l_Dinv + lane], di1 = L[K.l_Dinv + i1];
+      L[K.l_qacc + lane] = wq0;                                       // (lean: the staging image J qacc reads below)
+      if (ok1) L[K.l_qacc + i1] = wq1;
+      if (TMW_QAREG(K)) { c.qa0[TMW_LI] = wq0; c.ma0[TMW_LI] = ma0; if (ok1) { c.qa1[TMW_LI] = wq1; c.ma1[TMW_LI] = ma1; } }     // ... and M * warm start, parked in l_Ma = l_Mgrad since tmw_forward took it
+      c.dg0[TMW_LI] = 1.f / di0; c.wp0[TMW_LI] = 0.f;
+      if (ok1) { c.dg1[TMW_LI] = 1.f / di1; c.wp1[TMW_LI] = 0.f; }
     }
   }
   TMW_SYNC();
@@ -2341,7 +2363,7 @@ TM_DEV void tmw_forward(WCtx &c, const WLayout &K, bool emit) {
   tmw_make_constraint(c, K);
   TMW_TICK(4);
   if (TMW_STOP <= 4) return;
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_qacc_smooth + i] = TMW_QFS(i); }
+  TMW_FOR { L[K.l_qacc_smooth + lane] = TMW_QFS(lane); if (TMW_OK1(K)) L[K.l_qacc_smooth + lane + 64] = TMW_QFS(lane + 64); }
   TMW_SYNC();
   tmw_solve(c, K, K.l_qacc_smooth, K.l_Mgrad);
   // (tests: qacc_smooth shares its words with the CG's search vector in the lean layout — copied out while it is there)
@@ -2365,11 +2387,11 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   }
   // the right-hand side goes to l_Mgrad, dead since the CG loop ended; it is read here, lane by lane, BEFORE timestep * damping below overwrites
   // the words l_qfrc_constraint shares with l_search = l_hdamp in the lean layout
-  TMW_FOR { for (int i = lane; i < K.nv; i += 64) L[K.l_Mgrad + i] = TMW_QFS(i) + L[K.l_qfrc_constraint + i]; }
+  TMW_FOR { const int i1 = TMW_I1(K); const float f0 = L[K.l_qfrc_constraint + lane], f1 = L[K.l_qfrc_constraint + i1]; L[K.l_Mgrad + lane] = TMW_QFS(lane) + f0; if (TMW_OK1(K)) L[K.l_Mgrad + i1] = TMW_QFS(lane + 64) + f1; }
   // timestep * damping (the diagonal Euler adds to M) into the dead search vector; the activation state is advanced here already — nothing
   // reads act between tmw_velocity_inertia and the end of the substep — so that ctrl's global load sits next to the loads above
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) L[K.l_hdamp + i] = m.timestep * m.dof_damping[i];
+    { const int i1 = TMW_I1(K); const float dm0 = m.dof_damping[lane], dm1 = m.dof_damping[i1]; L[K.l_hdamp + lane] = m.timestep * dm0; if (TMW_OK1(K)) L[K.l_hdamp + i1] = m.timestep * dm1; }
     for (int a = lane; a < K.nu; a += 64) {
       // (record mode: the action rows were transposed in behind the state + output rows)
       float ctrl = c.rs ? c.st[(size_t)c.e * (size_t)c.rs + (size_t)(m.s_prev_ctrl + a)] : (c.action ? c.action[(size_t)a * c.n + c.e] : 0.f);
@@ -2391,7 +2413,7 @@ TM_DEV float tmw_euler(WCtx &c, const WLayout &K, float time) {
   if (K.chains) tmw_subst_chains(c, K, K.l_Mgrad); else tmw_subst_down(c, K, K.l_Mgrad);
   TMW_TICK(11);
   TMW_FOR {
-    for (int i = lane; i < K.nv; i += 64) L[K.l_qvel + i] += L[K.l_Mgrad + i] * h;
+    { const int i1 = TMW_I1(K); const float v0 = L[K.l_qvel + lane], v1 = L[K.l_qvel + i1], g0 = L[K.l_Mgrad + lane], g1 = L[K.l_Mgrad + i1]; L[K.l_qvel + lane] = v0 + g0 * h; if (TMW_OK1(K)) L[K.l_qvel + i1] = v1 + g1 * h; }
   }
   TMW_SYNC();
   TMW_FOR {
