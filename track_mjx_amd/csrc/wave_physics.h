@@ -2192,6 +2192,11 @@ TM_DEV float tmw_linesearch(WCtx &c, const WLayout &K, float &gauss) {
   TMW_FOR {
 #pragma unroll
     for (int sl = 0; sl < TMW_LS_SLOTS; sl++) {
+      // (wave-uniform: no row in this slot — slots 1 .. 3 in four solves of five: the padding row's constants without its three LDS reads)
+      if (sl > 0 && (w16 || 64 * sl >= c.nact)) {
+        R.ja[TMW_LI][sl] = 1.f; R.jv[TMW_LI][sl] = 0.f; R.D[TMW_LI][sl] = 0.f; R.t0[TMW_LI][sl] = 0.f; R.t1[TMW_LI][sl] = 0.f; R.t2[TMW_LI][sl] = 0.f;
+        continue;
+      }
       // nact <= 16: the rows sit in lanes 0-15 and are replicated in lanes 16-31 and 32-47 (tmw_ls_points16)
       int e = w16 ? (lane & 15) : lane + 64 * sl;
       bool ok = w16 ? (sl == 0 && lane < 48 && e < c.nact) : e < c.nact;
