@@ -1169,7 +1169,8 @@ def test_lds_tiled_acting_layer_matches_torch(M, N, K, lda, norm):
     """tmjx_linear_act (round 5: the acting policy's dense layer through a 20 KB LDS tile — what a CU has free next to twelve resident physics
     workgroups): C = op(A) W^T + b against a float64 product at the acting path's shapes (an env group's rows x the 2 x 256 / rodent-mc-intention
     widths, the first layer reading 472 of the observation's 696 columns with the normaliser applied on the way) and ragged ones; without a bias;
-    operands the entry does not take are refused, not mangled."""
+    operands the entry does not take are refused, not mangled.  Round 6: the entry picks 32-row tiles while 64-row ones would leave CUs without a
+    workgroup — the 1 365-row shapes here take those, the 2 732 x 1 024 one the 64-row tiles."""
     import ctypes as C
     from track_mjx_amd import hip as _hip
     L = _hip.lib()

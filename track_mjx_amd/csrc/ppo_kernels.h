@@ -656,21 +656,27 @@ __global__ __launch_bounds__(64, 5) void k_linear_nolds_mfma(const float *__rest
 #define ACT_BK 32
 // __launch_bounds__(256, 5): at most 96 registers (accumulators included) — three physics waves of 136 allocated registers leave 104 of a SIMD's 512
 #define ACT_LD 40          // floats per LDS row (32 + 8: b128 fragment reads of 16 consecutive rows hit 16 distinct slots, as in gemm_kernels.h)
-template <bool NORM>
+// BMR = 64: a 64 x 64 tile, every wave 32 x 32 (2 x 2 MFMA tiles).  BMR = 32 (round 6): a 32 x 64 tile, every wave 32 x 16 (2 x 1) — half the MFMAs per
+// K step and workgroup and twice the workgroups: at the acting policy's 1 365 rows a layer is ONE workgroup's time (88 resp. 172 workgroups all run at
+// once on 256 CUs), and of that time the 32 matrix instructions per wave and step were the larger half (12 -> ~8 us per 256-wide layer).  Same k order
+// per output element: bit-identical results.
+template <bool NORM, int BMR>
 __global__ __launch_bounds__(256, 5) void k_linear_act(const float *__restrict__ A, long long lda, const float *__restrict__ W, int ldw, const float *__restrict__ bias,
                                                     float *__restrict__ C, int M, int N, int K, const float *__restrict__ mean, const float *__restrict__ inv_std) {
   TM_PRIO_ACTING();
   typedef float __attribute__((ext_vector_type(4))) f4;
-  __shared__ __attribute__((aligned(16))) float sA[ACT_BM * ACT_LD], sW[ACT_BM * ACT_LD];
+  constexpr int NA = BMR / 32, NB = BMR == 64 ? 2 : 1;      // float4 of A per thread and K step; MFMA column tiles per wave
+  __shared__ __attribute__((aligned(16))) float sA[BMR * ACT_LD], sW[ACT_BM * ACT_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
-  const int row0 = blockIdx.x * ACT_BM, col0 = blockIdx.y * ACT_BM, wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int row0 = blockIdx.x * BMR, col0 = blockIdx.y * ACT_BM;
+  const int wr = BMR == 64 ? (wave >> 1) * 32 : 0, wc = BMR == 64 ? (wave & 1) * 32 : wave * 16;
   const float *pa[2], *pw[2];
   int sr[2], sc[2];
 #pragma unroll
   for (int p = 0; p < 2; p++) {
     const int f = t + 256 * p, r = f >> 3, c4 = f & 7;
     sr[p] = r; sc[p] = 4 * c4;
-    pa[p] = A + (long long)min(row0 + r, M - 1) * lda;                 // rows / columns outside the matrix: clamped (their products are never stored)
+    pa[p] = A + (long long)min(row0 + min(r, BMR - 1), M - 1) * lda;   // rows / columns outside the matrix: clamped (their products are never stored)
     pw[p] = W + (size_t)min(col0 + r, N - 1) * ldw;
   }
   f4 ra[2], rw[2];
@@ -679,50 +685,53 @@ __global__ __launch_bounds__(256, 5) void k_linear_act(const float *__restrict__
     for (int p = 0; p < 2; p++) {
       const bool ok = k0 + sc[p] < K;                // K % 4 == 0: a float4 lies inside or outside as a whole
       const int kc = ok ? k0 + sc[p] : 0;            // (outside: the row's FIRST float4, always readable — K >= 4 — and zeroed below)
-      f4 a = *reinterpret_cast<const f4 *>(pa[p] + kc), w = *reinterpret_cast<const f4 *>(pw[p] + kc);
-      if (NORM) {
-        const f4 mu = *reinterpret_cast<const f4 *>(mean + kc), is = *reinterpret_cast<const f4 *>(inv_std + kc);
-        a = (a - mu) * is;
-      }
-      ra[p] = ok ? a : f4{0.f, 0.f, 0.f, 0.f};
+      const f4 w = *reinterpret_cast<const f4 *>(pw[p] + kc);
       rw[p] = ok ? w : f4{0.f, 0.f, 0.f, 0.f};
+      if (p < NA) {
+        f4 a = *reinterpret_cast<const f4 *>(pa[p] + kc);
+        if (NORM) {
+          const f4 mu = *reinterpret_cast<const f4 *>(mean + kc), is = *reinterpret_cast<const f4 *>(inv_std + kc);
+          a = (a - mu) * is;
+        }
+        ra[p] = ok ? a : f4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
-  f4 acc[2][2];
+  f4 acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; b++) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
   load(0);
   for (int k0 = 0; k0 < K; k0 += ACT_BK) {
     __syncthreads();                                  // every wave has read the previous step's fragments
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-      *reinterpret_cast<f4 *>(sA + sr[p] * ACT_LD + sc[p]) = ra[p];
+      if (p < NA) *reinterpret_cast<f4 *>(sA + sr[p] * ACT_LD + sc[p]) = ra[p];
       *reinterpret_cast<f4 *>(sW + sr[p] * ACT_LD + sc[p]) = rw[p];
     }
     __syncthreads();
     if (k0 + ACT_BK < K) load(k0 + ACT_BK);           // in flight while this step's MFMAs issue
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      f4 fa[2], fw[2];
+      f4 fa[2], fw[NB];
 #pragma unroll
       for (int a = 0; a < 2; a++) fa[a] = *reinterpret_cast<const f4 *>(sA + (wr + 16 * a + li) * ACT_LD + 16 * c + 4 * kq);
 #pragma unroll
-      for (int b = 0; b < 2; b++) fw[b] = *reinterpret_cast<const f4 *>(sW + (wc + 16 * b + li) * ACT_LD + 16 * c + 4 * kq);
+      for (int b = 0; b < NB; b++) fw[b] = *reinterpret_cast<const f4 *>(sW + (wc + 16 * b + li) * ACT_LD + 16 * c + 4 * kq);
 #pragma unroll
       for (int e = 0; e < 4; e++)
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-          for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][e], fw[b][e], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NB; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][e], fw[b][e], acc[a][b], 0, 0, 0);
     }
   }
   // accumulator register r of lane l holds C[4 (l / 16) + r][l % 16] of its 16 x 16 tile
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < NB; b++) {
       const int c = col0 + wc + 16 * b + li;
       const float bv = (bias && c < N) ? bias[c] : 0.f;
 #pragma unroll

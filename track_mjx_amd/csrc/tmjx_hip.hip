@@ -873,10 +873,20 @@ int tmjx_linear_act(const float *A, int64_t lda, const float *W, int ldw, const 
   if (M < 1 || N < 1 || K < 1) return fail(TMJX_EINVAL, "bad sizes");
   if (!tmjx_linear_act_ok(A, lda, W, ldw, K)) return fail(TMJX_EINVAL, "tmjx_linear_act: K % 4 == 0, row-major operands with 16-byte aligned rows");
   if ((mean || inv_std) && (!mean || !inv_std || (((uintptr_t)mean | (uintptr_t)inv_std) & 15))) return fail(TMJX_EINVAL, "tmjx_linear_act: mean and inv_std together, 16-byte aligned");
-  dim3 grid((M + ACT_BM - 1) / ACT_BM, (N + ACT_BM - 1) / ACT_BM);
   hipStream_t s = (hipStream_t)stream;
-  if (mean) hipLaunchKernelGGL((k_linear_act<true>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, mean, inv_std);
-  else hipLaunchKernelGGL((k_linear_act<false>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, (const float *)nullptr, (const float *)nullptr);
+  // 32-row tiles while 64-row ones would leave CUs without a workgroup (the acting policy's 1 365 rows: 88 -> 172 workgroups); TMJX_ACT_ROWS=64 / 32 forces one
+  static const int force = getenv("TMJX_ACT_ROWS") ? atoi(getenv("TMJX_ACT_ROWS")) : 0;
+  const int ncol = (N + ACT_BM - 1) / ACT_BM;
+  const bool small = force ? force == 32 : ((M + 63) / 64) * ncol < 128;
+  if (small) {
+    dim3 grid((M + 31) / 32, ncol);
+    if (mean) hipLaunchKernelGGL((k_linear_act<true, 32>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, mean, inv_std);
+    else hipLaunchKernelGGL((k_linear_act<false, 32>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, (const float *)nullptr, (const float *)nullptr);
+  } else {
+    dim3 grid((M + ACT_BM - 1) / ACT_BM, ncol);
+    if (mean) hipLaunchKernelGGL((k_linear_act<true, 64>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, mean, inv_std);
+    else hipLaunchKernelGGL((k_linear_act<false, 64>), grid, dim3(256), 0, s, A, (long long)lda, W, ldw, bias, C, M, N, K, (const float *)nullptr, (const float *)nullptr);
+  }
   return check_launch("k_linear_act");
 }
 int tmjx_linear_nolds(const float *A, int64_t sa_row, int64_t sa_k, const float *W, const float *bias, float *C, int M, int N, int K,
