@@ -230,7 +230,6 @@ int tmjx_sample_action(const float *logits, const float *noise, float *raw, floa
 /* The acting policy's dense layer (brax acting.actor_step through make_inference_fn, track_mjx/agent/mlp_ppo/ppo_networks.py:46-96; layers of
  * intention_network.py:32-44,68-76) through a 20 KB LDS tile — what the CUs have free next to twelve resident physics workgroups since round 5:
  * C[M][N] = op(A) W^T (+ bias), A row-major [M][lda], W [N][ldw], op = identity or (A - mean[k]) * inv_std[k] (mean / inv_std: both or neither).
- * The tile is 32 x 64 while 64 x 64 tiles would leave CUs without a workgroup, 64 x 64 otherwise (same k order per element: the result does not depend on it).
  * tmjx_linear_act_ok: 1 when the operands qualify (K % 4 == 0, 16-byte aligned rows); otherwise use tmjx_linear_nolds. */
 int tmjx_linear_act_ok(const float *A, int64_t lda, const float *W, int ldw, int K);
 int tmjx_linear_act(const float *A, int64_t lda, const float *W, int ldw, const float *bias, float *C, int M, int N, int K,
