@@ -50,3 +50,9 @@ if __name__ == "__main__":
         neq = (x != ref)
         first = int(np.argmax(neq.any(1))) if neq.any() else -1
         print(f"{so}: {'IDENTICAL' if not neq.any() else f'{int(neq.sum())} words differ, first in control step {first}'}")
+        if neq.any():      # which envs: the state block is [rows][n] (env = word % n); non-finite words of the reference in those envs at that step
+            n = 384
+            srows = (ref.shape[1] - 0) // n
+            blk = neq[:, : (ref.shape[1] // n) * n].reshape(neq.shape[0], -1, n)
+            envs = sorted(set(np.nonzero(blk.any((0, 1)))[0].tolist()))
+            print(f"    envs (word % {n}) with a differing word: {envs[:12]}{' ...' if len(envs) > 12 else ''} ({len(envs)} of {n})")
